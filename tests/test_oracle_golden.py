@@ -1,0 +1,148 @@
+"""Pins the CPU oracle (oracle/ddif_oracle.py) against vectors produced by the real reference
+(tools/make_golden.py).  CPU only.  Tolerances: the oracle calls the same torch CPU ops as the reference, so
+whole-forward agreement is ~1e-6 (summation order inside einsum/reshape paths may differ); schedule tables and
+the manifest are exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from ddif.layout import param_manifest
+from oracle import ddif_oracle as O
+
+
+def _load(name):
+    return np.load(os.path.join(gc.GOLDEN_DIR, name + ".npz"))
+
+
+def _chk(t):
+    return np.array([float(t.double().sum()), float(t.double().abs().max())])
+
+
+@pytest.mark.parametrize("ds", list(gc.DATASETS))
+def test_manifest_matches_reference(ds):
+    with open(os.path.join(gc.GOLDEN_DIR, f"manifest_{ds}.json")) as f:
+        ref = json.load(f)
+    mine = param_manifest(gc.cfg_for(ds))
+    assert [k for k, _ in mine] == [k for k, _ in ref["keys"]]
+    assert [list(s) for _, s in mine] == [s for _, s in ref["keys"]]
+    n = sum(int(np.prod(s)) for _, s in mine)
+    assert n == ref["n_params"]
+    assert {"wv3": 10397208, "gf2": 10250324, "cave": 11332511}[ds] == n
+
+
+def test_layer_plans_agree():
+    from ddif.layout import layer_plan
+
+    for ds in gc.DATASETS:
+        a, b = layer_plan(gc.cfg_for(ds)), O.layer_plan(gc.cfg_for(ds))
+        assert a == b
+
+
+@pytest.mark.parametrize("case", gc.FORWARD_CASES, ids=[c[0] for c in gc.FORWARD_CASES])
+def test_forward_matches_reference(case):
+    g = _load(case[0])
+    x, t, cond, sc = gc.forward_inputs(case)
+    np.testing.assert_allclose(_chk(x), g["x_chk"], rtol=0, atol=0)  # generators are bit-stable
+    np.testing.assert_allclose(_chk(cond), g["cond_chk"], rtol=0, atol=0)
+    with torch.no_grad():
+        y = O.unet_forward(gc.weights_for(case[1]), gc.cfg_for(case[1]), x, t, cond, sc)
+    err = float((y - torch.from_numpy(g["y"])).abs().max())
+    assert err <= 5e-6, err
+
+
+def test_schedule_tables_exact():
+    g = _load("schedules")
+    for T in gc.SCHEDULE_T:
+        tabs = O.schedule_tables(O.cosine_betas(T))
+        for k in O.TABLE_NAMES:
+            assert np.array_equal(tabs[k].numpy(), g[f"T{T}.{k}"]), (T, k)
+    for T in gc.DDIM_FROM:
+        tabs = O.schedule_tables(O.cosine_betas(T))
+        keep = O.ddim_stride_set(T, "ddim25")
+        assert keep == list(g[f"ddim25_from_T{T}.keep"])
+        nt = O.schedule_tables(O.respaced_betas(tabs["alphas_cumprod"], keep))
+        for k in O.TABLE_NAMES:
+            assert np.array_equal(nt[k].numpy(), g[f"ddim25_from_T{T}.{k}"]), (T, k)
+
+
+def _ddpm(case, record=None, max_steps=None):
+    cid, ds, B, H, W, T, seed = case
+    cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        return O.ddpm_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, tabs, record=record, max_steps=max_steps)
+
+
+@pytest.mark.parametrize("case", [c for c in gc.DDPM_CASES if c[5] * c[3] * c[4] <= 100 * 32 * 32],
+                         ids=lambda c: c[0])
+def test_ddpm_short_matches_reference(case):
+    g = _load(case[0])
+    rec = {n: None for n in gc.DDPM_SNAPSHOTS.get(case[0], [])}
+    out = _ddpm(case, record=rec)
+    for n, v in rec.items():
+        assert float((v - torch.from_numpy(g[f"after_{n}"])).abs().max()) <= 1e-5
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-5
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", [c for c in gc.DDPM_CASES if c[0] == "ddpm_wv3_16_T1000"], ids=lambda c: c[0])
+def test_ddpm_T1000_matches_reference(case):
+    g = _load(case[0])
+    out = _ddpm(case)
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-4  # north-star atol
+
+
+@pytest.mark.parametrize("case", gc.DDIM_CASES, ids=lambda c: c[0])
+def test_ddim_matches_reference(case):
+    cid, ds, B, H, W, T, sect, seed = case
+    g = _load(cid)
+    cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        out, nt = O.ddim_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, tabs, sect)
+    assert nt["betas"].numel() == int(g["num_timesteps_after"])
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("case", gc.DPM_CASES, ids=lambda c: c[0])
+def test_dpm_solver_matches_reference(case):
+    cid, ds, H, W, T, steps, order, seed = case
+    g = _load(cid)
+    C = gc.DATASETS[ds][0]
+    cond = gc.tiles_for(ds, 1, H, W, seed=seed)["cond"]
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    xT = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        out = O.dpmpp_multistep_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, tabs["betas"], xT, steps, order)
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("case", gc.LOSS_CASES, ids=lambda c: c[0])
+def test_p_losses_matches_reference(case):
+    cid, ds, B, H, W, T, tvals, sc_branch, seed = case
+    g = _load(cid)
+    C = gc.DATASETS[ds][0]
+    tiles = gc.tiles_for(ds, B, H, W, seed=seed)
+    res = tiles["gt"] - tiles["lms"]
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    noise = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        loss, recon = O.p_losses_eval(gc.weights_for(ds), gc.cfg_for(ds), tabs, res, tiles["cond"],
+                                      torch.tensor(tvals), noise, sc_branch)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert float((recon - torch.from_numpy(g["recon"])).abs().max()) <= 1e-5
+
+
+def test_psnr_sign_quirk():
+    g = _load("psnr")
+    gen = torch.Generator().manual_seed(5)
+    a = torch.rand(8, 33, 35, generator=gen)
+    b = (a + 0.05 * torch.randn(8, 33, 35, generator=gen)).clamp(0, 1)
+    assert abs(O.psnr_reference_sign(a, b) - float(g["ref_psnr"])) < 1e-4
+    assert O.psnr(a, b) > 0 > O.psnr_reference_sign(a, b)
