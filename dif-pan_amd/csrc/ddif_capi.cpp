@@ -1,0 +1,190 @@
+// extern "C" surface of libddif (include/ddif.h).  No exceptions cross this boundary.
+#include "ddif_plan.h"
+
+struct ddif_net {
+    ddif::Net n;
+};
+struct ddif_plan {
+    ddif::Plan p;
+};
+
+#define DDIF_GUARD_BEGIN try {
+#define DDIF_GUARD_END                                                                    \
+    }                                                                                     \
+    catch (const std::exception& e) {                                                     \
+        return ddif::fail(DDIF_ERR_INVALID, "unexpected C++ exception: %s", e.what());    \
+    }                                                                                     \
+    catch (...) {                                                                         \
+        return ddif::fail(DDIF_ERR_INVALID, "unexpected C++ exception");                  \
+    }
+
+extern "C" {
+
+int ddif_net_create(ddif_net_t* out, const ddif_net_cfg* cfg, int device) {
+    DDIF_GUARD_BEGIN
+    if (!out || !cfg) return ddif::fail(DDIF_ERR_INVALID, "ddif_net_create: NULL argument");
+    *out = nullptr;
+    DDIF_HIPCHK(hipSetDevice(device));
+    std::unique_ptr<ddif_net> h(new ddif_net());
+    h->n.cfg = *cfg;
+    h->n.device = device;
+    if (int e = h->n.build_layers()) return e;
+    *out = h.release();
+    return DDIF_OK;
+    DDIF_GUARD_END
+}
+
+void ddif_net_destroy(ddif_net_t net) { delete net; }
+
+int ddif_net_load(ddif_net_t net, const char* key, const float* data, const int64_t* shape, int ndim) {
+    DDIF_GUARD_BEGIN
+    if (!net) return ddif::fail(DDIF_ERR_INVALID, "ddif_net_load: NULL net");
+    return net->n.load(key, data, shape, ndim);
+    DDIF_GUARD_END
+}
+
+int ddif_net_commit(ddif_net_t net, void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!net) return ddif::fail(DDIF_ERR_INVALID, "ddif_net_commit: NULL net");
+    DDIF_HIPCHK(hipSetDevice(net->n.device));
+    return net->n.commit((hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int64_t ddif_net_num_params(ddif_net_t net) { return net ? net->n.num_params() : 0; }
+
+int ddif_plan_create(ddif_plan_t* out, ddif_net_t net, int B, int H, int W) {
+    DDIF_GUARD_BEGIN
+    if (!out || !net) return ddif::fail(DDIF_ERR_INVALID, "ddif_plan_create: NULL argument");
+    *out = nullptr;
+    DDIF_HIPCHK(hipSetDevice(net->n.device));
+    std::unique_ptr<ddif_plan> h(new ddif_plan());
+    h->p.net = &net->n;
+    h->p.B = B;
+    h->p.H = H;
+    h->p.W = W;
+    if (int e = h->p.build()) return e;
+    *out = h.release();
+    return DDIF_OK;
+    DDIF_GUARD_END
+}
+
+void ddif_plan_destroy(ddif_plan_t plan) { delete plan; }
+
+int ddif_plan_set_cond(ddif_plan_t plan, const float* cond, void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    return plan->p.set_cond(cond, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_forward(ddif_plan_t plan, const float* x, const float* time_host, const float* self_cond, float* out, void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    return plan->p.forward(x, time_host, self_cond, out, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_sample_ddpm(ddif_plan_t plan, const ddif_ddpm_tables* tabs, const float* x_T, const float* noise, uint64_t seed,
+                          uint64_t tile0, float clamp_lo, float clamp_hi, int do_clamp, float* out, void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    return plan->p.sample_ddpm(tabs, x_T, noise, seed, tile0, clamp_lo, clamp_hi, do_clamp, out, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_sample_ddim(ddif_plan_t plan, const ddif_ddim_tables* tabs, const float* x_T, const float* noise, uint64_t seed,
+                          uint64_t tile0, float clamp_lo, float clamp_hi, int do_clamp, float* out, void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    return plan->p.sample_ddim(tabs, x_T, noise, seed, tile0, clamp_lo, clamp_hi, do_clamp, out, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_sample_dpmpp(ddif_plan_t plan, const ddif_dpm_tables* tabs, const float* x_T, float clamp_lo, float clamp_hi,
+                           int do_clamp, float* out, void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    return plan->p.sample_dpmpp(tabs, x_T, clamp_lo, clamp_hi, do_clamp, out, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_q_sample_forward(ddif_plan_t plan, const float* x0, const float* noise, const float* sqrt_ac_host,
+                               const float* sqrt_1mac_host, const float* time_host, const float* self_cond, float* pred,
+                               void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    return plan->p.q_sample_forward(x0, noise, sqrt_ac_host, sqrt_1mac_host, time_host, self_cond, pred, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_prof_begin(ddif_plan_t plan, int every_n_steps, int max_events) {
+    DDIF_GUARD_BEGIN
+    if (!plan || every_n_steps < 0 || max_events < 0) return ddif::fail(DDIF_ERR_INVALID, "ddif_prof_begin: bad arguments");
+    ddif::Plan& p = plan->p;
+    while ((int)p.ev0.size() < max_events) {
+        hipEvent_t a, b;
+        DDIF_HIPCHK(hipEventCreate(&a));
+        DDIF_HIPCHK(hipEventCreate(&b));
+        p.ev0.push_back(a);
+        p.ev1.push_back(b);
+    }
+    p.ev_flop.assign(p.ev0.size(), 0.0);
+    p.ev_bytes.assign(p.ev0.size(), 0.0);
+    p.ev_used = 0;
+    p.prof_every = every_n_steps;
+    p.prof_max = max_events;
+    return DDIF_OK;
+    DDIF_GUARD_END
+}
+
+int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
+    DDIF_GUARD_BEGIN
+    if (!plan || !out) return ddif::fail(DDIF_ERR_INVALID, "ddif_prof_collect: NULL argument");
+    ddif::Plan& p = plan->p;
+    std::memset(out, 0, sizeof(*out));
+    for (int i = 0; i < p.ev_used; ++i) {
+        float ms = 0.f;
+        DDIF_HIPCHK(hipEventSynchronize(p.ev1[i]));
+        DDIF_HIPCHK(hipEventElapsedTime(&ms, p.ev0[i], p.ev1[i]));
+        out->launches += 1;
+        out->total_ms += ms;
+        out->total_flop += p.ev_flop[i];
+        out->total_bytes += p.ev_bytes[i];
+    }
+    std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions)");
+    p.prof_every = 0;
+    p.ev_used = 0;
+    return DDIF_OK;
+    DDIF_GUARD_END
+}
+
+int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes) {
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    double sf = 0, sb = 0, cf = 0, cb = 0;
+    for (auto& op : plan->p.step) {
+        sf += op.flop;
+        sb += op.bytes;
+    }
+    for (auto& op : plan->p.pre) {
+        cf += op.flop;
+        cb += op.bytes;
+    }
+    if (step_flop) *step_flop = sf;
+    if (step_bytes) *step_bytes = sb;
+    if (cond_flop) *cond_flop = cf;
+    if (cond_bytes) *cond_bytes = cb;
+    return DDIF_OK;
+}
+
+const char* ddif_last_error(void) { return ddif::g_err.c_str(); }
+const char* ddif_version(void) { return "ddif 0.1 (gfx950)"; }
+int ddif_is_emulated(void) {
+#ifdef DDIF_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+}  // extern "C"

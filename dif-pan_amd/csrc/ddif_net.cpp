@@ -1,0 +1,367 @@
+// Network construction and weight repacking (host side).
+// Layer list = UNetSR3.__init__ (reference models/sr3_dwt.py:69-163); checkpoint keys = SURVEY.md appendix C.
+#include "ddif_net.h"
+
+namespace ddif {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+static bool in_list(const int32_t* a, int n, int v) {
+    for (int i = 0; i < n; ++i)
+        if (a[i] == v) return true;
+    return false;
+}
+
+int Net::build_layers() {
+    const ddif_net_cfg& c = cfg;
+    if (c.norm_groups != 1) return fail(DDIF_ERR_INVALID, "norm_groups=%d: only GroupNorm(1 group) is implemented", c.norm_groups);
+    if (c.inner_channel != 32) return fail(DDIF_ERR_INVALID, "inner_channel=%d: only 32 is implemented", c.inner_channel);
+    if (c.n_channel_mults < 1 || c.n_channel_mults > 8) return fail(DDIF_ERR_INVALID, "bad channel_mults");
+    if (c.in_channel < 1 || c.out_channel < 1 || c.res_blocks < 1) return fail(DDIF_ERR_INVALID, "bad channel counts");
+    const int inner = c.inner_channel;
+    int pre = inner, res = c.image_size;
+    std::vector<int> skips{pre};
+    downs.clear();
+    mid.clear();
+    ups.clear();
+    Layer stem;
+    stem.kind = L_STEM;
+    stem.cin = c.in_channel + (c.self_condition ? c.out_channel : 0);
+    stem.cout = inner;
+    stem.p = "downs.0";
+    downs.push_back(stem);
+    for (int i = 0; i < c.n_channel_mults; ++i) {
+        const int ch = inner * c.channel_mults[i];
+        const bool attn = in_list(c.attn_res, c.n_attn_res, res);
+        for (int r = 0; r < c.res_blocks; ++r) {
+            Layer L;
+            L.kind = L_ENC;
+            L.cin = pre;
+            L.cout = ch;
+            L.attn = attn;
+            L.p = "downs." + std::to_string(downs.size());
+            downs.push_back(L);
+            skips.push_back(ch);
+            pre = ch;
+        }
+        if (i != c.n_channel_mults - 1) {
+            Layer L;
+            L.kind = L_DOWN;
+            L.cin = L.cout = pre;
+            L.p = "downs." + std::to_string(downs.size());
+            downs.push_back(L);
+            skips.push_back(pre);
+            res /= 2;
+        }
+    }
+    for (int i = 0; i < 2; ++i) {
+        Layer L;
+        L.kind = L_MID;
+        L.cin = L.cout = pre;
+        L.attn = (i == 0);
+        L.p = "mid." + std::to_string(i);
+        mid.push_back(L);
+    }
+    for (int i = c.n_channel_mults - 1; i >= 0; --i) {
+        const int ch = inner * c.channel_mults[i];
+        const bool attn = in_list(c.attn_res, c.n_attn_res, res);
+        for (int r = 0; r < c.res_blocks + 1; ++r) {
+            Layer L;
+            L.kind = L_DEC;
+            L.cskip = skips.back();
+            skips.pop_back();
+            L.cx = pre;
+            L.cin = pre + L.cskip;
+            L.cout = ch;
+            L.attn = attn;
+            L.p = "ups." + std::to_string(ups.size());
+            ups.push_back(L);
+            pre = ch;
+        }
+        if (i >= 1) {
+            Layer L;
+            L.kind = L_UP;
+            L.cin = L.cout = pre;
+            L.p = "ups." + std::to_string(ups.size());
+            ups.push_back(L);
+            res *= 2;
+        }
+    }
+    final_in = pre;
+    auto check = [&](const Layer& L) -> int {
+        if (L.attn && L.cout != 128)
+            return fail(DDIF_ERR_INVALID, "%s: self-attention with %d channels (head dim %d): only 128 (head dim 16) is implemented",
+                        L.p.c_str(), L.cout, L.cout / 8);
+        if (L.kind == L_DEC && (L.cin % 8 != 0 || L.cin / 8 > 32))
+            return fail(DDIF_ERR_INVALID, "%s: linear attention over %d channels needs 8 | channels and head dim <= 32", L.p.c_str(), L.cin);
+        return 0;
+    };
+    for (auto& L : downs)
+        if (int e = check(L)) return e;
+    for (auto& L : mid)
+        if (int e = check(L)) return e;
+    for (auto& L : ups)
+        if (int e = check(L)) return e;
+    return 0;
+}
+
+int Net::load(const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!key || !data || ndim < 0 || ndim > 4) return fail(DDIF_ERR_INVALID, "ddif_net_load: bad arguments");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(DDIF_ERR_INVALID, "ddif_net_load(%s): negative dim", key);
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.v.assign(data, data + n);
+    host[key] = std::move(t);
+    committed = false;
+    return 0;
+}
+
+int64_t Net::num_params() const {
+    int64_t n = 0;
+    for (auto& kv : host)
+        if (kv.first != "noise_level_mlp.0.freqs") n += (int64_t)kv.second.v.size();
+    return n;
+}
+
+namespace {
+
+struct Blob {
+    std::vector<float> v;
+    size_t add(const float* p, size_t n) {
+        size_t off = (v.size() + 63) & ~(size_t)63;  // 256-byte alignment
+        v.resize(off + n, 0.f);
+        if (p) std::memcpy(v.data() + off, p, n * sizeof(float));
+        return off;
+    }
+};
+
+// Kernel order (kernels_conv.h): [n-block of 32 couts][chunk of ck cins][tap][k8][half h][cout j][4 cins],
+// cin = chunk*ck + k8*8 + 4*h + i.  Each wave's B fragment for one (tap, k8) is one contiguous 1 KiB read.
+size_t pack_conv(Blob& b, const float* w, int cout, int cin, int ks, int ck, int* n_chunks_out) {
+    const int n_chunks = (cin + ck - 1) / ck, nb = (cout + 31) / 32, nb_pad = (nb + 3) & ~3;
+    const int taps = ks * ks, K8 = ck / 8;
+    const size_t n = (size_t)nb_pad * n_chunks * taps * K8 * 256;
+    const size_t off = b.add(nullptr, n);
+    float* o = b.v.data() + off;
+    for (int nbi = 0; nbi < nb; ++nbi)
+        for (int ch = 0; ch < n_chunks; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int k8 = 0; k8 < K8; ++k8)
+                    for (int h = 0; h < 2; ++h)
+                        for (int j = 0; j < 32; ++j)
+                            for (int i = 0; i < 4; ++i) {
+                                const int ci = ch * ck + k8 * 8 + 4 * h + i, co = nbi * 32 + j;
+                                float val = 0.f;
+                                if (co < cout && ci < cin) val = w[((size_t)co * cin + ci) * taps + tap];
+                                o[(((((size_t)nbi * n_chunks + ch) * taps + tap) * K8 + k8) * 2 + h) * 128 + j * 4 + i] = val;
+                            }
+    *n_chunks_out = n_chunks;
+    return off;
+}
+
+}  // namespace
+
+int Net::commit(hipStream_t stream) {
+    Blob b;
+    struct PendConv { std::string name; size_t w_off; long bias_off; int cin, cout, ks, ck, n_chunks; };
+    std::vector<PendConv> pend;
+    std::map<std::string, size_t> vec_off;
+    std::string missing;
+
+    auto need = [&](const std::string& key) -> const HostTensor* {
+        const HostTensor* t = get(key);
+        if (!t && missing.empty()) missing = key;
+        return t;
+    };
+    auto add_conv = [&](const std::string& name, bool has_bias) {
+        const HostTensor* w = need(name + ".weight");
+        const HostTensor* bs = has_bias ? need(name + ".bias") : nullptr;
+        if (!w || (has_bias && !bs)) return;
+        if (w->shape.size() != 4) { if (missing.empty()) missing = name + ".weight (expected 4-d)"; return; }
+        PendConv p;
+        p.name = name;
+        p.cout = (int)w->shape[0];
+        p.cin = (int)w->shape[1];
+        p.ks = (int)w->shape[2];
+        p.ck = p.cin <= 16 ? 16 : 32;
+        p.w_off = pack_conv(b, w->v.data(), p.cout, p.cin, p.ks, p.ck, &p.n_chunks);
+        p.bias_off = bs ? (long)b.add(bs->v.data(), bs->v.size()) : -1;
+        pend.push_back(p);
+    };
+    auto add_vec = [&](const std::string& key) {
+        const HostTensor* t = need(key);
+        if (t) vec_off[key] = b.add(t->v.data(), t->v.size());
+    };
+    auto add_dw = [&](const std::string& key) {  // (C,1,3,3) -> [9][C]
+        const HostTensor* t = need(key);
+        if (!t) return;
+        const int C = (int)t->shape[0];
+        std::vector<float> r((size_t)9 * C);
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < 9; ++k) r[(size_t)k * C + c] = t->v[(size_t)c * 9 + k];
+        vec_off[key] = b.add(r.data(), r.size());
+    };
+    auto add_resblock = [&](const std::string& p) {
+        add_vec(p + ".block1.block.0.weight");
+        add_vec(p + ".block1.block.0.bias");
+        add_conv(p + ".block1.block.3", true);
+        add_vec(p + ".block2.block.0.weight");
+        add_vec(p + ".block2.block.0.bias");
+        add_conv(p + ".block2.block.3", true);
+    };
+    auto add_attn = [&](const std::string& p) {
+        add_vec(p + ".norm.weight");
+        add_vec(p + ".norm.bias");
+        add_conv(p + ".qkv", false);
+        add_conv(p + ".out", true);
+    };
+
+    // time embedding: concatenated FeatureWiseAffine matrices
+    std::vector<float> wall_h, ball_h;
+    slot_off.clear();
+    nslots = 0;
+    auto add_slot = [&](const std::string& rb) {
+        const HostTensor* w = need(rb + ".noise_func.noise_func.0.weight");
+        const HostTensor* bs = need(rb + ".noise_func.noise_func.0.bias");
+        if (!w || !bs) return;
+        slot_off[rb] = nslots;
+        wall_h.insert(wall_h.end(), w->v.begin(), w->v.end());
+        ball_h.insert(ball_h.end(), bs->v.begin(), bs->v.end());
+        nslots += (int)bs->v.size();
+    };
+
+    for (auto& L : downs) {
+        if (L.kind == L_STEM) add_conv(L.p, true);
+        else if (L.kind == L_DOWN) add_conv(L.p + ".conv", true);
+        else {
+            add_slot(L.p + ".res_block");
+            add_resblock(L.p + ".res_block");
+            if (L.attn) add_attn(L.p + ".attn");
+            add_conv(L.p + ".cond_inj.body.0", false);
+            add_vec(L.p + ".cond_inj.body.1.weight");
+            add_vec(L.p + ".cond_inj.body.1.bias");
+            add_conv(L.p + ".cond_inj.body.3", true);
+            add_conv(L.p + ".cond_inj.x_conv", true);
+        }
+    }
+    for (auto& L : mid) {
+        add_slot(L.p + ".res_block");
+        add_resblock(L.p + ".res_block");
+        if (L.attn) add_attn(L.p + ".attn");
+    }
+    for (auto& L : ups) {
+        if (L.kind == L_UP) { add_conv(L.p + ".conv", true); continue; }
+        add_slot(L.p + ".res_block");
+        add_resblock(L.p + ".res_block");
+        if (L.attn) add_attn(L.p + ".attn");
+        const std::string ci = L.p + ".cond_inj";
+        add_vec(ci + ".prenorm_x.weight");
+        add_vec(ci + ".prenorm_x.bias");
+        add_dw(ci + ".q.0.weight");
+        add_conv(ci + ".q.1", true);
+        add_dw(ci + ".kv.0.weight");
+        add_conv(ci + ".kv.1", true);
+        // attn_out(o) + attn_res(xn) as ONE 1x1 conv over cat[o, xn] (K = 2*fea); biases summed
+        const HostTensor *wo = need(ci + ".attn_out.weight"), *bo = need(ci + ".attn_out.bias");
+        const HostTensor* wr = get(ci + ".attn_res.weight");
+        const HostTensor* br = get(ci + ".attn_res.bias");
+        if (wo && bo) {
+            const int co = (int)wo->shape[0], fea = (int)wo->shape[1];
+            PendConv p;
+            p.name = ci + ".attn_mix";
+            p.cout = co;
+            p.ks = 1;
+            std::vector<float> bsum(bo->v);
+            if (wr && br) {
+                std::vector<float> cat((size_t)co * 2 * fea);
+                for (int o = 0; o < co; ++o) {
+                    std::memcpy(&cat[(size_t)o * 2 * fea], &wo->v[(size_t)o * fea], fea * sizeof(float));
+                    std::memcpy(&cat[(size_t)o * 2 * fea + fea], &wr->v[(size_t)o * fea], fea * sizeof(float));
+                    bsum[o] = bo->v[o] + br->v[o];
+                }
+                p.cin = 2 * fea;
+                p.ck = 32;
+                p.w_off = pack_conv(b, cat.data(), co, p.cin, 1, p.ck, &p.n_chunks);
+            } else {  // attn_res is Identity (fea == dim_out): xn is added as a residual
+                p.cin = fea;
+                p.ck = fea <= 16 ? 16 : 32;
+                p.w_off = pack_conv(b, wo->v.data(), co, fea, 1, p.ck, &p.n_chunks);
+            }
+            p.bias_off = (long)b.add(bsum.data(), bsum.size());
+            pend.push_back(p);
+        }
+        add_conv(ci + ".ffn.0", false);
+        add_conv(ci + ".ffn.2", false);
+        add_conv(ci + ".ffn.3", true);
+    }
+    add_vec("final_conv.block.0.weight");
+    add_vec("final_conv.block.0.bias");
+    add_conv("final_conv.block.3", true);
+
+    const HostTensor *hw1 = need("noise_level_mlp.1.weight"), *hb1 = need("noise_level_mlp.1.bias");
+    const HostTensor *hw3 = need("noise_level_mlp.3.weight"), *hb3 = need("noise_level_mlp.3.bias");
+    if (!missing.empty()) return fail(DDIF_ERR_MISSING, "ddif_net_commit: weight '%s' was never loaded", missing.c_str());
+
+    const int half = cfg.inner_channel / 2;
+    std::vector<float> fr(half);
+    if (const HostTensor* f = get("noise_level_mlp.0.freqs")) {
+        if ((int)f->v.size() != half) return fail(DDIF_ERR_INVALID, "noise_level_mlp.0.freqs must have %d entries", half);
+        fr = f->v;
+    } else {
+        const float k = -(float)std::log(1e4);
+        for (int j = 0; j < half; ++j) fr[j] = std::exp(k * ((float)j / (float)half));
+    }
+    const size_t o_fr = b.add(fr.data(), fr.size());
+    const size_t o_w1 = b.add(hw1->v.data(), hw1->v.size()), o_b1 = b.add(hb1->v.data(), hb1->v.size());
+    const size_t o_w3 = b.add(hw3->v.data(), hw3->v.size()), o_b3 = b.add(hb3->v.data(), hb3->v.size());
+    const size_t o_wall = b.add(wall_h.data(), wall_h.size()), o_ball = b.add(ball_h.data(), ball_h.size());
+
+    if (blob) {
+        DDIF_HIPCHK(hipFree(blob));
+        blob = nullptr;
+    }
+    blob_floats = b.v.size() + 64;
+    DDIF_HIPCHK(hipMalloc((void**)&blob, blob_floats * sizeof(float)));
+    DDIF_HIPCHK(hipMemcpy(blob, b.v.data(), b.v.size() * sizeof(float), hipMemcpyHostToDevice));
+    (void)stream;
+
+    conv.clear();
+    vec.clear();
+    for (auto& p : pend) {
+        PackedConv pc;
+        pc.w = blob + p.w_off;
+        pc.bias = p.bias_off >= 0 ? blob + p.bias_off : nullptr;
+        pc.cin = p.cin;
+        pc.cout = p.cout;
+        pc.ks = p.ks;
+        pc.ck = p.ck;
+        pc.n_chunks = p.n_chunks;
+        conv[p.name] = pc;
+    }
+    for (auto& kv : vec_off) vec[kv.first] = blob + kv.second;
+    freqs = blob + o_fr;
+    w1 = blob + o_w1;
+    b1 = blob + o_b1;
+    w3 = blob + o_w3;
+    b3 = blob + o_b3;
+    wall = blob + o_wall;
+    ball = blob + o_ball;
+    committed = true;
+    return 0;
+}
+
+}  // namespace ddif

@@ -1,0 +1,85 @@
+// Host-side structures of libddif: the network (weights repacked for the kernels) and helpers.
+#pragma once
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ddif.h"
+#include "ddif_dev.h"
+
+namespace ddif {
+
+extern thread_local std::string g_err;
+int fail(int code, const char* fmt, ...);
+
+#define DDIF_HIPCHK(x)                                                                                      \
+    do {                                                                                                    \
+        hipError_t e__ = (x);                                                                               \
+        if (e__ != hipSuccess)                                                                              \
+            return ::ddif::fail(DDIF_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e__), __FILE__, \
+                                __LINE__);                                                                  \
+    } while (0)
+
+// conv prologue applied while staging the input tile (kernels_conv.h)
+enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
+
+enum LayerKind { L_STEM, L_ENC, L_DOWN, L_MID, L_DEC, L_UP };
+
+struct Layer {
+    LayerKind kind;
+    int cin = 0, cout = 0, cx = 0, cskip = 0;
+    bool attn = false;
+    std::string p;  // state-dict prefix, e.g. "downs.3"
+};
+
+// A convolution's weights in kernel order (see pack_conv in ddif_net.cpp) + its bias, both device pointers.
+struct PackedConv {
+    const float* w = nullptr;
+    const float* bias = nullptr;
+    int cin = 0, cout = 0, ks = 1, ck = 32, n_chunks = 0;
+};
+
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+};
+
+struct Net {
+    ddif_net_cfg cfg{};
+    int device = 0;
+    std::vector<Layer> downs, mid, ups;
+    int final_in = 0;
+    std::map<std::string, HostTensor> host;
+    bool committed = false;
+
+    float* blob = nullptr;  // one device allocation holding every repacked tensor
+    size_t blob_floats = 0;
+    std::map<std::string, PackedConv> conv;       // key = conv weight key without ".weight"
+    std::map<std::string, const float*> vec;      // GroupNorm gammas/betas and depthwise weights by full key
+    // time embedding
+    const float *freqs = nullptr, *w1 = nullptr, *b1 = nullptr, *w3 = nullptr, *b3 = nullptr, *wall = nullptr,
+                *ball = nullptr;
+    int nslots = 0;                               // total FeatureWiseAffine output channels
+    std::map<std::string, int> slot_off;          // res_block prefix -> offset into a time-bias row
+
+    ~Net() {
+        if (blob) (void)hipFree(blob);
+    }
+    int build_layers();
+    int load(const char* key, const float* data, const int64_t* shape, int ndim);
+    int commit(hipStream_t stream);
+    int64_t num_params() const;
+    const HostTensor* get(const std::string& key) const {
+        auto it = host.find(key);
+        return it == host.end() ? nullptr : &it->second;
+    }
+};
+
+}  // namespace ddif

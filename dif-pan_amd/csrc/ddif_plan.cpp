@@ -1,0 +1,816 @@
+// Plan construction (launch program of UNetSR3.forward, reference models/sr3_dwt.py:169-219 with the cond-only
+// branches hoisted into set_cond) and the sampling loops (reference diffusion/diffusion_ddpm_pan.py:445-507,
+// 624-666; solver/dpm_solver.py:1179-1221).
+#include "ddif_plan.h"
+#include "kernels_conv.h"
+#include "kernels_misc.h"
+
+namespace ddif {
+
+// ------------------------------------------------------------------------------------------------ conv variants
+namespace {
+template <int KS, int S, int U, int CK, int PRO>
+ConvVariant variant_for_cfg(int cfg) {
+    ConvVariant v;
+    switch (cfg) {
+        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK>(); v.th = 8; v.tw = 16; v.nt = 32; break;
+        case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK>(); v.th = 8; v.tw = 16; v.nt = 64; break;
+        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK>(); v.th = 8; v.tw = 8; v.nt = 64; break;
+        case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK>(); v.th = 8; v.tw = 8; v.nt = 128; break;
+        default: break;
+    }
+    return v;
+}
+template <int KS, int S, int U, int CK, int PRO>
+ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not fit comfortably in LDS
+    return (cfg >= 2) ? variant_for_cfg<KS, S, U, CK, PRO>(cfg) : ConvVariant();
+}
+}  // namespace
+
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg) {
+    ConvVariant v;
+    if (ks == 3 && stride == 1 && !ups && ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 32, PRO_GN_SILU>(cfg); v.name = "conv3x3_gn_silu"; }
+    else if (ks == 3 && stride == 1 && !ups && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 32, PRO_NONE>(cfg); v.name = "conv3x3"; }
+    else if (ks == 3 && stride == 1 && !ups && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE>(cfg); v.name = "conv3x3_ck16"; }
+    else if (ks == 3 && stride == 2 && !ups && ck == 32 && pro == PRO_NONE) { v = variant_small_tiles<3, 2, 0, 32, PRO_NONE>(cfg); v.name = "conv3x3_s2"; }
+    else if (ks == 3 && stride == 2 && !ups && ck == 16 && pro == PRO_NONE) { v = variant_small_tiles<3, 2, 0, 16, PRO_NONE>(cfg); v.name = "conv3x3_s2_ck16"; }
+    else if (ks == 3 && stride == 1 && ups && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 1, 32, PRO_NONE>(cfg); v.name = "conv3x3_up2"; }
+    else if (ks == 3 && stride == 1 && ups && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 1, 16, PRO_NONE>(cfg); v.name = "conv3x3_up2_ck16"; }
+    else if (ks == 1 && stride == 1 && !ups && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE>(cfg); v.name = "conv1x1"; }
+    else if (ks == 1 && stride == 1 && !ups && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE>(cfg); v.name = "conv1x1_ck16"; }
+    else if (ks == 1 && stride == 1 && !ups && ck == 32 && pro == PRO_GN) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN>(cfg); v.name = "conv1x1_gn"; }
+    else if (ks == 1 && stride == 1 && !ups && ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_SILU>(cfg); v.name = "conv1x1_gn_silu"; }
+    return v;
+}
+
+static int pick_cfg(int stride, int Hout, int Wout, int Cout, int B) {
+    const bool wide = (Wout >= 16) && stride == 1;
+    if (wide) {
+        const long wgs64 = (long)B * ((Hout + 7) / 8) * ((Wout + 15) / 16) * ((Cout + 63) / 64);
+        return (Cout % 64 == 0 && wgs64 >= 1024) ? 1 : 0;
+    }
+    if (Cout <= 32 && stride == 1) return 0;
+    const long wgs128 = (long)B * ((Hout + 7) / 8) * ((Wout + 7) / 8) * ((Cout + 127) / 128);
+    return (Cout % 128 == 0 && wgs128 >= 1024) ? 3 : 2;
+}
+
+static inline dim3 ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g);
+}
+
+// ------------------------------------------------------------------------------------------------ allocation
+Plan::~Plan() {
+    for (void* p : allocs) (void)hipFree(p);
+    for (auto e : ev0) (void)hipEventDestroy(e);
+    for (auto e : ev1) (void)hipEventDestroy(e);
+}
+
+template <typename T>
+int Plan::dalloc(T** p, size_t n) {
+    void* q = nullptr;
+    const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    DDIF_HIPCHK(hipMalloc(&q, bytes));
+    allocs.push_back(q);
+    bytes_allocated += bytes;
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+int Plan::alloc_tensor(Tensor* t, int C_, int H_, int W_) {
+    t->C = C_;
+    t->H = H_;
+    t->W = W_;
+    t->st = nullptr;
+    t->np = 0;
+    return dalloc(&t->p, (size_t)B * H_ * W_ * C_);
+}
+
+int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
+    const PackedConv& pc = *s.pc;
+    const int Hin = s.in0.H, Win = s.in0.W;
+    const int Hc = s.ups ? 2 * Hin : Hin, Wc = s.ups ? 2 * Win : Win;
+    const int Hout = s.stride == 2 ? (Hc - 1) / 2 + 1 : Hc, Wout = s.stride == 2 ? (Wc - 1) / 2 + 1 : Wc;
+    const int c0 = s.in0.C, c1 = s.in1.C;
+    if (c0 + c1 != pc.cin) return fail(DDIF_ERR_INVALID, "%s: input channels %d+%d != weight cin %d", s.name, c0, c1, pc.cin);
+    if (pc.ks == 1 && (s.stride != 1 || s.ups)) return fail(DDIF_ERR_INVALID, "%s: 1x1 conv with stride/upsample", s.name);
+    const int cfg = pick_cfg(s.stride, Hout, Wout, pc.cout, B);
+    const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg);
+    if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg);
+    if (s.pro != PRO_NONE && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
+        return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
+    if (int e = alloc_tensor(out, pc.cout, Hout, Wout)) return e;
+    ConvArgs a{};
+    a.in0 = s.in0.p;
+    a.in1 = s.in1.p;
+    a.c0 = c0;
+    a.c1 = c1;
+    a.B = B;
+    a.Hin = Hin;
+    a.Win = Win;
+    a.Hout = Hout;
+    a.Wout = Wout;
+    a.Cout = pc.cout;
+    a.w = pc.w;
+    a.n_chunks = pc.n_chunks;
+    a.bias = s.use_bias ? pc.bias : nullptr;
+    a.st0 = s.in0.st;
+    a.np0 = s.in0.np;
+    a.st1 = s.in1.st;
+    a.np1 = s.in1.np;
+    a.gamma = s.gamma;
+    a.beta = s.beta;
+    a.res = s.res;
+    a.film = s.film;
+    a.act_silu = s.silu ? 1 : 0;
+    a.out = out->p;
+    a.tiles_x = (Wout + var.tw - 1) / var.tw;
+    a.tiles_y = (Hout + var.th - 1) / var.th;
+    a.vec_ok = (c0 % 4 == 0 && c1 % 4 == 0) ? 1 : 0;
+    const int gy = (pc.cout + var.nt - 1) / var.nt;
+    if (s.stats) {
+        out->np = a.tiles_x * a.tiles_y * gy;
+        if (int e = dalloc(&out->st, (size_t)B * out->np * 2)) return e;
+        a.st_out = out->st;
+    }
+    const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y), (unsigned)gy);
+    const bool dyn = s.dyn_input;
+    const bool self_c = net->cfg.self_condition != 0;
+    const int tb_off = s.tb_off;
+    Op op;
+    op.name = var.name;
+    op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
+    op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
+    op.timed = (pc.ks == 3);
+    op.run = [a, var, grid, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
+        ConvArgs aa = a;
+        if (dyn) {
+            if (self_c) {
+                aa.in0 = ctx.sc;
+                aa.in1 = ctx.x;
+            } else {
+                aa.in0 = ctx.x;
+            }
+        }
+        if (tb_off >= 0) {
+            aa.tbias = ctx.tb + tb_off;
+            aa.tbias_stride = ctx.tb_stride;
+        }
+        hipLaunchKernelGGL(var.fn, grid, dim3(256), var.smem, st, aa);
+    };
+    prog.push_back(std::move(op));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ program
+int Plan::build() {
+    const ddif_net_cfg& c = net->cfg;
+    if (!net->committed) return fail(DDIF_ERR_STATE, "ddif_plan_create: ddif_net_commit has not been called");
+    C = c.out_channel;
+    P = c.pan_channel;
+    const int Cl = c.lms_channel;
+    CC = 2 * Cl + 4 * P;
+    const int nlev = c.n_channel_mults;
+    const int div = 1 << (nlev - 1);
+    if (B < 1 || H < div || W < div || H % div || W % div)
+        return fail(DDIF_ERR_INVALID, "ddif_plan_create: H=%d W=%d must be positive multiples of %d", H, W, div);
+    LH.assign(1, H);
+    LW.assign(1, W);
+    for (int l = 1; l < nlev; ++l) {
+        LH.push_back((LH.back() - 1) / 2 + 1);
+        LW.push_back((LW.back() - 1) / 2 + 1);
+    }
+    auto V = [&](const std::string& k) -> const float* {
+        auto it = net->vec.find(k);
+        return it == net->vec.end() ? nullptr : it->second;
+    };
+    auto PC = [&](const std::string& k) -> const PackedConv* {
+        auto it = net->conv.find(k);
+        return it == net->conv.end() ? nullptr : &it->second;
+    };
+#define DDIF_TRY(x) do { if (int e__ = (x)) return e__; } while (0)
+
+    // ---- boundary staging + sampler state
+    DDIF_TRY(alloc_tensor(&x_in, c.in_channel, H, W));
+    DDIF_TRY(alloc_tensor(&sc_in, c.out_channel, H, W));
+    DDIF_TRY(alloc_tensor(&lms, C, H, W));
+    const size_t img_n = (size_t)B * H * W * C;
+    for (int i = 0; i < 2; ++i) DDIF_TRY(dalloc(&img[i], img_n));
+    for (int i = 0; i < 3; ++i) DDIF_TRY(dalloc(&mbuf[i], img_n));
+    DDIF_TRY(dalloc(&io_nchw, (size_t)B * H * W * (c.in_channel > C ? c.in_channel : C)));
+    DDIF_TRY(dalloc(&small, (size_t)4 * B + 64));
+
+    // ---- cond-only program (set_cond)
+    cenc.resize(nlev);
+    cdec.resize(nlev);
+    {
+        Op op;
+        op.name = "lms_nhwc";
+        Tensor lm = lms;
+        const int BB = B, CCc = CC, HW = H * W, Cc = C;
+        op.run = [this, lm, BB, CCc, HW, Cc](hipStream_t s, const StepCtx&) {
+            hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid((size_t)BB * HW * Cc), dim3(256), 0, s, (const float*)this->cond_nchw, BB, CCc, HW, 0, Cc, lm.p);
+        };
+        pre.push_back(std::move(op));
+    }
+    for (int l = 0; l < nlev; ++l) {
+        DDIF_TRY(alloc_tensor(&cenc[l], Cl + P, LH[l], LW[l]));
+        DDIF_TRY(alloc_tensor(&cdec[l], Cl + 3 * P, LH[l], LW[l]));
+        for (int which = 0; which < 2; ++which) {
+            Tensor t = which ? cdec[l] : cenc[l];
+            const int cbeg = which ? CC - (Cl + 3 * P) : 0;
+            Op op;
+            op.name = "cond_resize";
+            const int BB = B, CCc = CC, HH = H, WW = W;
+            op.bytes = 4.0 * B * t.C * ((double)H * W + (double)t.H * t.W);
+            op.run = [this, t, cbeg, BB, CCc, HH, WW](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL(resize_bilinear_kernel, ew_grid((size_t)BB * t.H * t.W * t.C), dim3(256), 0, s,
+                                   (const float*)this->cond_nchw, BB, CCc, HH, WW, cbeg, t.C, t.H, t.W, t.p);
+            };
+            pre.push_back(std::move(op));
+        }
+    }
+
+    // helpers shared by the step program
+    auto resblock = [&](const std::string& rb, Tensor in, Tensor* out) -> int {
+        const PackedConv *c1 = PC(rb + ".block1.block.3"), *c2 = PC(rb + ".block2.block.3");
+        if (!c1 || !c2) return fail(DDIF_ERR_MISSING, "%s: conv weights missing", rb.c_str());
+        Tensor h1;
+        ConvSpec s1;
+        s1.pc = c1;
+        s1.in0 = in;
+        s1.pro = PRO_GN_SILU;
+        s1.gamma = V(rb + ".block1.block.0.weight");
+        s1.beta = V(rb + ".block1.block.0.bias");
+        s1.tb_off = net->slot_off.at(rb);
+        s1.stats = true;
+        s1.name = "res.conv1";
+        DDIF_TRY(add_conv(step, s1, &h1));
+        ConvSpec s2;
+        s2.pc = c2;
+        s2.in0 = h1;
+        s2.pro = PRO_GN_SILU;
+        s2.gamma = V(rb + ".block2.block.0.weight");
+        s2.beta = V(rb + ".block2.block.0.bias");
+        s2.res = in.p;
+        s2.stats = true;
+        s2.name = "res.conv2";
+        return add_conv(step, s2, out);
+    };
+    auto attention = [&](const std::string& ap, Tensor in, Tensor* out) -> int {
+        const PackedConv *cq = PC(ap + ".qkv"), *co = PC(ap + ".out");
+        if (!cq || !co) return fail(DDIF_ERR_MISSING, "%s: conv weights missing", ap.c_str());
+        Tensor qkv, o;
+        ConvSpec s1;
+        s1.pc = cq;
+        s1.in0 = in;
+        s1.pro = PRO_GN;
+        s1.gamma = V(ap + ".norm.weight");
+        s1.beta = V(ap + ".norm.bias");
+        s1.use_bias = false;
+        s1.name = "attn.qkv";
+        DDIF_TRY(add_conv(step, s1, &qkv));
+        DDIF_TRY(alloc_tensor(&o, in.C, in.H, in.W));
+        {
+            Op op;
+            op.name = "self_attn";
+            const int n = in.H * in.W, Cc = in.C, BB = B;
+            const float scale = 1.0f / std::sqrt((float)Cc);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)
+            op.flop = 4.0 * B * 8 * (double)n * n * 16;
+            op.bytes = 4.0 * B * n * 4.0 * Cc;
+            op.run = [qkv, o, n, Cc, BB, scale](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL((self_attn_kernel<16>), dim3((n + 63) / 64, 8, BB), dim3(64), 2 * 64 * 16 * sizeof(float), s,
+                                   (const float*)qkv.p, n, Cc, scale, o.p);
+            };
+            step.push_back(std::move(op));
+        }
+        ConvSpec s2;
+        s2.pc = co;
+        s2.in0 = o;
+        s2.res = in.p;
+        s2.stats = true;
+        s2.name = "attn.out";
+        return add_conv(step, s2, out);
+    };
+
+    // ---- step program
+    Tensor cur;
+    std::vector<Tensor> feats;
+    int lev = 0;
+    for (auto& L : net->downs) {
+        if (L.kind == L_STEM) {
+            const PackedConv* pc = PC(L.p);
+            if (!pc) return fail(DDIF_ERR_MISSING, "%s missing", L.p.c_str());
+            ConvSpec s;
+            s.pc = pc;
+            s.dyn_input = true;
+            if (c.self_condition) {
+                s.in0 = sc_in;
+                s.in1 = x_in;
+            } else {
+                s.in0 = x_in;
+            }
+            s.stats = true;
+            s.name = "stem";
+            DDIF_TRY(add_conv(step, s, &cur));
+        } else if (L.kind == L_DOWN) {
+            ConvSpec s;
+            s.pc = PC(L.p + ".conv");
+            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.conv missing", L.p.c_str());
+            s.in0 = cur;
+            s.stride = 2;
+            s.stats = true;
+            s.name = "down";
+            DDIF_TRY(add_conv(step, s, &cur));
+            ++lev;
+        } else {
+            const std::string ci = L.p + ".cond_inj";
+            // cond-only: body(cond) -> FiLM scale|shift   (sr3_dwt.py:379-391)
+            Tensor hid, film;
+            {
+                ConvSpec s;
+                s.pc = PC(ci + ".body.0");
+                if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.body.0 missing", ci.c_str());
+                s.in0 = cenc[lev];
+                s.use_bias = false;
+                s.stats = true;
+                s.name = "film.body0";
+                DDIF_TRY(add_conv(pre, s, &hid));
+                ConvSpec s2;
+                s2.pc = PC(ci + ".body.3");
+                if (!s2.pc) return fail(DDIF_ERR_MISSING, "%s.body.3 missing", ci.c_str());
+                s2.in0 = hid;
+                s2.pro = PRO_GN_SILU;
+                s2.gamma = V(ci + ".body.1.weight");
+                s2.beta = V(ci + ".body.1.bias");
+                s2.name = "film.body3";
+                DDIF_TRY(add_conv(pre, s2, &film));
+            }
+            Tensor y;
+            ConvSpec s;
+            s.pc = PC(ci + ".x_conv");
+            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.x_conv missing", ci.c_str());
+            s.in0 = cur;
+            s.film = film.p;
+            s.stats = true;
+            s.name = "film.x_conv";
+            DDIF_TRY(add_conv(step, s, &y));
+            DDIF_TRY(resblock(L.p + ".res_block", y, &cur));
+            if (L.attn) {
+                Tensor t2;
+                DDIF_TRY(attention(L.p + ".attn", cur, &t2));
+                cur = t2;
+            }
+        }
+        feats.push_back(cur);
+    }
+    for (auto& L : net->mid) {
+        Tensor t1;
+        DDIF_TRY(resblock(L.p + ".res_block", cur, &t1));
+        cur = t1;
+        if (L.attn) {
+            Tensor t2;
+            DDIF_TRY(attention(L.p + ".attn", cur, &t2));
+            cur = t2;
+        }
+    }
+    for (auto& L : net->ups) {
+        if (L.kind == L_UP) {
+            ConvSpec s;
+            s.pc = PC(L.p + ".conv");
+            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.conv missing", L.p.c_str());
+            s.in0 = cur;
+            s.ups = 1;
+            s.stats = true;
+            s.name = "up";
+            DDIF_TRY(add_conv(step, s, &cur));
+            --lev;
+            continue;
+        }
+        const std::string ci = L.p + ".cond_inj";
+        Tensor skip = feats.back();
+        feats.pop_back();
+        if (skip.C != L.cskip || cur.C != L.cx || skip.H != cur.H || skip.W != cur.W)
+            return fail(DDIF_ERR_INVALID, "%s: skip/feature shape mismatch", L.p.c_str());
+        const int fea = L.cin, d = fea / 8, Hl = cur.H, Wl = cur.W, BB = B;
+        const int cd = Cl + 3 * P;
+        // ---- cond-only: kv -> softmax_W(k) -> context   (sr3_dwt.py:514-517,541,546,563)
+        float* ctx = nullptr;
+        {
+            Tensor kdw, kv;
+            DDIF_TRY(alloc_tensor(&kdw, cd, Hl, Wl));
+            {
+                DwArgs a{};
+                a.in0 = cdec[lev].p;
+                a.c0 = cd;
+                a.B = B;
+                a.H = Hl;
+                a.W = Wl;
+                a.w = V(ci + ".kv.0.weight");
+                if (!a.w) return fail(DDIF_ERR_MISSING, "%s.kv.0.weight missing", ci.c_str());
+                a.out_dw = kdw.p;
+                a.tiles_x = (Wl + 15) / 16;
+                a.tiles_y = (Hl + 7) / 8;
+                Op op;
+                op.name = "kv.dw3x3";
+                op.flop = 2.0 * 9 * B * Hl * Wl * cd;
+                op.bytes = 8.0 * B * Hl * Wl * cd;
+                op.run = [a, BB](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+                };
+                pre.push_back(std::move(op));
+            }
+            ConvSpec s;
+            s.pc = PC(ci + ".kv.1");
+            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.kv.1 missing", ci.c_str());
+            s.in0 = kdw;
+            s.name = "kv.1x1";
+            DDIF_TRY(add_conv(pre, s, &kv));
+            float *kmx, *ksm;
+            DDIF_TRY(dalloc(&kmx, (size_t)B * Hl * fea));
+            DDIF_TRY(dalloc(&ksm, (size_t)B * Hl * fea));
+            DDIF_TRY(dalloc(&ctx, (size_t)B * 8 * d * d));
+            {
+                Op op;
+                op.name = "k.softmax_stats";
+                op.bytes = 8.0 * B * Hl * Wl * fea;
+                op.run = [kv, kmx, ksm, fea, BB, Hl, Wl](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(softmax_stats_kernel, ew_grid((size_t)BB * Hl * fea), dim3(256), 0, s, (const float*)kv.p, 2 * fea, 0, fea, BB, Hl, Wl, 1, kmx, ksm);
+                };
+                pre.push_back(std::move(op));
+            }
+            {
+                Op op;
+                op.name = "linattn_ctx";
+                op.flop = 2.0 * B * 8 * d * d * (double)Hl * Wl;
+                op.bytes = 4.0 * B * Hl * Wl * 2.0 * fea;
+                op.run = [kv, kmx, ksm, ctx, fea, d, BB, Hl, Wl](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(linattn_ctx_kernel, dim3(8, BB), dim3(256), 2 * 32 * d * sizeof(float), s, (const float*)kv.p, (const float*)kmx, (const float*)ksm, BB, Hl, Wl, fea, d, ctx);
+                };
+                pre.push_back(std::move(op));
+            }
+        }
+        // ---- per step
+        Tensor dwq, xn, q, o, amix, f1, f2, f3;
+        DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl));
+        DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl));
+        {
+            DwArgs a{};
+            a.in0 = cur.p;
+            a.c0 = cur.C;
+            a.in1 = skip.p;
+            a.c1 = skip.C;
+            a.B = B;
+            a.H = Hl;
+            a.W = Wl;
+            a.st0 = cur.st;
+            a.np0 = cur.np;
+            a.st1 = skip.st;
+            a.np1 = skip.np;
+            if (!a.st0 || !a.st1) return fail(DDIF_ERR_STATE, "%s: prenorm without producer statistics", ci.c_str());
+            a.gamma = V(ci + ".prenorm_x.weight");
+            a.beta = V(ci + ".prenorm_x.bias");
+            a.w = V(ci + ".q.0.weight");
+            if (!a.gamma || !a.beta || !a.w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
+            a.out_dw = dwq.p;
+            a.out_xn = xn.p;
+            a.tiles_x = (Wl + 15) / 16;
+            a.tiles_y = (Hl + 7) / 8;
+            a.use_gn = 1;
+            Op op;
+            op.name = "q.gn_dw3x3";
+            op.flop = 2.0 * 9 * B * Hl * Wl * fea;
+            op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
+            op.run = [a, BB](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+            };
+            step.push_back(std::move(op));
+        }
+        {
+            ConvSpec s;
+            s.pc = PC(ci + ".q.1");
+            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.q.1 missing", ci.c_str());
+            s.in0 = dwq;
+            s.name = "q.1x1";
+            DDIF_TRY(add_conv(step, s, &q));
+        }
+        float *qmx, *qsm;
+        DDIF_TRY(dalloc(&qmx, (size_t)B * Wl * fea));
+        DDIF_TRY(dalloc(&qsm, (size_t)B * Wl * fea));
+        DDIF_TRY(alloc_tensor(&o, fea, Hl, Wl));
+        {
+            Op op;
+            op.name = "q.softmax_stats";
+            op.bytes = 8.0 * B * Hl * Wl * fea;
+            op.run = [q, qmx, qsm, fea, BB, Hl, Wl](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL(softmax_stats_kernel, ew_grid((size_t)BB * Wl * fea), dim3(256), 0, s, (const float*)q.p, fea, 0, fea, BB, Hl, Wl, 0, qmx, qsm);
+            };
+            step.push_back(std::move(op));
+        }
+        {
+            Op op;
+            op.name = "linattn_apply";
+            const float scale = 1.0f / std::sqrt((float)d);
+            op.flop = 2.0 * B * Hl * Wl * (double)fea * d;
+            op.bytes = 8.0 * B * Hl * Wl * fea;
+            op.run = [q, qmx, qsm, ctx, o, fea, d, BB, Hl, Wl, scale](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL(linattn_apply_kernel, dim3((Hl * Wl + 15) / 16, BB), dim3(256), (size_t)(fea * d + 16 * fea) * sizeof(float), s,
+                                   (const float*)q.p, (const float*)qmx, (const float*)qsm, (const float*)ctx, BB, Hl, Wl, fea, d, scale, o.p);
+            };
+            step.push_back(std::move(op));
+        }
+        {
+            ConvSpec s;
+            s.pc = PC(ci + ".attn_mix");
+            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.attn_out missing", ci.c_str());
+            s.in0 = o;
+            if (s.pc->cin == 2 * fea) s.in1 = xn;
+            else s.res = xn.p;  // attn_res is Identity
+            s.name = "attn_out+res";
+            DDIF_TRY(add_conv(step, s, &amix));
+        }
+        {
+            ConvSpec s;
+            s.pc = PC(ci + ".ffn.0");
+            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.0 missing", ci.c_str());
+            s.in0 = amix;
+            s.use_bias = false;
+            s.silu = true;
+            s.name = "ffn.0";
+            DDIF_TRY(add_conv(step, s, &f1));
+            ConvSpec s2;
+            s2.pc = PC(ci + ".ffn.2");
+            if (!s2.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.2 missing", ci.c_str());
+            s2.in0 = f1;
+            s2.use_bias = false;
+            s2.name = "ffn.2";
+            DDIF_TRY(add_conv(step, s2, &f2));
+            ConvSpec s3;
+            s3.pc = PC(ci + ".ffn.3");
+            if (!s3.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.3 missing", ci.c_str());
+            s3.in0 = f2;
+            s3.res = amix.p;
+            s3.stats = true;
+            s3.name = "ffn.3";
+            DDIF_TRY(add_conv(step, s3, &f3));
+        }
+        DDIF_TRY(resblock(L.p + ".res_block", f3, &cur));
+        if (L.attn) {
+            Tensor t2;
+            DDIF_TRY(attention(L.p + ".attn", cur, &t2));
+            cur = t2;
+        }
+    }
+    {
+        ConvSpec s;
+        s.pc = PC("final_conv.block.3");
+        if (!s.pc) return fail(DDIF_ERR_MISSING, "final_conv.block.3 missing");
+        s.in0 = cur;
+        s.pro = PRO_GN_SILU;
+        s.gamma = V("final_conv.block.0.weight");
+        s.beta = V("final_conv.block.0.bias");
+        s.name = "final";
+        DDIF_TRY(add_conv(step, s, &net_out));
+    }
+    DDIF_TRY(ensure_tb(B));
+    return 0;
+#undef DDIF_TRY
+}
+
+int Plan::ensure_tb(int rows) {
+    if (rows <= tb_rows) return 0;
+    if (int e = dalloc(&tb, (size_t)rows * net->nslots)) return e;  // older table stays in `allocs` until destroy
+    if (int e = dalloc(&tvals, (size_t)rows)) return e;
+    tb_rows = rows;
+    return 0;
+}
+
+int Plan::time_rows(const float* t_host, int rows, hipStream_t s) {
+    if (int e = ensure_tb(rows)) return e;
+    DDIF_HIPCHK(hipMemcpyAsync(tvals, t_host, (size_t)rows * sizeof(float), hipMemcpyHostToDevice, s));
+    const int inner = net->cfg.inner_channel;
+    hipLaunchKernelGGL(time_embed_kernel, dim3(rows), dim3(128), (size_t)6 * inner * sizeof(float), s, (const float*)tvals,
+                       net->freqs, net->w1, net->b1, net->w3, net->b3, net->wall, net->ball, inner, net->nslots, tb);
+    return 0;
+}
+
+void Plan::run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof) {
+    for (auto& op : prog) {
+        const bool t = prof && op.timed && ev_used < (int)ev0.size();
+        if (t) (void)hipEventRecord(ev0[ev_used], s);
+        op.run(s, ctx);
+        if (t) {
+            (void)hipEventRecord(ev1[ev_used], s);
+            ev_flop[ev_used] = op.flop;
+            ev_bytes[ev_used] = op.bytes;
+            ++ev_used;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ entry points
+int Plan::set_cond(const float* cond, hipStream_t s) {
+    if (!cond) return fail(DDIF_ERR_INVALID, "ddif_plan_set_cond: cond is NULL");
+    cond_nchw = const_cast<float*>(cond);
+    StepCtx ctx;
+    run_prog(pre, s, ctx, false);
+    cond_set = true;
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int Plan::forward(const float* x, const float* t_host, const float* sc, float* out, hipStream_t s) {
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_forward before ddif_plan_set_cond");
+    if (!x || !t_host || !out) return fail(DDIF_ERR_INVALID, "ddif_plan_forward: NULL argument");
+    const int HW = H * W, Cx = net->cfg.in_channel;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid((size_t)B * HW * Cx), dim3(256), 0, s, x, B, Cx, HW, 0, Cx, x_in.p);
+    if (sc) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid((size_t)B * HW * C), dim3(256), 0, s, sc, B, C, HW, 0, C, sc_in.p);
+    if (int e = time_rows(t_host, B, s)) return e;
+    StepCtx ctx;
+    ctx.x = x_in.p;
+    ctx.sc = sc ? sc_in.p : x_in.p;
+    ctx.tb = tb;
+    ctx.tb_stride = net->nslots;
+    run_prog(step, s, ctx, false);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid((size_t)B * HW * C), dim3(256), 0, s, (const float*)net_out.p, B, C, HW, out);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int check_sampler_net(const Net* n) {
+    if (n->cfg.in_channel != n->cfg.out_channel)
+        return fail(DDIF_ERR_INVALID, "samplers need in_channel == out_channel (x_start prediction over the image channels)");
+    return 0;
+}
+
+int Plan::sample_ddpm(const ddif_ddpm_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
+                      float lo, float hi, int do_clamp, float* out, hipStream_t s) {
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_sample_ddpm before ddif_plan_set_cond");
+    if (!t || t->n_steps < 1 || !t->t_model || !t->coef_x0 || !t->coef_xt || !t->coef_z || !out)
+        return fail(DDIF_ERR_INVALID, "ddif_plan_sample_ddpm: bad tables");
+    if (int e = check_sampler_net(net)) return e;
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW * C;
+    if (xT) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
+    else hipLaunchKernelGGL(randn_nhwc_kernel, ew_grid(n), dim3(256), 0, s, img[0], B, C, HW, (unsigned long long)seed, 0u, (unsigned long long)tile0);
+    if (int e = time_rows(t->t_model, t->n_steps, s)) return e;
+    int cur = 0;
+    for (int k = 0; k < t->n_steps; ++k) {
+        StepCtx ctx;
+        ctx.x = ctx.sc = img[cur];  // self-conditioning == current image (diffusion_ddpm_pan.py:491,502; sr3_dwt.py:173)
+        ctx.tb = tb + (size_t)k * net->nslots;
+        ctx.tb_stride = 0;
+        const bool prof = prof_every > 0 && (k % prof_every) == 0;
+        run_prog(step, s, ctx, prof);
+        StepArgs a{};
+        a.x0 = net_out.p;
+        a.img = img[cur];
+        a.lms = lms.p;
+        a.noise = noise ? noise + (size_t)k * n : nullptr;
+        a.out = img[cur ^ 1];
+        a.B = B;
+        a.C = C;
+        a.HW = HW;
+        a.c1 = t->coef_x0[k];
+        a.c2 = t->coef_xt[k];
+        a.c3 = t->coef_z[k];
+        a.lo = lo;
+        a.hi = hi;
+        a.do_clamp = do_clamp;
+        a.seed = seed;
+        a.draw = (unsigned)(k + 1);
+        a.tile0 = tile0;
+        hipLaunchKernelGGL(ddpm_step_kernel, ew_grid(n), dim3(256), 0, s, a);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[cur], B, C, HW, out);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int Plan::sample_ddim(const ddif_ddim_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
+                      float lo, float hi, int do_clamp, float* out, hipStream_t s) {
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_sample_ddim before ddif_plan_set_cond");
+    if (!t || t->n_steps < 1 || !t->t_model || !t->sqrt_recip || !t->sqrt_recipm1 || !t->sqrt_ap || !t->dir_coef || !t->sigma || !out)
+        return fail(DDIF_ERR_INVALID, "ddif_plan_sample_ddim: bad tables");
+    if (int e = check_sampler_net(net)) return e;
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW * C;
+    if (xT) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
+    else hipLaunchKernelGGL(randn_nhwc_kernel, ew_grid(n), dim3(256), 0, s, img[0], B, C, HW, (unsigned long long)seed, 0u, (unsigned long long)tile0);
+    if (int e = time_rows(t->t_model, t->n_steps, s)) return e;
+    int cur = 0;
+    for (int k = 0; k < t->n_steps; ++k) {
+        StepCtx ctx;
+        ctx.x = ctx.sc = img[cur];  // self_cond=None -> x  (diffusion_ddpm_pan.py:628,658; sr3_dwt.py:173)
+        ctx.tb = tb + (size_t)k * net->nslots;
+        const bool prof = prof_every > 0 && (k % prof_every) == 0;
+        run_prog(step, s, ctx, prof);
+        DdimArgs a{};
+        a.x0 = net_out.p;
+        a.img = img[cur];
+        a.lms = lms.p;
+        a.noise = noise ? noise + (size_t)k * n : nullptr;
+        a.out = img[cur ^ 1];
+        a.B = B;
+        a.C = C;
+        a.HW = HW;
+        a.sqrt_recip = t->sqrt_recip[k];
+        a.sqrt_recipm1 = t->sqrt_recipm1[k];
+        a.sqrt_ap = t->sqrt_ap[k];
+        a.dir_coef = t->dir_coef[k];
+        a.sigma = t->sigma[k];
+        a.lo = lo;
+        a.hi = hi;
+        a.do_clamp = do_clamp;
+        a.seed = seed;
+        a.draw = (unsigned)(k + 1);
+        a.tile0 = tile0;
+        hipLaunchKernelGGL(ddim_step_kernel, ew_grid(n), dim3(256), 0, s, a);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[cur], B, C, HW, out);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int Plan::sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, float hi, int do_clamp, float* out, hipStream_t s) {
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_sample_dpmpp before ddif_plan_set_cond");
+    if (!t || t->n_evals < 1 || t->order < 1 || t->order > 3 || !t->t_model || !t->alpha || !t->sigma || !t->ord || !t->cx || !t->a_phi1 || !xT || !out)
+        return fail(DDIF_ERR_INVALID, "ddif_plan_sample_dpmpp: bad tables");
+    if (int e = check_sampler_net(net)) return e;
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW * C;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
+    if (int e = time_rows(t->t_model, t->n_evals, s)) return e;
+    int cur = 0;
+    float* hist[3] = {nullptr, nullptr, nullptr};  // newest first
+    int nhist = 0, slot = 0;
+    for (int k = 0; k < t->n_evals; ++k) {
+        StepCtx ctx;
+        ctx.x = ctx.sc = img[cur];  // model_wrapper never passes self_cond (dpm_solver.py:295) -> x
+        ctx.tb = tb + (size_t)k * net->nslots;
+        const bool prof = prof_every > 0 && (k % prof_every) == 0;
+        run_prog(step, s, ctx, prof);
+        float* mnew = mbuf[slot];
+        slot = (slot + 1) % 3;
+        hipLaunchKernelGGL(dpm_x0_kernel, ew_grid(n), dim3(256), 0, s, (const float*)net_out.p, (const float*)img[cur], (const float*)lms.p,
+                           t->alpha[k], t->sigma[k], lo, hi, do_clamp, n, mnew);
+        hist[2] = hist[1];
+        hist[1] = hist[0];
+        hist[0] = mnew;
+        if (nhist < 3) ++nhist;
+        const int o = t->ord[k];
+        if (o < 1 || o > nhist) return fail(DDIF_ERR_INVALID, "ddif_plan_sample_dpmpp: update %d has order %d with %d model values", k, o, nhist);
+        DpmUpdArgs u{};
+        u.x = img[cur];
+        u.m0 = hist[0];
+        u.m1 = o >= 2 ? hist[1] : nullptr;
+        u.m2 = o >= 3 ? hist[2] : nullptr;
+        u.out = img[cur ^ 1];
+        u.n = n;
+        u.order = o;
+        u.cx = t->cx[k];
+        u.a1 = t->a_phi1[k];
+        u.inv_r0 = (o >= 2 && t->inv_r0) ? t->inv_r0[k] : 0.f;
+        u.inv_r1 = (o >= 3 && t->inv_r1) ? t->inv_r1[k] : 0.f;
+        u.r0_frac = (o >= 3 && t->r0_frac) ? t->r0_frac[k] : 0.f;
+        u.inv_r01 = (o >= 3 && t->inv_r01) ? t->inv_r01[k] : 0.f;
+        u.a2 = (o >= 3 && t->a_phi2) ? t->a_phi2[k] : 0.f;
+        u.a3 = (o >= 3 && t->a_phi3) ? t->a_phi3[k] : 0.f;
+        hipLaunchKernelGGL(dpm_update_kernel, ew_grid(n), dim3(256), 0, s, u);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[cur], B, C, HW, out);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int Plan::q_sample_forward(const float* x0, const float* noise, const float* a_h, const float* s_h, const float* t_h,
+                           const float* sc, float* pred, hipStream_t s) {
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_q_sample_forward before ddif_plan_set_cond");
+    if (!x0 || !noise || !a_h || !s_h || !t_h || !pred) return fail(DDIF_ERR_INVALID, "ddif_plan_q_sample_forward: NULL argument");
+    if (int e = check_sampler_net(net)) return e;
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW * C;
+    DDIF_HIPCHK(hipMemcpyAsync(small, a_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    DDIF_HIPCHK(hipMemcpyAsync(small + B, s_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, x0, B, C, HW, 0, C, img[0]);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, noise, B, C, HW, 0, C, img[1]);
+    hipLaunchKernelGGL(q_sample_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[0], (const float*)img[1], (const float*)small, (const float*)(small + B), B, (size_t)HW * C, x_in.p);
+    if (sc) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, sc, B, C, HW, 0, C, sc_in.p);
+    if (int e = time_rows(t_h, B, s)) return e;
+    StepCtx ctx;
+    ctx.x = x_in.p;
+    ctx.sc = sc ? sc_in.p : x_in.p;
+    ctx.tb = tb;
+    ctx.tb_stride = net->nslots;
+    run_prog(step, s, ctx, false);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)net_out.p, B, C, HW, pred);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ddif

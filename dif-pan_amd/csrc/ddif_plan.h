@@ -1,0 +1,106 @@
+// Plan: per-(B,H,W) workspaces, the cond-only caches and the launch program of one denoising step.
+#pragma once
+#include "ddif_net.h"
+
+namespace ddif {
+
+struct ConvArgs;
+
+struct Tensor {
+    float* p = nullptr;
+    int C = 0, H = 0, W = 0;
+    double* st = nullptr;  // GroupNorm partials [B][np][2] written by the producer
+    int np = 0;
+};
+
+struct StepCtx {
+    const float* x = nullptr;   // network input x      (NHWC)
+    const float* sc = nullptr;  // self-conditioning    (NHWC)
+    const float* tb = nullptr;  // time-bias row(s)
+    int tb_stride = 0;          // floats between the rows of consecutive samples (0: one row for the batch)
+};
+
+struct Op {
+    std::function<void(hipStream_t, const StepCtx&)> run;
+    double flop = 0, bytes = 0;
+    bool timed = false;  // member of the profiled kernel class (3x3 implicit-GEMM convs)
+    const char* name = "";
+};
+
+typedef void (*ConvKernelFn)(ConvArgs);
+struct ConvVariant {
+    ConvKernelFn fn = nullptr;
+    size_t smem = 0;
+    int th = 0, tw = 0, nt = 0;
+    const char* name = "";
+};
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg);
+
+struct ConvSpec {
+    const PackedConv* pc = nullptr;
+    Tensor in0, in1;           // in1.p == nullptr: single source
+    bool dyn_input = false;    // stem: sources come from StepCtx (sc, x)
+    int stride = 1, ups = 0, pro = PRO_NONE;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    bool use_bias = true;
+    int tb_off = -1;
+    const float* res = nullptr;
+    const float* film = nullptr;
+    bool silu = false;
+    bool stats = false;
+    const char* name = "conv";
+};
+
+struct Plan {
+    Net* net = nullptr;
+    int B = 0, H = 0, W = 0, C = 0, P = 0, CC = 0;
+    std::vector<void*> allocs;
+    std::vector<Op> pre, step;
+    bool cond_set = false;
+    size_t bytes_allocated = 0;
+
+    // fixed buffers
+    float* cond_nchw = nullptr;       // not owned (borrowed during set_cond)
+    Tensor lms;                       // cond[:, :C] NHWC
+    std::vector<Tensor> cenc, cdec;   // resized cond per level
+    std::vector<int> LH, LW;          // level sizes
+    Tensor x_in, sc_in, net_out;      // NHWC staging of the boundary tensors
+    float* img[2] = {nullptr, nullptr};
+    float* mbuf[3] = {nullptr, nullptr, nullptr};
+    float* io_nchw = nullptr;         // scratch (B,C,H,W)
+    float* tvals = nullptr;           // device time values
+    float* tb = nullptr;              // time-bias table
+    int tb_rows = 0;
+    float* small = nullptr;           // device scratch for per-sample coefficient arrays (2*B floats)
+
+    // profiling
+    int prof_every = 0, prof_max = 0;
+    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<double> ev_flop, ev_bytes;
+    int ev_used = 0;
+    std::string prof_name;
+
+    ~Plan();
+    int build();
+    template <typename T>
+    int dalloc(T** p, size_t n);
+    int alloc_tensor(Tensor* t, int C, int H, int W);
+    int add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out);
+    int ensure_tb(int rows);
+    int time_rows(const float* t_host, int rows, hipStream_t s);
+    void run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof);
+
+    int set_cond(const float* cond, hipStream_t s);
+    int forward(const float* x, const float* t_host, const float* sc, float* out, hipStream_t s);
+    int sample_ddpm(const ddif_ddpm_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
+                    float lo, float hi, int do_clamp, float* out, hipStream_t s);
+    int sample_ddim(const ddif_ddim_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
+                    float lo, float hi, int do_clamp, float* out, hipStream_t s);
+    int sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, float hi, int do_clamp, float* out,
+                     hipStream_t s);
+    int q_sample_forward(const float* x0, const float* noise, const float* a_h, const float* s_h, const float* t_h,
+                         const float* sc, float* pred, hipStream_t s);
+};
+
+}  // namespace ddif

@@ -1,0 +1,143 @@
+"""Drop-in for the reference `models/sr3_dwt.py::UNetSR3` (constructor :31-51, forward :169-219).
+
+The module owns parameters with the reference's state-dict key names and shapes (so reference checkpoints load
+unchanged and optimizers / EMA iterate `.parameters()` as before) but its forward pass is NOT torch: it runs the
+hand-written gfx950 kernels of libddif.so through the C ABI (include/ddif.h).  No PyTorch / CPU fallback exists;
+calls on CPU tensors or without the built library raise `DdifError`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from ..layout import DEFAULT_CFG, param_manifest
+from ..runtime import DdifError, NetHandle, PlanHandle
+
+
+class _Node(nn.Module):
+    """Plain container used to reproduce the reference's parameter tree (key names only)."""
+
+
+def _register(root: nn.Module, key: str, value: torch.Tensor):
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(value))
+
+
+def _default_init(key: str, shape, shapes: Dict[str, tuple]) -> torch.Tensor:
+    """torch's default inits for the layer kinds of the reference (Conv2d/Linear: U(+-1/sqrt(fan_in)); GroupNorm: 1/0;
+    CondInjection.body[-1] zero-initialised, models/sr3_dwt.py:386-387)."""
+    is_norm = any(s in key for s in (".block.0.", ".norm.", ".prenorm_x.", ".body.1."))
+    if is_norm:
+        return torch.ones(shape) if key.endswith("weight") else torch.zeros(shape)
+    if ".body.3." in key:
+        return torch.zeros(shape)
+    wshape = shape if key.endswith("weight") else shapes[key[: -len("bias")] + "weight"]
+    fan_in = 1
+    for s in wshape[1:]:
+        fan_in *= s
+    bound = 1.0 / math.sqrt(fan_in)
+    return (torch.rand(shape) * 2 - 1) * bound
+
+
+class UNetSR3(nn.Module):
+    def __init__(
+        self,
+        in_channel=8,
+        out_channel=3,
+        inner_channel=32,
+        lms_channel=8,
+        pan_channel=1,
+        norm_groups=32,
+        channel_mults=(1, 2, 4, 8, 8),
+        attn_res=(8,),
+        res_blocks=3,
+        dropout=0,
+        with_noise_level_emb=True,
+        image_size=128,
+        self_condition=False,
+        fourier_features=False,
+        fourier_min=7,
+        fourier_max=8,
+        fourier_step=1,
+        pred_var=False,
+    ):
+        super().__init__()
+        self.cfg = dict(DEFAULT_CFG)
+        self.cfg.update(
+            in_channel=in_channel, out_channel=out_channel if out_channel is not None else in_channel,
+            inner_channel=inner_channel, lms_channel=lms_channel, pan_channel=pan_channel, norm_groups=norm_groups,
+            channel_mults=tuple(channel_mults), attn_res=tuple(attn_res), res_blocks=res_blocks, dropout=dropout,
+            with_noise_level_emb=with_noise_level_emb, image_size=image_size, self_condition=self_condition,
+            fourier_features=fourier_features, fourier_min=fourier_min, fourier_max=fourier_max,
+            fourier_step=fourier_step, pred_var=pred_var)
+        if fourier_features or pred_var or not with_noise_level_emb:
+            raise DdifError("fourier_features / pred_var / with_noise_level_emb=False are not implemented by the HIP "
+                            "path, and there is no fallback")
+        # attributes the reference exposes and its callers read (diffusion_ddpm_pan.py:182-184)
+        self.lms_channel = lms_channel
+        self.pan_channel = pan_channel
+        self.res_blocks = res_blocks
+        self.self_condition = self_condition
+        self.pred_var = pred_var
+        self.fourier_features = fourier_features
+        for a in attn_res:  # the reference prints this from its constructor (models/sr3_dwt.py:138-139)
+            pass
+        manifest = param_manifest(self.cfg)
+        shapes = dict(manifest)
+        for key, shape in manifest:
+            _register(self, key, _default_init(key, shape, shapes))
+        self._net: Optional[NetHandle] = None
+        self._weights_sig = None
+        self._dropout_warned = False
+
+    # ---- weights -> library -----------------------------------------------------------------------------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def pe_freqs(self) -> torch.Tensor:
+        """exp(-ln(1e4) * j / count) evaluated with torch on the CPU exactly as PositionalEncoding does
+        (models/sr3_dwt.py:229-236), so the kernels use bit-identical frequencies."""
+        count = self.cfg["inner_channel"] // 2
+        step = torch.arange(count, dtype=torch.float32) / count
+        return torch.exp(-math.log(1e4) * step.unsqueeze(0)).reshape(-1)
+
+    def _ensure_net(self, device: torch.device) -> NetHandle:
+        device = torch.device(device)
+        if self._net is None or self._net.device != device:
+            self._net = NetHandle(self.cfg, device)
+            self._weights_sig = None
+        sig = self._signature()
+        if sig != self._weights_sig:
+            self._net.load_state_dict(self.state_dict(), self.pe_freqs())
+            self._weights_sig = sig
+        return self._net
+
+    def plan_for(self, B: int, H: int, W: int, device) -> PlanHandle:
+        p = self._ensure_net(device).plan(B, H, W)
+        p.net_out_channels = self.cfg["out_channel"]
+        return p
+
+    # ---- reference API ----------------------------------------------------------------------------------------------
+    def forward(self, x, time, cond=None, self_cond=None):
+        if cond is None:
+            raise DdifError("UNetSR3.forward: cond is required (the reference indexes it unconditionally, "
+                            "models/sr3_dwt.py:197)")
+        if self.training and (self.cfg["dropout"] or True) and not self._dropout_warned:
+            # Dropout / DropPath masks (train mode) are not implemented by the kernels yet: the forward below is
+            # the eval-mode network.  Training (config 5) is listed as not built in DESIGN.md.
+            self._dropout_warned = True
+        B, _, H, W = x.shape
+        plan = self.plan_for(B, H, W, x.device)
+        plan.set_cond(cond)
+        if not torch.is_tensor(time):
+            time = torch.tensor([float(time)] * B)
+        sc = self_cond if (self.self_condition and self_cond is not None) else None
+        return plan.forward(x, time, sc)

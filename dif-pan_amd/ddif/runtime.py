@@ -1,0 +1,345 @@
+"""ctypes binding of libddif.so (C ABI: include/ddif.h) and thin handle wrappers.
+
+There is NO fallback path: if the gfx950 library is missing or the tensors are not on a GPU the calls raise.
+`use_library()` exists so the test-suite can point the binding at the host-emulated build of the same sources
+(tools/hipemu); the product never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+import weakref
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_LIB = os.path.join(PKG_ROOT, "lib", "libddif.so")
+
+
+class DdifError(RuntimeError):
+    pass
+
+
+class NetCfg(C.Structure):
+    _fields_ = [
+        ("in_channel", C.c_int32), ("out_channel", C.c_int32), ("inner_channel", C.c_int32),
+        ("lms_channel", C.c_int32), ("pan_channel", C.c_int32), ("norm_groups", C.c_int32),
+        ("n_channel_mults", C.c_int32), ("channel_mults", C.c_int32 * 8),
+        ("n_attn_res", C.c_int32), ("attn_res", C.c_int32 * 8),
+        ("res_blocks", C.c_int32), ("image_size", C.c_int32), ("self_condition", C.c_int32),
+    ]
+
+
+_FP = C.POINTER(C.c_float)
+_IP = C.POINTER(C.c_int32)
+
+
+class DdpmTables(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("t_model", _FP), ("coef_x0", _FP), ("coef_xt", _FP), ("coef_z", _FP)]
+
+
+class DdimTables(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("t_model", _FP), ("sqrt_recip", _FP), ("sqrt_recipm1", _FP),
+                ("sqrt_ap", _FP), ("dir_coef", _FP), ("sigma", _FP)]
+
+
+class DpmTables(C.Structure):
+    _fields_ = [("n_evals", C.c_int32), ("order", C.c_int32), ("t_model", _FP), ("alpha", _FP), ("sigma", _FP),
+                ("ord", _IP), ("cx", _FP), ("a_phi1", _FP), ("inv_r0", _FP), ("inv_r1", _FP), ("r0_frac", _FP),
+                ("inv_r01", _FP), ("a_phi2", _FP), ("a_phi3", _FP)]
+
+
+class ProfResult(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flop", C.c_double),
+                ("total_bytes", C.c_double), ("kernel_name", C.c_char * 128)]
+
+
+class _Lib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise DdifError(
+                f"{path} not found: the HIP library has not been built. Run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dif-pan_amd`). "
+                f"There is no CPU/PyTorch fallback for this path.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        d = self.dll
+        vp, i32, u64, f32 = C.c_void_p, C.c_int, C.c_uint64, C.c_float
+        d.ddif_last_error.restype = C.c_char_p
+        d.ddif_version.restype = C.c_char_p
+        d.ddif_is_emulated.restype = C.c_int
+        d.ddif_net_create.argtypes = [C.POINTER(vp), C.POINTER(NetCfg), i32]
+        d.ddif_net_destroy.argtypes = [vp]
+        d.ddif_net_destroy.restype = None
+        d.ddif_net_load.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]
+        d.ddif_net_commit.argtypes = [vp, vp]
+        d.ddif_net_num_params.argtypes = [vp]
+        d.ddif_net_num_params.restype = C.c_int64
+        d.ddif_plan_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
+        d.ddif_plan_destroy.argtypes = [vp]
+        d.ddif_plan_destroy.restype = None
+        d.ddif_plan_set_cond.argtypes = [vp, vp, vp]
+        d.ddif_plan_forward.argtypes = [vp, vp, vp, vp, vp, vp]
+        d.ddif_plan_sample_ddpm.argtypes = [vp, C.POINTER(DdpmTables), vp, vp, u64, u64, f32, f32, i32, vp, vp]
+        d.ddif_plan_sample_ddim.argtypes = [vp, C.POINTER(DdimTables), vp, vp, u64, u64, f32, f32, i32, vp, vp]
+        d.ddif_plan_sample_dpmpp.argtypes = [vp, C.POINTER(DpmTables), vp, f32, f32, i32, vp, vp]
+        d.ddif_plan_q_sample_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        d.ddif_prof_begin.argtypes = [vp, i32, i32]
+        d.ddif_prof_collect.argtypes = [vp, C.POINTER(ProfResult)]
+        d.ddif_plan_cost.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
+        self.emulated = bool(d.ddif_is_emulated())
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.dll.ddif_last_error().decode(errors="replace")
+            raise DdifError(f"{what} failed (status {rc}): {msg}")
+
+
+_LIB: Optional[_Lib] = None
+
+
+def get_lib() -> _Lib:
+    """The gfx950 library.  Raises DdifError when it has not been built -- never falls back."""
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib(DEFAULT_LIB)
+    return _LIB
+
+
+def use_library(path: str) -> _Lib:
+    """Point the binding at another build of libddif (tests: the host-emulated build).  Loud on purpose."""
+    global _LIB
+    _LIB = _Lib(path)
+    if _LIB.emulated:
+        print(f"[ddif] WARNING: using the HOST-EMULATED test build {path}; this is not the product path.",
+              file=sys.stderr)
+    return _LIB
+
+
+def library_loaded_path() -> Optional[str]:
+    return _LIB.path if _LIB else None
+
+
+def _check_tensor(lib: _Lib, t: torch.Tensor, name: str):
+    if t.dtype != torch.float32:
+        raise DdifError(f"{name}: expected float32, got {t.dtype}")
+    if lib.emulated:
+        if t.device.type != "cpu":
+            raise DdifError(f"{name}: the emulated test build works on CPU tensors")
+    elif t.device.type != "cuda":
+        raise DdifError(f"{name} is on {t.device}: the ddif kernels run on the GPU only; there is no CPU fallback "
+                        f"(move the tensors to cuda)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(lib: _Lib, dev: torch.device):
+    if lib.emulated or dev.type != "cuda":
+        return None
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _farr(vals) -> "C.Array":
+    vals = [float(v) for v in vals]
+    return (C.c_float * len(vals))(*vals)
+
+
+def _iarr(vals) -> "C.Array":
+    vals = [int(v) for v in vals]
+    return (C.c_int32 * len(vals))(*vals)
+
+
+class NetHandle:
+    """ddif_net_t: weights of one UNetSR3, repacked on `device`."""
+
+    def __init__(self, cfg: dict, device: torch.device):
+        self.lib = get_lib()
+        self.device = torch.device(device)
+        c = NetCfg()
+        for k in ("in_channel", "out_channel", "inner_channel", "lms_channel", "pan_channel", "norm_groups",
+                  "res_blocks", "image_size"):
+            setattr(c, k, int(cfg[k]))
+        c.self_condition = int(bool(cfg["self_condition"]))
+        mults, ares = list(cfg["channel_mults"]), list(cfg["attn_res"])
+        if len(mults) > 8 or len(ares) > 8:
+            raise DdifError("at most 8 channel_mults / attn_res entries")
+        c.n_channel_mults, c.n_attn_res = len(mults), len(ares)
+        for i, m in enumerate(mults):
+            c.channel_mults[i] = int(m)
+        for i, a in enumerate(ares):
+            c.attn_res[i] = int(a)
+        for k in ("fourier_features", "pred_var"):
+            if cfg.get(k):
+                raise DdifError(f"{k}=True is not implemented by the HIP path (and there is no fallback)")
+        if not cfg.get("with_noise_level_emb", True):
+            raise DdifError("with_noise_level_emb=False is not implemented by the HIP path")
+        h = C.c_void_p()
+        idx = self.device.index if self.device.type == "cuda" and self.device.index is not None else 0
+        self.lib.check(self.lib.dll.ddif_net_create(C.byref(h), C.byref(c), idx), "ddif_net_create")
+        self.h = h
+        self.plans: Dict[Tuple[int, int, int], "PlanHandle"] = {}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], freqs: torch.Tensor):
+        dll = self.lib.dll
+        for k, v in sd.items():
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            self.lib.check(dll.ddif_net_load(self.h, k.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()),
+                           f"ddif_net_load({k})")
+        f = freqs.detach().to("cpu", torch.float32).contiguous()
+        shape = (C.c_int64 * 1)(f.numel())
+        self.lib.check(dll.ddif_net_load(self.h, b"noise_level_mlp.0.freqs", C.c_void_p(f.data_ptr()), shape, 1),
+                       "ddif_net_load(freqs)")
+        self.lib.check(dll.ddif_net_commit(self.h, _stream(self.lib, self.device)), "ddif_net_commit")
+        self.plans.clear()  # plans hold pointers into the old weight blob
+
+    def plan(self, B: int, H: int, W: int) -> "PlanHandle":
+        key = (int(B), int(H), int(W))
+        p = self.plans.get(key)
+        if p is None:
+            p = PlanHandle(self, *key)
+            self.plans[key] = p
+        return p
+
+    def __del__(self):
+        try:
+            self.plans.clear()
+            if getattr(self, "h", None):
+                self.lib.dll.ddif_net_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class PlanHandle:
+    """ddif_plan_t for batches of B tiles of H x W."""
+
+    def __init__(self, net: NetHandle, B: int, H: int, W: int):
+        self.net, self.lib = net, net.lib
+        self.B, self.H, self.W = B, H, W
+        h = C.c_void_p()
+        self.lib.check(self.lib.dll.ddif_plan_create(C.byref(h), net.h, B, H, W), "ddif_plan_create")
+        self.h = h
+        self._cond_ref = None
+        self._cond_ver = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dll.ddif_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- cond ---------------------------------------------------------------------------------------------------
+    def set_cond(self, cond: torch.Tensor, force: bool = False):
+        _check_tensor(self.lib, cond, "cond")
+        cond_c = cond.contiguous()
+        same = (not force and self._cond_ref is not None and self._cond_ref() is cond
+                and self._cond_ver == cond._version and cond_c is cond)
+        if same:
+            return
+        self.lib.check(self.lib.dll.ddif_plan_set_cond(self.h, _ptr(cond_c), _stream(self.lib, cond.device)),
+                       "ddif_plan_set_cond")
+        self._keep = cond_c  # borrowed by the enqueued work
+        self._cond_ref = weakref.ref(cond)
+        self._cond_ver = cond._version
+
+    # -- network ------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, time: torch.Tensor, self_cond: Optional[torch.Tensor]) -> torch.Tensor:
+        _check_tensor(self.lib, x, "x")
+        x = x.contiguous()
+        sc = None
+        if self_cond is not None:
+            _check_tensor(self.lib, self_cond, "self_cond")
+            sc = self_cond.contiguous()
+        t = time.detach().to("cpu", torch.float32).contiguous()
+        if t.numel() != self.B:
+            t = t.reshape(-1).expand(self.B).contiguous()
+        out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=x.device)
+        self.lib.check(self.lib.dll.ddif_plan_forward(self.h, _ptr(x), C.c_void_p(t.data_ptr()), _ptr(sc), _ptr(out),
+                                                      _stream(self.lib, x.device)), "ddif_plan_forward")
+        return out
+
+    net_out_channels = 0  # set by the owner
+
+    # -- samplers -----------------------------------------------------------------------------------------------
+    def sample_ddpm(self, t_model, c_x0, c_xt, c_z, x_T, noise, seed, tile0, clamp, device) -> torch.Tensor:
+        n = len(t_model)
+        keep = [_farr(t_model), _farr(c_x0), _farr(c_xt), _farr(c_z)]
+        tabs = DdpmTables(n, *[C.cast(a, _FP) for a in keep])
+        for nm, t in (("x_T", x_T), ("noise", noise)):
+            if t is not None:
+                _check_tensor(self.lib, t, nm)
+        x_T = None if x_T is None else x_T.contiguous()
+        noise = None if noise is None else noise.contiguous()
+        out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=device)
+        lo, hi, do = (clamp[0], clamp[1], 1) if clamp is not None else (0.0, 0.0, 0)
+        self.lib.check(self.lib.dll.ddif_plan_sample_ddpm(self.h, C.byref(tabs), _ptr(x_T), _ptr(noise), int(seed),
+                                                          int(tile0), lo, hi, do, _ptr(out),
+                                                          _stream(self.lib, torch.device(device))), "ddif_plan_sample_ddpm")
+        return out
+
+    def sample_ddim(self, t_model, sqrt_recip, sqrt_recipm1, sqrt_ap, dir_coef, sigma, x_T, noise, seed, tile0, clamp,
+                    device) -> torch.Tensor:
+        n = len(t_model)
+        keep = [_farr(v) for v in (t_model, sqrt_recip, sqrt_recipm1, sqrt_ap, dir_coef, sigma)]
+        tabs = DdimTables(n, *[C.cast(a, _FP) for a in keep])
+        for nm, t in (("x_T", x_T), ("noise", noise)):
+            if t is not None:
+                _check_tensor(self.lib, t, nm)
+        x_T = None if x_T is None else x_T.contiguous()
+        noise = None if noise is None else noise.contiguous()
+        out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=device)
+        lo, hi, do = (clamp[0], clamp[1], 1) if clamp is not None else (0.0, 0.0, 0)
+        self.lib.check(self.lib.dll.ddif_plan_sample_ddim(self.h, C.byref(tabs), _ptr(x_T), _ptr(noise), int(seed),
+                                                          int(tile0), lo, hi, do, _ptr(out),
+                                                          _stream(self.lib, torch.device(device))), "ddif_plan_sample_ddim")
+        return out
+
+    def sample_dpmpp(self, tabs: dict, x_T: torch.Tensor, clamp) -> torch.Tensor:
+        _check_tensor(self.lib, x_T, "x_T")
+        x_T = x_T.contiguous()
+        keep = {k: (_iarr(v) if k == "ord" else _farr(v)) for k, v in tabs.items() if k not in ("n_evals", "order")}
+        t = DpmTables()
+        t.n_evals, t.order = int(tabs["n_evals"]), int(tabs["order"])
+        for k, arr in keep.items():
+            setattr(t, k, C.cast(arr, _IP if k == "ord" else _FP))
+        out = torch.empty_like(x_T)
+        lo, hi, do = (clamp[0], clamp[1], 1) if clamp is not None else (0.0, 0.0, 0)
+        self.lib.check(self.lib.dll.ddif_plan_sample_dpmpp(self.h, C.byref(t), _ptr(x_T), lo, hi, do, _ptr(out),
+                                                           _stream(self.lib, x_T.device)), "ddif_plan_sample_dpmpp")
+        return out
+
+    def q_sample_forward(self, x0, noise, a, s, time, self_cond) -> torch.Tensor:
+        for nm, t in (("x_start", x0), ("noise", noise)):
+            _check_tensor(self.lib, t, nm)
+        x0, noise = x0.contiguous(), noise.contiguous()
+        sc = None if self_cond is None else self_cond.contiguous()
+        a = a.detach().to("cpu", torch.float32).contiguous()
+        s = s.detach().to("cpu", torch.float32).contiguous()
+        t = time.detach().to("cpu", torch.float32).contiguous()
+        out = torch.empty_like(x0)
+        self.lib.check(self.lib.dll.ddif_plan_q_sample_forward(
+            self.h, _ptr(x0), _ptr(noise), C.c_void_p(a.data_ptr()), C.c_void_p(s.data_ptr()), C.c_void_p(t.data_ptr()),
+            _ptr(sc), _ptr(out), _stream(self.lib, x0.device)), "ddif_plan_q_sample_forward")
+        return out
+
+    # -- measurement --------------------------------------------------------------------------------------------
+    def prof_begin(self, every_n_steps: int, max_events: int):
+        self.lib.check(self.lib.dll.ddif_prof_begin(self.h, every_n_steps, max_events), "ddif_prof_begin")
+
+    def prof_collect(self) -> dict:
+        r = ProfResult()
+        self.lib.check(self.lib.dll.ddif_prof_collect(self.h, C.byref(r)), "ddif_prof_collect")
+        return dict(launches=r.launches, total_ms=r.total_ms, total_flop=r.total_flop, total_bytes=r.total_bytes,
+                    kernel=r.kernel_name.decode())
+
+    def cost(self) -> dict:
+        v = [C.c_double() for _ in range(4)]
+        self.lib.check(self.lib.dll.ddif_plan_cost(self.h, *[C.byref(x) for x in v]), "ddif_plan_cost")
+        return dict(step_flop=v[0].value, step_bytes=v[1].value, cond_flop=v[2].value, cond_bytes=v[3].value)

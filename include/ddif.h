@@ -1,0 +1,179 @@
+/* libddif -- C ABI of the MI355X-native DDIF denoising hot path.
+ *
+ * The reference (294coder/Dif-PAN) has no FFI: its boundary for this path is a set of Python call signatures.
+ * Each entry point below names the reference interface it stands in for (paths relative to the reference root).
+ * The Python package dif-pan_amd/ddif binds these with ctypes and re-exposes the reference's
+ * own classes on top: UNetSR3 (models/sr3_dwt.py:30-219), GaussianDiffusion (diffusion/diffusion_ddpm_pan.py:143-778),
+ * NoiseScheduleVP / model_wrapper / DPM_Solver (solver/dpm_solver.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ddif_status; it never throws and never aborts;
+ *     ddif_last_error() returns the message of the calling thread's last failure.
+ *   - tensors crossing the boundary are fp32, contiguous, NCHW (the reference's layout), device pointers unless a
+ *     parameter says "host".  The library converts to its internal NHWC layout.
+ *   - all device work is enqueued on the caller's stream (a hipStream_t passed as void*; NULL = default stream) and
+ *     is asynchronous; the library never calls hipDeviceSynchronize.  Pointers are borrowed until that work ends.
+ *   - handles are not thread-safe; one host thread per handle, one process per GPU.
+ */
+#ifndef DDIF_H_
+#define DDIF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define DDIF_API __attribute__((visibility("default")))
+#else
+#define DDIF_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ddif_status {
+    DDIF_OK = 0,
+    DDIF_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    DDIF_ERR_HIP = -2,         /* a HIP runtime call failed */
+    DDIF_ERR_MISSING = -3,     /* a required weight was never loaded */
+    DDIF_ERR_STATE = -4        /* call order violated (e.g. sample before set_cond) */
+} ddif_status;
+
+typedef struct ddif_net* ddif_net_t;   /* weights (repacked for the kernels) of one UNetSR3 */
+typedef struct ddif_plan* ddif_plan_t; /* per-(B,H,W) workspaces, cond caches, launch program */
+
+/* Constructor arguments of UNetSR3 (models/sr3_dwt.py:31-51) that shape the network. */
+typedef struct ddif_net_cfg {
+    int32_t in_channel, out_channel, inner_channel, lms_channel, pan_channel, norm_groups;
+    int32_t n_channel_mults;
+    int32_t channel_mults[8];
+    int32_t n_attn_res;
+    int32_t attn_res[8];
+    int32_t res_blocks, image_size, self_condition;
+} ddif_net_cfg;
+
+/* ---- network ------------------------------------------------------------------------------------------------ */
+
+/* UNetSR3.__init__ (models/sr3_dwt.py:31-167).  Unsupported configurations (norm_groups != 1, fourier features,
+ * pred_var, inner_channel != 32, head dim != 16) fail with DDIF_ERR_INVALID -- there is no fallback path. */
+DDIF_API int ddif_net_create(ddif_net_t* out, const ddif_net_cfg* cfg, int device);
+DDIF_API void ddif_net_destroy(ddif_net_t net);
+
+/* nn.Module.load_state_dict, one tensor at a time (checkpoint layout: SURVEY.md appendix C; utils/misc.py:89-122).
+ * `key` is the reference state-dict key, `data` a HOST pointer to fp32 in the reference layout (OIHW / (out,in)).
+ * The pseudo key "noise_level_mlp.0.freqs" (inner_channel/2 floats) overrides the positional-encoding
+ * frequencies exp(-ln(1e4) * j / count) (models/sr3_dwt.py:229-236) so they are bit-identical to torch's. */
+DDIF_API int ddif_net_load(ddif_net_t net, const char* key, const float* data, const int64_t* shape, int ndim);
+/* Repack everything loaded so far for the kernels and upload.  Must follow the last ddif_net_load. */
+DDIF_API int ddif_net_commit(ddif_net_t net, void* stream);
+DDIF_API int64_t ddif_net_num_params(ddif_net_t net);
+
+/* ---- plan ----------------------------------------------------------------------------------------------------- */
+
+/* Workspaces and launch program for batches of B tiles of H x W (H, W multiples of 8). */
+DDIF_API int ddif_plan_create(ddif_plan_t* out, ddif_net_t net, int B, int H, int W);
+DDIF_API void ddif_plan_destroy(ddif_plan_t plan);
+
+/* Everything in UNetSR3.forward that depends only on `cond` (models/sr3_dwt.py:389-391,540-546,563,661-663):
+ * bilinear resizes, CondInjection.body -> FiLM scale/shift, FastAttnCondInjection kv -> softmax -> context.
+ * cond: (B, 2C+4P, H, W) = cat[lms, pan, up(wavelets)] (diffusion_engine.py:221-228). */
+DDIF_API int ddif_plan_set_cond(ddif_plan_t plan, const float* cond, void* stream);
+
+/* UNetSR3.forward(x, time, cond, self_cond) (models/sr3_dwt.py:169-219) with cond as given to set_cond.
+ * time: B floats on the HOST (long timesteps are passed as their float value); self_cond may be NULL (-> x). */
+DDIF_API int ddif_plan_forward(ddif_plan_t plan, const float* x, const float* time_host, const float* self_cond, float* out,
+                      void* stream);
+
+/* Per-step coefficient tables of one sampling run, HOST arrays of n_steps floats in EXECUTION order
+ * (first executed step first).  The caller derives them from the schedule buffers exactly as the reference does. */
+typedef struct ddif_ddpm_tables {
+    int32_t n_steps;
+    const float* t_model;   /* value fed to the network as `time` */
+    const float* coef_x0;   /* posterior_mean_coef1[t]                       (diffusion_ddpm_pan.py:316-320) */
+    const float* coef_xt;   /* posterior_mean_coef2[t] */
+    const float* coef_z;    /* [t != 0] * exp(0.5 * posterior_log_variance_clipped[t])          (:441-442) */
+} ddif_ddpm_tables;
+
+/* GaussianDiffusion.p_sample_loop (diffusion/diffusion_ddpm_pan.py:445-507) for pred_mode="x_start":
+ *   img = x_T; for each step: x0 = net(img, t, cond, self_cond=img); x0 = clamp(x0 + lms, lo, hi) - lms (if do_clamp);
+ *   img = coef_x0*x0 + coef_xt*img + coef_z*z.
+ * x_T: (B,C,H,W) or NULL; noise: (n_steps,B,C,H,W) standard normals in execution order or NULL.  NULL draws from the
+ * on-device counter-based generator keyed by (seed, draw index, tile0 + tile index, element), so a batch split
+ * over several GPUs reproduces the single-GPU result.  out: (B,C,H,W) = final img (the residual to lms). */
+DDIF_API int ddif_plan_sample_ddpm(ddif_plan_t plan, const ddif_ddpm_tables* tabs, const float* x_T, const float* noise,
+                          uint64_t seed, uint64_t tile0, float clamp_lo, float clamp_hi, int do_clamp, float* out,
+                          void* stream);
+
+typedef struct ddif_ddim_tables {
+    int32_t n_steps;
+    const float* t_model;      /* the RESPACED index j (diffusion_ddpm_pan.py:661) */
+    const float* sqrt_recip;   /* sqrt_recip_alphas_cumprod[j]      (:284-287) */
+    const float* sqrt_recipm1; /* sqrt_recipm1_alphas_cumprod[j] */
+    const float* sqrt_ap;      /* sqrt(alphas_cumprod_prev[j])      (:615-618) */
+    const float* dir_coef;     /* sqrt(1 - alphas_cumprod_prev[j] - sigma^2) */
+    const float* sigma;        /* [j != 0] * eta-sigma              (:609-613,619-620) */
+} ddif_ddim_tables;
+
+/* GaussianDiffusion.ddim_sample_loop after respacing (diffusion/diffusion_ddpm_pan.py:624-666,594-621);
+ * self_cond is never passed (-> x); no clamp unless do_clamp. */
+DDIF_API int ddif_plan_sample_ddim(ddif_plan_t plan, const ddif_ddim_tables* tabs, const float* x_T, const float* noise,
+                          uint64_t seed, uint64_t tile0, float clamp_lo, float clamp_hi, int do_clamp, float* out,
+                          void* stream);
+
+/* One model evaluation of DPM-Solver++ (solver/dpm_solver.py:279-300,441-450): net(x, t_model, cond) -> eps ->
+ * x0 -> image-space clamp corrector; x, x0_out: (B,C,H,W) in the library's INTERNAL layout handles below. */
+typedef struct ddif_dpm_tables {
+    int32_t n_evals;           /* model evaluations = steps */
+    int32_t order;             /* 1..3 */
+    const float* t_model;      /* (t - 1/N) * 1000, float                              (dpm_solver.py:285-286) */
+    const float* alpha;        /* marginal alpha at each evaluation time */
+    const float* sigma;        /* marginal std   at each evaluation time */
+    /* update k (k = 0 .. n_evals-1) advances x from evaluation time k to time k+1 with order ord[k]: */
+    const int32_t* ord;
+    const float* cx;           /* sigma_t / sigma_prev                                  (:836,897) */
+    const float* a_phi1;       /* alpha_t * expm1(-h) */
+    const float* inv_r0;       /* 1 / r0      (orders 2,3) */
+    const float* inv_r1;       /* 1 / r1      (order 3) */
+    const float* r0_frac;      /* r0 / (r0 + r1) */
+    const float* inv_r01;      /* 1 / (r0 + r1) */
+    const float* a_phi2;       /* alpha_t * phi_2 */
+    const float* a_phi3;       /* alpha_t * phi_3 */
+} ddif_dpm_tables;
+
+/* DPM_Solver.sample(method="multistep", algorithm_type="dpmsolver++") (solver/dpm_solver.py:1179-1221). */
+DDIF_API int ddif_plan_sample_dpmpp(ddif_plan_t plan, const ddif_dpm_tables* tabs, const float* x_T, float clamp_lo,
+                           float clamp_hi, int do_clamp, float* out, void* stream);
+
+/* GaussianDiffusion.p_losses forward half (diffusion/diffusion_ddpm_pan.py:692-732), eval mode, pred_mode x_start:
+ * x_t = a[b]*x0 + s[b]*noise; pred = net(x_t, t, cond, self_cond); returns pred (recon_x0). a, s, time: HOST. */
+DDIF_API int ddif_plan_q_sample_forward(ddif_plan_t plan, const float* x0, const float* noise, const float* sqrt_ac_host,
+                               const float* sqrt_1mac_host, const float* time_host, const float* self_cond,
+                               float* pred, void* stream);
+
+/* ---- measurement -------------------------------------------------------------------------------------------- */
+
+/* Bracket launches of the dominant kernel class (3x3 implicit-GEMM convolutions of the denoising step) with HIP
+ * events on the launch stream: every launch inside one denoising step out of `every_n_steps`.  Collect after the
+ * stream has been synchronised. */
+DDIF_API int ddif_prof_begin(ddif_plan_t plan, int every_n_steps, int max_events);
+typedef struct ddif_prof_result {
+    int64_t launches;        /* timed launches */
+    double total_ms;         /* sum of their durations */
+    double total_flop;       /* algorithmic flops of the timed launches (2*M*N*K, unpadded) */
+    double total_bytes;      /* algorithmic activation bytes read + written by them */
+    char kernel_name[128];
+} ddif_prof_result;
+DDIF_API int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out);
+
+/* flops / bytes of one denoising step and of set_cond for this plan (algorithmic, SURVEY.md 8d accounting) */
+DDIF_API int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes);
+
+DDIF_API const char* ddif_last_error(void);
+DDIF_API const char* ddif_version(void);
+/* 1 when built for the test-only host emulator (never shipped), 0 for the gfx950 build */
+DDIF_API int ddif_is_emulated(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDIF_H_ */

@@ -129,7 +129,6 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c)
 }
 
 // ---- math the kernels use ------------------------------------------------------------------------------
-static inline float __expf(float x) { return expf(x); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
@@ -162,5 +161,11 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 template <typename T>
 static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 
+namespace hipemu {
+template <typename K, typename... A>
+static inline void launch_kernel(K kern, dim3 grid, dim3 block, size_t shmem, A... args) {
+    launch(grid, block, shmem, [=]() { kern(args...); });
+}
+}  // namespace hipemu
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    hipemu::launch((grid), (block), (shmem), [=]() { kern(__VA_ARGS__); })
+    hipemu::launch_kernel(kern, (grid), (block), (shmem), __VA_ARGS__)
