@@ -105,3 +105,22 @@ def test_unsupported_configurations_fail_loudly():
     net = UNetSR3(in_channel=8, out_channel=8, norm_groups=32, channel_mults=(1, 2), image_size=16)  # reference defaults
     with pytest.raises(DdifError, match="norm_groups"):
         net(torch.zeros(1, 8, 16, 16), torch.zeros(1), torch.zeros(1, 20, 16, 16))
+
+
+def test_emulated_dpm_solver_matches_oracle():
+    from ddif.solver.dpm_solver import DPM_Solver, ImageSpaceClamp, NoiseScheduleVP, model_wrapper
+
+    ds, H, W, T, steps, order = "gf2", 8, 8, 100, 4, 3
+    C, cond, g = _tiny(ds, 1, H, W, 6)
+    xT = torch.randn(1, C, H, W, generator=g)
+    net = net_for(ds)
+    d = make_diffusion(net, C, T, H, "cpu")
+    ns = NoiseScheduleVP("discrete", betas=d.betas)
+    fn = model_wrapper(net, ns, model_type="x_start", guidance_type="classifier-free", guidance_scale=1.0, condition=cond)
+    slv = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(cond[:, :C]))
+    assert slv._fused_target() is not None
+    out = slv.sample(xT, steps=steps, order=order)
+    with torch.no_grad():
+        ref = O.dpmpp_multistep_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, O.schedule_tables(O.cosine_betas(T))["betas"],
+                                       xT, steps, order)
+    assert float((out - ref).abs().max()) <= 2e-5
