@@ -99,7 +99,7 @@ def main():
 
     def one_step(seed):
         plan.set_cond(cond, force=True)  # once-per-tile precompute is part of the job
-        res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=rank * B)
+        res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=rank * B, device_rng=True)
         sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
         if world > 1:
             dist.all_gather_into_tensor(gathered, sr)  # stitch: every rank ends with the whole scene

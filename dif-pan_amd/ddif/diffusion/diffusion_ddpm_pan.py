@@ -171,11 +171,13 @@ class GaussianDiffusion(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ DDPM
     @torch.no_grad()
-    def p_sample_loop(self, x_in, continous=False, get_interm_fm=False, *, x_T=None, noise=None, seed=None, tile0=0):
+    def p_sample_loop(self, x_in, continous=False, get_interm_fm=False, *, x_T=None, noise=None, seed=None, tile0=0,
+                      device_rng=False):
         """Reference :445-507.  `x_in` is cond.  Extra keyword-only arguments (not in the reference):
         x_T (B,C,H,W) and noise (T,B,C,H,W) in execution order pin the random stream (parity tests); otherwise
         x_T is drawn with torch.randn on the device and the per-step noise comes from the library's counter-based
-        generator seeded from torch's RNG."""
+        generator seeded from torch's RNG.  device_rng=True also draws x_T from that generator, keyed by global tile
+        index `tile0 + b` (tile-sharded runs reproduce the single-GPU result whatever the split)."""
         if get_interm_fm:
             raise DdifError("get_interm_fm is not supported")
         cond = x_in
@@ -192,11 +194,13 @@ class GaussianDiffusion(nn.Module):
         cx0 = [float(c1[i]) for i in order]
         cxt = [float(c2[i]) for i in order]
         czz = [0.0 if i == 0 else float(cz[i]) for i in order]
-        if x_T is None:
+        if x_T is None and not device_rng:
             x_T = torch.randn((B, self.channels, H, W), device=dev)
         if noise is None and seed is None:
             seed = self._seed_from_torch()
         seed = 0 if seed is None else seed
+        if continous and x_T is None:
+            raise DdifError("continous=True needs an explicit or torch-drawn x_T (device_rng=False)")
         if not continous:
             return plan.sample_ddpm(t_model, cx0, cxt, czz, x_T, noise, seed, tile0, clamp, dev)
         # continous=True: snapshots whenever i % sample_inter == 0 (:448,500-501) -> run the loop in segments
@@ -249,7 +253,7 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def ddim_sample_loop(self, x_in, section_counts="ddim300", eta=0.0, *, x_T=None, noise=None, seed=None, tile0=0,
-                         clip_denoised=False):
+                         clip_denoised=False, device_rng=False):
         """Reference :623-666 (+ ddim_sample :594-621).  Respaces the schedule IN PLACE, feeds the respaced index as
         the timestep and applies no clamp -- all as the reference does."""
         assert isinstance(x_in, torch.Tensor)
@@ -268,7 +272,7 @@ class GaussianDiffusion(nn.Module):
         sr = self.sqrt_recip_alphas_cumprod.detach().cpu()
         srm1 = self.sqrt_recipm1_alphas_cumprod.detach().cpu()
         order = list(reversed(range(N)))
-        if x_T is None:
+        if x_T is None and not device_rng:
             x_T = torch.randn((B, self.channels, H, W), device=dev)
         if noise is None and seed is None:
             seed = self._seed_from_torch()

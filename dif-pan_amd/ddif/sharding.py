@@ -1,0 +1,56 @@
+"""Tile sharding across the GPUs of one node.
+
+Tiles (batch entries) are independent through the whole sampler, so a scene's tiles are split into contiguous
+blocks, one per rank; every rank runs the full sampler on its block with a full weight replica and NO data-path
+collective.  The only exchange is one all-gather of the fused tiles (RCCL over xGMI; `nccl` backend) to stitch the
+scene.  The reference itself never tiles (it feeds whole images, diffusion_engine.py:373-377), so tiles here are
+non-overlapping and the stitch is a pure index permutation.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_tiles: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of tile indices owned by `rank`; n_tiles must divide evenly."""
+    if n_tiles % world:
+        raise ValueError(f"{n_tiles} tiles do not split evenly over {world} ranks")
+    per = n_tiles // world
+    return rank * per, (rank + 1) * per
+
+
+def cut_tiles(scene: torch.Tensor, tile: int) -> torch.Tensor:
+    """(C, H, W) -> (ny*nx, C, tile, tile), row-major over the tile grid."""
+    C, H, W = scene.shape
+    if H % tile or W % tile:
+        raise ValueError("scene size must be a multiple of the tile size")
+    ny, nx = H // tile, W // tile
+    return scene.reshape(C, ny, tile, nx, tile).permute(1, 3, 0, 2, 4).reshape(ny * nx, C, tile, tile).contiguous()
+
+
+def stitch_tiles(tiles: torch.Tensor, ny: int, nx: int) -> torch.Tensor:
+    """Inverse of cut_tiles: (ny*nx, C, h, w) -> (C, ny*h, nx*w)."""
+    n, C, h, w = tiles.shape
+    assert n == ny * nx
+    return tiles.reshape(ny, nx, C, h, w).permute(2, 0, 3, 1, 4).reshape(C, ny * h, nx * w).contiguous()
+
+
+def sample_sharded(diffusion, cond_all: torch.Tensor, mode: str = "ddpm_sample", seed: int = 0, **kw) -> torch.Tensor:
+    """Sample every tile of `cond_all` (n_tiles, 2C+4P, h, w; the same tensor on every rank) with the tiles split over
+    the ranks of the default process group, then all-gather.  Returns sr = clip(residual + lms, 0, 1) for ALL tiles on
+    every rank.  The noise stream is keyed by global tile index, so the result does not depend on the world size."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_range(cond_all.shape[0], rank, world)
+    cond = cond_all[lo:hi].contiguous()
+    C = diffusion.channels
+    res = diffusion(cond, mode=mode, seed=seed, tile0=lo, device_rng=True, **kw)
+    sr = (res + cond[:, :C]).clip(0, 1)  # diffusion_engine.py:446-447
+    if world == 1:
+        return sr
+    out = torch.empty((cond_all.shape[0],) + tuple(sr.shape[1:]), dtype=sr.dtype, device=sr.device)
+    dist.all_gather_into_tensor(out, sr.contiguous())
+    return out
