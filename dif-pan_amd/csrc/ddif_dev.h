@@ -20,10 +20,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DDIF_WAVE 64
 #define DDIF_GN_EPS 1e-5
 
+#ifdef DDIF_EMU
+static inline long long wall_clock64() { return 0; }
+#endif
+
 namespace ddif {
 
-__device__ __forceinline__ float dd_exp(float x) { return expf(x); }
-__device__ __forceinline__ float dd_sigmoid(float x) { return 1.0f / (1.0f + dd_exp(-x)); }
+__device__ __forceinline__ float dd_exp(float x) { return expf(x); }  // accurate (softmax paths)
+// SiLU on the hardware transcendental units: x * rcp(1 + exp2(-x*log2e)) = 2 quarter-rate + 3 full-rate VALU ops per
+// element (v_exp_f32 / v_rcp_f32 are ~1 ulp; |error| of silu <~ 1e-7*|x|, the size of an fp32 rounding of the result).
+__device__ __forceinline__ float dd_sigmoid(float x) {
+#ifdef DDIF_EMU
+    return 1.0f / (1.0f + exp2f(-1.4426950408889634f * x));
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+#endif
+}
 __device__ __forceinline__ float dd_silu(float x) { return x * dd_sigmoid(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -44,9 +56,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // GroupNorm(1 group) statistics travel with a tensor as per-producer-workgroup partials:
 //   st[(b * np + i) * 2 + {0,1}] = {sum, sum of squares} over the elements workgroup i wrote for sample b.
-// Called by ALL threads of the first wavefront (tid < 64); returns mean / rstd for sample b over the concatenation
-// of up to two tensors.  Deterministic (fixed summation order), fp64 combine.
-__device__ __forceinline__ void gn_finalize_wave0(const double* st0, int np0, const double* st1, int np1, int b,
+// Called by ALL 64 lanes of a wavefront; returns mean / rstd for sample b over the concatenation of up to two
+// tensors.  Deterministic (fixed summation order), fp64 combine.
+__device__ __forceinline__ void gn_finalize_wave(const double* st0, int np0, const double* st1, int np1, int b,
                                                   double count, float* mean_out, float* rstd_out) {
     const int lane = threadIdx.x & 63;
     double s = 0.0, ss = 0.0;

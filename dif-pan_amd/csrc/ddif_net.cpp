@@ -197,7 +197,7 @@ int Net::commit(hipStream_t stream) {
         p.cout = (int)w->shape[0];
         p.cin = (int)w->shape[1];
         p.ks = (int)w->shape[2];
-        p.ck = p.cin <= 16 ? 16 : 32;
+        p.ck = (p.ks == 3 || p.cin <= 16) ? 16 : 32;  // 3x3: 16-channel chunks (A + W double-buffered = 65 KB of LDS)
         p.w_off = pack_conv(b, w->v.data(), p.cout, p.cin, p.ks, p.ck, &p.n_chunks);
         p.bias_off = bs ? (long)b.add(bs->v.data(), bs->v.size()) : -1;
         pend.push_back(p);

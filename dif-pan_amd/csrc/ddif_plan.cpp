@@ -9,49 +9,77 @@ namespace ddif {
 
 // ------------------------------------------------------------------------------------------------ conv variants
 namespace {
-template <int KS, int S, int U, int CK, int PRO>
+template <int KS, int S, int U, int CK, int PRO, int VEC>
 ConvVariant variant_for_cfg(int cfg) {
     ConvVariant v;
     switch (cfg) {
-        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK>(); v.th = 8; v.tw = 16; v.nt = 32; break;
-        case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK>(); v.th = 8; v.tw = 16; v.nt = 64; break;
-        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK>(); v.th = 8; v.tw = 8; v.nt = 64; break;
-        case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK>(); v.th = 8; v.tw = 8; v.nt = 128; break;
+        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1>(); v.th = 8; v.tw = 16; v.nt = 32; break;
+        case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2>(); v.th = 8; v.tw = 16; v.nt = 64; break;
+        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2>(); v.th = 8; v.tw = 8; v.nt = 64; break;
+        case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4>(); v.th = 8; v.tw = 8; v.nt = 128; break;
         default: break;
     }
     return v;
 }
-template <int KS, int S, int U, int CK, int PRO>
+template <int KS, int S, int U, int CK, int PRO, int VEC>
 ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not fit comfortably in LDS
-    return (cfg >= 2) ? variant_for_cfg<KS, S, U, CK, PRO>(cfg) : ConvVariant();
+    return (cfg >= 2) ? variant_for_cfg<KS, S, U, CK, PRO, VEC>(cfg) : ConvVariant();
 }
 }  // namespace
 
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg) {
+// vec = 1: every source channel count is a multiple of 4 (float4 staging).  The scalar-staging variants exist only for
+// the prologue-free 3x3 / 1x1 kernels (stem with C = 31, cond convs with 9 / 11 / 34 / 40 input channels).
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec) {
     ConvVariant v;
-    if (ks == 3 && stride == 1 && !ups && ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 32, PRO_GN_SILU>(cfg); v.name = "conv3x3_gn_silu"; }
-    else if (ks == 3 && stride == 1 && !ups && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 32, PRO_NONE>(cfg); v.name = "conv3x3"; }
-    else if (ks == 3 && stride == 1 && !ups && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE>(cfg); v.name = "conv3x3_ck16"; }
-    else if (ks == 3 && stride == 2 && !ups && ck == 32 && pro == PRO_NONE) { v = variant_small_tiles<3, 2, 0, 32, PRO_NONE>(cfg); v.name = "conv3x3_s2"; }
-    else if (ks == 3 && stride == 2 && !ups && ck == 16 && pro == PRO_NONE) { v = variant_small_tiles<3, 2, 0, 16, PRO_NONE>(cfg); v.name = "conv3x3_s2_ck16"; }
-    else if (ks == 3 && stride == 1 && ups && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 1, 32, PRO_NONE>(cfg); v.name = "conv3x3_up2"; }
-    else if (ks == 3 && stride == 1 && ups && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 1, 16, PRO_NONE>(cfg); v.name = "conv3x3_up2_ck16"; }
-    else if (ks == 1 && stride == 1 && !ups && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE>(cfg); v.name = "conv1x1"; }
-    else if (ks == 1 && stride == 1 && !ups && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE>(cfg); v.name = "conv1x1_ck16"; }
-    else if (ks == 1 && stride == 1 && !ups && ck == 32 && pro == PRO_GN) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN>(cfg); v.name = "conv1x1_gn"; }
-    else if (ks == 1 && stride == 1 && !ups && ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_SILU>(cfg); v.name = "conv1x1_gn_silu"; }
+    if (ks == 3 && ck == 16) {  // 3x3 convs always use 16-channel chunks
+        if (!vec) {
+            if (stride == 1 && !ups && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv3x3_scalar"; }
+        } else if (stride == 1 && !ups && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1>(cfg); v.name = "conv3x3_gn_silu"; }
+        else if (stride == 1 && !ups && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3"; }
+        else if (stride == 2 && !ups && pro == PRO_NONE) { v = variant_small_tiles<3, 2, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3_s2"; }
+        else if (stride == 1 && ups && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 1, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3_up2"; }
+    } else if (ks == 1 && stride == 1 && !ups) {
+        if (!vec) {
+            if (ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 0>(cfg); v.name = "conv1x1_scalar"; }
+            else if (ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv1x1_ck16_scalar"; }
+        } else if (ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1>(cfg); v.name = "conv1x1"; }
+        else if (ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv1x1_ck16"; }
+        else if (ck == 32 && pro == PRO_GN) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN, 1>(cfg); v.name = "conv1x1_gn"; }
+        else if (ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_SILU, 1>(cfg); v.name = "conv1x1_gn_silu"; }
+    }
     return v;
 }
 
 static int pick_cfg(int stride, int Hout, int Wout, int Cout, int B) {
+    static const int force = [] { const char* e = getenv("DDIF_CONV_CFG"); return e ? atoi(e) : -1; }();
+    if (force >= 0 && !(stride == 2 && force < 2)) return force;
     const bool wide = (Wout >= 16) && stride == 1;
-    if (wide) {
-        const long wgs64 = (long)B * ((Hout + 7) / 8) * ((Wout + 15) / 16) * ((Cout + 63) / 64);
-        return (Cout % 64 == 0 && wgs64 >= 1024) ? 1 : 0;
-    }
+    if (wide) return 0;  // NT = 64 needs 102 KB of LDS (one workgroup per CU): measured slower than two NT = 32 passes
     if (Cout <= 32 && stride == 1) return 0;
     const long wgs128 = (long)B * ((Hout + 7) / 8) * ((Wout + 7) / 8) * ((Cout + 127) / 128);
     return (Cout % 128 == 0 && wgs128 >= 1024) ? 3 : 2;
+}
+
+static int num_cus() {
+    static int n = [] {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu = v;
+        }
+        return cu;
+    }();
+    return n;
+}
+static int wg_per_cu(size_t smem) {
+    static int forced = [] {
+        const char* e = getenv("DDIF_WG_PER_CU");
+        return e ? atoi(e) : 0;
+    }();
+    int byl = (int)((160 * 1024) / (smem ? smem : 1));
+    if (byl < 1) byl = 1;
+    int want = forced > 0 ? forced : 2;
+    return want < byl ? want : byl;
 }
 
 static inline dim3 ew_grid(size_t n) {
@@ -97,8 +125,9 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     if (c0 + c1 != pc.cin) return fail(DDIF_ERR_INVALID, "%s: input channels %d+%d != weight cin %d", s.name, c0, c1, pc.cin);
     if (pc.ks == 1 && (s.stride != 1 || s.ups)) return fail(DDIF_ERR_INVALID, "%s: 1x1 conv with stride/upsample", s.name);
     const int cfg = pick_cfg(s.stride, Hout, Wout, pc.cout, B);
-    const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg);
-    if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg);
+    const int vec = (c0 % 4 == 0 && c1 % 4 == 0) ? 1 : 0;
+    const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
+    if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
     if (s.pro != PRO_NONE && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
     if (int e = alloc_tensor(out, pc.cout, Hout, Wout)) return e;
@@ -128,14 +157,20 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.out = out->p;
     a.tiles_x = (Wout + var.tw - 1) / var.tw;
     a.tiles_y = (Hout + var.th - 1) / var.th;
-    a.vec_ok = (c0 % 4 == 0 && c1 % 4 == 0) ? 1 : 0;
     const int gy = (pc.cout + var.nt - 1) / var.nt;
     if (s.stats) {
         out->np = a.tiles_x * a.tiles_y * gy;
         if (int e = dalloc(&out->st, (size_t)B * out->np * 2)) return e;
         a.st_out = out->st;
     }
-    const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y), (unsigned)gy);
+    a.n_ct = gy;
+    // persistent launch: a few workgroups per CU, each walking a contiguous range of (cout tile, pixel tile) items
+    const long nwork = (long)B * a.tiles_x * a.tiles_y * gy;
+    const long cap = (long)num_cus() * wg_per_cu(var.smem);
+    const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
+    if (var.smem > 64 * 1024) {
+        DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(var.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)var.smem));
+    }
     const bool dyn = s.dyn_input;
     const bool self_c = net->cfg.self_condition != 0;
     const int tb_off = s.tb_off;

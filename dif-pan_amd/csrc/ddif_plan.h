@@ -34,7 +34,7 @@ struct ConvVariant {
     int th = 0, tw = 0, nt = 0;
     const char* name = "";
 };
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg);
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec);
 
 struct ConvSpec {
     const PackedConv* pc = nullptr;

@@ -10,12 +10,19 @@
 //     + SiLU prologue applied while staging (zero padding is applied after the activation, as in the reference);
 //     two input tensors can be concatenated along channels without materialising the concat (skip connections,
 //     self-conditioning cat[x, x]); nearest x2 upsampling and stride 2 are index maps of the staging pass;
-//   * A fragments come from LDS as ds_read_b128 (row stride CK+4 floats), B fragments (weights, pre-packed on the
-//     host in exactly the per-lane order) come straight from global/L2 as one coalesced 1 KiB wave load;
+//   * A fragments come from LDS as ds_read_b128 (row stride CK+4 floats); the weight chunk (pre-packed on the host in
+//     exactly the per-lane B-fragment order) is staged through LDS as well, one conflict-free 1 KiB ds_read_b128 per
+//     wave and (tap, k8) step -- so the MFMA loop issues NO global load: vmcnt retires in order, and a B fragment
+//     fetched from L2 inside the loop would make its first use wait for the older HBM tile prefetch too;
 //   * the contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32, bitwise an fmaf chain: no precision change vs.
 //     an FMA loop, but 64 FLOP/clk/SIMD from one wave);
 //   * epilogue: + bias, + per-sample time bias, FiLM (1+scale)*y+shift, SiLU, + residual, store, and the
-//     per-workgroup {sum, sum^2} partials the NEXT GroupNorm needs (fp64, deterministic order, no atomics).
+//     per-(tile, cout-tile) {sum, sum^2} partials the NEXT GroupNorm needs (fp64, deterministic order, no atomics).
+//   * PERSISTENT + SOFTWARE-PIPELINED: a launch is 2-3 workgroups per CU; each workgroup walks a contiguous range of
+//     (cout-tile, pixel-tile) work items x channel chunks.  While the MFMAs of item i run out of LDS buffer i&1, the
+//     global loads of item i+1 are in flight into registers; afterwards the prologue is applied and buffer (i+1)&1 is
+//     written (one barrier per item).  Without this every workgroup of a launch ran load / prologue / MFMA / store in
+//     lockstep (rocprof: waves alive 40 us for 4 us of MFMA work, 38 % MfmaUtil).
 #pragma once
 #include "ddif_dev.h"
 
@@ -44,57 +51,47 @@ struct ConvArgs {
     float* out;
     double* st_out;          // partials of out [B][tiles_x*tiles_y*gridDim.y][2] or null
     int tiles_x, tiles_y;
-    int vec_ok;              // float4 staging allowed (c0 % 4 == 0 && c1 % 4 == 0)
+    int n_ct;                // number of cout tiles (work item = cout tile x pixel tile; partial index uses it)
+    long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
 };
 
 
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+// ABL (microbenchmark ablations only, tools/mbench.cpp): 1 = no MFMA, 2 = no input loads, 4 = no stores, 8 = no weight loads
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr int LDA = CK + 4;
     constexpr int TAPS = KS * KS;
     constexpr int K8 = CK / 8;
     constexpr int C4 = CK / 4;
+    constexpr int NF = TAPS * K8;                         // (tap, k8) steps per chunk
+    constexpr int ABUF = IH * IW * LDA;                   // floats per LDS buffer
+    constexpr int NITEMS = (IH * IW * C4 + 255) / 256;    // float4 input-staging items per thread and chunk
+    constexpr int WBUF = NB * WN * NF * 256;              // floats of one weight chunk (all n-blocks of the cout tile)
+    constexpr int WITEMS = (WBUF / 4 + 255) / 256;        // float4 weight-staging items per thread and chunk
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(TH * TW == 32 * MB * WM, "pixel tile must match the wave layout");
     static_assert(CK % 8 == 0 && 256 % C4 == 0, "chunk size");
+    static_assert(NITEMS <= 32, "valid mask is 32 bits");
 
     DDIF_DYN_SMEM(smem);
-    float* As = reinterpret_cast<float*>(smem);
+    float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
+    float* Ws = As + 2 * ABUF;                    // [2][WBUF]  weight chunk in B-fragment order
+    double* red = reinterpret_cast<double*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float));  // [2][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, j = lane & 31;
     const int tiles = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles, t = blockIdx.x % tiles;
-    const int oy0 = (t / a.tiles_x) * TH, ox0 = (t % a.tiles_x) * TW;
+    const int ntiles = a.B * tiles;
+    const int nwork = ntiles * a.n_ct;
+    const int w0 = (int)((long long)blockIdx.x * nwork / gridDim.x);
+    const int w1 = (int)((long long)(blockIdx.x + 1) * nwork / gridDim.x);
+    if (w0 >= w1) return;  // whole workgroup leaves together
     const int Hc = UPS ? a.Hin * 2 : a.Hin, Wc = UPS ? a.Win * 2 : a.Win;
-    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
     const int Ctot = a.c0 + a.c1;
-
-    float mean = 0.f, rstd = 1.f;
-    if (PRO != PRO_NONE) {
-        if (tid < 64) {
-            gn_finalize_wave0(a.st0, a.np0, a.st1, a.np1, b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
-            if (tid == 0) {
-                As[0] = mean;
-                As[1] = rstd;
-            }
-        }
-        __syncthreads();
-        mean = As[0];
-        rstd = As[1];
-        __syncthreads();
-    }
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    const int c4 = tid % C4;
 
     int abase[MB];
 #pragma unroll
@@ -102,144 +99,334 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int m = (wm * MB + mb) * 32 + j;
         abase[mb] = ((m / TW) * STRIDE * IW + (m % TW) * STRIDE) * LDA + 4 * h;
     }
-    const int nbg0 = (blockIdx.y * WN + wn) * NB;
-    constexpr size_t WCHUNK = (size_t)TAPS * K8 * 2 * 32 * 4;  // floats per (n-block, chunk)
+    constexpr int WCHUNK = NF * 256;  // floats per (n-block, chunk)
 
-    for (int ch = 0; ch < a.n_chunks; ++ch) {
-        if (ch) __syncthreads();
-        // ---- stage the halo tile of this channel chunk (prologue applied once per element) ----
-        {
-            const int c4 = tid % C4;
-            const int cbase = ch * CK + c4 * 4;
-            float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (PRO != PRO_NONE) {
+    // ---- per-thread staging geometry: constant for the whole kernel (no divisions inside the stage loop) ----
+    int a_py[NITEMS], a_px[NITEMS], a_lds[NITEMS];
+    unsigned a_in = 0;
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) {
+        const int pixr = (tid + it * 256) / C4;
+        const bool in = pixr < IH * IW;
+        const int pix = in ? pixr : IH * IW - 1;
+        a_py[it] = pix / IW;
+        a_px[it] = pix % IW;
+        a_lds[it] = pix * LDA + c4 * 4;
+        a_in |= (in ? 1u : 0u) << it;
+    }
+    int w_goff[WITEMS], w_lds[WITEMS];
+    unsigned w_in = 0;
+#pragma unroll
+    for (int it = 0; it < WITEMS; ++it) {
+        const int qr = tid + it * 256;
+        const bool in = qr < WBUF / 4;
+        const int q = in ? qr : WBUF / 4 - 1;
+        w_goff[it] = (q / (NF * 64)) * (a.n_chunks * WCHUNK) + (q % (NF * 64)) * 4;
+        w_lds[it] = q * 4;
+        w_in |= (in ? 1u : 0u) << it;
+    }
+
+    // ---- work-item positions (workgroup-uniform); one division set per ITEM, none per chunk ----
+    struct Pos { int work, ct, b, oy0, ox0; };
+    auto locate = [&](int work) {
+        Pos p;
+        p.work = work;
+        p.ct = work / ntiles;
+        const int pt = work - p.ct * ntiles;
+        p.b = pt / tiles;
+        const int t = pt - p.b * tiles;
+        const int ty = t / a.tiles_x;
+        p.oy0 = ty * TH;
+        p.ox0 = (t - ty * a.tiles_x) * TW;
+        return p;
+    };
+
+    // ---- loading side: runs TWO stages (channel chunks) ahead of the MFMAs, into two register sets ----
+    // Measured on MI355X (tools/mbench.cpp, in-kernel clock stamps): with all workgroups of a launch prefetching in
+    // bursts a global load takes ~5 us to land, a stage of MFMAs ~2-3 us.  vmcnt retires IN ORDER, so (a) nothing that
+    // is consumed inside a stage may be loaded after a prefetch (epilogue operands are issued first), (b) one stage
+    // of lookahead is not enough.
+    Pos L = locate(w0);
+    int l_ch = 0;
+    int l_sp[NITEMS];   // clamped source pixel index of every staging item of work item L
+    unsigned l_ok = 0;  // which of them are real (inside the image): zero padding otherwise
+    auto item_geometry = [&]() {
+        const int iy0 = L.oy0 * STRIDE - PAD, ix0 = L.ox0 * STRIDE - PAD;
+        l_ok = 0;
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it) {
+            const int iy = iy0 + a_py[it], ix = ix0 + a_px[it];
+            const bool ok = (iy >= 0) & (iy < Hc) & (ix >= 0) & (ix < Wc);
+            l_ok |= (ok ? 1u : 0u) << it;
+            const int iyc = iy < 0 ? 0 : (iy >= Hc ? Hc - 1 : iy), ixc = ix < 0 ? 0 : (ix >= Wc ? Wc - 1 : ix);
+            l_sp[it] = (L.b * a.Hin + (UPS ? (iyc >> 1) : iyc)) * a.Win + (UPS ? (ixc >> 1) : ixc);
+        }
+        l_ok &= a_in;
+    };
+
+    struct StageRegs {
+        float4 sv[NITEMS], wv[WITEMS];
+        float gq[4], bq[4];
+        unsigned ok;
+        int cbase, ch;
+        Pos pos;
+    };
+    StageRegs R0, R1;
+    Pos bufpos[2];  // work item staged in LDS buffer 0 / 1
+    int bufch[2] = {0, 0};
+    int gn_b = -1;
+    float mean = 0.f, rstd = 1.f;
+
+    // Branch-free: every item loads from a CLAMPED (always valid) address; validity is a bit mask applied when the
+    // tile is written to LDS (with divergent bounds / source branches hipcc waits vmcnt(0) after every load).
+    auto issue_loads = [&](StageRegs& R) {
+        const int cbase = l_ch * CK + c4 * 4;
+        if (ABL & 2) {
+#pragma unroll
+            for (int it = 0; it < NITEMS; ++it) R.sv[it] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);
+        } else if (VEC) {
+            const int cb = cbase < Ctot ? cbase : Ctot - 4;
+            const bool s0 = cb < a.c0;
+            const float* base = s0 ? a.in0 + cb : a.in1 + (cb - a.c0);
+            const int cs = s0 ? a.c0 : a.c1;
+#pragma unroll
+            for (int it = 0; it < NITEMS; ++it) R.sv[it] = *reinterpret_cast<const float4*>(base + (size_t)l_sp[it] * cs);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NITEMS; ++it) {
+                float e[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int c = cbase + i;
-                    if (c < Ctot) {
-                        const float g = a.gamma[c] * rstd;
-                        ga[i] = g;
-                        gb[i] = a.beta[c] - mean * g;
-                    }
+                    const int c = cbase + i < Ctot ? cbase + i : Ctot - 1;
+                    const bool s0 = c < a.c0;
+                    const float* base = s0 ? a.in0 + c : a.in1 + (c - a.c0);
+                    e[i] = base[(size_t)l_sp[it] * (s0 ? a.c0 : a.c1)];
                 }
-            }
-            for (int item = tid; item < IH * IW * C4; item += 256) {
-                const int pix = item / C4;
-                const int py = pix / IW, px = pix % IW;
-                const int iy = iy0 + py, ix = ix0 + px;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && cbase < Ctot) {
-                    const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
-                    const size_t sp = ((size_t)b * a.Hin + sy) * a.Win + sx;
-                    if (a.vec_ok) {
-                        const float* p = (cbase < a.c0) ? a.in0 + sp * a.c0 + cbase : a.in1 + sp * a.c1 + (cbase - a.c0);
-                        const float4 q = *reinterpret_cast<const float4*>(p);
-                        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int c = cbase + i;
-                            if (c < Ctot) v[i] = (c < a.c0) ? a.in0[sp * a.c0 + c] : a.in1[sp * a.c1 + (c - a.c0)];
-                        }
-                    }
-                    if (PRO != PRO_NONE) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            v[i] = fmaf(v[i], ga[i], gb[i]);
-                            if (PRO == PRO_GN_SILU) v[i] = dd_silu(v[i]);
-                        }
-                    }
-                }
-                *reinterpret_cast<float4*>(&As[pix * LDA + c4 * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+                R.sv[it] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
-        __syncthreads();
-        // ---- contraction over taps x chunk channels ----
-        const float* wp[NB];
+        const float* wbase = a.w + ((size_t)L.ct * (NB * WN) * a.n_chunks + l_ch) * WCHUNK;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            wp[nb] = a.w + ((size_t)(nbg0 + nb) * a.n_chunks + ch) * WCHUNK + (size_t)h * 128 + j * 4;
+        for (int it = 0; it < WITEMS; ++it) {
+            if (ABL & 8) R.wv[it] = make_float4(0.01f, 0.02f, 0.03f, 0.04f);
+            else R.wv[it] = *reinterpret_cast<const float4*>(wbase + w_goff[it]);
+        }
+        if (PRO != PRO_NONE) {
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int aoff = ((tap / KS) * IW + (tap % KS)) * LDA;
+            for (int i = 0; i < 4; ++i) {
+                const int c = cbase + i < Ctot ? cbase + i : Ctot - 1;
+                R.gq[i] = a.gamma[c];
+                R.bq[i] = a.beta[c];
+            }
+        }
+        R.ok = l_ok;
+        R.cbase = cbase;
+        R.ch = l_ch;
+        R.pos = L;
+        // advance the loader
+        if (++l_ch == a.n_chunks) {
+            l_ch = 0;
+            if (L.work + 1 < w1) {
+                L = locate(L.work + 1);
+                item_geometry();
+            }
+        }
+    };
+    auto finish_stage = [&](StageRegs& R, int buf) {
+        float* dst = As + buf * ABUF;
+        float* wdst = Ws + buf * WBUF;
+        float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (PRO != PRO_NONE) {
+            if (R.pos.b != gn_b) {  // workgroup-uniform; every wavefront reduces the partials itself (no barrier)
+                gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
+                gn_b = R.pos.b;
+            }
 #pragma unroll
-            for (int k8 = 0; k8 < K8; ++k8) {
-                float4 af[MB], bf[NB];
+            for (int i = 0; i < 4; ++i) {
+                ga[i] = R.gq[i] * rstd;
+                gb[i] = R.bq[i] - mean * ga[i];
+            }
+        }
+        bool cok[4];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-                    af[mb] = *reinterpret_cast<const float4*>(&As[abase[mb] + aoff + k8 * 8]);
+        for (int i = 0; i < 4; ++i) cok[i] = R.cbase + i < Ctot;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    bf[nb] = *reinterpret_cast<const float4*>(wp[nb] + (size_t)(tap * K8 + k8) * 256);
+        for (int it = 0; it < NITEMS; ++it) {
+            const bool ok = (R.ok >> it) & 1u;
+            float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                float x = (&R.sv[it].x)[i];
+                if (PRO != PRO_NONE) {
+                    x = fmaf(x, ga[i], gb[i]);
+                    if (PRO == PRO_GN_SILU) x = dd_silu(x);
+                }
+                v[i] = (ok && cok[i]) ? x : 0.f;  // zero padding comes AFTER the activation
+            }
+            if ((a_in >> it) & 1u) *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int it = 0; it < WITEMS; ++it)
+            if ((w_in >> it) & 1u) *reinterpret_cast<float4*>(&wdst[w_lds[it]]) = R.wv[it];
+        bufpos[buf] = R.pos;
+        bufch[buf] = R.ch;
+    };
+
+    int pend_work = -1;  // work item whose statistics partial sits in red[pend_par]
+    int pend_par = 0;
+    auto flush_stats = [&]() {
+        if (a.st_out && pend_work >= 0 && tid == 0) {
+            const Pos p = locate(pend_work);
+            const int t = (p.oy0 / TH) * a.tiles_x + p.ox0 / TW;
+            const double* r = red + pend_par * 8;
+            const size_t pi = ((size_t)p.b * (tiles * a.n_ct) + (size_t)t * a.n_ct + p.ct) * 2;
+            a.st_out[pi + 0] = (r[0] + r[2]) + (r[4] + r[6]);
+            a.st_out[pi + 1] = (r[1] + r[3]) + (r[5] + r[7]);
+        }
+        pend_work = -1;
+    };
+
+    int dbg_n = 0;
+    auto stamp = [&]() {
+        if ((ABL & 16) && a.dbg && tid == 0 && dbg_n < 120) a.dbg[blockIdx.x * 128 + dbg_n++] = (long long)wall_clock64();
+    };
+    stamp();
+    f32x16 acc[MB][NB];
+    const int nflat = (w1 - w0) * a.n_chunks;
+
+    // one pipeline step: MFMAs of stage `flat` out of LDS buffer `cur`; Rn (stage flat+1, loaded during the previous
+    // step) is written to buffer cur^1; stage flat+2 is loaded into Rf.
+    auto step = [&](int flat, int cur, StageRegs& Rn, StageRegs& Rf) {
+        const float* Ac = As + cur * ABUF;
+        const Pos Cp = bufpos[cur];
+        const int c_ch = bufch[cur];
+        const bool last = c_ch == a.n_chunks - 1;
+        const int nbg0 = (Cp.ct * WN + wn) * NB;
+        // (1) epilogue operands FIRST (older than the prefetch below, so the epilogue's counted vmcnt wait does not
+        //     include the prefetch)
+        float e_bias[NB], e_tb[NB];
+        float e_res[MB][NB][16];
+        if (last) {
+            const float* tb = a.tbias ? a.tbias + (size_t)Cp.b * a.tbias_stride : nullptr;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = (nbg0 + nb) * 32 + j;
+                const int coc = co < a.Cout ? co : a.Cout - 1;
+                e_bias[nb] = a.bias ? a.bias[coc] : 0.f;
+                e_tb[nb] = tb ? tb[coc] : 0.f;
+                if (a.res) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = DDIF_MFMA_32x32x2((&af[mb].x)[i], (&bf[nb].x)[i], acc[mb][nb]);
-            }
-        }
-    }
-
-    // ---- epilogue ----
-    float s1 = 0.f, s2 = 0.f;
-    const float* tb = a.tbias ? a.tbias + (size_t)b * a.tbias_stride : nullptr;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int co = (nbg0 + nb) * 32 + j;
-        const bool cok = co < a.Cout;
-        float badd = 0.f, tadd = 0.f;
-        if (cok) {
-            if (a.bias) badd = a.bias[co];
-            if (tb) tadd = tb[co];
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-                if (cok && oy < a.Hout && ox < a.Wout) {
-                    const size_t op = ((size_t)b * a.Hout + oy) * a.Wout + ox;
-                    float v = acc[mb][nb][r] + badd;
-                    v += tadd;
-                    if (a.film) {
-                        const float sc = a.film[op * 2 * a.Cout + co], sh = a.film[op * 2 * a.Cout + a.Cout + co];
-                        v = v * (1.f + sc) + sh;
-                    }
-                    if (a.act_silu) v = dd_silu(v);
-                    if (a.res) v += a.res[op * a.Cout + co];
-                    a.out[op * a.Cout + co] = v;
-                    s1 += v;
-                    s2 += v * v;
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            int oy = Cp.oy0 + m / TW, ox = Cp.ox0 + m % TW;
+                            oy = oy < a.Hout ? oy : a.Hout - 1;
+                            ox = ox < a.Wout ? ox : a.Wout - 1;
+                            e_res[mb][nb][r] = a.res[(size_t)((Cp.b * a.Hout + oy) * a.Wout + ox) * a.Cout + coc];
+                        }
                 }
             }
         }
-    }
-    if (a.st_out) {
-        double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
-        __syncthreads();
-        double* red = reinterpret_cast<double*>(smem);
-        if (lane == 0) {
-            red[wave * 2 + 0] = d1;
-            red[wave * 2 + 1] = d2;
+        // (2) prefetch stage flat+2
+        if (flat + 2 < nflat) issue_loads(Rf);
+        flush_stats();
+        stamp();
+        if (c_ch == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
         }
-        __syncthreads();
-        if (tid == 0) {
-            const int np = tiles * gridDim.y;
-            const size_t pi = ((size_t)b * np + (size_t)t * gridDim.y + blockIdx.y) * 2;
-            a.st_out[pi + 0] = (red[0] + red[2]) + (red[4] + red[6]);
-            a.st_out[pi + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+        // (3) contraction over taps x chunk channels: A and B fragments both from LDS, no global load in here
+        const float* Wc = Ws + cur * WBUF + (wn * NB) * (NF * 256) + h * 128 + j * 4;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int tap = f / K8, k8 = f % K8;
+            const int aoff = ((tap / KS) * IW + (tap % KS)) * LDA;
+            float4 af[MB], bf[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + k8 * 8]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(&Wc[nb * (NF * 256) + f * 256]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (ABL & 1) acc[mb][nb][i] += (&af[mb].x)[i] * (&bf[nb].x)[i];
+                        else acc[mb][nb] = DDIF_MFMA_32x32x2((&af[mb].x)[i], (&bf[nb].x)[i], acc[mb][nb]);
         }
+        stamp();
+        if (last) {
+            // (4) epilogue of work item Cp
+            float s1 = 0.f, s2 = 0.f;
+            const int rowpix = Cp.b * a.Hout;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = (nbg0 + nb) * 32 + j;
+                const bool cok = co < a.Cout;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int oy = Cp.oy0 + m / TW, ox = Cp.ox0 + m % TW;
+                        if (cok && oy < a.Hout && ox < a.Wout) {
+                            const size_t op = (size_t)((rowpix + oy) * a.Wout + ox);
+                            float v = acc[mb][nb][r] + e_bias[nb];
+                            v += e_tb[nb];
+                            if (a.film) {
+                                const float sc = a.film[op * 2 * a.Cout + co], sh = a.film[op * 2 * a.Cout + a.Cout + co];
+                                v = v * (1.f + sc) + sh;
+                            }
+                            if (a.act_silu) v = dd_silu(v);
+                            if (a.res) v += e_res[mb][nb][r];
+                            if (!(ABL & 4) || v == 12345.678f) a.out[op * a.Cout + co] = v;
+                            s1 += v;
+                            s2 += v * v;
+                        }
+                    }
+                }
+            }
+            if (a.st_out) {
+                const double d1 = (double)wave_sum(s1), d2 = (double)wave_sum(s2);  // pairwise fp32 tree, fp64 beyond
+                pend_par ^= 1;
+                if (lane == 0) {
+                    red[pend_par * 8 + wave * 2 + 0] = d1;
+                    red[pend_par * 8 + wave * 2 + 1] = d2;
+                }
+                pend_work = Cp.work;
+            }
+        }
+        stamp();
+        // (5) stage flat+1 (loaded one step ago) -> the other LDS buffer
+        if (flat + 1 < nflat) finish_stage(Rn, cur ^ 1);
+        stamp();
+        __syncthreads();
+        stamp();
+    };
+
+    item_geometry();
+    issue_loads(R0);
+    if (nflat > 1) issue_loads(R1);
+    finish_stage(R0, 0);
+    __syncthreads();
+    stamp();
+    for (int flat = 0; flat < nflat; flat += 2) {
+        step(flat, 0, R1, R0);
+        if (flat + 1 < nflat) step(flat + 1, 1, R0, R1);
     }
+    flush_stats();
 }
 
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK>
-constexpr size_t conv_smem_bytes() {
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT>
+constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    constexpr size_t a = (size_t)IH * IW * (CK + 4) * sizeof(float);
-    return a < 256 ? 256 : a;
+    return (size_t)2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) * sizeof(float) + 16 * sizeof(double);
 }
 
 }  // namespace ddif

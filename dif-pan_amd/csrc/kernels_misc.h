@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
     float mean = 0.f, rstd = 1.f;
     if (a.use_gn) {
         if (tid < 64) {
-            gn_finalize_wave0(a.st0, a.np0, a.st1, a.np1, b, (double)C * a.H * a.W, &mean, &rstd);
+            gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, b, (double)C * a.H * a.W, &mean, &rstd);
             if (tid == 0) {
                 As[0] = mean;
                 As[1] = rstd;

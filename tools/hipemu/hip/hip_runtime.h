@@ -160,6 +160,10 @@ hipError_t hipEventSynchronize(hipEvent_t);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 template <typename T>
 static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }
 
 namespace hipemu {
 template <typename K, typename... A>
