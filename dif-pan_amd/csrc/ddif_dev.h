@@ -37,6 +37,20 @@ __device__ __forceinline__ float dd_sigmoid(float x) {
 #endif
 }
 __device__ __forceinline__ float dd_silu(float x) { return x * dd_sigmoid(x); }
+__device__ __forceinline__ float dd_exp2_fast(float x) {
+#ifdef DDIF_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+__device__ __forceinline__ float dd_rcp_fast(float x) {
+#ifdef DDIF_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

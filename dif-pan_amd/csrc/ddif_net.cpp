@@ -279,6 +279,8 @@ int Net::commit(hipStream_t stream) {
         const HostTensor *wo = need(ci + ".attn_out.weight"), *bo = need(ci + ".attn_out.bias");
         const HostTensor* wr = get(ci + ".attn_res.weight");
         const HostTensor* br = get(ci + ".attn_res.bias");
+        if (wo) vec_off[ci + ".attn_out.weight"] = b.add(wo->v.data(), wo->v.size());
+        if (wr) vec_off[ci + ".attn_res.weight"] = b.add(wr->v.data(), wr->v.size());
         if (wo && bo) {
             const int co = (int)wo->shape[0], fea = (int)wo->shape[1];
             PendConv p;

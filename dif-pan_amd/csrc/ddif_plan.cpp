@@ -46,6 +46,7 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
         else if (ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv1x1_ck16"; }
         else if (ck == 32 && pro == PRO_GN) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN, 1>(cfg); v.name = "conv1x1_gn"; }
         else if (ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_SILU, 1>(cfg); v.name = "conv1x1_gn_silu"; }
+        else if (ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1>(cfg); v.name = "conv1x1_colsoftmax"; }
     }
     return v;
 }
@@ -128,7 +129,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 == 0 && c1 % 4 == 0) ? 1 : 0;
     const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
-    if (s.pro != PRO_NONE && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
+    if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
     if (int e = alloc_tensor(out, pc.cout, Hout, Wout)) return e;
     ConvArgs a{};
@@ -142,7 +143,11 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.Hout = Hout;
     a.Wout = Wout;
     a.Cout = pc.cout;
-    a.w = pc.w;
+    a.w = s.w_override ? s.w_override : pc.w;
+    a.w_bstride = s.w_bstride;
+    a.cs_mx = s.cs_mx;
+    a.cs_sm = s.cs_sm;
+    if (s.pro == PRO_COLSM && (!s.cs_mx || !s.cs_sm || c0 % pc.ck != 0)) return fail(DDIF_ERR_INVALID, "%s: column-softmax prologue needs statistics and c0 %% %d == 0", s.name, pc.ck);
     a.n_chunks = pc.n_chunks;
     a.bias = s.use_bias ? pc.bias : nullptr;
     a.st0 = s.in0.st;
@@ -315,9 +320,13 @@ int Plan::build() {
             const float scale = 1.0f / std::sqrt((float)Cc);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)
             op.flop = 4.0 * B * 8 * (double)n * n * 16;
             op.bytes = 4.0 * B * n * 4.0 * Cc;
+            static const bool valu_attn = getenv("DDIF_ATTN_VALU") != nullptr;  // A/B switch: the pre-MFMA kernel
             op.run = [qkv, o, n, Cc, BB, scale](hipStream_t s, const StepCtx&) {
-                hipLaunchKernelGGL((self_attn_kernel<16>), dim3((n + 63) / 64, 8, BB), dim3(64), 2 * 64 * 16 * sizeof(float), s,
-                                   (const float*)qkv.p, n, Cc, scale, o.p);
+                if (valu_attn)
+                    hipLaunchKernelGGL((self_attn_kernel<16>), dim3((n + 63) / 64, 8, BB), dim3(64), 2 * 64 * 16 * sizeof(float), s,
+                                       (const float*)qkv.p, n, Cc, scale, o.p);
+                else
+                    hipLaunchKernelGGL(self_attn_mfma_kernel, dim3((n + 63) / 64, 8, BB), dim3(64), 0, s, (const float*)qkv.p, n, Cc, scale, o.p);
             };
             step.push_back(std::move(op));
         }
@@ -534,7 +543,6 @@ int Plan::build() {
         float *qmx, *qsm;
         DDIF_TRY(dalloc(&qmx, (size_t)B * Wl * fea));
         DDIF_TRY(dalloc(&qsm, (size_t)B * Wl * fea));
-        DDIF_TRY(alloc_tensor(&o, fea, Hl, Wl));
         {
             Op op;
             op.name = "q.softmax_stats";
@@ -544,24 +552,59 @@ int Plan::build() {
             };
             step.push_back(std::move(op));
         }
-        {
-            Op op;
-            op.name = "linattn_apply";
-            const float scale = 1.0f / std::sqrt((float)d);
-            op.flop = 2.0 * B * Hl * Wl * (double)fea * d;
-            op.bytes = 8.0 * B * Hl * Wl * fea;
-            op.run = [q, qmx, qsm, ctx, o, fea, d, BB, Hl, Wl, scale](hipStream_t s, const StepCtx&) {
-                hipLaunchKernelGGL(linattn_apply_kernel, dim3((Hl * Wl + 15) / 16, BB), dim3(256), (size_t)(fea * d + 16 * fea) * sizeof(float), s,
-                                   (const float*)q.p, (const float*)qmx, (const float*)qsm, (const float*)ctx, BB, Hl, Wl, fea, d, scale, o.p);
-            };
-            step.push_back(std::move(op));
-        }
-        {
+        const PackedConv* pmix = PC(ci + ".attn_mix");
+        if (!pmix) return fail(DDIF_ERR_MISSING, "%s.attn_out missing", ci.c_str());
+        const bool fold = (fea % 32 == 0) && pmix->ck == 32;  // context folded into per-sample attn_out weights
+        if (fold) {
+            // cond-only: M_b = scale * W_out . blockdiag(ctx_b^T), packed per sample next to W_res
+            const int nb_pad = (((pmix->cout + 31) / 32) + 3) & ~3;
+            const size_t per = (size_t)nb_pad * pmix->n_chunks * (pmix->ck / 8) * 256;
+            float* wmix = nullptr;
+            DDIF_TRY(dalloc(&wmix, per * B));
+            const float* wo = V(ci + ".attn_out.weight");
+            const float* wr = V(ci + ".attn_res.weight");  // null: attn_res is Identity
+            if (!wo) return fail(DDIF_ERR_MISSING, "%s.attn_out.weight missing", ci.c_str());
+            {
+                Op op;
+                op.name = "pack_mix_weights";
+                const float scale = 1.0f / std::sqrt((float)d);
+                const int co_n = pmix->cout, ck = pmix->ck, nch = pmix->n_chunks;
+                op.flop = 2.0 * B * co_n * (double)fea * d;
+                op.run = [wo, wr, ctx, wmix, BB, co_n, fea, d, scale, ck, nch, nb_pad, per](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(pack_mix_weights_kernel, ew_grid(per * BB), dim3(256), 0, s, wo, wr, (const float*)ctx, BB, co_n, fea, d, scale, ck, nch, nb_pad, wmix);
+                };
+                pre.push_back(std::move(op));
+            }
             ConvSpec s;
-            s.pc = PC(ci + ".attn_mix");
-            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.attn_out missing", ci.c_str());
+            s.pc = pmix;
+            s.in0 = q;
+            if (pmix->cin == 2 * fea) s.in1 = xn;
+            else s.res = xn.p;  // attn_res is Identity
+            s.pro = PRO_COLSM;
+            s.cs_mx = qmx;
+            s.cs_sm = qsm;
+            s.w_override = wmix;
+            s.w_bstride = (long long)per;
+            s.name = "softmax_H(q).ctx.attn_out+res";
+            DDIF_TRY(add_conv(step, s, &amix));
+        } else {
+            DDIF_TRY(alloc_tensor(&o, fea, Hl, Wl));
+            {
+                Op op;
+                op.name = "linattn_apply";
+                const float scale = 1.0f / std::sqrt((float)d);
+                op.flop = 2.0 * B * Hl * Wl * (double)fea * d;
+                op.bytes = 8.0 * B * Hl * Wl * fea;
+                op.run = [q, qmx, qsm, ctx, o, fea, d, BB, Hl, Wl, scale](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(linattn_apply_kernel, dim3((Hl * Wl + 15) / 16, BB), dim3(256), (size_t)(fea * d + 16 * fea) * sizeof(float), s,
+                                       (const float*)q.p, (const float*)qmx, (const float*)qsm, (const float*)ctx, BB, Hl, Wl, fea, d, scale, o.p);
+                };
+                step.push_back(std::move(op));
+            }
+            ConvSpec s;
+            s.pc = pmix;
             s.in0 = o;
-            if (s.pc->cin == 2 * fea) s.in1 = xn;
+            if (pmix->cin == 2 * fea) s.in1 = xn;
             else s.res = xn.p;  // attn_res is Identity
             s.name = "attn_out+res";
             DDIF_TRY(add_conv(step, s, &amix));

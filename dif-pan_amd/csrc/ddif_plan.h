@@ -47,6 +47,10 @@ struct ConvSpec {
     int tb_off = -1;
     const float* res = nullptr;
     const float* film = nullptr;
+    const float* w_override = nullptr;  // per-sample weights (packed) instead of pc->w
+    long long w_bstride = 0;
+    const float* cs_mx = nullptr;       // PRO_COLSM statistics of in0
+    const float* cs_sm = nullptr;
     bool silu = false;
     bool stats = false;
     const char* name = "conv";

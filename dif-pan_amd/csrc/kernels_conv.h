@@ -52,6 +52,9 @@ struct ConvArgs {
     double* st_out;          // partials of out [B][tiles_x*tiles_y*gridDim.y][2] or null
     int tiles_x, tiles_y;
     int n_ct;                // number of cout tiles (work item = cout tile x pixel tile; partial index uses it)
+    long long w_bstride;     // floats between the packed weights of consecutive samples (0: shared weights)
+    const float* cs_mx;      // PRO_COLSM: column-softmax max / sum of source 0, [B][Win][c0]
+    const float* cs_sm;
     long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
 };
 
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     Pos L = locate(w0);
     int l_ch = 0;
     int l_sp[NITEMS];   // clamped source pixel index of every staging item of work item L
+    int l_cs[NITEMS];   // PRO_COLSM: (b * Win + x) of the item, index into the column-softmax statistics
     unsigned l_ok = 0;  // which of them are real (inside the image): zero padding otherwise
     auto item_geometry = [&]() {
         const int iy0 = L.oy0 * STRIDE - PAD, ix0 = L.ox0 * STRIDE - PAD;
@@ -160,12 +164,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
             l_ok |= (ok ? 1u : 0u) << it;
             const int iyc = iy < 0 ? 0 : (iy >= Hc ? Hc - 1 : iy), ixc = ix < 0 ? 0 : (ix >= Wc ? Wc - 1 : ix);
             l_sp[it] = (L.b * a.Hin + (UPS ? (iyc >> 1) : iyc)) * a.Win + (UPS ? (ixc >> 1) : ixc);
+            if (PRO == PRO_COLSM) l_cs[it] = L.b * a.Win + ixc;
         }
         l_ok &= a_in;
     };
 
     struct StageRegs {
         float4 sv[NITEMS], wv[WITEMS];
+        float4 mxv[PRO == PRO_COLSM ? NITEMS : 1], smv[PRO == PRO_COLSM ? NITEMS : 1];
         float gq[4], bq[4];
         unsigned ok;
         int cbase, ch;
@@ -205,13 +211,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
                 R.sv[it] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
-        const float* wbase = a.w + ((size_t)L.ct * (NB * WN) * a.n_chunks + l_ch) * WCHUNK;
+        if (PRO == PRO_COLSM) {  // softmax_H(q) statistics of the channels of source 0 (c0 is a multiple of CK)
+            const int cb = cbase < a.c0 ? cbase : 0;
+#pragma unroll
+            for (int it = 0; it < NITEMS; ++it) {
+                R.mxv[it] = *reinterpret_cast<const float4*>(a.cs_mx + (size_t)l_cs[it] * a.c0 + cb);
+                R.smv[it] = *reinterpret_cast<const float4*>(a.cs_sm + (size_t)l_cs[it] * a.c0 + cb);
+            }
+        }
+        const float* wbase = a.w + (size_t)L.b * a.w_bstride + ((size_t)L.ct * (NB * WN) * a.n_chunks + l_ch) * WCHUNK;
 #pragma unroll
         for (int it = 0; it < WITEMS; ++it) {
             if (ABL & 8) R.wv[it] = make_float4(0.01f, 0.02f, 0.03f, 0.04f);
             else R.wv[it] = *reinterpret_cast<const float4*>(wbase + w_goff[it]);
         }
-        if (PRO != PRO_NONE) {
+        if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = cbase + i < Ctot ? cbase + i : Ctot - 1;
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         float* dst = As + buf * ABUF;
         float* wdst = Ws + buf * WBUF;
         float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (PRO != PRO_NONE) {
+        if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
             if (R.pos.b != gn_b) {  // workgroup-uniform; every wavefront reduces the partials itself (no barrier)
                 gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
                 gn_b = R.pos.b;
@@ -257,9 +271,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float x = (&R.sv[it].x)[i];
-                if (PRO != PRO_NONE) {
+                if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
                     x = fmaf(x, ga[i], gb[i]);
                     if (PRO == PRO_GN_SILU) x = dd_silu(x);
+                }
+                if (PRO == PRO_COLSM) {
+                    if (R.cbase < a.c0) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
                 }
                 v[i] = (ok && cok[i]) ? x : 0.f;  // zero padding comes AFTER the activation
             }

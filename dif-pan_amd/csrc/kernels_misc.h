@@ -262,6 +262,159 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const float* qkv, int n, 
     }
 }
 
+// Folds the cond-only linear-attention context into the attn_out weights (once per tile batch):
+//   attn_out(ctx^T (q_n * scale)) + attn_res(xn) = [M_b | W_res] . cat[q_n, xn],   M_b[co][hd*d+i] = scale * sum_e
+//   W_out[co][hd*d+e] * ctx[b,hd,i,e]       (FastAttnCondInjection, models/sr3_dwt.py:561-573)
+// and writes the per-sample 1x1 weights in the conv kernel's packed B-fragment order (ks = 1, chunk ck).
+__global__ void pack_mix_weights_kernel(const float* wo, const float* wr, const float* ctx, int B, int co_n, int fea, int d,
+                                        float scale, int ck, int n_chunks, int nb_pad, float* out) {
+    const int K8 = ck / 8;
+    const size_t per = (size_t)nb_pad * n_chunks * K8 * 256;
+    const int cin_n = wr ? 2 * fea : fea;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per * B; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / per);
+        size_t r = idx % per;
+        const int i = (int)(r % 4); r /= 4;
+        const int j = (int)(r % 32); r /= 32;
+        const int h = (int)(r % 2); r /= 2;
+        const int k8 = (int)(r % K8); r /= K8;
+        const int ch = (int)(r % n_chunks); r /= n_chunks;
+        const int nbi = (int)r;
+        const int ci = ch * ck + k8 * 8 + 4 * h + i, co = nbi * 32 + j;
+        float v = 0.f;
+        if (co < co_n && ci < cin_n) {
+            if (ci < fea) {
+                const int hd = ci / d, ii = ci % d;
+                const float* cx = ctx + (((size_t)b * (fea / d) + hd) * d + ii) * d;
+                float s = 0.f;
+                for (int e = 0; e < d; ++e) s = fmaf(wo[(size_t)co * fea + hd * d + e], cx[e], s);
+                v = s * scale;
+            } else {
+                v = wr[(size_t)co * fea + (ci - fea)];
+            }
+        }
+        out[idx] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// bottleneck self-attention on the matrix cores (the ONE place the north star asks for MFMA): exact-fp32
+// v_mfma_f32_16x16x4_f32.  One wavefront = 64 queries of one (tile, head); D = 16.
+//   S^T tile (16 keys x 16 queries) = K_tile (A: key rows)  x  Q_tile^T (B)      -> D layout: col = lane&15 = query,
+//                                                                                    row = 4*(lane>>4)+r = key
+//   so a lane's four accumulator values of a tile are P[query = lane&15][keys 4g..4g+3] -- exactly the A-operand layout
+//   (A[i = lane&15][k = lane>>4]) of the second contraction O = P x V: no transpose, no LDS round trip.
+//   Softmax over keys = over the rows of S^T: 16 values per lane (4 key tiles x 4 regs) + xor-shuffles 16, 32.
+// Two passes over the key blocks (pass 1: running max / sum per query; pass 2: p = exp(s - m) / l, O += P V) keep the
+// output accumulator free of rescaling; QK^T is recomputed (K = 16: 4 MFMAs per tile).  The contraction index d is
+// permuted (step kk uses d = 4*(lane>>4) + kk) so Q / K rows are single float4 loads.
+__global__ __launch_bounds__(64) void self_attn_mfma_kernel(const float* qkv, int n, int C, float scale, float* out) {
+    constexpr int D = 16;
+    const int hd = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int j = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 64;
+    const size_t rs = (size_t)3 * C;                                  // floats per token row of qkv
+    const float* base = qkv + (size_t)b * n * rs + (size_t)hd * 3 * D;  // + token*rs + {0, D, 2D} + d
+    float4 qf[4];  // B operand of S^T: Q[query = q0 + 16*qt + j][4g .. 4g+3]
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        int qi = q0 + qt * 16 + j;
+        qi = qi < n ? qi : n - 1;
+        qf[qt] = *reinterpret_cast<const float4*>(base + (size_t)qi * rs + 4 * g);
+    }
+    float m[4], l[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        m[qt] = -INFINITY;
+        l[qt] = 0.f;
+    }
+    f32x4 oacc[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[qt][r] = 0.f;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            float4 kf[4];  // A operand of S^T: K[key = k0 + 16*kt + j][4g .. 4g+3]
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                int ki = k0 + kt * 16 + j;
+                ki = ki < n ? ki : n - 1;
+                kf[kt] = *reinterpret_cast<const float4*>(base + (size_t)ki * rs + D + 4 * g);
+            }
+            f32x4 st[4][4];  // [kt][qt]: S^T tiles; value r <-> key k0 + 16*kt + 4*g + r, query q0 + 16*qt + j
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) c = DDIF_MFMA_16x16x4((&kf[kt].x)[kk], (&qf[qt].x)[kk], c);
+                    st[kt][qt] = c;
+                }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kok = k0 + kt * 16 + 4 * g + r < n;
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) st[kt][qt][r] = kok ? st[kt][qt][r] * scale : -INFINITY;
+                }
+            if (pass == 0) {
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    float bm = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bm = fmaxf(bm, st[kt][qt][r]);
+                    bm = fmaxf(bm, __shfl_xor(bm, 16));
+                    bm = fmaxf(bm, __shfl_xor(bm, 32));
+                    const float mn = fmaxf(m[qt], bm);
+                    float ps = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ps += dd_exp(st[kt][qt][r] - mn);
+                    ps += __shfl_xor(ps, 16);
+                    ps += __shfl_xor(ps, 32);
+                    l[qt] = l[qt] * (m[qt] == -INFINITY ? 0.f : dd_exp(m[qt] - mn)) + ps;
+                    m[qt] = mn;
+                }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    float vf[4];  // B operand of P V: V[key = k0 + 16*kt + 4*g + r][channel j]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int ki = k0 + kt * 16 + 4 * g + r;
+                        ki = ki < n ? ki : n - 1;
+                        vf[r] = base[(size_t)ki * rs + 2 * D + j];
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) {
+                        const float inv = 1.f / l[qt];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = dd_exp(st[kt][qt][r] - m[qt]) * inv;  // masked keys: exp(-inf) = 0
+                            oacc[qt] = DDIF_MFMA_16x16x4(p, vf[r], oacc[qt]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // O tile layout: col = lane&15 = channel, row = 4*g + r = query inside the tile
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + qt * 16 + 4 * g + r;
+            if (qi < n) out[((size_t)b * n + qi) * C + hd * D + j] = oacc[qt][r];
+        }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // time embedding (PositionalEncoding + noise_level_mlp + every FeatureWiseAffine, :223-258,59-64):
 // row r: pe = [sin(t*f_j), cos(t*f_j)], temb = W3 swish(W1 pe + b1) + b3, out[r][s] = Wall[s] . temb + ball[s].

@@ -197,3 +197,19 @@ def test_p_losses_forward_matches_reference_golden(case, monkeypatch):
     loss, recon = d(res, mode="train", noise=noise, cond=tiles["cond"].to(DEV))
     assert abs(float(loss) - float(g["loss"])) <= 2e-6
     assert _maxerr(recon, torch.from_numpy(g["recon"])) <= 2e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128), (2, 8, 8), (1, 72, 200)], ids=["128x128", "8x8", "72x200"])
+def test_forward_matches_oracle_other_sizes(shape):
+    """Sizes beyond the golden set: 128x128 (CAVE-sized, 256 bottleneck tokens -> multi-block attention), the smallest
+    legal tile, and a non-square scene with partial tiles; expected values from the pinned CPU oracle."""
+    B, H, W = shape
+    ds = "wv3"
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randn(B, 8, H, W, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    cond = gc.tiles_for(ds, B, H, W, seed=H + W)["cond"]
+    with torch.no_grad():
+        ref = O.unet_forward(gc.weights_for(ds), gc.cfg_for(ds), x, t, cond, None)
+    y = net_for(ds)(x.to(DEV), t.to(DEV), cond.to(DEV))
+    assert _maxerr(y, ref) <= 2e-5
