@@ -57,6 +57,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+// Sum over the 64 lanes with DPP row operations (full-rate VALU, no LDS round trips); the total lands in LANE 63 only.
+// Sequence as in rocPRIM's warp_reduce_dpp: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8,
+// row_bcast:15 (row_mask 0xa), row_bcast:31 (row_mask 0xc).
+__device__ __forceinline__ float wave_sum_fast(float v) {
+#ifdef DDIF_EMU
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+#else
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+#endif
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

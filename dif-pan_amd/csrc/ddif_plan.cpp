@@ -17,6 +17,7 @@ ConvVariant variant_for_cfg(int cfg) {
         case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2>(); v.th = 8; v.tw = 16; v.nt = 64; break;
         case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2>(); v.th = 8; v.tw = 8; v.nt = 64; break;
         case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4>(); v.th = 8; v.tw = 8; v.nt = 128; break;
+        case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, 2>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, 2>(); v.th = 8; v.tw = 16; v.nt = 32; v.groups = 2; break;
         default: break;
     }
     return v;
@@ -55,7 +56,8 @@ static int pick_cfg(int stride, int Hout, int Wout, int Cout, int B) {
     static const int force = [] { const char* e = getenv("DDIF_CONV_CFG"); return e ? atoi(e) : -1; }();
     if (force >= 0 && !(stride == 2 && force < 2)) return force;
     const bool wide = (Wout >= 16) && stride == 1;
-    if (wide) return 0;  // NT = 64 needs 102 KB of LDS (one workgroup per CU): measured slower than two NT = 32 passes
+    static const bool pingpong = [] { const char* e = getenv("DDIF_PINGPONG"); return e && atoi(e) != 0; }();  // measured slower, off
+    if (wide) return pingpong ? 4 : 0;  // 4: 512-thread workgroup, two anti-phase 4-wave groups (NT = 64 needs 102 KB of LDS per group: slower)
     if (Cout <= 32 && stride == 1) return 0;
     const long wgs128 = (long)B * ((Hout + 7) / 8) * ((Wout + 7) / 8) * ((Cout + 127) / 128);
     return (Cout % 128 == 0 && wgs128 >= 1024) ? 3 : 2;
@@ -92,6 +94,10 @@ static inline dim3 ew_grid(size_t n) {
 
 // ------------------------------------------------------------------------------------------------ allocation
 Plan::~Plan() {
+    drop_graphs();
+#ifndef DDIF_EMU
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+#endif
     for (void* p : allocs) (void)hipFree(p);
     for (auto e : ev0) (void)hipEventDestroy(e);
     for (auto e : ev1) (void)hipEventDestroy(e);
@@ -171,8 +177,10 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.n_ct = gy;
     // persistent launch: a few workgroups per CU, each walking a contiguous range of (cout tile, pixel tile) items
     const long nwork = (long)B * a.tiles_x * a.tiles_y * gy;
-    const long cap = (long)num_cus() * wg_per_cu(var.smem);
-    const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
+    const long cap = (long)num_cus() * (var.groups == 2 ? 1 : wg_per_cu(var.smem));
+    const long want = (nwork + var.groups - 1) / var.groups;
+    const dim3 grid((unsigned)(want < cap ? want : cap), 1u);
+    const dim3 block((unsigned)(256 * var.groups));
     if (var.smem > 64 * 1024) {
         DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(var.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)var.smem));
     }
@@ -184,7 +192,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
     op.timed = (pc.ks == 3);
-    op.run = [a, var, grid, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
+    op.run = [a, var, grid, block, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
         ConvArgs aa = a;
         if (dyn) {
             if (self_c) {
@@ -197,8 +205,10 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         if (tb_off >= 0) {
             aa.tbias = ctx.tb + tb_off;
             aa.tbias_stride = ctx.tb_stride;
+            aa.step_ptr = ctx.step_ptr;
+            aa.tb_rowstride = ctx.tb_rowstride;
         }
-        hipLaunchKernelGGL(var.fn, grid, dim3(256), var.smem, st, aa);
+        hipLaunchKernelGGL(var.fn, grid, block, var.smem, st, aa);
     };
     prog.push_back(std::move(op));
     return 0;
@@ -657,8 +667,18 @@ int Plan::build() {
 #undef DDIF_TRY
 }
 
+void Plan::drop_graphs() {
+#ifndef DDIF_EMU
+    for (auto& g : graph_exec) {
+        if (g) (void)hipGraphExecDestroy((hipGraphExec_t)g);
+        g = nullptr;
+    }
+#endif
+}
+
 int Plan::ensure_tb(int rows) {
     if (rows <= tb_rows) return 0;
+    drop_graphs();  // captured launches point at the old table
     if (int e = dalloc(&tb, (size_t)rows * net->nslots)) return e;  // older table stays in `allocs` until destroy
     if (int e = dalloc(&tvals, (size_t)rows)) return e;
     tb_rows = rows;
@@ -723,49 +743,125 @@ static int check_sampler_net(const Net* n) {
     return 0;
 }
 
-int Plan::sample_ddpm(const ddif_ddpm_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
-                      float lo, float hi, int do_clamp, float* out, hipStream_t s) {
-    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_sample_ddpm before ddif_plan_set_cond");
-    if (!t || t->n_steps < 1 || !t->t_model || !t->coef_x0 || !t->coef_xt || !t->coef_z || !out)
-        return fail(DDIF_ERR_INVALID, "ddif_plan_sample_ddpm: bad tables");
+// Shared loop of the DDPM (kind 0) and DDIM (kind 1) samplers.  Everything that changes from step to step is read
+// from device memory (step counter, coefficient tables, SamplerRun), so two consecutive steps (img0 -> img1 -> img0)
+// are captured ONCE into a hipGraph and replayed: ~270 launches per replay instead of per-kernel host launches.
+int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int n_tabs, const float* t_model, const float* xT,
+                      const float* noise, uint64_t seed, uint64_t tile0, float lo, float hi, int do_clamp, float* out, hipStream_t s) {
     if (int e = check_sampler_net(net)) return e;
     const int HW = H * W;
     const size_t n = (size_t)B * HW * C;
     if (xT) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
     else hipLaunchKernelGGL(randn_nhwc_kernel, ew_grid(n), dim3(256), 0, s, img[0], B, C, HW, (unsigned long long)seed, 0u, (unsigned long long)tile0);
-    if (int e = time_rows(t->t_model, t->n_steps, s)) return e;
-    int cur = 0;
-    for (int k = 0; k < t->n_steps; ++k) {
+    if (int e = time_rows(t_model, n_steps, s)) return e;
+    if (!d_step) {
+        if (int e = dalloc(&d_step, 16)) return e;
+        SamplerRun* r = nullptr;
+        if (int e = dalloc(&r, 1)) return e;
+        d_run = r;
+    }
+    if (tabs_cap < n_steps) {
+        drop_graphs();
+        if (int e = dalloc(&d_tabs, (size_t)6 * n_steps)) return e;
+        tabs_cap = n_steps;
+    }
+    SamplerRun run{};
+    run.noise = noise;
+    run.seed = seed;
+    run.tile0 = tile0;
+    run.lo = lo;
+    run.hi = hi;
+    run.do_clamp = do_clamp;
+    run.n_steps = n_steps;
+    for (int i = 0; i < n_tabs; ++i) {
+        run.tab[i] = d_tabs + (size_t)i * tabs_cap;
+        DDIF_HIPCHK(hipMemcpyAsync(d_tabs + (size_t)i * tabs_cap, tabs_host[i], (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    DDIF_HIPCHK(hipMemcpyAsync(d_run, &run, sizeof(run), hipMemcpyHostToDevice, s));
+    DDIF_HIPCHK(hipMemsetAsync(d_step, 0, sizeof(int), s));
+    // the host copies above must have been consumed before `run` (stack) goes away: pageable H2D copies are staged
+    // synchronously by the runtime, so returning after the enqueue is safe.
+
+    auto one_step = [&](int parity, hipStream_t st, bool prof) {
         StepCtx ctx;
-        ctx.x = ctx.sc = img[cur];  // self-conditioning == current image (diffusion_ddpm_pan.py:491,502; sr3_dwt.py:173)
-        ctx.tb = tb + (size_t)k * net->nslots;
+        ctx.x = ctx.sc = img[parity];  // self-conditioning == current image (diffusion_ddpm_pan.py:491,502; sr3_dwt.py:173)
+        ctx.tb = tb;
         ctx.tb_stride = 0;
-        const bool prof = prof_every > 0 && (k % prof_every) == 0;
-        run_prog(step, s, ctx, prof);
+        ctx.step_ptr = d_step;
+        ctx.tb_rowstride = net->nslots;
+        run_prog(step, st, ctx, prof);
         StepArgs a{};
         a.x0 = net_out.p;
-        a.img = img[cur];
+        a.img = img[parity];
         a.lms = lms.p;
-        a.noise = noise ? noise + (size_t)k * n : nullptr;
-        a.out = img[cur ^ 1];
+        a.out = img[parity ^ 1];
         a.B = B;
         a.C = C;
         a.HW = HW;
-        a.c1 = t->coef_x0[k];
-        a.c2 = t->coef_xt[k];
-        a.c3 = t->coef_z[k];
-        a.lo = lo;
-        a.hi = hi;
-        a.do_clamp = do_clamp;
-        a.seed = seed;
-        a.draw = (unsigned)(k + 1);
-        a.tile0 = tile0;
-        hipLaunchKernelGGL(ddpm_step_kernel, ew_grid(n), dim3(256), 0, s, a);
-        cur ^= 1;
+        a.run = reinterpret_cast<const SamplerRun*>(d_run);
+        a.step = d_step;
+        if (kind == 0) hipLaunchKernelGGL(ddpm_step_kernel, ew_grid(n), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(ddim_step_kernel, ew_grid(n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, st, d_step);
+    };
+
+    bool graph_ok = false;
+    (void)graph_ok;
+#ifndef DDIF_EMU
+    static const bool graph_env = [] { const char* e = getenv("DDIF_GRAPH"); return !e || atoi(e) != 0; }();
+    if (use_graph && graph_env && n_steps >= 4) {
+        if (!graph_exec[kind]) {
+            if (!cap_stream) DDIF_HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+            hipGraph_t g = nullptr;
+            hipError_t e1 = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal);
+            if (e1 == hipSuccess) {
+                one_step(0, cap_stream, false);
+                one_step(1, cap_stream, false);
+                e1 = hipStreamEndCapture(cap_stream, &g);
+            }
+            hipGraphExec_t ge = nullptr;
+            if (e1 == hipSuccess && g) e1 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e1 == hipSuccess && ge) graph_exec[kind] = ge;
+            else {
+                (void)hipGetLastError();
+                use_graph = false;  // capture unsupported here: plain stream launches (same kernels, same results)
+            }
+        }
+        graph_ok = graph_exec[kind] != nullptr;
     }
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[cur], B, C, HW, out);
+#endif
+    int k = 0;
+    while (k < n_steps) {
+        const bool pair = k + 1 < n_steps;
+        const bool prof = prof_every > 0 && ((k % prof_every) == 0 || (pair && ((k + 1) % prof_every) == 0));
+        (void)prof;
+#ifndef DDIF_EMU
+        if (graph_ok && pair && !prof) {
+            DDIF_HIPCHK(hipGraphLaunch((hipGraphExec_t)graph_exec[kind], s));
+            k += 2;
+            continue;
+        }
+#endif
+        one_step(0, s, prof_every > 0 && (k % prof_every) == 0);
+        ++k;
+        if (pair) {
+            one_step(1, s, prof_every > 0 && (k % prof_every) == 0);
+            ++k;
+        }
+    }
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[n_steps & 1], B, C, HW, out);
     DDIF_HIPCHK(hipGetLastError());
     return 0;
+}
+
+int Plan::sample_ddpm(const ddif_ddpm_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
+                      float lo, float hi, int do_clamp, float* out, hipStream_t s) {
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_sample_ddpm before ddif_plan_set_cond");
+    if (!t || t->n_steps < 1 || !t->t_model || !t->coef_x0 || !t->coef_xt || !t->coef_z || !out)
+        return fail(DDIF_ERR_INVALID, "ddif_plan_sample_ddpm: bad tables");
+    const float* tabs[3] = {t->coef_x0, t->coef_xt, t->coef_z};
+    return run_sampler(0, t->n_steps, tabs, 3, t->t_model, xT, noise, seed, tile0, lo, hi, do_clamp, out, s);
 }
 
 int Plan::sample_ddim(const ddif_ddim_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
@@ -773,45 +869,8 @@ int Plan::sample_ddim(const ddif_ddim_tables* t, const float* xT, const float* n
     if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_sample_ddim before ddif_plan_set_cond");
     if (!t || t->n_steps < 1 || !t->t_model || !t->sqrt_recip || !t->sqrt_recipm1 || !t->sqrt_ap || !t->dir_coef || !t->sigma || !out)
         return fail(DDIF_ERR_INVALID, "ddif_plan_sample_ddim: bad tables");
-    if (int e = check_sampler_net(net)) return e;
-    const int HW = H * W;
-    const size_t n = (size_t)B * HW * C;
-    if (xT) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
-    else hipLaunchKernelGGL(randn_nhwc_kernel, ew_grid(n), dim3(256), 0, s, img[0], B, C, HW, (unsigned long long)seed, 0u, (unsigned long long)tile0);
-    if (int e = time_rows(t->t_model, t->n_steps, s)) return e;
-    int cur = 0;
-    for (int k = 0; k < t->n_steps; ++k) {
-        StepCtx ctx;
-        ctx.x = ctx.sc = img[cur];  // self_cond=None -> x  (diffusion_ddpm_pan.py:628,658; sr3_dwt.py:173)
-        ctx.tb = tb + (size_t)k * net->nslots;
-        const bool prof = prof_every > 0 && (k % prof_every) == 0;
-        run_prog(step, s, ctx, prof);
-        DdimArgs a{};
-        a.x0 = net_out.p;
-        a.img = img[cur];
-        a.lms = lms.p;
-        a.noise = noise ? noise + (size_t)k * n : nullptr;
-        a.out = img[cur ^ 1];
-        a.B = B;
-        a.C = C;
-        a.HW = HW;
-        a.sqrt_recip = t->sqrt_recip[k];
-        a.sqrt_recipm1 = t->sqrt_recipm1[k];
-        a.sqrt_ap = t->sqrt_ap[k];
-        a.dir_coef = t->dir_coef[k];
-        a.sigma = t->sigma[k];
-        a.lo = lo;
-        a.hi = hi;
-        a.do_clamp = do_clamp;
-        a.seed = seed;
-        a.draw = (unsigned)(k + 1);
-        a.tile0 = tile0;
-        hipLaunchKernelGGL(ddim_step_kernel, ew_grid(n), dim3(256), 0, s, a);
-        cur ^= 1;
-    }
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[cur], B, C, HW, out);
-    DDIF_HIPCHK(hipGetLastError());
-    return 0;
+    const float* tabs[5] = {t->sqrt_recip, t->sqrt_recipm1, t->sqrt_ap, t->dir_coef, t->sigma};
+    return run_sampler(1, t->n_steps, tabs, 5, t->t_model, xT, noise, seed, tile0, lo, hi, do_clamp, out, s);
 }
 
 int Plan::sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, float hi, int do_clamp, float* out, hipStream_t s) {

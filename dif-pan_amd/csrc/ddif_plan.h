@@ -18,6 +18,8 @@ struct StepCtx {
     const float* sc = nullptr;  // self-conditioning    (NHWC)
     const float* tb = nullptr;  // time-bias row(s)
     int tb_stride = 0;          // floats between the rows of consecutive samples (0: one row for the batch)
+    const int* step_ptr = nullptr;  // samplers: device step counter selecting the time-bias row (row stride tb_rowstride)
+    int tb_rowstride = 0;
 };
 
 struct Op {
@@ -31,7 +33,7 @@ typedef void (*ConvKernelFn)(ConvArgs);
 struct ConvVariant {
     ConvKernelFn fn = nullptr;
     size_t smem = 0;
-    int th = 0, tw = 0, nt = 0;
+    int th = 0, tw = 0, nt = 0, groups = 1;
     const char* name = "";
 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec);
@@ -77,6 +79,14 @@ struct Plan {
     float* tb = nullptr;              // time-bias table
     int tb_rows = 0;
     float* small = nullptr;           // device scratch for per-sample coefficient arrays (2*B floats)
+    // sampler run state (device) + hipGraph replay of a pair of denoising steps
+    int* d_step = nullptr;
+    void* d_run = nullptr;            // SamplerRun
+    float* d_tabs = nullptr;
+    int tabs_cap = 0;
+    hipStream_t cap_stream = nullptr;
+    void* graph_exec[2] = {nullptr, nullptr};  // [0] DDPM pair, [1] DDIM pair
+    bool use_graph = true;
 
     // profiling
     int prof_every = 0, prof_max = 0;
@@ -97,6 +107,9 @@ struct Plan {
 
     int set_cond(const float* cond, hipStream_t s);
     int forward(const float* x, const float* t_host, const float* sc, float* out, hipStream_t s);
+    int run_sampler(int kind, int n_steps, const float* const* tabs_host, int n_tabs, const float* t_model, const float* xT,
+                    const float* noise, uint64_t seed, uint64_t tile0, float lo, float hi, int do_clamp, float* out, hipStream_t s);
+    void drop_graphs();
     int sample_ddpm(const ddif_ddpm_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,
                     float lo, float hi, int do_clamp, float* out, hipStream_t s);
     int sample_ddim(const ddif_ddim_tables* t, const float* xT, const float* noise, uint64_t seed, uint64_t tile0,

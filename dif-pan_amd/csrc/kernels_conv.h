@@ -37,8 +37,10 @@ struct ConvArgs {
     const float* w;          // packed weights, see pack_conv_weights()
     int n_chunks;            // ceil((c0 + c1) / CK)
     const float* bias;       // [Cout] or null
-    const float* tbias;      // time bias rows or null; row of sample b = tbias + b * tbias_stride
+    const float* tbias;      // time bias rows or null; row of sample b = tbias + step * tb_rowstride + b * tbias_stride
     int tbias_stride;
+    const int* step_ptr;     // device step counter of the running sampler (null: step = 0)
+    int tb_rowstride;
     const double* st0;       // GroupNorm partials of in0 / in1 (prologue), [B][np][2]
     int np0;
     const double* st1;
@@ -60,8 +62,13 @@ struct ConvArgs {
 
 
 // ABL (microbenchmark ablations only, tools/mbench.cpp): 1 = no MFMA, 2 = no input loads, 4 = no stores, 8 = no weight loads
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+// GROUPS = 2: one 512-thread workgroup = two 4-wave groups, each with its own work range, LDS buffers and pipeline,
+// running in ANTI-PHASE: while group 0 issues its MFMAs (phase H1) group 1 does its epilogue + LDS staging (phase H2),
+// swapped at every barrier.  rocprof showed why this is needed: two independent workgroups per CU drift into lockstep,
+// both waves of a SIMD queue on the one MFMA pipe (SQ_WAIT_INST_ANY = 2 x the MFMA time) and then both leave it idle
+// while they stage.
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int GROUPS = 1, int ABL = 0>
+__global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr int LDA = CK + 4;
@@ -78,20 +85,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     static_assert(CK % 8 == 0 && 256 % C4 == 0, "chunk size");
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
 
-    DDIF_DYN_SMEM(smem);
+    DDIF_DYN_SMEM(smem_all);
+    constexpr size_t GSZ = (size_t)2 * (ABUF + WBUF) * sizeof(float) + 16 * sizeof(double);  // LDS bytes per group
+    const int grp = GROUPS == 1 ? 0 : (int)(threadIdx.x >> 8);
+    char* smem = smem_all + grp * GSZ;
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
     float* Ws = As + 2 * ABUF;                    // [2][WBUF]  weight chunk in B-fragment order
     double* red = reinterpret_cast<double*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float));  // [2][8]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // group-local thread / wave index
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, j = lane & 31;
     const int tiles = a.tiles_x * a.tiles_y;
     const int ntiles = a.B * tiles;
     const int nwork = ntiles * a.n_ct;
-    const int w0 = (int)((long long)blockIdx.x * nwork / gridDim.x);
-    const int w1 = (int)((long long)(blockIdx.x + 1) * nwork / gridDim.x);
-    if (w0 >= w1) return;  // whole workgroup leaves together
+    const int nvb = gridDim.x * GROUPS;  // virtual workgroups (one per 4-wave group)
+    const int vb = blockIdx.x * GROUPS + grp;
+    const int w0 = (int)((long long)vb * nwork / nvb);
+    const int w1 = (int)((long long)(vb + 1) * nwork / nvb);
+    if (GROUPS == 1 && w0 >= w1) return;  // whole workgroup leaves together (a group of a pair must keep its barriers)
     const int Hc = UPS ? a.Hin * 2 : a.Hin, Wc = UPS ? a.Win * 2 : a.Win;
     const int Ctot = a.c0 + a.c1;
     const int c4 = tid % C4;
@@ -141,6 +153,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         const int ty = t / a.tiles_x;
         p.oy0 = ty * TH;
         p.ox0 = (t - ty * a.tiles_x) * TW;
+        return p;
+    };
+
+    auto next_pos = [&](Pos p) {  // work + 1 without divisions
+        p.work += 1;
+        p.ox0 += TW;
+        if (p.ox0 >= a.tiles_x * TW) {
+            p.ox0 = 0;
+            p.oy0 += TH;
+            if (p.oy0 >= a.tiles_y * TH) {
+                p.oy0 = 0;
+                if (++p.b == a.B) {
+                    p.b = 0;
+                    ++p.ct;
+                }
+            }
+        }
         return p;
     };
 
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         if (++l_ch == a.n_chunks) {
             l_ch = 0;
             if (L.work + 1 < w1) {
-                L = locate(L.work + 1);
+                L = next_pos(L);
                 item_geometry();
             }
         }
@@ -289,42 +318,47 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         bufch[buf] = R.ch;
     };
 
-    int pend_work = -1;  // work item whose statistics partial sits in red[pend_par]
+    bool pend = false;  // a statistics partial of work item pend_pos sits in red[pend_par]
+    Pos pend_pos = L;
     int pend_par = 0;
     auto flush_stats = [&]() {
-        if (a.st_out && pend_work >= 0 && tid == 0) {
-            const Pos p = locate(pend_work);
+        if (a.st_out && pend && tid == 0) {
+            const Pos p = pend_pos;
             const int t = (p.oy0 / TH) * a.tiles_x + p.ox0 / TW;
             const double* r = red + pend_par * 8;
             const size_t pi = ((size_t)p.b * (tiles * a.n_ct) + (size_t)t * a.n_ct + p.ct) * 2;
             a.st_out[pi + 0] = (r[0] + r[2]) + (r[4] + r[6]);
             a.st_out[pi + 1] = (r[1] + r[3]) + (r[5] + r[7]);
         }
-        pend_work = -1;
+        pend = false;
     };
 
     int dbg_n = 0;
     auto stamp = [&]() {
-        if ((ABL & 16) && a.dbg && tid == 0 && dbg_n < 120) a.dbg[blockIdx.x * 128 + dbg_n++] = (long long)wall_clock64();
+        if ((ABL & 16) && a.dbg && tid == 0 && dbg_n < 120) a.dbg[vb * 128 + dbg_n++] = (long long)wall_clock64();
     };
     stamp();
     f32x16 acc[MB][NB];
     const int nflat = (w1 - w0) * a.n_chunks;
 
-    // one pipeline step: MFMAs of stage `flat` out of LDS buffer `cur`; Rn (stage flat+1, loaded during the previous
-    // step) is written to buffer cur^1; stage flat+2 is loaded into Rf.
-    auto step = [&](int flat, int cur, StageRegs& Rn, StageRegs& Rf) {
+    // One pipeline step of stage `flat`, in two halves:
+    //   H1: epilogue-operand loads, prefetch of stage flat+2 into Rf, the MFMAs out of LDS buffer `cur`;
+    //   H2: epilogue (last chunk of an item), then stage flat+1 (loaded one step ago, Rn) -> LDS buffer cur^1.
+    Pos Cp = L;
+    int c_ch = 0, nbg0 = 0;
+    bool last = false;
+    float e_bias[NB], e_tb[NB];
+    float e_res[MB][NB][16];
+    auto h1 = [&](int flat, int cur, StageRegs& Rf) {
         const float* Ac = As + cur * ABUF;
-        const Pos Cp = bufpos[cur];
-        const int c_ch = bufch[cur];
-        const bool last = c_ch == a.n_chunks - 1;
-        const int nbg0 = (Cp.ct * WN + wn) * NB;
+        Cp = bufpos[cur];
+        c_ch = bufch[cur];
+        last = c_ch == a.n_chunks - 1;
+        nbg0 = (Cp.ct * WN + wn) * NB;
         // (1) epilogue operands FIRST (older than the prefetch below, so the epilogue's counted vmcnt wait does not
         //     include the prefetch)
-        float e_bias[NB], e_tb[NB];
-        float e_res[MB][NB][16];
         if (last) {
-            const float* tb = a.tbias ? a.tbias + (size_t)Cp.b * a.tbias_stride : nullptr;
+            const float* tb = a.tbias ? a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0) + (size_t)Cp.b * a.tbias_stride : nullptr;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int co = (nbg0 + nb) * 32 + j;
@@ -378,31 +412,38 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
                         else acc[mb][nb] = DDIF_MFMA_32x32x2((&af[mb].x)[i], (&bf[nb].x)[i], acc[mb][nb]);
         }
         stamp();
+    };
+    auto h2 = [&](int flat, int cur, StageRegs& Rn) {
         if (last) {
-            // (4) epilogue of work item Cp
+            // (4) epilogue of work item Cp.  Addresses = tile base + compile-time pixel offsets; bounds are only
+            //     checked for tiles that stick out of the image.
             float s1 = 0.f, s2 = 0.f;
-            const int rowpix = Cp.b * a.Hout;
+            const bool full = (Cp.oy0 + TH <= a.Hout) & (Cp.ox0 + TW <= a.Wout);
+            const size_t tile_pix = (size_t)((Cp.b * a.Hout + Cp.oy0) * a.Wout + Cp.ox0);
+            const int rowc = a.Wout * a.Cout;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int co = (nbg0 + nb) * 32 + j;
                 const bool cok = co < a.Cout;
+                float* obase = a.out + tile_pix * a.Cout + co;
+                const float* fbase = a.film ? a.film + tile_pix * 2 * a.Cout + co : nullptr;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const int oy = Cp.oy0 + m / TW, ox = Cp.ox0 + m % TW;
-                        if (cok && oy < a.Hout && ox < a.Wout) {
-                            const size_t op = (size_t)((rowpix + oy) * a.Wout + ox);
+                        const int my = m / TW, mx = m % TW;
+                        if (cok && (full || (Cp.oy0 + my < a.Hout && Cp.ox0 + mx < a.Wout))) {
+                            const int poff = my * rowc + mx * a.Cout;
                             float v = acc[mb][nb][r] + e_bias[nb];
                             v += e_tb[nb];
                             if (a.film) {
-                                const float sc = a.film[op * 2 * a.Cout + co], sh = a.film[op * 2 * a.Cout + a.Cout + co];
+                                const float sc = fbase[2 * poff], sh = fbase[2 * poff + a.Cout];
                                 v = v * (1.f + sc) + sh;
                             }
                             if (a.act_silu) v = dd_silu(v);
                             if (a.res) v += e_res[mb][nb][r];
-                            if (!(ABL & 4) || v == 12345.678f) a.out[op * a.Cout + co] = v;
+                            if (!(ABL & 4) || v == 12345.678f) obase[poff] = v;
                             s1 += v;
                             s2 += v * v;
                         }
@@ -410,40 +451,70 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
                 }
             }
             if (a.st_out) {
-                const double d1 = (double)wave_sum(s1), d2 = (double)wave_sum(s2);  // pairwise fp32 tree, fp64 beyond
+                const double d1 = (double)wave_sum_fast(s1), d2 = (double)wave_sum_fast(s2);  // fp32 tree in-wave, fp64 beyond
                 pend_par ^= 1;
-                if (lane == 0) {
+                if (lane == 63) {
                     red[pend_par * 8 + wave * 2 + 0] = d1;
                     red[pend_par * 8 + wave * 2 + 1] = d2;
                 }
-                pend_work = Cp.work;
+                pend = true;
+                pend_pos = Cp;
             }
         }
         stamp();
         // (5) stage flat+1 (loaded one step ago) -> the other LDS buffer
         if (flat + 1 < nflat) finish_stage(Rn, cur ^ 1);
         stamp();
-        __syncthreads();
-        stamp();
     };
 
-    item_geometry();
-    issue_loads(R0);
-    if (nflat > 1) issue_loads(R1);
-    finish_stage(R0, 0);
+    if (nflat > 0) {
+        item_geometry();
+        issue_loads(R0);
+        if (nflat > 1) issue_loads(R1);
+        finish_stage(R0, 0);
+    }
     __syncthreads();
     stamp();
-    for (int flat = 0; flat < nflat; flat += 2) {
-        step(flat, 0, R1, R0);
-        if (flat + 1 < nflat) step(flat + 1, 1, R0, R1);
+    if (GROUPS == 1) {
+        for (int flat = 0; flat < nflat; flat += 2) {
+            h1(flat, 0, R0);
+            h2(flat, 0, R1);
+            __syncthreads();
+            if (flat + 1 < nflat) {
+                h1(flat + 1, 1, R1);
+                h2(flat + 1, 1, R0);
+                __syncthreads();
+            }
+        }
+    } else {
+        // anti-phase schedule: group g runs H1(f) in phase 2f+g and H2(f) in phase 2f+g+1; one barrier per phase
+        const int o0 = (int)((long long)(blockIdx.x * 2) * nwork / nvb), o1 = (int)((long long)(blockIdx.x * 2 + 1) * nwork / nvb),
+                  o2 = (int)((long long)(blockIdx.x * 2 + 2) * nwork / nvb);
+        const int nf0 = (o1 - o0) * a.n_chunks, nf1 = (o2 - o1) * a.n_chunks;
+        const int nphase = 2 * nf0 > 2 * nf1 + 1 ? 2 * nf0 : 2 * nf1 + 1;
+        int flat = 0;
+        for (int ph = 0; ph < nphase; ++ph) {
+            if (flat < nflat) {
+                if (((ph + grp) & 1) == 0) {
+                    if (flat & 1) h1(flat, 1, R1);
+                    else h1(flat, 0, R0);
+                } else if (ph >= grp + 1) {
+                    if (flat & 1) h2(flat, 1, R0);
+                    else h2(flat, 0, R1);
+                    ++flat;
+                }
+            }
+            __syncthreads();
+        }
     }
     flush_stats();
 }
 
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT>
-constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN
+
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int GROUPS = 1>
+constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per 4-wave group = NB * WN
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    return (size_t)2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) * sizeof(float) + 16 * sizeof(double);
+    return GROUPS * ((size_t)2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) * sizeof(float) + 16 * sizeof(double));
 }
 
 }  // namespace ddif

@@ -540,77 +540,77 @@ __global__ void randn_nhwc_kernel(float* out, int B, int C, int HW, unsigned lon
 // ----------------------------------------------------------------------------------------------------------------
 // sampler updates.  All tensors NHWC [B,HW,C] except `noise` (NCHW, as drawn by the reference) which may be null
 // (-> Philox).  lms = cond[:, :C].
-struct StepArgs {
-    const float* x0;     // network output
-    const float* img;    // x_t
-    const float* lms;
-    const float* noise;  // NCHW or null
-    float* out;          // x_{t-1}
-    float* x0_out;       // clamped x0 (optional, DPM-Solver model buffer) or null
-    int B, C, HW;
-    float c1, c2, c3;    // sampler coefficients
+// Per-run sampler state lives in DEVICE memory (rewritten at the start of every sampling call) and the step index is a
+// device counter advanced by step_advance_kernel: the kernels of a denoising step therefore take the same arguments
+// at every step, which is what lets the whole step be replayed from a hipGraph.
+struct SamplerRun {
+    const float* noise;  // (n_steps, B, C, H, W) NCHW standard normals in execution order, or null -> Philox
+    unsigned long long seed, tile0;
     float lo, hi;
-    int do_clamp;
-    unsigned long long seed;
-    unsigned draw;
-    unsigned long long tile0;
+    int do_clamp, n_steps;
+    const float* tab[6];  // per-step coefficient tables (device), meaning depends on the sampler
 };
+struct StepArgs {
+    const float* x0;   // network output
+    const float* img;  // x_t
+    const float* lms;
+    float* out;        // x_{t-1}
+    int B, C, HW;
+    const SamplerRun* run;
+    const int* step;
+};
+__global__ void step_advance_kernel(int* step) { *step += 1; }
 
 // DDPM p_sample (:418-442, 346-415, 316-325): x0c = clamp(x0 + lms) - lms; out = c1*x0c + c2*img + c3*z
-// with c1/c2 = posterior_mean_coef1/2[t], c3 = [t != 0] * exp(0.5 * posterior_log_variance_clipped[t]).
+// with c1/c2 = posterior_mean_coef1/2[t] (tab 0/1), c3 = [t != 0] * exp(0.5 * posterior_log_variance_clipped[t]) (tab 2).
 __global__ void ddpm_step_kernel(StepArgs a) {
 #pragma clang fp contract(off)
+    const SamplerRun r = *a.run;
+    const int k = *a.step;
+    const float c1 = r.tab[0][k], c2 = r.tab[1][k], c3 = r.tab[2][k];
     const size_t total = (size_t)a.B * a.HW * a.C;
+    const float* noise = r.noise ? r.noise + (size_t)k * total : nullptr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % a.C);
         const size_t p = (i / a.C) % a.HW;
         const size_t b = i / ((size_t)a.C * a.HW);
         float x0 = a.x0[i];
-        if (a.do_clamp) {
+        if (r.do_clamp) {
             const float l = a.lms[i];
-            x0 = fminf(fmaxf(x0 + l, a.lo), a.hi) - l;
+            x0 = fminf(fmaxf(x0 + l, r.lo), r.hi) - l;
         }
         const size_t e = (b * a.C + c) * a.HW + p;
-        const float z = a.noise ? a.noise[e] : philox_normal(a.seed, a.draw, (a.tile0 * a.C * a.HW) + e);
-        const float mean = a.c1 * x0 + a.c2 * a.img[i];
-        a.out[i] = mean + a.c3 * z;
+        const float z = noise ? noise[e] : philox_normal(r.seed, (unsigned)(k + 1), (r.tile0 * a.C * a.HW) + e);
+        const float mean = c1 * x0 + c2 * a.img[i];
+        a.out[i] = mean + c3 * z;
     }
 }
 
-// DDIM step (:594-621), eta = 0 path generalised: eps = (c1*img - x0)/c2 ; out = sqrt(ap)*x0 + c3*eps + c4*z
-struct DdimArgs {
-    const float* x0;
-    const float* img;
-    const float* lms;
-    const float* noise;
-    float* out;
-    int B, C, HW;
-    float sqrt_recip, sqrt_recipm1, sqrt_ap, dir_coef, sigma;
-    float lo, hi;
-    int do_clamp;
-    unsigned long long seed;
-    unsigned draw;
-    unsigned long long tile0;
-};
-__global__ void ddim_step_kernel(DdimArgs a) {
+// DDIM step (:594-621): eps = (sqrt_recip*img - x0)/sqrt_recipm1 ; out = sqrt(ap)*x0 + dir*eps + sigma*z
+// tables: 0 sqrt_recip, 1 sqrt_recipm1, 2 sqrt(alphas_cumprod_prev), 3 sqrt(1 - ap - sigma^2), 4 [j != 0]*sigma.
+__global__ void ddim_step_kernel(StepArgs a) {
 #pragma clang fp contract(off)
+    const SamplerRun r = *a.run;
+    const int k = *a.step;
+    const float sqrt_recip = r.tab[0][k], sqrt_recipm1 = r.tab[1][k], sqrt_ap = r.tab[2][k], dir_coef = r.tab[3][k], sigma = r.tab[4][k];
     const size_t total = (size_t)a.B * a.HW * a.C;
+    const float* noise = r.noise ? r.noise + (size_t)k * total : nullptr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % a.C);
         const size_t p = (i / a.C) % a.HW;
         const size_t b = i / ((size_t)a.C * a.HW);
         float x0 = a.x0[i];
-        if (a.do_clamp) {
+        if (r.do_clamp) {
             const float l = a.lms[i];
-            x0 = fminf(fmaxf(x0 + l, a.lo), a.hi) - l;
+            x0 = fminf(fmaxf(x0 + l, r.lo), r.hi) - l;
         }
         const float img = a.img[i];
-        const float eps = (a.sqrt_recip * img - x0) / a.sqrt_recipm1;
-        float v = x0 * a.sqrt_ap + a.dir_coef * eps;
-        if (a.sigma != 0.f) {
+        const float eps = (sqrt_recip * img - x0) / sqrt_recipm1;
+        float v = x0 * sqrt_ap + dir_coef * eps;
+        if (sigma != 0.f) {
             const size_t e = (b * a.C + c) * a.HW + p;
-            const float z = a.noise ? a.noise[e] : philox_normal(a.seed, a.draw, (a.tile0 * a.C * a.HW) + e);
-            v += a.sigma * z;
+            const float z = noise ? noise[e] : philox_normal(r.seed, (unsigned)(k + 1), (r.tile0 * a.C * a.HW) + e);
+            v += sigma * z;
         }
         a.out[i] = v;
     }

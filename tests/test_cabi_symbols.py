@@ -1,0 +1,41 @@
+"""The gfx950 library must build without a GPU, load, and export every entry point include/ddif.h declares
+(no compute calls here: that is what the -m gpu tests do)."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "dif-pan_amd")
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "ddif.h")).read()
+    return sorted(set(re.findall(r"DDIF_API\s+[\w\s\*]+?\b(ddif_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_documented_surface():
+    names = _declared()
+    for must in ("ddif_net_create", "ddif_net_load", "ddif_net_commit", "ddif_plan_create", "ddif_plan_set_cond",
+                 "ddif_plan_forward", "ddif_plan_sample_ddpm", "ddif_plan_sample_ddim", "ddif_plan_sample_dpmpp",
+                 "ddif_plan_q_sample_forward", "ddif_last_error"):
+        assert must in names
+
+
+def test_gfx950_library_builds_loads_and_exports_every_symbol():
+    subprocess.run(["make", "-C", PKG, "-j8", "all"], check=True, stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(PKG, "lib", "libddif.so"))
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in include/ddif.h but not exported by libddif.so"
+    lib.ddif_is_emulated.restype = ctypes.c_int
+    assert lib.ddif_is_emulated() == 0
+    lib.ddif_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.ddif_version()
+
+
+def test_product_loader_never_picks_the_emulated_build():
+    from ddif import runtime
+
+    assert runtime.DEFAULT_LIB.endswith(os.path.join("lib", "libddif.so"))
+    src = open(runtime.__file__).read()
+    assert "libddif_emu" not in src  # the emulated build is only ever named by tests/
