@@ -28,7 +28,7 @@ int fail(int code, const char* fmt, ...);
     } while (0)
 
 // conv prologue applied while staging the input tile (kernels_conv.h)
-enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_COLSM = 3 };
+enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_COLSM = 3, PRO_GN_DW = 4 };
 
 enum LayerKind { L_STEM, L_ENC, L_DOWN, L_MID, L_DEC, L_UP };
 

@@ -13,11 +13,11 @@ template <int KS, int S, int U, int CK, int PRO, int VEC>
 ConvVariant variant_for_cfg(int cfg) {
     ConvVariant v;
     switch (cfg) {
-        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1>(); v.th = 8; v.tw = 16; v.nt = 32; break;
-        case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2>(); v.th = 8; v.tw = 16; v.nt = 64; break;
-        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2>(); v.th = 8; v.tw = 8; v.nt = 64; break;
-        case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4>(); v.th = 8; v.tw = 8; v.nt = 128; break;
-        case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, 2>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, 2>(); v.th = 8; v.tw = 16; v.nt = 32; v.groups = 2; break;
+        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, 1, PRO>(); v.th = 8; v.tw = 16; v.nt = 32; break;
+        case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, 1, PRO>(); v.th = 8; v.tw = 16; v.nt = 64; break;
+        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, 1, PRO>(); v.th = 8; v.tw = 8; v.nt = 64; break;
+        case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, 1, PRO>(); v.th = 8; v.tw = 8; v.nt = 128; break;
+        case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, 2>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, 2, PRO>(); v.th = 8; v.tw = 16; v.nt = 32; v.groups = 2; break;
         default: break;
     }
     return v;
@@ -48,6 +48,7 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
         else if (ck == 32 && pro == PRO_GN) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN, 1>(cfg); v.name = "conv1x1_gn"; }
         else if (ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_SILU, 1>(cfg); v.name = "conv1x1_gn_silu"; }
         else if (ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1>(cfg); v.name = "conv1x1_colsoftmax"; }
+        else if (ck == 32 && pro == PRO_GN_DW && cfg < 4) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_DW, 1>(cfg); v.name = "conv1x1_gn_dw3x3"; }
     }
     return v;
 }
@@ -135,7 +136,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 == 0 && c1 % 4 == 0) ? 1 : 0;
     const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
-    if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
+    if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
     if (int e = alloc_tensor(out, pc.cout, Hout, Wout)) return e;
     ConvArgs a{};
@@ -153,6 +154,9 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.w_bstride = s.w_bstride;
     a.cs_mx = s.cs_mx;
     a.cs_sm = s.cs_sm;
+    a.dw_w = s.dw_w;
+    a.out_xn = s.out_xn;
+    if (s.pro == PRO_GN_DW && (!s.dw_w || c0 + c1 > 256)) return fail(DDIF_ERR_INVALID, "%s: depthwise staging needs weights and <= 256 channels", s.name);
     if (s.pro == PRO_COLSM && (!s.cs_mx || !s.cs_sm || c0 % pc.ck != 0)) return fail(DDIF_ERR_INVALID, "%s: column-softmax prologue needs statistics and c0 %% %d == 0", s.name, pc.ck);
     a.n_chunks = pc.n_chunks;
     a.bias = s.use_bias ? pc.bias : nullptr;
@@ -508,44 +512,61 @@ int Plan::build() {
         }
         // ---- per step
         Tensor dwq, xn, q, o, amix, f1, f2, f3;
-        DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl));
         DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl));
-        {
-            DwArgs a{};
-            a.in0 = cur.p;
-            a.c0 = cur.C;
-            a.in1 = skip.p;
-            a.c1 = skip.C;
-            a.B = B;
-            a.H = Hl;
-            a.W = Wl;
-            a.st0 = cur.st;
-            a.np0 = cur.np;
-            a.st1 = skip.st;
-            a.np1 = skip.np;
-            if (!a.st0 || !a.st1) return fail(DDIF_ERR_STATE, "%s: prenorm without producer statistics", ci.c_str());
-            a.gamma = V(ci + ".prenorm_x.weight");
-            a.beta = V(ci + ".prenorm_x.bias");
-            a.w = V(ci + ".q.0.weight");
-            if (!a.gamma || !a.beta || !a.w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
-            a.out_dw = dwq.p;
-            a.out_xn = xn.p;
-            a.tiles_x = (Wl + 15) / 16;
-            a.tiles_y = (Hl + 7) / 8;
-            a.use_gn = 1;
-            Op op;
-            op.name = "q.gn_dw3x3";
-            op.flop = 2.0 * 9 * B * Hl * Wl * fea;
-            op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
-            op.run = [a, BB](hipStream_t s, const StepCtx&) {
-                hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
-            };
-            step.push_back(std::move(op));
-        }
-        {
+        const PackedConv* pq1 = PC(ci + ".q.1");
+        if (!pq1) return fail(DDIF_ERR_MISSING, "%s.q.1 missing", ci.c_str());
+        if (!cur.st || !skip.st) return fail(DDIF_ERR_STATE, "%s: prenorm without producer statistics", ci.c_str());
+        const float *pn_g = V(ci + ".prenorm_x.weight"), *pn_b = V(ci + ".prenorm_x.bias"), *q0w = V(ci + ".q.0.weight");
+        if (!pn_g || !pn_b || !q0w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
+        static const bool no_dw_fuse = getenv("DDIF_NO_DW_FUSE") != nullptr;
+        const bool dwfuse = !no_dw_fuse && pq1->ck == 32 && cur.C % 4 == 0 && skip.C % 4 == 0 && fea <= 256;
+        if (dwfuse) {
+            // q = q.1(depthwise3x3(GroupNorm(cat[h, skip]))) in ONE kernel; also emits xn (sr3_dwt.py:507-513,537,540)
             ConvSpec s;
-            s.pc = PC(ci + ".q.1");
-            if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.q.1 missing", ci.c_str());
+            s.pc = pq1;
+            s.in0 = cur;
+            s.in1 = skip;
+            s.pro = PRO_GN_DW;
+            s.gamma = pn_g;
+            s.beta = pn_b;
+            s.dw_w = q0w;
+            s.out_xn = xn.p;
+            s.name = "q = 1x1(dw3x3(GN(cat)))";
+            DDIF_TRY(add_conv(step, s, &q));
+        } else {
+            DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl));
+            {
+                DwArgs a{};
+                a.in0 = cur.p;
+                a.c0 = cur.C;
+                a.in1 = skip.p;
+                a.c1 = skip.C;
+                a.B = B;
+                a.H = Hl;
+                a.W = Wl;
+                a.st0 = cur.st;
+                a.np0 = cur.np;
+                a.st1 = skip.st;
+                a.np1 = skip.np;
+                a.gamma = pn_g;
+                a.beta = pn_b;
+                a.w = q0w;
+                a.out_dw = dwq.p;
+                a.out_xn = xn.p;
+                a.tiles_x = (Wl + 15) / 16;
+                a.tiles_y = (Hl + 7) / 8;
+                a.use_gn = 1;
+                Op op;
+                op.name = "q.gn_dw3x3";
+                op.flop = 2.0 * 9 * B * Hl * Wl * fea;
+                op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
+                op.run = [a, BB](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+                };
+                step.push_back(std::move(op));
+            }
+            ConvSpec s;
+            s.pc = pq1;
             s.in0 = dwq;
             s.name = "q.1x1";
             DDIF_TRY(add_conv(step, s, &q));

@@ -53,6 +53,8 @@ struct ConvSpec {
     long long w_bstride = 0;
     const float* cs_mx = nullptr;       // PRO_COLSM statistics of in0
     const float* cs_sm = nullptr;
+    const float* dw_w = nullptr;        // PRO_GN_DW: depthwise weights [9][C]
+    float* out_xn = nullptr;            // PRO_GN_DW: normalised input written out
     bool silu = false;
     bool stats = false;
     const char* name = "conv";

@@ -57,6 +57,8 @@ struct ConvArgs {
     long long w_bstride;     // floats between the packed weights of consecutive samples (0: shared weights)
     const float* cs_mx;      // PRO_COLSM: column-softmax max / sum of source 0, [B][Win][c0]
     const float* cs_sm;
+    const float* dw_w;       // PRO_GN_DW: depthwise 3x3 weights [9][c0 + c1] applied to the normalised input
+    float* out_xn;           // PRO_GN_DW: the normalised input itself, [B,H,W,c0+c1] (consumed by attn_res) or null
     long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
 };
 
@@ -77,7 +79,16 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     constexpr int C4 = CK / 4;
     constexpr int NF = TAPS * K8;                         // (tap, k8) steps per chunk
     constexpr int ABUF = IH * IW * LDA;                   // floats per LDS buffer
-    constexpr int NITEMS = (IH * IW * C4 + 255) / 256;    // float4 input-staging items per thread and chunk
+    // PRO_GN_DW (1x1 conv over depthwise3x3(GroupNorm(x))): the LOAD tile has a one-pixel halo and goes to a scratch
+    // LDS region; the depthwise conv turns it into the A tile of the 1x1 contraction.
+    constexpr bool DWM = (PRO == PRO_GN_DW);
+    static_assert(!DWM || (KS == 1 && STRIDE == 1 && !UPS && VEC), "depthwise staging is for plain 1x1 convs");
+    constexpr int LPAD = DWM ? 1 : PAD;
+    constexpr int LH = DWM ? TH + 2 : IH, LW = DWM ? TW + 2 : IW;   // extent of the loaded tile
+    constexpr int HBUF = DWM ? LH * LW * LDA : 0;                  // scratch for the normalised halo tile
+    constexpr int DWMAX = DWM ? 9 * 256 : 0;                       // depthwise weights of up to 256 channels
+    constexpr int DITEMS = (TH * TW * C4 + 255) / 256;
+    constexpr int NITEMS = (LH * LW * C4 + 255) / 256;    // float4 input-staging items per thread and chunk
     constexpr int WBUF = NB * WN * NF * 256;              // floats of one weight chunk (all n-blocks of the cout tile)
     constexpr int WITEMS = (WBUF / 4 + 255) / 256;        // float4 weight-staging items per thread and chunk
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
@@ -86,12 +97,14 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
 
     DDIF_DYN_SMEM(smem_all);
-    constexpr size_t GSZ = (size_t)2 * (ABUF + WBUF) * sizeof(float) + 16 * sizeof(double);  // LDS bytes per group
+    constexpr size_t GSZ = (size_t)(2 * (ABUF + WBUF) + HBUF + DWMAX) * sizeof(float) + 16 * sizeof(double);  // LDS bytes per group
     const int grp = GROUPS == 1 ? 0 : (int)(threadIdx.x >> 8);
     char* smem = smem_all + grp * GSZ;
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
     float* Ws = As + 2 * ABUF;                    // [2][WBUF]  weight chunk in B-fragment order
     double* red = reinterpret_cast<double*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float));  // [2][8]
+    float* Hs = reinterpret_cast<float*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float) + 16 * sizeof(double));  // [HBUF]
+    float* DWs = Hs + HBUF;                                                                                      // [9][Ctot]
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // group-local thread / wave index
     const int wm = wave / WN, wn = wave % WN;
@@ -122,10 +135,10 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) {
         const int pixr = (tid + it * 256) / C4;
-        const bool in = pixr < IH * IW;
-        const int pix = in ? pixr : IH * IW - 1;
-        a_py[it] = pix / IW;
-        a_px[it] = pix % IW;
+        const bool in = pixr < LH * LW;
+        const int pix = in ? pixr : LH * LW - 1;
+        a_py[it] = pix / LW;
+        a_px[it] = pix % LW;
         a_lds[it] = pix * LDA + c4 * 4;
         a_in |= (in ? 1u : 0u) << it;
     }
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     int l_cs[NITEMS];   // PRO_COLSM: (b * Win + x) of the item, index into the column-softmax statistics
     unsigned l_ok = 0;  // which of them are real (inside the image): zero padding otherwise
     auto item_geometry = [&]() {
-        const int iy0 = L.oy0 * STRIDE - PAD, ix0 = L.ox0 * STRIDE - PAD;
+        const int iy0 = L.oy0 * STRIDE - LPAD, ix0 = L.ox0 * STRIDE - LPAD;
         l_ok = 0;
 #pragma unroll
         for (int it = 0; it < NITEMS; ++it) {
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
             if (ABL & 8) R.wv[it] = make_float4(0.01f, 0.02f, 0.03f, 0.04f);
             else R.wv[it] = *reinterpret_cast<const float4*>(wbase + w_goff[it]);
         }
-        if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
+        if (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = cbase + i < Ctot ? cbase + i : Ctot - 1;
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         float* dst = As + buf * ABUF;
         float* wdst = Ws + buf * WBUF;
         float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
+        if (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW) {
             if (R.pos.b != gn_b) {  // workgroup-uniform; every wavefront reduces the partials itself (no barrier)
                 gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
                 gn_b = R.pos.b;
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float x = (&R.sv[it].x)[i];
-                if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
+                if (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW) {
                     x = fmaf(x, ga[i], gb[i]);
                     if (PRO == PRO_GN_SILU) x = dd_silu(x);
                 }
@@ -309,11 +322,92 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
                 }
                 v[i] = (ok && cok[i]) ? x : 0.f;  // zero padding comes AFTER the activation
             }
-            if ((a_in >> it) & 1u) *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+            if (DWM) {
+                if ((a_in >> it) & 1u) {
+                    *reinterpret_cast<float4*>(&Hs[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+                    // centre pixels inside the image: this IS xn = GroupNorm(cat[h, skip]) (attn_res input)
+                    if (a.out_xn && ok && cok[0] && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
+                        *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cbase) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                if ((a_in >> it) & 1u) *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (DWM) {
+            __syncthreads();  // halo tile complete in Hs
+            const int cb = R.cbase < Ctot ? R.cbase : 0;
+#pragma unroll
+            for (int it = 0; it < DITEMS; ++it) {
+                const int item = tid + it * 256;
+                const int p = item / C4;
+                if (p < TH * TW) {
+                    const int ty = p / TW, tx = p % TW;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float4 hv = *reinterpret_cast<const float4*>(&Hs[((ty + k / 3) * LW + tx + k % 3) * LDA + c4 * 4]);
+                        const float4 wk = *reinterpret_cast<const float4*>(&DWs[k * Ctot + cb]);
+                        s0 = fmaf(hv.x, wk.x, s0);
+                        s1 = fmaf(hv.y, wk.y, s1);
+                        s2 = fmaf(hv.z, wk.z, s2);
+                        s3 = fmaf(hv.w, wk.w, s3);
+                    }
+                    *reinterpret_cast<float4*>(&dst[p * LDA + c4 * 4]) = make_float4(s0, s1, s2, s3);
+                }
+            }
         }
 #pragma unroll
         for (int it = 0; it < WITEMS; ++it)
             if ((w_in >> it) & 1u) *reinterpret_cast<float4*>(&wdst[w_lds[it]]) = R.wv[it];
+        bufpos[buf] = R.pos;
+        bufch[buf] = R.ch;
+    };
+
+    // ---- the same staging work as finish_stage(), cut into pieces that h1 interleaves BETWEEN the MFMA groups of the
+    //      running stage (MFMA issue is asynchronous: the wave keeps issuing these VALU / ds_write instructions while
+    //      the matrix pipe works), so a wave overlaps its own staging with its own MFMAs.  Not used for PRO_GN_DW.
+    float pga[4], pgb[4];
+    bool pcok[4];
+    auto finish_prepare = [&](StageRegs& R) {
+        if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
+            if (R.pos.b != gn_b) {
+                gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
+                gn_b = R.pos.b;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pga[i] = R.gq[i] * rstd;
+                pgb[i] = R.bq[i] - mean * pga[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pcok[i] = R.cbase + i < Ctot;
+    };
+    auto finish_piece = [&](StageRegs& R, int buf, int piece) {  // piece: 0..NITEMS-1 input items, then weight items
+        if (piece < NITEMS) {
+            const int it = piece;
+            const bool ok = (R.ok >> it) & 1u;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x = (&R.sv[it].x)[i];
+                if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
+                    x = fmaf(x, pga[i], pgb[i]);
+                    if (PRO == PRO_GN_SILU) x = dd_silu(x);
+                }
+                if (PRO == PRO_COLSM) {
+                    if (R.cbase < a.c0) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
+                }
+                v[i] = (ok && pcok[i]) ? x : 0.f;
+            }
+            if ((a_in >> it) & 1u) *reinterpret_cast<float4*>(&As[buf * ABUF + a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (piece < NITEMS + WITEMS) {
+            const int it = piece - NITEMS;
+            if ((w_in >> it) & 1u) *reinterpret_cast<float4*>(&Ws[buf * WBUF + w_lds[it]]) = R.wv[it];
+        }
+    };
+    auto finish_commit = [&](StageRegs& R, int buf) {
         bufpos[buf] = R.pos;
         bufch[buf] = R.ch;
     };
@@ -349,7 +443,9 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     bool last = false;
     float e_bias[NB], e_tb[NB];
     float e_res[MB][NB][16];
-    auto h1 = [&](int flat, int cur, StageRegs& Rf) {
+    constexpr bool INTERLEAVE = false;  // measured slower (the pieces drag vmcnt/lgkmcnt waits into the MFMA loop); kept for A/B
+    constexpr int PPF = (NITEMS + WITEMS + NF - 1) / NF;  // staging pieces per (tap, k8) step
+    auto h1 = [&](int flat, int cur, StageRegs& Rn, StageRegs& Rf) {
         const float* Ac = As + cur * ABUF;
         Cp = bufpos[cur];
         c_ch = bufch[cur];
@@ -391,7 +487,11 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
         }
-        // (3) contraction over taps x chunk channels: A and B fragments both from LDS, no global load in here
+        // (3) contraction over taps x chunk channels: A and B fragments both from LDS, no global load in here;
+        //     stage flat+1 (register set Rn, loaded one step ago) is written to the OTHER LDS buffer piece by piece
+        //     between the MFMA groups
+        const bool stage_next = INTERLEAVE && (flat + 1 < nflat) && !(ABL & 32);
+        if (stage_next) finish_prepare(Rn);
         const float* Wc = Ws + cur * WBUF + (wn * NB) * (NF * 256) + h * 128 + j * 4;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -410,11 +510,16 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
                     for (int nb = 0; nb < NB; ++nb)
                         if (ABL & 1) acc[mb][nb][i] += (&af[mb].x)[i] * (&bf[nb].x)[i];
                         else acc[mb][nb] = DDIF_MFMA_32x32x2((&af[mb].x)[i], (&bf[nb].x)[i], acc[mb][nb]);
+            if (stage_next) {
+#pragma unroll
+                for (int pp = 0; pp < PPF; ++pp) finish_piece(Rn, cur ^ 1, f * PPF + pp);
+            }
         }
+        if (stage_next) finish_commit(Rn, cur ^ 1);
         stamp();
     };
     auto h2 = [&](int flat, int cur, StageRegs& Rn) {
-        if (last) {
+        if (last && !(ABL & 64)) {
             // (4) epilogue of work item Cp.  Addresses = tile base + compile-time pixel offsets; bounds are only
             //     checked for tiles that stick out of the image.
             float s1 = 0.f, s2 = 0.f;
@@ -463,10 +568,15 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         }
         stamp();
         // (5) stage flat+1 (loaded one step ago) -> the other LDS buffer
-        if (flat + 1 < nflat) finish_stage(Rn, cur ^ 1);
+        if (!INTERLEAVE && flat + 1 < nflat && !(ABL & 32)) finish_stage(Rn, cur ^ 1);
+        if ((ABL & 32) && flat + 1 < nflat) finish_commit(Rn, cur ^ 1);
         stamp();
     };
 
+    if (DWM) {
+        for (int i = tid; i < 9 * Ctot; i += 256) DWs[i] = a.dw_w[i];
+        __syncthreads();
+    }
     if (nflat > 0) {
         item_geometry();
         issue_loads(R0);
@@ -477,11 +587,11 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     stamp();
     if (GROUPS == 1) {
         for (int flat = 0; flat < nflat; flat += 2) {
-            h1(flat, 0, R0);
+            h1(flat, 0, R1, R0);
             h2(flat, 0, R1);
             __syncthreads();
             if (flat + 1 < nflat) {
-                h1(flat + 1, 1, R1);
+                h1(flat + 1, 1, R0, R1);
                 h2(flat + 1, 1, R0);
                 __syncthreads();
             }
@@ -496,8 +606,8 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         for (int ph = 0; ph < nphase; ++ph) {
             if (flat < nflat) {
                 if (((ph + grp) & 1) == 0) {
-                    if (flat & 1) h1(flat, 1, R1);
-                    else h1(flat, 0, R0);
+                    if (flat & 1) h1(flat, 1, R0, R1);
+                    else h1(flat, 0, R1, R0);
                 } else if (ph >= grp + 1) {
                     if (flat & 1) h2(flat, 1, R0);
                     else h2(flat, 0, R1);
@@ -511,10 +621,11 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 }
 
 
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int GROUPS = 1>
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int GROUPS = 1, int PRO = 0>
 constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per 4-wave group = NB * WN
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    return GROUPS * ((size_t)2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) * sizeof(float) + 16 * sizeof(double));
+    constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
+    return GROUPS * ((size_t)(2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) + dw) * sizeof(float) + 16 * sizeof(double));
 }
 
 }  // namespace ddif

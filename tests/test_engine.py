@@ -1,0 +1,74 @@
+"""Host-side engine pieces (CPU) and the test_fn mirror (GPU): cond assembly, Haar identities, tiling."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from ddif import diffusion_engine as E
+from ddif.synth import synth_tiles
+
+
+def test_haar_identities():
+    """PyWavelets is not installed in the build image, so the level-1 db1 analysis is pinned by its defining
+    identities and the documented example pywt.dwt([1,2,3,4], 'db1') = ([2.1213, 4.9497], [-0.7071, -0.7071])."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 8, 12, generator=g)
+    ll, (ch, cv, cd) = E.haar_dwt2(x)
+    assert ll.shape == (2, 3, 4, 6)
+    # orthonormal: energy is preserved
+    e = (ll ** 2 + ch ** 2 + cv ** 2 + cd ** 2).sum()
+    assert abs(float(e) - float((x ** 2).sum())) < 1e-3
+    # constant image: only LL (= 2 * value); row ramp: detail along the rows axis only
+    c = torch.full((1, 1, 4, 4), 0.25)
+    ll, (ch, cv, cd) = E.haar_dwt2(c)
+    assert torch.allclose(ll, torch.full_like(ll, 0.5)) and float(ch.abs().max() + cv.abs().max() + cd.abs().max()) == 0
+    ramp = torch.arange(4.0).view(1, 1, 4, 1).expand(1, 1, 4, 4)
+    _, (ch, cv, cd) = E.haar_dwt2(ramp)
+    assert torch.allclose(ch, torch.full_like(ch, -1.0)) and float(cv.abs().max() + cd.abs().max()) == 0
+    # 1-D example from the PyWavelets documentation, as the separable row transform of a 1x4 signal repeated on 2 rows
+    s = torch.tensor([[1.0, 2.0, 3.0, 4.0]]).repeat(2, 1).view(1, 1, 2, 4)
+    ll, (ch, cv, cd) = E.haar_dwt2(s)
+    assert torch.allclose(ll.flatten() / 2 ** 0.5, torch.tensor([2.1213, 4.9497]), atol=1e-4)
+    assert torch.allclose(cv.flatten() / 2 ** 0.5, torch.tensor([-0.7071, -0.7071]), atol=1e-4)
+
+
+def test_assemble_cond_matches_the_fixture_generator():
+    t = synth_tiles(2, 8, 1, 16, 16, seed=3)
+    cond = E.assemble_cond(t["lms"], t["pan"], None, "wv3")
+    assert cond.shape == (2, 20, 16, 16)
+    assert torch.equal(cond, t["cond"])
+    hs = synth_tiles(1, 31, 3, 16, 16, seed=4, order="hisr")
+    assert torch.equal(E.assemble_cond(hs["lms"], hs["pan"], None, "cave"), hs["cond"])
+
+
+def test_engine_google_refuses_loudly():
+    from ddif import DdifError
+
+    with pytest.raises(DdifError, match="backward"):
+        E.engine_google("train.h5", "valid.h5", dataset_name="wv3")
+
+
+@pytest.mark.gpu
+def test_test_fn_on_in_memory_set():
+    from ddif_testlib import use_gpu_library
+    from oracle import ddif_oracle as O
+
+    use_gpu_library()
+    ds, N, H = "gf2", 3, 16
+    t = gc.tiles_for(ds, N, H, H, seed=8)
+    div = 1023.0
+    data = dict(lms=(t["lms"] * div).numpy(), pan=(t["pan"] * div).numpy(), gt=(t["gt"] * div).numpy())
+    out = E.test_fn(None, None, batch_size=2, n_steps=50, device="cuda:0", dataset_name=ds, division=div, data=data,
+                    state_dict=gc.weights_for(ds), seed=5)
+    assert out["sr"].shape == (N, 4, H, H) and len(out["psnr"]) == 2
+    assert float(out["sr"].min()) >= 0 and float(out["sr"].max()) <= div
+    # same job through the oracle for the first batch (ddim25 from T=50; eta = 0 -> only x_T is random)
+    torch.manual_seed(5)
+    xT = torch.randn(2, 4, H, H, device="cuda:0").cpu()
+    it = iter([xT] + [torch.zeros(2, 4, H, H)] * 25)
+    cond = t["cond"][:2]
+    with torch.no_grad():
+        ref, _ = O.ddim_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, O.schedule_tables(O.cosine_betas(50)), "ddim25",
+                               noise_fn=lambda s: next(it))
+    ref_sr = ((ref + cond[:, :4]).clip(0, 1) * div).numpy()
+    assert float(np.abs(out["sr"][:2] - ref_sr).max()) <= 1e-4 * div
