@@ -136,6 +136,7 @@ def main():
     value = mp_per_step * args.steps / dt
     ach_tflops = prof["total_flop"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] > 0 else 0.0
     step_flop_total = cost["step_flop"] * T + cost["cond_flop"]
+    traffic, traffic_src = committed_traffic()
     result = {
         "metric": "fused megapixels/sec at T=%d, WV3 64x64x8 tiles" % T,
         "value": value,
@@ -157,7 +158,10 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "bytes of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)",
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": (prof["total_bytes"] / prof["launches"]) if prof["launches"] else None,
             "kernel": prof["kernel"],
             "launches_timed": prof["launches"],
             "avg_launch_us": (prof["total_ms"] * 1e3 / prof["launches"]) if prof["launches"] else None,
@@ -176,6 +180,22 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel class.  PMC counters need their own rocprofv3 passes (they cannot
+    be collected from inside this process), so this reads the newest summary committed under profiles/ -- produced
+    from the same `bench.py` command by tools/gpu_full.sh + tools/pmc_traffic.py -- and reports null when none exists."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            return float(json.load(f)["class_hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def usable_cpus():

@@ -65,7 +65,11 @@ int main(int argc, char** argv) {
         SHAPE_A(0, 2); SHAPE_A(14, 2); SHAPE_A(15, 2); SHAPE_A(1, 2);
         return 0;
     }
-    SHAPE_A(0, 2); SHAPE_A(14, 2); SHAPE_A(15, 2); SHAPE_A(46, 2); SHAPE_A(110, 2); SHAPE_A(110, 1); SHAPE_A(110, 3);
+    SHAPE_A(0, 2); SHAPE_A(14, 2);
+    run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,MB2)", B, 64, 64, 32, 32, 1);
+    run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 14>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,MB2)", B, 64, 64, 32, 32, 1);
+    run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (16x16,NT32,MB2)", B, 32, 32, 64, 64, 1);
+    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 2, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (8x16,NT64)", B, 32, 32, 64, 64, 1);
 #define SHAPE_A2(ABL) run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, ABL, 2>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) PINGPONG", B, 64, 64, 32, 32, 1)
     SHAPE_A2(0); SHAPE_A2(14); SHAPE_A2(15);
 #define SHAPE_B2(ABL) run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, ABL, 2>("3x3 gn_silu 64->64 @32^2 (8x16,NT32) PINGPONG", B, 32, 32, 64, 64, 1)
