@@ -9,16 +9,23 @@ namespace ddif {
 
 // ------------------------------------------------------------------------------------------------ conv variants
 namespace {
-template <int KS, int S, int U, int CK, int PRO, int VEC>
+// cfg: 0 = 8x16 pixels x 32 couts, 1 = 8x16 x 64, 3 = 8x16 x 128 (1x1 convs only: a wide cout tile stages -- and for
+// PRO_GN_DW recomputes -- the input once instead of once per 32 couts), 2 = 8x8 x 64, 4 = 8x8 x 128 (1x1 only)
+template <int KS, int S, int U, int CK, int PRO, int VEC, int EPI = 0>
 ConvVariant variant_for_cfg(int cfg) {
     ConvVariant v;
     switch (cfg) {
-        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, 1, PRO>(); v.th = 8; v.tw = 16; v.nt = 32; break;
-        case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, 1, PRO>(); v.th = 8; v.tw = 16; v.nt = 64; break;
-        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, 1, PRO>(); v.th = 8; v.tw = 8; v.nt = 64; break;
-        case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, 1, PRO>(); v.th = 8; v.tw = 8; v.nt = 128; break;
-        case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, 2>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, 2, PRO>(); v.th = 8; v.tw = 16; v.nt = 32; v.groups = 2; break;
+        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO>(); v.th = 8; v.tw = 16; v.nt = 32; break;
+        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO>(); v.th = 8; v.tw = 8; v.nt = 64; break;
         default: break;
+    }
+    if constexpr (KS == 1 && VEC == 1) {
+        switch (cfg) {
+            case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, PRO>(); v.th = 8; v.tw = 16; v.nt = 64; break;
+            case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 4, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 4, PRO>(); v.th = 8; v.tw = 16; v.nt = 128; break;
+            case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO>(); v.th = 8; v.tw = 8; v.nt = 128; break;
+            default: break;
+        }
     }
     return v;
 }
@@ -30,16 +37,35 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 
 // vec = 1: every source channel count is a multiple of 4 (float4 staging).  The scalar-staging variants exist only for
 // the prologue-free 3x3 / 1x1 kernels (stem with C = 31, cond convs with 9 / 11 / 34 / 40 input channels).
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec) {
+// epi: EPI_* bits (kernels_conv.h) -- FiLM (CondInjection.x_conv), scalar output path (Cout % 4 != 0), residual add.
+// Only the combinations the network uses are instantiated.
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi) {
     ConvVariant v;
-    if (ks == 3 && ck == 16) {  // 3x3 convs always use 16-channel chunks
+    const bool plain = stride == 1 && !ups;
+    if (epi == EPI_FILM) {
+        if (ks == 1 && ck == 32 && vec && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
+    } else if (epi == EPI_SOUT) {
+        if (ks == 3 && ck == 16 && vec && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_SOUT>(cfg); v.name = "conv3x3_gn_silu_sout"; }
+    } else if (epi == EPI_RES) {
+        if (!vec || !plain) return v;
+        if (ks == 3 && ck == 16 && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_RES>(cfg); v.name = "conv3x3_gn_silu_res"; }
+        else if (ks == 3 && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv3x3_res"; }
+        else if (ks == 1 && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv1x1_res"; }
+        else if (ks == 1 && ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1, EPI_RES>(cfg); v.name = "conv1x1_colsoftmax_res"; }
+    } else if (epi == EPI_TBS) {
+        if (ks == 3 && ck == 16 && vec && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_TBS>(cfg); v.name = "conv3x3_gn_silu_tbs"; }
+    } else if (epi == EPI_SILU) {
+        if (ks == 3 && ck == 16 && vec && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_SILU>(cfg); v.name = "conv3x3_silu"; }
+    } else if (epi != 0) {
+        return v;
+    } else if (ks == 3 && ck == 16) {  // 3x3 convs always use 16-channel chunks
         if (!vec) {
-            if (stride == 1 && !ups && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv3x3_scalar"; }
-        } else if (stride == 1 && !ups && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1>(cfg); v.name = "conv3x3_gn_silu"; }
-        else if (stride == 1 && !ups && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3"; }
+            if (plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv3x3_scalar"; }
+        } else if (plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1>(cfg); v.name = "conv3x3_gn_silu"; }
+        else if (plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3"; }
         else if (stride == 2 && !ups && pro == PRO_NONE) { v = variant_small_tiles<3, 2, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3_s2"; }
         else if (stride == 1 && ups && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 1, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3_up2"; }
-    } else if (ks == 1 && stride == 1 && !ups) {
+    } else if (ks == 1 && plain) {
         if (!vec) {
             if (ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 0>(cfg); v.name = "conv1x1_scalar"; }
             else if (ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv1x1_ck16_scalar"; }
@@ -48,20 +74,21 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
         else if (ck == 32 && pro == PRO_GN) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN, 1>(cfg); v.name = "conv1x1_gn"; }
         else if (ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_SILU, 1>(cfg); v.name = "conv1x1_gn_silu"; }
         else if (ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1>(cfg); v.name = "conv1x1_colsoftmax"; }
-        else if (ck == 32 && pro == PRO_GN_DW && cfg < 4) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_DW, 1>(cfg); v.name = "conv1x1_gn_dw3x3"; }
+        else if (ck == 32 && pro == PRO_GN_DW) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_DW, 1>(cfg); v.name = "conv1x1_gn_dw3x3"; }
     }
     return v;
 }
 
-static int pick_cfg(int stride, int Hout, int Wout, int Cout, int B) {
-    static const int force = [] { const char* e = getenv("DDIF_CONV_CFG"); return e ? atoi(e) : -1; }();
-    if (force >= 0 && !(stride == 2 && force < 2)) return force;
+static int pick_cfg(int ks, int vec, int stride, int Hout, int Wout, int Cout, int B) {
+    static const int wide1 = [] { const char* e = getenv("DDIF_CONV1_WIDE"); return e ? atoi(e) : 1; }();  // A/B switch
     const bool wide = (Wout >= 16) && stride == 1;
-    static const bool pingpong = [] { const char* e = getenv("DDIF_PINGPONG"); return e && atoi(e) != 0; }();  // measured slower, off
-    if (wide) return pingpong ? 4 : 0;  // 4: 512-thread workgroup, two anti-phase 4-wave groups (NT = 64 needs 102 KB of LDS per group: slower)
+    if (ks == 1 && vec && wide1) {
+        if (wide) return Cout > 64 ? 3 : (Cout > 32 ? 1 : 0);
+        return Cout > 64 ? 4 : 2;
+    }
+    if (wide) return 0;
     if (Cout <= 32 && stride == 1) return 0;
-    const long wgs128 = (long)B * ((Hout + 7) / 8) * ((Wout + 7) / 8) * ((Cout + 127) / 128);
-    return (Cout % 128 == 0 && wgs128 >= 1024) ? 3 : 2;
+    return 2;
 }
 
 static int num_cus() {
@@ -132,10 +159,11 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int c0 = s.in0.C, c1 = s.in1.C;
     if (c0 + c1 != pc.cin) return fail(DDIF_ERR_INVALID, "%s: input channels %d+%d != weight cin %d", s.name, c0, c1, pc.cin);
     if (pc.ks == 1 && (s.stride != 1 || s.ups)) return fail(DDIF_ERR_INVALID, "%s: 1x1 conv with stride/upsample", s.name);
-    const int cfg = pick_cfg(s.stride, Hout, Wout, pc.cout, B);
     const int vec = (c0 % 4 == 0 && c1 % 4 == 0) ? 1 : 0;
-    const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
-    if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec);
+    const int cfg = pick_cfg(pc.ks, vec, s.stride, Hout, Wout, pc.cout, B);
+    const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0);
+    const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
     if (int e = alloc_tensor(out, pc.cout, Hout, Wout)) return e;
@@ -159,7 +187,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     if (s.pro == PRO_GN_DW && (!s.dw_w || c0 + c1 > 256)) return fail(DDIF_ERR_INVALID, "%s: depthwise staging needs weights and <= 256 channels", s.name);
     if (s.pro == PRO_COLSM && (!s.cs_mx || !s.cs_sm || c0 % pc.ck != 0)) return fail(DDIF_ERR_INVALID, "%s: column-softmax prologue needs statistics and c0 %% %d == 0", s.name, pc.ck);
     a.n_chunks = pc.n_chunks;
-    a.bias = s.use_bias ? pc.bias : nullptr;
+    a.bias = (s.use_bias && pc.bias) ? pc.bias : zeros;
+    a.tbias = zeros;  // strides 0: a row of zeros for every sample and step
     a.st0 = s.in0.st;
     a.np0 = s.in0.np;
     a.st1 = s.in1.st;
@@ -168,7 +197,6 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.beta = s.beta;
     a.res = s.res;
     a.film = s.film;
-    a.act_silu = s.silu ? 1 : 0;
     a.out = out->p;
     a.tiles_x = (Wout + var.tw - 1) / var.tw;
     a.tiles_y = (Hout + var.th - 1) / var.th;
@@ -181,22 +209,38 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.n_ct = gy;
     // persistent launch: a few workgroups per CU, each walking a contiguous range of (cout tile, pixel tile) items
     const long nwork = (long)B * a.tiles_x * a.tiles_y * gy;
-    const long cap = (long)num_cus() * (var.groups == 2 ? 1 : wg_per_cu(var.smem));
-    const long want = (nwork + var.groups - 1) / var.groups;
-    const dim3 grid((unsigned)(want < cap ? want : cap), 1u);
-    const dim3 block((unsigned)(256 * var.groups));
-    if (var.smem > 64 * 1024) {
-        DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(var.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)var.smem));
+    const int gy0 = (pc.cout + var.nt - 1) / var.nt;
+    const size_t smem = var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
+    const long cap = (long)num_cus() * wg_per_cu(smem);
+    const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
+    const dim3 block(256u);
+    if (var.smem + 8192 > 64 * 1024) {  // the attribute is per kernel function: set it to the variant's maximum
+        DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(var.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(var.smem + 8192)));
+    }
+    if (smem > var.smem + 8192) return fail(DDIF_ERR_INVALID, "%s: %d input channels exceed the GroupNorm staging area", s.name, c0 + c1);
+    // convs with a time bias: in the samplers every sample shares the step's row (bias + row live in LDS); forward() /
+    // q_sample_forward with one t per sample use the EPI_TBS instantiation (rows loaded per work item)
+    ConvKernelFn fn_tbs = nullptr;
+    if (s.tb_off >= 0) {
+        const ConvVariant vt = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi | EPI_TBS);
+        if (!vt.fn || vt.smem != var.smem) return fail(DDIF_ERR_INVALID, "%s: no per-sample time-bias kernel variant", s.name);
+        fn_tbs = vt.fn;
+        if (var.smem + 8192 > 64 * 1024)
+            DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_tbs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(var.smem + 8192)));
     }
     const bool dyn = s.dyn_input;
     const bool self_c = net->cfg.self_condition != 0;
     const int tb_off = s.tb_off;
+    static const bool dump = getenv("DDIF_DUMP_PLAN") != nullptr;
+    if (dump)
+        fprintf(stderr, "[ddif plan] %-34s %-24s ks=%d s=%d u=%d  %3d+%3d -> %3d  @%3dx%-3d pro=%d epi=%d cfg=%d items=%ld grid=%u smem=%zu\n", s.name, var.name, pc.ks, s.stride,
+                s.ups, c0, c1, pc.cout, Hout, Wout, s.pro, epi, cfg, nwork, grid.x, smem);
     Op op;
     op.name = var.name;
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
     op.timed = (pc.ks == 3);
-    op.run = [a, var, grid, block, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
+    op.run = [a, var, fn_tbs, grid, block, smem, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
         ConvArgs aa = a;
         if (dyn) {
             if (self_c) {
@@ -212,7 +256,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
             aa.step_ptr = ctx.step_ptr;
             aa.tb_rowstride = ctx.tb_rowstride;
         }
-        hipLaunchKernelGGL(var.fn, grid, block, var.smem, st, aa);
+        hipLaunchKernelGGL((tb_off >= 0 && ctx.tb_stride != 0) ? fn_tbs : var.fn, grid, block, smem, st, aa);
     };
     prog.push_back(std::move(op));
     return 0;
@@ -247,6 +291,8 @@ int Plan::build() {
 #define DDIF_TRY(x) do { if (int e__ = (x)) return e__; } while (0)
 
     // ---- boundary staging + sampler state
+    DDIF_TRY(dalloc(&zeros, (size_t)1024));
+    DDIF_HIPCHK(hipMemset(zeros, 0, 1024 * sizeof(float)));
     DDIF_TRY(alloc_tensor(&x_in, c.in_channel, H, W));
     DDIF_TRY(alloc_tensor(&sc_in, c.out_channel, H, W));
     DDIF_TRY(alloc_tensor(&lms, C, H, W));

@@ -33,10 +33,10 @@ typedef void (*ConvKernelFn)(ConvArgs);
 struct ConvVariant {
     ConvKernelFn fn = nullptr;
     size_t smem = 0;
-    int th = 0, tw = 0, nt = 0, groups = 1;
+    int th = 0, tw = 0, nt = 0;
     const char* name = "";
 };
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec);
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi);
 
 struct ConvSpec {
     const PackedConv* pc = nullptr;
@@ -74,6 +74,7 @@ struct Plan {
     std::vector<Tensor> cenc, cdec;   // resized cond per level
     std::vector<int> LH, LW;          // level sizes
     Tensor x_in, sc_in, net_out;      // NHWC staging of the boundary tensors
+    float* zeros = nullptr;     // 4 KiB of 0.0f: stands in for absent conv biases / time-bias rows
     float* img[2] = {nullptr, nullptr};
     float* mbuf[3] = {nullptr, nullptr, nullptr};
     float* io_nchw = nullptr;         // scratch (B,C,H,W)

@@ -18,11 +18,19 @@
 //     an FMA loop, but 64 FLOP/clk/SIMD from one wave);
 //   * epilogue: + bias, + per-sample time bias, FiLM (1+scale)*y+shift, SiLU, + residual, store, and the
 //     per-(tile, cout-tile) {sum, sum^2} partials the NEXT GroupNorm needs (fp64, deterministic order, no atomics).
-//   * PERSISTENT + SOFTWARE-PIPELINED: a launch is 2-3 workgroups per CU; each workgroup walks a contiguous range of
-//     (cout-tile, pixel-tile) work items x channel chunks.  While the MFMAs of item i run out of LDS buffer i&1, the
-//     global loads of item i+1 are in flight into registers; afterwards the prologue is applied and buffer (i+1)&1 is
-//     written (one barrier per item).  Without this every workgroup of a launch ran load / prologue / MFMA / store in
-//     lockstep (rocprof: waves alive 40 us for 4 us of MFMA work, 38 % MfmaUtil).
+//   * PERSISTENT + SOFTWARE-PIPELINED: a launch is 2 workgroups per CU; each workgroup walks a contiguous range of
+//     (cout-tile, pixel-tile) work items x channel chunks ("stages").  While the MFMAs of stage s run out of LDS buffer
+//     s&1, the global loads of stage s+2 are in flight into registers and the loads of stage s+1 (issued one stage
+//     earlier) get the prologue applied and are written to buffer (s+1)&1 (one barrier per stage).
+//   * the MFMA is issued as D^T = W^T . X^T (rows = couts, columns = pixels): a lane then owns 4 CONSECUTIVE couts of one
+//     pixel per accumulator quad, so the epilogue moves float4s (4 stores / 4 residual loads per 32x32 block instead
+//     of 16 scalar ones).  Same products, same k order: bitwise the same result as the untransposed form.
+//   * vmcnt discipline (gfx9 counters retire IN ORDER and hipcc merges wait states conservatively at control-flow
+//     joins): the steady-state loop is straight-line per stage kind -- `stage<LAST>` is instantiated separately for
+//     "last chunk of an item" (epilogue) and "inner chunk", the prefetch is unconditional, the odd tail stage is peeled,
+//     epilogue operands are loaded BEFORE the prefetch and live only inside stage<true>.  The previous form (one body
+//     with `if (last)` / `if (flat + 2 < nflat)` around the loads) compiled to `s_waitcnt vmcnt(0)` before every
+//     epilogue store and before the prefetch, i.e. no overlap of HBM latency with the MFMAs at all.
 #pragma once
 #include "ddif_dev.h"
 
@@ -36,8 +44,9 @@ struct ConvArgs {
     int Hout, Wout, Cout;
     const float* w;          // packed weights, see pack_conv_weights()
     int n_chunks;            // ceil((c0 + c1) / CK)
-    const float* bias;       // [Cout] or null
-    const float* tbias;      // time bias rows or null; row of sample b = tbias + step * tb_rowstride + b * tbias_stride
+    const float* bias;       // [Cout]; NEVER null (a zero vector when the conv has no bias: a conditional load would
+                             // put a select on the loaded value in front of the MFMAs and drag its vmcnt wait there)
+    const float* tbias;      // time bias rows, never null (zeros, strides 0, without one); row of sample b = tbias + step * tb_rowstride + b * tbias_stride
     int tbias_stride;
     const int* step_ptr;     // device step counter of the running sampler (null: step = 0)
     int tb_rowstride;
@@ -47,9 +56,8 @@ struct ConvArgs {
     int np1;
     const float* gamma;      // [c0 + c1]
     const float* beta;
-    const float* res;        // residual, same shape as out, or null
-    const float* film;       // [B, Hout, Wout, 2*Cout]: scale | shift, or null
-    int act_silu;            // SiLU on the output
+    const float* res;        // residual, same shape as out (kernel template EPI_RES must match)
+    const float* film;       // [B, Hout, Wout, 2*Cout]: scale | shift (kernel template EPI_FILM must match)
     float* out;
     double* st_out;          // partials of out [B][tiles_x*tiles_y*gridDim.y][2] or null
     int tiles_x, tiles_y;
@@ -59,18 +67,24 @@ struct ConvArgs {
     const float* cs_sm;
     const float* dw_w;       // PRO_GN_DW: depthwise 3x3 weights [9][c0 + c1] applied to the normalised input
     float* out_xn;           // PRO_GN_DW: the normalised input itself, [B,H,W,c0+c1] (consumed by attn_res) or null
-    long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
 };
 
+template <int F>
+struct StageKind {
+    static constexpr bool LAST = (F & 1) != 0;  // last channel chunk of a work item: epilogue
+    static constexpr bool TAIL = (F & 2) != 0;  // very last stage of the workgroup: nothing to prefetch or stage
+};
 
 // ABL (microbenchmark ablations only, tools/mbench.cpp): 1 = no MFMA, 2 = no input loads, 4 = no stores, 8 = no weight loads
-// GROUPS = 2: one 512-thread workgroup = two 4-wave groups, each with its own work range, LDS buffers and pipeline,
-// running in ANTI-PHASE: while group 0 issues its MFMAs (phase H1) group 1 does its epilogue + LDS staging (phase H2),
-// swapped at every barrier.  rocprof showed why this is needed: two independent workgroups per CU drift into lockstep,
-// both waves of a SIMD queue on the one MFMA pipe (SQ_WAIT_INST_ANY = 2 x the MFMA time) and then both leave it idle
-// while they stage.
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int GROUPS = 1, int ABL = 0>
-__global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
+// EPI (epilogue variant, compile-time so that every epilogue-operand load is unconditional straight-line code -- a load
+// under `if (a.res)` becomes a phi with undef, hipcc copies the loaded registers right after the load and the copy's
+// vmcnt wait lands in front of the prefetch):  1 = FiLM (1+scale)*y+shift,  2 = scalar output path (Cout % 4 != 0),
+// 4 = residual add,  8 = SiLU on the output (a runtime flag gets if-converted: exp + rcp computed for every conv),
+// 16 = per-SAMPLE time-bias rows (tbias_stride != 0: forward() / p_losses with one t per sample; in the samplers every
+// sample shares the step's row and bias + time bias sit in LDS for the whole launch).
+enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16 };
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr int LDA = CK + 4;
@@ -82,6 +96,8 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     // PRO_GN_DW (1x1 conv over depthwise3x3(GroupNorm(x))): the LOAD tile has a one-pixel halo and goes to a scratch
     // LDS region; the depthwise conv turns it into the A tile of the 1x1 contraction.
     constexpr bool DWM = (PRO == PRO_GN_DW);
+    constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW);
+    constexpr bool FILM = (EPI & EPI_FILM) != 0, SOUT = (EPI & EPI_SOUT) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0, TBS = (EPI & EPI_TBS) != 0;
     static_assert(!DWM || (KS == 1 && STRIDE == 1 && !UPS && VEC), "depthwise staging is for plain 1x1 convs");
     constexpr int LPAD = DWM ? 1 : PAD;
     constexpr int LH = DWM ? TH + 2 : IH, LW = DWM ? TW + 2 : IW;   // extent of the loaded tile
@@ -96,36 +112,37 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     static_assert(CK % 8 == 0 && 256 % C4 == 0, "chunk size");
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
 
-    DDIF_DYN_SMEM(smem_all);
-    constexpr size_t GSZ = (size_t)(2 * (ABUF + WBUF) + HBUF + DWMAX) * sizeof(float) + 16 * sizeof(double);  // LDS bytes per group
-    const int grp = GROUPS == 1 ? 0 : (int)(threadIdx.x >> 8);
-    char* smem = smem_all + grp * GSZ;
+    DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
     float* Ws = As + 2 * ABUF;                    // [2][WBUF]  weight chunk in B-fragment order
     double* red = reinterpret_cast<double*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float));  // [2][8]
     float* Hs = reinterpret_cast<float*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float) + 16 * sizeof(double));  // [HBUF]
-    float* DWs = Hs + HBUF;                                                                                      // [9][Ctot]
+    float* DWs = Hs + HBUF;                       // [9][Ctot]
+    float* GBs = DWs + DWMAX;                     // GroupNorm gamma | beta, [2][n_chunks * CK] (host adds the bytes)
+    float* BTs = GBs + (GNP ? 2 * a.n_chunks * CK : 0);  // bias (+ the step's time-bias row) of all n_ct * NT couts
 
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // group-local thread / wave index
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, j = lane & 31;
     const int tiles = a.tiles_x * a.tiles_y;
     const int ntiles = a.B * tiles;
     const int nwork = ntiles * a.n_ct;
-    const int nvb = gridDim.x * GROUPS;  // virtual workgroups (one per 4-wave group)
-    const int vb = blockIdx.x * GROUPS + grp;
-    const int w0 = (int)((long long)vb * nwork / nvb);
-    const int w1 = (int)((long long)(vb + 1) * nwork / nvb);
-    if (GROUPS == 1 && w0 >= w1) return;  // whole workgroup leaves together (a group of a pair must keep its barriers)
+    const int w0 = (int)((long long)blockIdx.x * nwork / gridDim.x);
+    const int w1 = (int)((long long)(blockIdx.x + 1) * nwork / gridDim.x);
+    if (w0 >= w1) return;  // whole workgroup leaves together
     const int Hc = UPS ? a.Hin * 2 : a.Hin, Wc = UPS ? a.Win * 2 : a.Win;
     const int Ctot = a.c0 + a.c1;
+    const int GBN = a.n_chunks * CK;
     const int c4 = tid % C4;
+    const float* tbrow = a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0);
 
-    int abase[MB];
+    int abase[MB], e_my[MB], e_mx[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = (wm * MB + mb) * 32 + j;
         abase[mb] = ((m / TW) * STRIDE * IW + (m % TW) * STRIDE) * LDA + 4 * h;
+        e_my[mb] = m / TW;  // the pixel this lane owns in the (transposed) accumulator block mb
+        e_mx[mb] = m % TW;
     }
     constexpr int WCHUNK = NF * 256;  // floats per (n-block, chunk)
 
@@ -159,8 +176,8 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     auto locate = [&](int work) {
         Pos p;
         p.work = work;
-        p.ct = work / ntiles;
-        const int pt = work - p.ct * ntiles;
+        const int pt = work / a.n_ct;  // cout tile FASTEST: consecutive items re-read the same input tile out of L2
+        p.ct = work - pt * a.n_ct;
         p.b = pt / tiles;
         const int t = pt - p.b * tiles;
         const int ty = t / a.tiles_x;
@@ -168,19 +185,17 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         p.ox0 = (t - ty * a.tiles_x) * TW;
         return p;
     };
-
     auto next_pos = [&](Pos p) {  // work + 1 without divisions
         p.work += 1;
+        if (++p.ct < a.n_ct) return p;
+        p.ct = 0;
         p.ox0 += TW;
         if (p.ox0 >= a.tiles_x * TW) {
             p.ox0 = 0;
             p.oy0 += TH;
             if (p.oy0 >= a.tiles_y * TH) {
                 p.oy0 = 0;
-                if (++p.b == a.B) {
-                    p.b = 0;
-                    ++p.ct;
-                }
+                ++p.b;
             }
         }
         return p;
@@ -188,9 +203,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 
     // ---- loading side: runs TWO stages (channel chunks) ahead of the MFMAs, into two register sets ----
     // Measured on MI355X (tools/mbench.cpp, in-kernel clock stamps): with all workgroups of a launch prefetching in
-    // bursts a global load takes ~5 us to land, a stage of MFMAs ~2-3 us.  vmcnt retires IN ORDER, so (a) nothing that
-    // is consumed inside a stage may be loaded after a prefetch (epilogue operands are issued first), (b) one stage
-    // of lookahead is not enough.
+    // bursts a global load takes ~5 us to land, a stage of MFMAs ~2-3 us: one stage of lookahead is not enough.
     Pos L = locate(w0);
     int l_ch = 0;
     int l_sp[NITEMS];   // clamped source pixel index of every staging item of work item L
@@ -214,7 +227,6 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     struct StageRegs {
         float4 sv[NITEMS], wv[WITEMS];
         float4 mxv[PRO == PRO_COLSM ? NITEMS : 1], smv[PRO == PRO_COLSM ? NITEMS : 1];
-        float gq[4], bq[4];
         unsigned ok;
         int cbase, ch;
         Pos pos;
@@ -225,8 +237,10 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
     int gn_b = -1;
     float mean = 0.f, rstd = 1.f;
 
-    // Branch-free: every item loads from a CLAMPED (always valid) address; validity is a bit mask applied when the
-    // tile is written to LDS (with divergent bounds / source branches hipcc waits vmcnt(0) after every load).
+    // Branch-free and UNCONDITIONAL: every item loads from a clamped (always valid) address; validity is a bit mask
+    // applied when the tile is written to LDS.  Past the end of the work range the loader re-reads the last item (L2
+    // hits, never consumed): a conditional prefetch would make the number of loads in flight path-dependent, and every
+    // later counted vmcnt wait would degrade to vmcnt(0).
     auto issue_loads = [&](StageRegs& R) {
         const int cbase = l_ch * CK + c4 * 4;
         if (ABL & 2) {
@@ -267,14 +281,6 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
             if (ABL & 8) R.wv[it] = make_float4(0.01f, 0.02f, 0.03f, 0.04f);
             else R.wv[it] = *reinterpret_cast<const float4*>(wbase + w_goff[it]);
         }
-        if (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = cbase + i < Ctot ? cbase + i : Ctot - 1;
-                R.gq[i] = a.gamma[c];
-                R.bq[i] = a.beta[c];
-            }
-        }
         R.ok = l_ok;
         R.cbase = cbase;
         R.ch = l_ch;
@@ -283,8 +289,9 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         if (++l_ch == a.n_chunks) {
             l_ch = 0;
             if (L.work + 1 < w1) {
+                const bool same_tile = L.ct + 1 < a.n_ct;
                 L = next_pos(L);
-                item_geometry();
+                if (!same_tile) item_geometry();
             }
         }
     };
@@ -292,15 +299,17 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         float* dst = As + buf * ABUF;
         float* wdst = Ws + buf * WBUF;
         float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW) {
+        if (GNP) {
             if (R.pos.b != gn_b) {  // workgroup-uniform; every wavefront reduces the partials itself (no barrier)
                 gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
                 gn_b = R.pos.b;
             }
+            const float4 gq = *reinterpret_cast<const float4*>(&GBs[R.cbase]);
+            const float4 bq = *reinterpret_cast<const float4*>(&GBs[GBN + R.cbase]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ga[i] = R.gq[i] * rstd;
-                gb[i] = R.bq[i] - mean * ga[i];
+                ga[i] = (&gq.x)[i] * rstd;
+                gb[i] = (&bq.x)[i] - mean * ga[i];
             }
         }
         bool cok[4];
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float x = (&R.sv[it].x)[i];
-                if (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW) {
+                if (GNP) {
                     x = fmaf(x, ga[i], gb[i]);
                     if (PRO == PRO_GN_SILU) x = dd_silu(x);
                 }
@@ -364,54 +373,6 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         bufch[buf] = R.ch;
     };
 
-    // ---- the same staging work as finish_stage(), cut into pieces that h1 interleaves BETWEEN the MFMA groups of the
-    //      running stage (MFMA issue is asynchronous: the wave keeps issuing these VALU / ds_write instructions while
-    //      the matrix pipe works), so a wave overlaps its own staging with its own MFMAs.  Not used for PRO_GN_DW.
-    float pga[4], pgb[4];
-    bool pcok[4];
-    auto finish_prepare = [&](StageRegs& R) {
-        if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
-            if (R.pos.b != gn_b) {
-                gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
-                gn_b = R.pos.b;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pga[i] = R.gq[i] * rstd;
-                pgb[i] = R.bq[i] - mean * pga[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pcok[i] = R.cbase + i < Ctot;
-    };
-    auto finish_piece = [&](StageRegs& R, int buf, int piece) {  // piece: 0..NITEMS-1 input items, then weight items
-        if (piece < NITEMS) {
-            const int it = piece;
-            const bool ok = (R.ok >> it) & 1u;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = (&R.sv[it].x)[i];
-                if (PRO == PRO_GN || PRO == PRO_GN_SILU) {
-                    x = fmaf(x, pga[i], pgb[i]);
-                    if (PRO == PRO_GN_SILU) x = dd_silu(x);
-                }
-                if (PRO == PRO_COLSM) {
-                    if (R.cbase < a.c0) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
-                }
-                v[i] = (ok && pcok[i]) ? x : 0.f;
-            }
-            if ((a_in >> it) & 1u) *reinterpret_cast<float4*>(&As[buf * ABUF + a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (piece < NITEMS + WITEMS) {
-            const int it = piece - NITEMS;
-            if ((w_in >> it) & 1u) *reinterpret_cast<float4*>(&Ws[buf * WBUF + w_lds[it]]) = R.wv[it];
-        }
-    };
-    auto finish_commit = [&](StageRegs& R, int buf) {
-        bufpos[buf] = R.pos;
-        bufch[buf] = R.ch;
-    };
-
     bool pend = false;  // a statistics partial of work item pend_pos sits in red[pend_par]
     Pos pend_pos = L;
     int pend_par = 0;
@@ -427,58 +388,57 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
         pend = false;
     };
 
-    int dbg_n = 0;
-    auto stamp = [&]() {
-        if ((ABL & 16) && a.dbg && tid == 0 && dbg_n < 120) a.dbg[vb * 128 + dbg_n++] = (long long)wall_clock64();
-    };
-    stamp();
     f32x16 acc[MB][NB];
     const int nflat = (w1 - w0) * a.n_chunks;
 
-    // One pipeline step of stage `flat`, in two halves:
-    //   H1: epilogue-operand loads, prefetch of stage flat+2 into Rf, the MFMAs out of LDS buffer `cur`;
-    //   H2: epilogue (last chunk of an item), then stage flat+1 (loaded one step ago, Rn) -> LDS buffer cur^1.
-    Pos Cp = L;
-    int c_ch = 0, nbg0 = 0;
-    bool last = false;
-    float e_bias[NB], e_tb[NB];
-    float e_res[MB][NB][16];
-    constexpr bool INTERLEAVE = false;  // measured slower (the pieces drag vmcnt/lgkmcnt waits into the MFMA loop); kept for A/B
-    constexpr int PPF = (NITEMS + WITEMS + NF - 1) / NF;  // staging pieces per (tap, k8) step
-    auto h1 = [&](int flat, int cur, StageRegs& Rn, StageRegs& Rf) {
+    // One pipeline stage out of LDS buffer `cur`:
+    //   [LAST: epilogue-operand loads]  prefetch of stage +2 into Rf  MFMAs  [LAST: epilogue]  stage +1 (Rn, loaded one
+    //   stage ago) -> prologue -> LDS buffer cur^1.  The caller puts one barrier after it.
+    auto stage = [&](auto kind, const int cur, StageRegs& Rn, StageRegs& Rf) {
+        constexpr bool LAST = decltype(kind)::LAST, TAIL = decltype(kind)::TAIL;
         const float* Ac = As + cur * ABUF;
-        Cp = bufpos[cur];
-        c_ch = bufch[cur];
-        last = c_ch == a.n_chunks - 1;
-        nbg0 = (Cp.ct * WN + wn) * NB;
-        // (1) epilogue operands FIRST (older than the prefetch below, so the epilogue's counted vmcnt wait does not
-        //     include the prefetch)
-        if (last) {
-            const float* tb = a.tbias ? a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0) + (size_t)Cp.b * a.tbias_stride : nullptr;
+        const Pos Cp = bufpos[cur];
+        const int c_ch = bufch[cur];
+        const int nbg0 = (Cp.ct * WN + wn) * NB;
+        // (1) epilogue operands FIRST: older than the prefetch below, so the epilogue's counted vmcnt wait leaves the
+        //     prefetch in flight.  Nothing here may be COMPUTED on before the MFMAs (that would pull the wait up).
+        float4 e_t[(LAST && TBS) ? NB : 1][4];
+        float4 e_res[(LAST && RES) ? MB : 1][(LAST && RES) ? NB : 1][4];
+        float4 e_fs[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4], e_fh[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4];
+        bool full = true;
+        size_t e_pix[MB];
+        bool e_pok[MB];
+        if constexpr (LAST) {
+            full = (Cp.oy0 + TH <= a.Hout) & (Cp.ox0 + TW <= a.Wout);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int co = (nbg0 + nb) * 32 + j;
-                const int coc = co < a.Cout ? co : a.Cout - 1;
-                e_bias[nb] = a.bias ? a.bias[coc] : 0.f;
-                e_tb[nb] = tb ? tb[coc] : 0.f;
-                if (a.res) {
+            for (int mb = 0; mb < MB; ++mb) {
+                e_pok[mb] = full || ((Cp.oy0 + e_my[mb] < a.Hout) & (Cp.ox0 + e_mx[mb] < a.Wout));
+                const int oy = e_pok[mb] ? Cp.oy0 + e_my[mb] : Cp.oy0, ox = e_pok[mb] ? Cp.ox0 + e_mx[mb] : Cp.ox0;
+                e_pix[mb] = (size_t)((Cp.b * a.Hout + oy) * a.Wout + ox);
+            }
+            if constexpr (!SOUT) {
+                [[maybe_unused]] const float* tb = tbrow + (size_t)Cp.b * a.tbias_stride;
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            int oy = Cp.oy0 + m / TW, ox = Cp.ox0 + m % TW;
-                            oy = oy < a.Hout ? oy : a.Hout - 1;
-                            ox = ox < a.Wout ? ox : a.Wout - 1;
-                            e_res[mb][nb][r] = a.res[(size_t)((Cp.b * a.Hout + oy) * a.Wout + ox) * a.Cout + coc];
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = (nbg0 + nb) * 32 + 8 * g + 4 * h;
+                        const int coc = co < a.Cout ? co : 0;
+                        if constexpr (TBS) e_t[nb][g] = *reinterpret_cast<const float4*>(tb + coc);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            if constexpr (RES) e_res[mb][nb][g] = *reinterpret_cast<const float4*>(a.res + e_pix[mb] * a.Cout + coc);
+                            if constexpr (FILM) {
+                                e_fs[mb][nb][g] = *reinterpret_cast<const float4*>(a.film + e_pix[mb] * 2 * a.Cout + coc);
+                                e_fh[mb][nb][g] = *reinterpret_cast<const float4*>(a.film + e_pix[mb] * 2 * a.Cout + a.Cout + coc);
+                            }
                         }
-                }
+                    }
             }
         }
-        // (2) prefetch stage flat+2
-        if (flat + 2 < nflat) issue_loads(Rf);
+        // (2) prefetch stage +2
+        if constexpr (!TAIL) issue_loads(Rf);
         flush_stats();
-        stamp();
         if (c_ch == 0) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
@@ -487,11 +447,8 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
         }
-        // (3) contraction over taps x chunk channels: A and B fragments both from LDS, no global load in here;
-        //     stage flat+1 (register set Rn, loaded one step ago) is written to the OTHER LDS buffer piece by piece
-        //     between the MFMA groups
-        const bool stage_next = INTERLEAVE && (flat + 1 < nflat) && !(ABL & 32);
-        if (stage_next) finish_prepare(Rn);
+        // (3) contraction over taps x chunk channels: both fragments from LDS, no global load in here.  Weights are
+        //     the MFMA's FIRST operand: D[cout][pixel] (see the header comment).
         const float* Wc = Ws + cur * WBUF + (wn * NB) * (NF * 256) + h * 128 + j * 4;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -509,51 +466,64 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
                         if (ABL & 1) acc[mb][nb][i] += (&af[mb].x)[i] * (&bf[nb].x)[i];
-                        else acc[mb][nb] = DDIF_MFMA_32x32x2((&af[mb].x)[i], (&bf[nb].x)[i], acc[mb][nb]);
-            if (stage_next) {
-#pragma unroll
-                for (int pp = 0; pp < PPF; ++pp) finish_piece(Rn, cur ^ 1, f * PPF + pp);
-            }
+                        else acc[mb][nb] = DDIF_MFMA_32x32x2((&bf[nb].x)[i], (&af[mb].x)[i], acc[mb][nb]);
         }
-        if (stage_next) finish_commit(Rn, cur ^ 1);
-        stamp();
-    };
-    auto h2 = [&](int flat, int cur, StageRegs& Rn) {
-        if (last && !(ABL & 64)) {
-            // (4) epilogue of work item Cp.  Addresses = tile base + compile-time pixel offsets; bounds are only
-            //     checked for tiles that stick out of the image.
+        if constexpr (LAST) {
+            // (4) epilogue of work item Cp: lane (j, h) owns pixel j of each 32-pixel block and, per accumulator quad g,
+            //     the 4 consecutive couts 8g + 4h .. +3 of each 32-cout block
             float s1 = 0.f, s2 = 0.f;
-            const bool full = (Cp.oy0 + TH <= a.Hout) & (Cp.ox0 + TW <= a.Wout);
-            const size_t tile_pix = (size_t)((Cp.b * a.Hout + Cp.oy0) * a.Wout + Cp.ox0);
-            const int rowc = a.Wout * a.Cout;
+            if constexpr (!SOUT) {
+                auto epi = [&](auto guard) {
+                    constexpr bool GUARD = decltype(guard)::LAST;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int co = (nbg0 + nb) * 32 + j;
-                const bool cok = co < a.Cout;
-                float* obase = a.out + tile_pix * a.Cout + co;
-                const float* fbase = a.film ? a.film + tile_pix * 2 * a.Cout + co : nullptr;
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
+                        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const int my = m / TW, mx = m % TW;
-                        if (cok && (full || (Cp.oy0 + my < a.Hout && Cp.ox0 + mx < a.Wout))) {
-                            const int poff = my * rowc + mx * a.Cout;
-                            float v = acc[mb][nb][r] + e_bias[nb];
-                            v += e_tb[nb];
-                            if (a.film) {
-                                const float sc = fbase[2 * poff], sh = fbase[2 * poff + a.Cout];
-                                v = v * (1.f + sc) + sh;
+                            for (int g = 0; g < 4; ++g) {
+                                const int co = (nbg0 + nb) * 32 + 8 * g + 4 * h;
+                                const float4 bt = *reinterpret_cast<const float4*>(&BTs[co]);
+                                float v[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float x = acc[mb][nb][4 * g + i] + (&bt.x)[i];
+                                    if constexpr (TBS) x += (&e_t[nb][g].x)[i];
+                                    if constexpr (FILM) x = x * (1.f + (&e_fs[mb][nb][g].x)[i]) + (&e_fh[mb][nb][g].x)[i];
+                                    if constexpr (SILU) x = dd_silu(x);
+                                    if constexpr (RES) x += (&e_res[mb][nb][g].x)[i];
+                                    v[i] = x;
+                                }
+                                float* op = a.out + e_pix[mb] * a.Cout + co;
+                                if (!GUARD || (e_pok[mb] && co < a.Cout)) {
+                                    if (!(ABL & 4) || v[0] == 12345.678f) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                                    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                                    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                                }
                             }
-                            if (a.act_silu) v = dd_silu(v);
-                            if (a.res) v += e_res[mb][nb][r];
-                            if (!(ABL & 4) || v == 12345.678f) obase[poff] = v;
-                            s1 += v;
-                            s2 += v * v;
+                };
+                if (full && (nbg0 + NB) * 32 <= a.Cout) epi(StageKind<0>{});
+                else epi(StageKind<1>{});
+            } else {
+                // scalar slow path (Cout not a multiple of 4): operands are loaded here, latency exposed -- rare
+                [[maybe_unused]] const float* tb = tbrow + (size_t)Cp.b * a.tbias_stride;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = (nbg0 + nb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (e_pok[mb] && co < a.Cout) {
+                                float x = acc[mb][nb][r] + BTs[co];
+                                if constexpr (TBS) x += tb[co];
+                                if constexpr (FILM) x = x * (1.f + a.film[e_pix[mb] * 2 * a.Cout + co]) + a.film[e_pix[mb] * 2 * a.Cout + a.Cout + co];
+                                if constexpr (SILU) x = dd_silu(x);
+                                if constexpr (RES) x += a.res[e_pix[mb] * a.Cout + co];
+                                if (!(ABL & 4) || x == 12345.678f) a.out[e_pix[mb] * a.Cout + co] = x;
+                                s1 += x;
+                                s2 += x * x;
+                            }
                         }
-                    }
-                }
             }
             if (a.st_out) {
                 const double d1 = (double)wave_sum_fast(s1), d2 = (double)wave_sum_fast(s2);  // fp32 tree in-wave, fp64 beyond
@@ -566,66 +536,56 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_mfma_kernel(ConvArgs a) {
                 pend_pos = Cp;
             }
         }
-        stamp();
-        // (5) stage flat+1 (loaded one step ago) -> the other LDS buffer
-        if (!INTERLEAVE && flat + 1 < nflat && !(ABL & 32)) finish_stage(Rn, cur ^ 1);
-        if ((ABL & 32) && flat + 1 < nflat) finish_commit(Rn, cur ^ 1);
-        stamp();
+        // (5) stage +1 (loaded one stage ago) -> the other LDS buffer
+        //     (after the very last stage this writes a never-consumed copy of the last item's chunk 0: cheaper than a
+        //     `has_next` branch, whose skip path would leave Rn pending at the loop-head merge)
+        if constexpr (!TAIL) finish_stage(Rn, cur ^ 1);
     };
 
     if (DWM) {
         for (int i = tid; i < 9 * Ctot; i += 256) DWs[i] = a.dw_w[i];
-        __syncthreads();
     }
-    if (nflat > 0) {
-        item_geometry();
-        issue_loads(R0);
-        if (nflat > 1) issue_loads(R1);
-        finish_stage(R0, 0);
+    if (GNP) {
+        for (int i = tid; i < GBN; i += 256) {
+            const int c = i < Ctot ? i : Ctot - 1;
+            GBs[i] = a.gamma[c];
+            GBs[GBN + i] = a.beta[c];
+        }
+    }
+    for (int i = tid; i < a.n_ct * (32 * NB * WN); i += 256) {
+        const int c = i < a.Cout ? i : a.Cout - 1;
+        BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
     }
     __syncthreads();
-    stamp();
-    if (GROUPS == 1) {
-        for (int flat = 0; flat < nflat; flat += 2) {
-            h1(flat, 0, R1, R0);
-            h2(flat, 0, R1);
-            __syncthreads();
-            if (flat + 1 < nflat) {
-                h1(flat + 1, 1, R0, R1);
-                h2(flat + 1, 1, R0);
-                __syncthreads();
-            }
-        }
-    } else {
-        // anti-phase schedule: group g runs H1(f) in phase 2f+g and H2(f) in phase 2f+g+1; one barrier per phase
-        const int o0 = (int)((long long)(blockIdx.x * 2) * nwork / nvb), o1 = (int)((long long)(blockIdx.x * 2 + 1) * nwork / nvb),
-                  o2 = (int)((long long)(blockIdx.x * 2 + 2) * nwork / nvb);
-        const int nf0 = (o1 - o0) * a.n_chunks, nf1 = (o2 - o1) * a.n_chunks;
-        const int nphase = 2 * nf0 > 2 * nf1 + 1 ? 2 * nf0 : 2 * nf1 + 1;
-        int flat = 0;
-        for (int ph = 0; ph < nphase; ++ph) {
-            if (flat < nflat) {
-                if (((ph + grp) & 1) == 0) {
-                    if (flat & 1) h1(flat, 1, R0, R1);
-                    else h1(flat, 0, R1, R0);
-                } else if (ph >= grp + 1) {
-                    if (flat & 1) h2(flat, 1, R0);
-                    else h2(flat, 0, R1);
-                    ++flat;
-                }
-            }
-            __syncthreads();
-        }
+    item_geometry();
+    issue_loads(R0);
+    issue_loads(R1);
+    finish_stage(R0, 0);
+    __syncthreads();
+    const int npairs = nflat >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+        if (bufch[0] == a.n_chunks - 1) stage(StageKind<1>{}, 0, R1, R0);
+        else stage(StageKind<0>{}, 0, R1, R0);
+        __syncthreads();
+        if (bufch[1] == a.n_chunks - 1) stage(StageKind<1>{}, 1, R0, R1);
+        else stage(StageKind<0>{}, 1, R0, R1);
+        __syncthreads();
     }
+    if (nflat & 1) stage(StageKind<3>{}, 0, R1, R0);  // odd tail: always the last chunk of the last item
+    __syncthreads();
     flush_stats();
 }
 
 
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int GROUPS = 1, int PRO = 0>
-constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per 4-wave group = NB * WN
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO = 0>
+constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN; + conv_smem_extra() at launch
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
-    return GROUPS * ((size_t)(2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) + dw) * sizeof(float) + 16 * sizeof(double));
+    return (size_t)(2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) + dw) * sizeof(float) + 16 * sizeof(double);
+}
+// GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts
+inline size_t conv_smem_extra(int pro, int n_chunks, int ck, int cout_pad) {
+    return ((pro == PRO_GN || pro == PRO_GN_SILU || pro == PRO_GN_DW) ? (size_t)2 * n_chunks * ck : 0) * sizeof(float) + (size_t)cout_pad * sizeof(float);
 }
 
 }  // namespace ddif

@@ -11,76 +11,70 @@ namespace ddif { thread_local std::string g_err; int fail(int c, const char*, ..
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int KS, int S, int U, int TH, int TW, int CKc, int WM, int WN, int MB, int NB, int PRO, int ABL, int G = 1>
+template <int KS, int S, int U, int TH, int TW, int CKc, int WM, int WN, int MB, int NB, int PRO, int ABL, int EPI = 0>
 void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu) {
     const int Hout = S == 2 ? (H - 1) / 2 + 1 : (U ? 2 * H : H), Wout = S == 2 ? (W - 1) / 2 + 1 : (U ? 2 * W : W);
     const int n_chunks = (Cin + CKc - 1) / CKc, nb = (Cout + 31) / 32, nb_pad = (nb + 3) & ~3;
     const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Hout * Wout * Cout;
     const size_t nw = (size_t)nb_pad * n_chunks * KS * KS * (CKc / 8) * 256;
-    float *in, *w, *out, *gamma, *beta, *bias; double *st, *sto;
-    CK_(hipMalloc(&in, nin * 4)); CK_(hipMalloc(&w, nw * 4)); CK_(hipMalloc(&out, nout * 4));
+    float *in, *w, *out, *gamma, *beta, *bias, *res; double *st, *sto;
+    CK_(hipMalloc(&in, nin * 4)); CK_(hipMalloc(&w, nw * 4)); CK_(hipMalloc(&out, nout * 4)); CK_(hipMalloc(&res, nout * 4));
     CK_(hipMalloc(&gamma, Cin * 4)); CK_(hipMalloc(&beta, Cin * 4)); CK_(hipMalloc(&bias, Cout * 4));
-    std::vector<float> h(std::max(nin, nw)); for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-3f;
+    std::vector<float> h(std::max(std::max(nin, nw), nout)); for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-3f;
     CK_(hipMemcpy(in, h.data(), nin * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(w, h.data(), nw * 4, hipMemcpyHostToDevice));
+    CK_(hipMemcpy(res, h.data(), nout * 4, hipMemcpyHostToDevice));
     CK_(hipMemcpy(gamma, h.data(), Cin * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(beta, h.data(), Cin * 4, hipMemcpyHostToDevice));
     CK_(hipMemcpy(bias, h.data(), Cout * 4, hipMemcpyHostToDevice));
     ConvArgs a{}; a.in0 = in; a.c0 = Cin; a.B = B; a.Hin = H; a.Win = W; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.w = w; a.n_chunks = n_chunks;
     a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out; a.tiles_x = (Wout + TW - 1) / TW; a.tiles_y = (Hout + TH - 1) / TH;
+    if (EPI & EPI_RES) a.res = res;
+    float* dww; CK_(hipMalloc(&dww, 9 * Cin * 4)); CK_(hipMemcpy(dww, h.data(), 9 * Cin * 4, hipMemcpyHostToDevice)); a.dw_w = dww;
+    float* xn; CK_(hipMalloc(&xn, nin * 4)); if (PRO == PRO_GN_DW) a.out_xn = xn;
+    float* zeros; CK_(hipMalloc(&zeros, 4096)); CK_(hipMemset(zeros, 0, 4096)); a.tbias = zeros;
     constexpr int NT = 32 * NB * WN; a.n_ct = (Cout + NT - 1) / NT;
     const int np = a.tiles_x * a.tiles_y * a.n_ct;
     CK_(hipMalloc(&st, (size_t)B * 64 * 16)); CK_(hipMalloc(&sto, (size_t)B * np * 16));
     std::vector<double> hs((size_t)B * 64 * 2); for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 10.0; hs[i + 1] = 5000.0; }
     CK_(hipMemcpy(st, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
     a.st0 = st; a.np0 = 64; a.st_out = sto;
-    long long* dbg = nullptr; if (ABL & 16) { CK_(hipMalloc(&dbg, 1024 * 128 * 8)); CK_(hipMemset(dbg, 0, 1024 * 128 * 8)); a.dbg = dbg; }
     const long nwork = (long)B * a.tiles_x * a.tiles_y * a.n_ct;
     const long cap = 256L * wg_per_cu;
-    const long want = (nwork + G - 1) / G;
-    dim3 grid((unsigned)(want < cap ? want : cap));
-    auto fn = conv_mfma_kernel<KS, S, U, TH, TW, CKc, WM, WN, MB, NB, PRO, 1, G, ABL>;
-    const size_t smem = conv_smem_bytes<KS, S, U, TH, TW, CKc, NB * WN, G>();
+    dim3 grid((unsigned)(nwork < cap ? nwork : cap));
+    auto fn = conv_mfma_kernel<KS, S, U, TH, TW, CKc, WM, WN, MB, NB, PRO, 1, EPI, ABL>;
+    const size_t smem = conv_smem_bytes<KS, S, U, TH, TW, CKc, NB * WN, PRO>() + conv_smem_extra(PRO, n_chunks, CKc, a.n_ct * NT);
     if (smem > 65536) CK_(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipEvent_t e0, e1; CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fn, grid, dim3(256 * G), smem, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fn, grid, dim3(256), smem, 0, a);
     CK_(hipDeviceSynchronize());
     const int iters = 20;
     CK_(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(fn, grid, dim3(256 * G), smem, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(fn, grid, dim3(256), smem, 0, a);
     CK_(hipEventRecord(e1, 0)); CK_(hipEventSynchronize(e1));
     float ms; CK_(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, flop = 2.0 * B * Hout * Wout * Cout * Cin * KS * KS;
-    if (ABL & 16) {
-        std::vector<long long> hd(1024 * 128); CK_(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
-        for (int blk : {0, 1, 300}) { printf("  block %d stamps (100MHz ticks x10ns):", blk); long long t0 = hd[blk * 128];
-            for (int i = 0; i < 60 && hd[blk * 128 + i]; ++i) printf(" %lld", hd[blk * 128 + i] - t0); printf("\n"); }
-    }
-    printf("%-44s abl=%2d wg/cu=%d grid=%5u smem=%6zu  %8.1f us  %6.1f TF\n", name, ABL, wg_per_cu, grid.x, smem, us, flop / us / 1e6);
-    hipFree(in); hipFree(w); hipFree(out); hipFree(gamma); hipFree(beta); hipFree(bias); hipFree(st); hipFree(sto);
+    printf("%-46s abl=%2d wg/cu=%d grid=%5u smem=%6zu  %8.1f us  %6.1f TF\n", name, ABL, wg_per_cu, grid.x, smem, us, flop / us / 1e6);
+    hipFree(in); hipFree(w); hipFree(out); hipFree(res); hipFree(gamma); hipFree(beta); hipFree(bias); hipFree(st); hipFree(sto);
 }
 
 int main(int argc, char** argv) {
     const int B = 64;
-#define SHAPE_A(ABL, WG) run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, ABL>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, WG)
-    if (argc > 1) {  // PMC mode: few kernels, distinct template instantiations
-        SHAPE_A(0, 2); SHAPE_A(14, 2); SHAPE_A(15, 2); SHAPE_A(1, 2);
-        return 0;
-    }
-    SHAPE_A(0, 2); SHAPE_A(14, 2);
-    run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,MB2)", B, 64, 64, 32, 32, 1);
-    run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 14>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,MB2)", B, 64, 64, 32, 32, 1);
-    run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (16x16,NT32,MB2)", B, 32, 32, 64, 64, 1);
-    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 2, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (8x16,NT64)", B, 32, 32, 64, 64, 1);
-#define SHAPE_A2(ABL) run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, ABL, 2>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) PINGPONG", B, 64, 64, 32, 32, 1)
-    SHAPE_A2(0); SHAPE_A2(14); SHAPE_A2(15);
-#define SHAPE_B2(ABL) run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, ABL, 2>("3x3 gn_silu 64->64 @32^2 (8x16,NT32) PINGPONG", B, 32, 32, 64, 64, 1)
-    SHAPE_B2(0); SHAPE_B2(14);
-#define SHAPE_E2(ABL) run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_NONE, ABL, 2>("1x1 64->32 @64^2 (8x16,NT32) PINGPONG", B, 64, 64, 64, 32, 1)
-    SHAPE_E2(0);
-#define SHAPE_B(ABL, WG) run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, ABL>("3x3 gn_silu 64->64 @32^2 (8x16,NT32)", B, 32, 32, 64, 64, WG)
-    SHAPE_B(0, 2); SHAPE_B(14, 2);
-#define SHAPE_D(ABL, WG) run<3, 1, 0, 8, 8, 16, 2, 2, 1, 1, PRO_GN_SILU, ABL>("3x3 gn_silu 128->128 @8^2 (8x8,NT64)", B, 8, 8, 128, 128, WG)
-    SHAPE_D(0, 2); SHAPE_D(14, 2);
-#define SHAPE_E(ABL, WG) run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_NONE, ABL>("1x1 64->32 @64^2 (8x16,NT32)", B, 64, 64, 64, 32, WG)
-    SHAPE_E(0, 2); SHAPE_E(1, 2);
+    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, 2);
+    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 14>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, 2);
+    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (8x16,NT32)", B, 32, 32, 64, 64, 2);
+    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, EPI_RES>("3x3 gn_silu 64->64 @32^2 +res (8x16,NT32)", B, 32, 32, 64, 64, 2);
+    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0>("3x3 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
+    run<3, 1, 0, 8, 8, 16, 2, 2, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 128->128 @8^2 (8x8,NT64)", B, 8, 8, 128, 128, 2);
+    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @16^2 (8x16,NT32)", B, 16, 16, 64, 64, 2);
+    run<3, 1, 0, 8, 8, 16, 2, 2, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @16^2 (8x8,NT64)", B, 16, 16, 64, 64, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_NONE, 0>("1x1 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_NONE, 0>("1x1 64->64 @64^2 (8x16,NT64)", B, 64, 64, 64, 64, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_GN_DW, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64)", B, 64, 64, 64, 64, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64) 1wg", B, 64, 64, 64, 64, 1);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_GN_DW, 0>("1x1 gn_dw 128->128 @32^2 (8x16,NT32)", B, 32, 32, 128, 128, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 4, PRO_GN_DW, 0>("1x1 gn_dw 128->128 @32^2 (8x16,NT128)", B, 32, 32, 128, 128, 1);
+    run<1, 1, 0, 8, 8, 32, 2, 2, 1, 2, PRO_GN_DW, 0>("1x1 gn_dw 128->128 @32^2 (8x8,NT128)", B, 32, 32, 128, 128, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_GN_SILU, 0>("1x1 gn_silu 256->128 @32^2 (8x16,NT32)", B, 32, 32, 256, 128, 2);
+    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 4, PRO_GN_SILU, 0>("1x1 gn_silu 256->128 @32^2 (8x16,NT128)", B, 32, 32, 256, 128, 2);
     return 0;
 }
