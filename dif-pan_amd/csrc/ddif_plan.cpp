@@ -10,7 +10,9 @@ namespace ddif {
 // ------------------------------------------------------------------------------------------------ conv variants
 namespace {
 // cfg: 0 = 8x16 pixels x 32 couts, 1 = 8x16 x 64, 3 = 8x16 x 128 (1x1 convs only: a wide cout tile stages -- and for
-// PRO_GN_DW recomputes -- the input once instead of once per 32 couts), 2 = 8x8 x 64, 4 = 8x8 x 128 (1x1 only)
+// PRO_GN_DW recomputes -- the input once instead of once per 32 couts), 2 = 8x8 x 64, 4 = 8x8 x 128 (1x1 only);
+// 5 = 16x16 x 32 and 6 = 16x16 x 64 with EIGHT wavefronts (plain 3x3 convs at the high-resolution levels: twice the
+// MFMAs per staged input / weight element, see kernels_conv.h)
 template <int KS, int S, int U, int CK, int PRO, int VEC, int EPI = 0>
 ConvVariant variant_for_cfg(int cfg) {
     ConvVariant v;
@@ -27,6 +29,13 @@ ConvVariant variant_for_cfg(int cfg) {
             default: break;
         }
     }
+    if constexpr (KS == 3 && S == 1 && U == 0 && VEC == 1) {
+        switch (cfg) {
+            case 5: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; break;
+            case 6: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 2, PRO, 8>(); v.th = 16; v.tw = 16; v.nt = 64; v.nthr = 512; break;
+            default: break;
+        }
+    }
     return v;
 }
 template <int KS, int S, int U, int CK, int PRO, int VEC>
@@ -35,29 +44,32 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 }
 }  // namespace
 
-// vec = 1: every source channel count is a multiple of 4 (float4 staging).  The scalar-staging variants exist only for
-// the prologue-free 3x3 / 1x1 kernels (stem with C = 31, cond convs with 9 / 11 / 34 / 40 input channels).
+// vec (kernels_conv.h VEC): 0 = scalar staging (stem with C = 31, cond convs with 9 / 11 / 34 / 40 input channels; only the
+// prologue-free 3x3 / 1x1 kernels), 1 = float4 staging with one source per channel chunk, 2 = float4 staging with a
+// per-thread source select (stem: cat[x, x] of 8 + 8 or 4 + 4 channels inside one 16-channel chunk).
 // epi: EPI_* bits (kernels_conv.h) -- FiLM (CondInjection.x_conv), scalar output path (Cout % 4 != 0), residual add.
 // Only the combinations the network uses are instantiated.
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi) {
     ConvVariant v;
     const bool plain = stride == 1 && !ups;
     if (epi == EPI_FILM) {
-        if (ks == 1 && ck == 32 && vec && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
+        if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
     } else if (epi == EPI_SOUT) {
-        if (ks == 3 && ck == 16 && vec && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_SOUT>(cfg); v.name = "conv3x3_gn_silu_sout"; }
+        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_SOUT>(cfg); v.name = "conv3x3_gn_silu_sout"; }
     } else if (epi == EPI_RES) {
-        if (!vec || !plain) return v;
+        if (vec != 1 || !plain) return v;
         if (ks == 3 && ck == 16 && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_RES>(cfg); v.name = "conv3x3_gn_silu_res"; }
         else if (ks == 3 && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv3x3_res"; }
         else if (ks == 1 && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv1x1_res"; }
         else if (ks == 1 && ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1, EPI_RES>(cfg); v.name = "conv1x1_colsoftmax_res"; }
     } else if (epi == EPI_TBS) {
-        if (ks == 3 && ck == 16 && vec && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_TBS>(cfg); v.name = "conv3x3_gn_silu_tbs"; }
+        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_TBS>(cfg); v.name = "conv3x3_gn_silu_tbs"; }
     } else if (epi == EPI_SILU) {
-        if (ks == 3 && ck == 16 && vec && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_SILU>(cfg); v.name = "conv3x3_silu"; }
+        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_SILU>(cfg); v.name = "conv3x3_silu"; }
     } else if (epi != 0) {
         return v;
+    } else if (vec == 2) {
+        if (ks == 3 && ck == 16 && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 2>(cfg); v.name = "conv3x3_cat"; }
     } else if (ks == 3 && ck == 16) {  // 3x3 convs always use 16-channel chunks
         if (!vec) {
             if (plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv3x3_scalar"; }
@@ -79,12 +91,18 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
     return v;
 }
 
-static int pick_cfg(int ks, int vec, int stride, int Hout, int Wout, int Cout, int B) {
+static int num_cus();
+static int pick_cfg(int ks, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B) {
     static const int wide1 = [] { const char* e = getenv("DDIF_CONV1_WIDE"); return e ? atoi(e) : 1; }();  // A/B switch
     const bool wide = (Wout >= 16) && stride == 1;
-    if (ks == 1 && vec && wide1) {
+    if (ks == 1 && vec == 1 && wide1) {
         if (wide) return Cout > 64 ? 3 : (Cout > 32 ? 1 : 0);
         return Cout > 64 ? 4 : 2;
+    }
+    static const int big3 = [] { const char* e = getenv("DDIF_CONV3_BIG"); return e ? atoi(e) : 1; }();  // A/B switch
+    if (ks == 3 && vec == 1 && wide && big3 && !ups_) {
+        const long items32 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
+        if (Hout >= 32 && Wout >= 32 && items32 >= 2L * num_cus()) return (Cout % 64 == 0 && items32 >= 4L * num_cus()) ? 6 : 5;
     }
     if (wide) return 0;
     if (Cout <= 32 && stride == 1) return 0;
@@ -159,8 +177,10 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int c0 = s.in0.C, c1 = s.in1.C;
     if (c0 + c1 != pc.cin) return fail(DDIF_ERR_INVALID, "%s: input channels %d+%d != weight cin %d", s.name, c0, c1, pc.cin);
     if (pc.ks == 1 && (s.stride != 1 || s.ups)) return fail(DDIF_ERR_INVALID, "%s: 1x1 conv with stride/upsample", s.name);
-    const int vec = (c0 % 4 == 0 && c1 % 4 == 0) ? 1 : 0;
-    const int cfg = pick_cfg(pc.ks, vec, s.stride, Hout, Wout, pc.cout, B);
+    const int vec = (c0 % 4 != 0 || c1 % 4 != 0) ? 0 : ((c1 == 0 || c0 % pc.ck == 0) ? 1 : 2);
+    if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
+        return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
+    const int cfg = pick_cfg(pc.ks, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0);
     const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
@@ -213,7 +233,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const size_t smem = var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
     const long cap = (long)num_cus() * wg_per_cu(smem);
     const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
-    const dim3 block(256u);
+    const dim3 block((unsigned)var.nthr);
     if (var.smem + 8192 > 64 * 1024) {  // the attribute is per kernel function: set it to the variant's maximum
         DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(var.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(var.smem + 8192)));
     }

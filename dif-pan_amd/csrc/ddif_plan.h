@@ -33,7 +33,7 @@ typedef void (*ConvKernelFn)(ConvArgs);
 struct ConvVariant {
     ConvKernelFn fn = nullptr;
     size_t smem = 0;
-    int th = 0, tw = 0, nt = 0;
+    int th = 0, tw = 0, nt = 0, nthr = 256;
     const char* name = "";
 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi);

@@ -67,6 +67,7 @@ struct ConvArgs {
     const float* cs_sm;
     const float* dw_w;       // PRO_GN_DW: depthwise 3x3 weights [9][c0 + c1] applied to the normalised input
     float* out_xn;           // PRO_GN_DW: the normalised input itself, [B,H,W,c0+c1] (consumed by attn_res) or null
+    long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
 };
 
 template <int F>
@@ -75,7 +76,8 @@ struct StageKind {
     static constexpr bool TAIL = (F & 2) != 0;  // very last stage of the workgroup: nothing to prefetch or stage
 };
 
-// ABL (microbenchmark ablations only, tools/mbench.cpp): 1 = no MFMA, 2 = no input loads, 4 = no stores, 8 = no weight loads
+// ABL (microbenchmark ablations only, tools/mbench.cpp): 1 = no MFMA, 2 = no input loads, 4 = no stores, 8 = no weight loads,
+// 16 = s_memtime stamps of wave 0 (5 per stage) into a.dbg
 // EPI (epilogue variant, compile-time so that every epilogue-operand load is unconditional straight-line code -- a load
 // under `if (a.res)` becomes a phi with undef, hipcc copies the loaded registers right after the load and the copy's
 // vmcnt wait lands in front of the prefetch):  1 = FiLM (1+scale)*y+shift,  2 = scalar output path (Cout % 4 != 0),
@@ -83,8 +85,20 @@ struct StageKind {
 // 16 = per-SAMPLE time-bias rows (tbias_stride != 0: forward() / p_losses with one t per sample; in the samplers every
 // sample shares the step's row and bias + time bias sit in LDS for the whole launch).
 enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16 };
+// VEC (input staging): 0 = scalar loads, any channel counts;  1 = float4 loads, every CK-channel chunk lies in ONE source
+// (c1 == 0 or c0 % CK == 0): the source base is wave-uniform (SGPR) and a load costs one VALU add;  2 = float4 loads with
+// a per-thread source select (the stem's cat[x, x] with 8 + 8 channels).
+//
+// Why the instruction count of everything around the MFMAs matters more than overlap: measured on MI355X
+// (tools/probes/mfma_coexec.cpp) v_mfma_f32_32x32x2_f32 does NOT co-execute with the issuing wave's own VALU work (each
+// v_fma between two MFMAs adds its ~5 cycles to the 64-cycle interval) and a second wave's VALU stream runs at half
+// speed beside it: the f32 matrix op shares the vector datapath.  So time ~ MFMA cycles + VALU/SALU issue cycles, and
+// the levers are (a) fewer non-MFMA instructions per stage (32-bit offsets off uniform bases, no per-item branches),
+// (b) more MFMAs per staged byte (8-wave workgroups: a 16x16-pixel tile shares one weight chunk, 64-cout tiles share
+// one input chunk).
 template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr int LDA = CK + 4;
@@ -98,30 +112,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr bool DWM = (PRO == PRO_GN_DW);
     constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW);
     constexpr bool FILM = (EPI & EPI_FILM) != 0, SOUT = (EPI & EPI_SOUT) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0, TBS = (EPI & EPI_TBS) != 0;
-    static_assert(!DWM || (KS == 1 && STRIDE == 1 && !UPS && VEC), "depthwise staging is for plain 1x1 convs");
+    static_assert(!DWM || (KS == 1 && STRIDE == 1 && !UPS && VEC == 1), "depthwise staging is for plain 1x1 convs");
+    static_assert(PRO != PRO_COLSM || VEC == 1, "column-softmax prologue needs uniform-source float4 staging");
     constexpr int LPAD = DWM ? 1 : PAD;
     constexpr int LH = DWM ? TH + 2 : IH, LW = DWM ? TW + 2 : IW;   // extent of the loaded tile
     constexpr int HBUF = DWM ? LH * LW * LDA : 0;                  // scratch for the normalised halo tile
     constexpr int DWMAX = DWM ? 9 * 256 : 0;                       // depthwise weights of up to 256 channels
-    constexpr int DITEMS = (TH * TW * C4 + 255) / 256;
-    constexpr int NITEMS = (LH * LW * C4 + 255) / 256;    // float4 input-staging items per thread and chunk
+    constexpr int DITEMS = (TH * TW * C4 + NTHR - 1) / NTHR;
+    constexpr int NITEMS = (LH * LW * C4 + NTHR - 1) / NTHR;  // float4 input-staging items per thread and chunk
     constexpr int WBUF = NB * WN * NF * 256;              // floats of one weight chunk (all n-blocks of the cout tile)
-    constexpr int WITEMS = (WBUF / 4 + 255) / 256;        // float4 weight-staging items per thread and chunk
-    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int WITEMS = (WBUF / 4 + NTHR - 1) / NTHR;  // float4 weight-staging items per thread and chunk
+    constexpr int DUMMY = CK;                             // pad slot of pixel 0 of an A buffer: staging items past the end write here
+    static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per workgroup");
     static_assert(TH * TW == 32 * MB * WM, "pixel tile must match the wave layout");
-    static_assert(CK % 8 == 0 && 256 % C4 == 0, "chunk size");
+    static_assert(CK % 8 == 0 && NTHR % C4 == 0, "chunk size");
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
 
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
     float* Ws = As + 2 * ABUF;                    // [2][WBUF]  weight chunk in B-fragment order
-    double* red = reinterpret_cast<double*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float));  // [2][8]
-    float* Hs = reinterpret_cast<float*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float) + 16 * sizeof(double));  // [HBUF]
+    double* red = reinterpret_cast<double*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float));  // [2][2 * NW]
+    float* Hs = reinterpret_cast<float*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float) + 4 * NW * sizeof(double));  // [HBUF]
     float* DWs = Hs + HBUF;                       // [9][Ctot]
     float* GBs = DWs + DWMAX;                     // GroupNorm gamma | beta, [2][n_chunks * CK] (host adds the bytes)
     float* BTs = GBs + (GNP ? 2 * a.n_chunks * CK : 0);  // bias (+ the step's time-bias row) of all n_ct * NT couts
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DDIF_EMU
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: everything derived from it is scalar math
+#endif
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, j = lane & 31;
     const int tiles = a.tiles_x * a.tiles_y;
@@ -137,12 +158,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const float* tbrow = a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0);
 
     int abase[MB], e_my[MB], e_mx[MB];
+    unsigned e_off[MB], e_foff[MB];  // byte offset of this lane's pixel (+ 4h couts) from the tile's first output / FiLM element
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = (wm * MB + mb) * 32 + j;
         abase[mb] = ((m / TW) * STRIDE * IW + (m % TW) * STRIDE) * LDA + 4 * h;
         e_my[mb] = m / TW;  // the pixel this lane owns in the (transposed) accumulator block mb
         e_mx[mb] = m % TW;
+        e_off[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * a.Cout + 4 * h) * 4);
+        e_foff[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * 2 * a.Cout + 4 * h) * 4);
     }
     constexpr int WCHUNK = NF * 256;  // floats per (n-block, chunk)
 
@@ -151,24 +175,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     unsigned a_in = 0;
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) {
-        const int pixr = (tid + it * 256) / C4;
+        const int pixr = (tid + it * NTHR) / C4;
         const bool in = pixr < LH * LW;
         const int pix = in ? pixr : LH * LW - 1;
         a_py[it] = pix / LW;
         a_px[it] = pix % LW;
-        a_lds[it] = pix * LDA + c4 * 4;
+        a_lds[it] = in ? pix * LDA + c4 * 4 : DUMMY;
         a_in |= (in ? 1u : 0u) << it;
     }
-    int w_goff[WITEMS], w_lds[WITEMS];
-    unsigned w_in = 0;
+    unsigned w_boff[WITEMS];
+    int w_lds[WITEMS];  // relative to Ws[buf]; items past the end go to the A buffer's dummy slot (negative)
 #pragma unroll
     for (int it = 0; it < WITEMS; ++it) {
-        const int qr = tid + it * 256;
+        const int qr = tid + it * NTHR;
         const bool in = qr < WBUF / 4;
         const int q = in ? qr : WBUF / 4 - 1;
-        w_goff[it] = (q / (NF * 64)) * (a.n_chunks * WCHUNK) + (q % (NF * 64)) * 4;
-        w_lds[it] = q * 4;
-        w_in |= (in ? 1u : 0u) << it;
+        w_boff[it] = (unsigned)(((q / (NF * 64)) * (a.n_chunks * WCHUNK) + (q % (NF * 64)) * 4) * 4);
+        w_lds[it] = in ? q * 4 : -1;
     }
 
     // ---- work-item positions (workgroup-uniform); one division set per ITEM, none per chunk ----
@@ -206,9 +229,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // bursts a global load takes ~5 us to land, a stage of MFMAs ~2-3 us: one stage of lookahead is not enough.
     Pos L = locate(w0);
     int l_ch = 0;
-    int l_sp[NITEMS];   // clamped source pixel index of every staging item of work item L
-    int l_cs[NITEMS];   // PRO_COLSM: (b * Win + x) of the item, index into the column-softmax statistics
-    unsigned l_ok = 0;  // which of them are real (inside the image): zero padding otherwise
+    [[maybe_unused]] int l_sp[(VEC == 1) ? 1 : NITEMS];  // VEC != 1: clamped source pixel index of every staging item of work item L
+    [[maybe_unused]] unsigned l_o0[NITEMS], l_o1[NITEMS];  // VEC == 1: byte offset of the item's source pixel in source 0 / source 1
+    unsigned l_cso[PRO == PRO_COLSM ? NITEMS : 1];  // PRO_COLSM: byte offset of (b, x) in the column-softmax statistics
+    unsigned l_ok = 0;  // which items are real (inside the image): zero padding otherwise
     auto item_geometry = [&]() {
         const int iy0 = L.oy0 * STRIDE - LPAD, ix0 = L.ox0 * STRIDE - LPAD;
         l_ok = 0;
@@ -218,8 +242,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             const bool ok = (iy >= 0) & (iy < Hc) & (ix >= 0) & (ix < Wc);
             l_ok |= (ok ? 1u : 0u) << it;
             const int iyc = iy < 0 ? 0 : (iy >= Hc ? Hc - 1 : iy), ixc = ix < 0 ? 0 : (ix >= Wc ? Wc - 1 : ix);
-            l_sp[it] = (L.b * a.Hin + (UPS ? (iyc >> 1) : iyc)) * a.Win + (UPS ? (ixc >> 1) : ixc);
-            if (PRO == PRO_COLSM) l_cs[it] = L.b * a.Win + ixc;
+            const int sp = (L.b * a.Hin + (UPS ? (iyc >> 1) : iyc)) * a.Win + (UPS ? (ixc >> 1) : ixc);
+            if constexpr (VEC == 1) {
+                l_o0[it] = (unsigned)sp * (unsigned)(a.c0 * 4);
+                if (a.c1) l_o1[it] = (unsigned)sp * (unsigned)(a.c1 * 4);
+            } else {
+                l_sp[it] = sp;
+            }
+            if (PRO == PRO_COLSM) l_cso[it] = (unsigned)(L.b * a.Win + ixc) * (unsigned)(a.c0 * 4);
         }
         l_ok &= a_in;
     };
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         float4 sv[NITEMS], wv[WITEMS];
         float4 mxv[PRO == PRO_COLSM ? NITEMS : 1], smv[PRO == PRO_COLSM ? NITEMS : 1];
         unsigned ok;
-        int cbase, ch;
+        int cb, ch;  // first channel of the chunk, chunk index
         Pos pos;
     };
     StageRegs R0, R1;
@@ -242,18 +272,32 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // hits, never consumed): a conditional prefetch would make the number of loads in flight path-dependent, and every
     // later counted vmcnt wait would degrade to vmcnt(0).
     auto issue_loads = [&](StageRegs& R) {
-        const int cbase = l_ch * CK + c4 * 4;
+        const int cb = l_ch * CK;
         if (ABL & 2) {
 #pragma unroll
             for (int it = 0; it < NITEMS; ++it) R.sv[it] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);
-        } else if (VEC) {
-            const int cb = cbase < Ctot ? cbase : Ctot - 4;
+        } else if constexpr (VEC == 1) {
+            // uniform source: SGPR base + 32-bit VGPR offset (tensors are < 4 GiB, checked by the host)
             const bool s0 = cb < a.c0;
-            const float* base = s0 ? a.in0 + cb : a.in1 + (cb - a.c0);
+            const int nvalid = (s0 ? a.c0 : Ctot) - cb;  // channels of this chunk that exist (>= 4, multiple of 4)
+            const int c4c = c4 * 4 < nvalid ? c4 * 4 : nvalid - 4;  // channels past the end re-read valid ones (their weights are 0)
+            const char* base = reinterpret_cast<const char*>(s0 ? a.in0 + cb : a.in1 + (cb - a.c0));
+            const unsigned co = (unsigned)c4c * 4u;
+#pragma unroll
+            for (int it = 0; it < NITEMS; ++it) {
+                const unsigned off = ((s0 || !a.c1) ? l_o0[it] : l_o1[it]) + co;
+                R.sv[it] = *reinterpret_cast<const float4*>(base + off);
+            }
+        } else if constexpr (VEC == 2) {
+            const int cbase = cb + c4 * 4;
+            const int cc = cbase < Ctot ? cbase : Ctot - 4;
+            const bool s0 = cc < a.c0;
+            const float* base = s0 ? a.in0 + cc : a.in1 + (cc - a.c0);
             const int cs = s0 ? a.c0 : a.c1;
 #pragma unroll
             for (int it = 0; it < NITEMS; ++it) R.sv[it] = *reinterpret_cast<const float4*>(base + (size_t)l_sp[it] * cs);
         } else {
+            const int cbase = cb + c4 * 4;
 #pragma unroll
             for (int it = 0; it < NITEMS; ++it) {
                 float e[4];
@@ -268,21 +312,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
         }
         if (PRO == PRO_COLSM) {  // softmax_H(q) statistics of the channels of source 0 (c0 is a multiple of CK)
-            const int cb = cbase < a.c0 ? cbase : 0;
+            const int cbc = cb < a.c0 ? cb : 0;
+            const char* bmx = reinterpret_cast<const char*>(a.cs_mx + cbc);
+            const char* bsm = reinterpret_cast<const char*>(a.cs_sm + cbc);
 #pragma unroll
             for (int it = 0; it < NITEMS; ++it) {
-                R.mxv[it] = *reinterpret_cast<const float4*>(a.cs_mx + (size_t)l_cs[it] * a.c0 + cb);
-                R.smv[it] = *reinterpret_cast<const float4*>(a.cs_sm + (size_t)l_cs[it] * a.c0 + cb);
+                R.mxv[it] = *reinterpret_cast<const float4*>(bmx + (l_cso[it] + (unsigned)c4 * 16u));
+                R.smv[it] = *reinterpret_cast<const float4*>(bsm + (l_cso[it] + (unsigned)c4 * 16u));
             }
         }
-        const float* wbase = a.w + (size_t)L.b * a.w_bstride + ((size_t)L.ct * (NB * WN) * a.n_chunks + l_ch) * WCHUNK;
+        const char* wbase = reinterpret_cast<const char*>(a.w + (size_t)L.b * a.w_bstride + ((size_t)L.ct * (NB * WN) * a.n_chunks + l_ch) * WCHUNK);
 #pragma unroll
         for (int it = 0; it < WITEMS; ++it) {
             if (ABL & 8) R.wv[it] = make_float4(0.01f, 0.02f, 0.03f, 0.04f);
-            else R.wv[it] = *reinterpret_cast<const float4*>(wbase + w_goff[it]);
+            else R.wv[it] = *reinterpret_cast<const float4*>(wbase + w_boff[it]);
         }
         R.ok = l_ok;
-        R.cbase = cbase;
+        R.cb = cb;
         R.ch = l_ch;
         R.pos = L;
         // advance the loader
@@ -304,17 +350,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
                 gn_b = R.pos.b;
             }
-            const float4 gq = *reinterpret_cast<const float4*>(&GBs[R.cbase]);
-            const float4 bq = *reinterpret_cast<const float4*>(&GBs[GBN + R.cbase]);
+            const float4 gq = *reinterpret_cast<const float4*>(&GBs[R.cb + c4 * 4]);
+            const float4 bq = *reinterpret_cast<const float4*>(&GBs[GBN + R.cb + c4 * 4]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ga[i] = (&gq.x)[i] * rstd;
                 gb[i] = (&bq.x)[i] - mean * ga[i];
             }
         }
-        bool cok[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cok[i] = R.cbase + i < Ctot;
+        const bool colsm = (PRO == PRO_COLSM) && R.cb < a.c0;
+        // channels past the end of a partial last chunk hold duplicates of real (finite) data: their packed weights are 0
 #pragma unroll
         for (int it = 0; it < NITEMS; ++it) {
             const bool ok = (R.ok >> it) & 1u;
@@ -327,28 +372,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     if (PRO == PRO_GN_SILU) x = dd_silu(x);
                 }
                 if (PRO == PRO_COLSM) {
-                    if (R.cbase < a.c0) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
+                    if (colsm) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
                 }
-                v[i] = (ok && cok[i]) ? x : 0.f;  // zero padding comes AFTER the activation
+                v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation
             }
             if (DWM) {
-                if ((a_in >> it) & 1u) {
-                    *reinterpret_cast<float4*>(&Hs[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
-                    // centre pixels inside the image: this IS xn = GroupNorm(cat[h, skip]) (attn_res input)
-                    if (a.out_xn && ok && cok[0] && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
-                        *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cbase) =
-                            make_float4(v[0], v[1], v[2], v[3]);
-                }
+                *reinterpret_cast<float4*>(&Hs[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+                // centre pixels inside the image: this IS xn = GroupNorm(cat[h, skip]) (attn_res input)
+                if (a.out_xn && ok && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
+                    *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cb + c4 * 4) =
+                        make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                if ((a_in >> it) & 1u) *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
         if (DWM) {
             __syncthreads();  // halo tile complete in Hs
-            const int cb = R.cbase < Ctot ? R.cbase : 0;
 #pragma unroll
             for (int it = 0; it < DITEMS; ++it) {
-                const int item = tid + it * 256;
+                const int item = tid + it * NTHR;
                 const int p = item / C4;
                 if (p < TH * TW) {
                     const int ty = p / TW, tx = p % TW;
@@ -356,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         const float4 hv = *reinterpret_cast<const float4*>(&Hs[((ty + k / 3) * LW + tx + k % 3) * LDA + c4 * 4]);
-                        const float4 wk = *reinterpret_cast<const float4*>(&DWs[k * Ctot + cb]);
+                        const float4 wk = *reinterpret_cast<const float4*>(&DWs[k * Ctot + R.cb + c4 * 4]);
                         s0 = fmaf(hv.x, wk.x, s0);
                         s1 = fmaf(hv.y, wk.y, s1);
                         s2 = fmaf(hv.z, wk.z, s2);
@@ -367,8 +409,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
         }
 #pragma unroll
-        for (int it = 0; it < WITEMS; ++it)
-            if ((w_in >> it) & 1u) *reinterpret_cast<float4*>(&wdst[w_lds[it]]) = R.wv[it];
+        for (int it = 0; it < WITEMS; ++it) {
+            float* wp = w_lds[it] >= 0 ? wdst + w_lds[it] : dst + DUMMY;
+            *reinterpret_cast<float4*>(wp) = R.wv[it];
+        }
         bufpos[buf] = R.pos;
         bufch[buf] = R.ch;
     };
@@ -380,14 +424,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         if (a.st_out && pend && tid == 0) {
             const Pos p = pend_pos;
             const int t = (p.oy0 / TH) * a.tiles_x + p.ox0 / TW;
-            const double* r = red + pend_par * 8;
+            const double* r = red + pend_par * 2 * NW;
             const size_t pi = ((size_t)p.b * (tiles * a.n_ct) + (size_t)t * a.n_ct + p.ct) * 2;
-            a.st_out[pi + 0] = (r[0] + r[2]) + (r[4] + r[6]);
-            a.st_out[pi + 1] = (r[1] + r[3]) + (r[5] + r[7]);
+            double t0 = (r[0] + r[2]) + (r[4] + r[6]), t1 = (r[1] + r[3]) + (r[5] + r[7]);
+            if (NW == 8) {
+                t0 += (r[8] + r[10]) + (r[12] + r[14]);
+                t1 += (r[9] + r[11]) + (r[13] + r[15]);
+            }
+            a.st_out[pi + 0] = t0;
+            a.st_out[pi + 1] = t1;
         }
         pend = false;
     };
 
+    [[maybe_unused]] int dbg_n = 0;
+    auto stamp = [&]() {
+#ifndef DDIF_EMU
+        if ((ABL & 16) && a.dbg && tid == 0 && dbg_n < 126) a.dbg[blockIdx.x * 128 + dbg_n++] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    };
     f32x16 acc[MB][NB];
     const int nflat = (w1 - w0) * a.n_chunks;
 
@@ -396,6 +451,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     //   stage ago) -> prologue -> LDS buffer cur^1.  The caller puts one barrier after it.
     auto stage = [&](auto kind, const int cur, StageRegs& Rn, StageRegs& Rf) {
         constexpr bool LAST = decltype(kind)::LAST, TAIL = decltype(kind)::TAIL;
+        stamp();
         const float* Ac = As + cur * ABUF;
         const Pos Cp = bufpos[cur];
         const int c_ch = bufch[cur];
@@ -406,31 +462,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         float4 e_res[(LAST && RES) ? MB : 1][(LAST && RES) ? NB : 1][4];
         float4 e_fs[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4], e_fh[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4];
         bool full = true;
-        size_t e_pix[MB];
+        unsigned e_po[MB], e_pf[MB];  // this item's byte offsets (clamped to the tile origin for pixels outside the image)
         bool e_pok[MB];
+        size_t tile_el = 0;           // element index of (tile origin pixel, first cout of this wave)
         if constexpr (LAST) {
             full = (Cp.oy0 + TH <= a.Hout) & (Cp.ox0 + TW <= a.Wout);
+            const size_t tile_pix = (size_t)((Cp.b * a.Hout + Cp.oy0) * a.Wout + Cp.ox0);
+            tile_el = tile_pix * a.Cout + nbg0 * 32;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 e_pok[mb] = full || ((Cp.oy0 + e_my[mb] < a.Hout) & (Cp.ox0 + e_mx[mb] < a.Wout));
-                const int oy = e_pok[mb] ? Cp.oy0 + e_my[mb] : Cp.oy0, ox = e_pok[mb] ? Cp.ox0 + e_mx[mb] : Cp.ox0;
-                e_pix[mb] = (size_t)((Cp.b * a.Hout + oy) * a.Wout + ox);
+                e_po[mb] = e_pok[mb] ? e_off[mb] : (unsigned)(16 * h);
+                e_pf[mb] = e_pok[mb] ? e_foff[mb] : (unsigned)(16 * h);
             }
             if constexpr (!SOUT) {
-                [[maybe_unused]] const float* tb = tbrow + (size_t)Cp.b * a.tbias_stride;
+                // a wave whose whole cout range lies past Cout (Cout = 32 under a 64-cout tile) loads from block 0 instead
+                const int nbl = nbg0 * 32 < a.Cout ? nbg0 * 32 : 0;
+                [[maybe_unused]] const char* tb = reinterpret_cast<const char*>(tbrow + (size_t)Cp.b * a.tbias_stride + nbl);
+                [[maybe_unused]] const char* rbase = reinterpret_cast<const char*>(a.res + tile_pix * a.Cout + nbl);
+                [[maybe_unused]] const char* fbase = reinterpret_cast<const char*>(a.film + tile_pix * 2 * a.Cout + nbl);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int co = (nbg0 + nb) * 32 + 8 * g + 4 * h;
-                        const int coc = co < a.Cout ? co : 0;
-                        if constexpr (TBS) e_t[nb][g] = *reinterpret_cast<const float4*>(tb + coc);
+                        // couts past Cout re-read the first quad of the (clamped) base block: always inside the tensor
+                        const unsigned cq = ((nbg0 + nb) * 32 + 8 * g + 4 * h < a.Cout) ? (unsigned)((nb * 32 + 8 * g) * 4) : (unsigned)(-16 * h);
+                        if constexpr (TBS) e_t[nb][g] = *reinterpret_cast<const float4*>(tb + (cq + 16u * h));
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
-                            if constexpr (RES) e_res[mb][nb][g] = *reinterpret_cast<const float4*>(a.res + e_pix[mb] * a.Cout + coc);
+                            if constexpr (RES) e_res[mb][nb][g] = *reinterpret_cast<const float4*>(rbase + (e_po[mb] + cq));
                             if constexpr (FILM) {
-                                e_fs[mb][nb][g] = *reinterpret_cast<const float4*>(a.film + e_pix[mb] * 2 * a.Cout + coc);
-                                e_fh[mb][nb][g] = *reinterpret_cast<const float4*>(a.film + e_pix[mb] * 2 * a.Cout + a.Cout + coc);
+                                e_fs[mb][nb][g] = *reinterpret_cast<const float4*>(fbase + (e_pf[mb] + cq));
+                                e_fh[mb][nb][g] = *reinterpret_cast<const float4*>(fbase + (size_t)a.Cout * 4 + (e_pf[mb] + cq));
                             }
                         }
                     }
@@ -439,6 +502,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         // (2) prefetch stage +2
         if constexpr (!TAIL) issue_loads(Rf);
         flush_stats();
+        stamp();
         if (c_ch == 0) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
@@ -468,13 +532,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                         if (ABL & 1) acc[mb][nb][i] += (&af[mb].x)[i] * (&bf[nb].x)[i];
                         else acc[mb][nb] = DDIF_MFMA_32x32x2((&bf[nb].x)[i], (&af[mb].x)[i], acc[mb][nb]);
         }
+        stamp();
         if constexpr (LAST) {
             // (4) epilogue of work item Cp: lane (j, h) owns pixel j of each 32-pixel block and, per accumulator quad g,
             //     the 4 consecutive couts 8g + 4h .. +3 of each 32-cout block
             float s1 = 0.f, s2 = 0.f;
             if constexpr (!SOUT) {
+                char* obase = reinterpret_cast<char*>(a.out + tile_el);
                 auto epi = [&](auto guard) {
-                    constexpr bool GUARD = decltype(guard)::LAST;
+                    constexpr bool GUARD = decltype(guard)::LAST;  // StageKind<1> = bounds-checked stores
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -493,9 +559,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                                     if constexpr (RES) x += (&e_res[mb][nb][g].x)[i];
                                     v[i] = x;
                                 }
-                                float* op = a.out + e_pix[mb] * a.Cout + co;
                                 if (!GUARD || (e_pok[mb] && co < a.Cout)) {
-                                    if (!(ABL & 4) || v[0] == 12345.678f) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                                    // (streaming / nontemporal stores measured slower: 1x1 64->64 @64^2 63 vs 38 us)
+                                    if (!(ABL & 4) || v[0] == 12345.678f)
+                                        *reinterpret_cast<float4*>(obase + (e_po[mb] + (unsigned)((nb * 32 + 8 * g) * 4))) = make_float4(v[0], v[1], v[2], v[3]);
                                     s1 += (v[0] + v[1]) + (v[2] + v[3]);
                                     s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                                 }
@@ -514,12 +581,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                         for (int r = 0; r < 16; ++r) {
                             const int co = (nbg0 + nb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                             if (e_pok[mb] && co < a.Cout) {
+                                const size_t pix = (size_t)((Cp.b * a.Hout + Cp.oy0 + e_my[mb]) * a.Wout + Cp.ox0 + e_mx[mb]);
                                 float x = acc[mb][nb][r] + BTs[co];
                                 if constexpr (TBS) x += tb[co];
-                                if constexpr (FILM) x = x * (1.f + a.film[e_pix[mb] * 2 * a.Cout + co]) + a.film[e_pix[mb] * 2 * a.Cout + a.Cout + co];
+                                if constexpr (FILM) x = x * (1.f + a.film[pix * 2 * a.Cout + co]) + a.film[pix * 2 * a.Cout + a.Cout + co];
                                 if constexpr (SILU) x = dd_silu(x);
-                                if constexpr (RES) x += a.res[e_pix[mb] * a.Cout + co];
-                                if (!(ABL & 4) || x == 12345.678f) a.out[e_pix[mb] * a.Cout + co] = x;
+                                if constexpr (RES) x += a.res[pix * a.Cout + co];
+                                if (!(ABL & 4) || x == 12345.678f) a.out[pix * a.Cout + co] = x;
                                 s1 += x;
                                 s2 += x * x;
                             }
@@ -529,39 +597,46 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 const double d1 = (double)wave_sum_fast(s1), d2 = (double)wave_sum_fast(s2);  // fp32 tree in-wave, fp64 beyond
                 pend_par ^= 1;
                 if (lane == 63) {
-                    red[pend_par * 8 + wave * 2 + 0] = d1;
-                    red[pend_par * 8 + wave * 2 + 1] = d2;
+                    red[pend_par * 2 * NW + wave * 2 + 0] = d1;
+                    red[pend_par * 2 * NW + wave * 2 + 1] = d2;
                 }
                 pend = true;
                 pend_pos = Cp;
             }
         }
+        stamp();
         // (5) stage +1 (loaded one stage ago) -> the other LDS buffer
         //     (after the very last stage this writes a never-consumed copy of the last item's chunk 0: cheaper than a
         //     `has_next` branch, whose skip path would leave Rn pending at the loop-head merge)
         if constexpr (!TAIL) finish_stage(Rn, cur ^ 1);
+        stamp();
     };
 
+    stamp();
+    // the first two stages' loads go out FIRST: their HBM latency overlaps the table fills below
+    item_geometry();
+    issue_loads(R0);
+    issue_loads(R1);
+    stamp();
     if (DWM) {
-        for (int i = tid; i < 9 * Ctot; i += 256) DWs[i] = a.dw_w[i];
+        for (int i = tid; i < 9 * Ctot; i += NTHR) DWs[i] = a.dw_w[i];
     }
     if (GNP) {
-        for (int i = tid; i < GBN; i += 256) {
+        for (int i = tid; i < GBN; i += NTHR) {
             const int c = i < Ctot ? i : Ctot - 1;
             GBs[i] = a.gamma[c];
             GBs[GBN + i] = a.beta[c];
         }
     }
-    for (int i = tid; i < a.n_ct * (32 * NB * WN); i += 256) {
+    for (int i = tid; i < a.n_ct * (32 * NB * WN); i += NTHR) {
         const int c = i < a.Cout ? i : a.Cout - 1;
         BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
     }
     __syncthreads();
-    item_geometry();
-    issue_loads(R0);
-    issue_loads(R1);
+    stamp();
     finish_stage(R0, 0);
     __syncthreads();
+    stamp();
     const int npairs = nflat >> 1;
     for (int pr = 0; pr < npairs; ++pr) {
         if (bufch[0] == a.n_chunks - 1) stage(StageKind<1>{}, 0, R1, R0);
@@ -574,14 +649,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     if (nflat & 1) stage(StageKind<3>{}, 0, R1, R0);  // odd tail: always the last chunk of the last item
     __syncthreads();
     flush_stats();
+    stamp();
 }
 
 
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO = 0>
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO = 0, int NW = 4>
 constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN; + conv_smem_extra() at launch
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
-    return (size_t)(2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) + dw) * sizeof(float) + 16 * sizeof(double);
+    return (size_t)(2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) + dw) * sizeof(float) + 4 * NW * sizeof(double);
 }
 // GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts
 inline size_t conv_smem_extra(int pro, int n_chunks, int ck, int cout_pad) {

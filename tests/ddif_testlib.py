@@ -19,6 +19,11 @@ CTOR_KEYS = ("in_channel", "out_channel", "inner_channel", "lms_channel", "pan_c
 
 
 def ensure_emu_lib() -> str:
+    # DDIF_EMU_LIB: another host build of the same sources, e.g. the AddressSanitizer one (`make -C dif-pan_amd emu-asan`,
+    # run under LD_PRELOAD of clang's asan runtime -- tools/asan_emu.sh): GPU sanitizers are not available on the pool
+    override = os.environ.get("DDIF_EMU_LIB")
+    if override:
+        return override
     subprocess.run(["make", "-C", PKG, "-j8", "emu"], check=True, stdout=subprocess.DEVNULL)
     return EMU_LIB
 

@@ -37,44 +37,72 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
     std::vector<double> hs((size_t)B * 64 * 2); for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 10.0; hs[i + 1] = 5000.0; }
     CK_(hipMemcpy(st, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
     a.st0 = st; a.np0 = 64; a.st_out = sto;
+    long long* dbg = nullptr; if (ABL & 16) { CK_(hipMalloc(&dbg, 1024 * 128 * 8)); CK_(hipMemset(dbg, 0, 1024 * 128 * 8)); a.dbg = dbg; }
     const long nwork = (long)B * a.tiles_x * a.tiles_y * a.n_ct;
     const long cap = 256L * wg_per_cu;
     dim3 grid((unsigned)(nwork < cap ? nwork : cap));
     auto fn = conv_mfma_kernel<KS, S, U, TH, TW, CKc, WM, WN, MB, NB, PRO, 1, EPI, ABL>;
-    const size_t smem = conv_smem_bytes<KS, S, U, TH, TW, CKc, NB * WN, PRO>() + conv_smem_extra(PRO, n_chunks, CKc, a.n_ct * NT);
+    const size_t smem = conv_smem_bytes<KS, S, U, TH, TW, CKc, NB * WN, PRO, WM * WN>() + conv_smem_extra(PRO, n_chunks, CKc, a.n_ct * NT);
     if (smem > 65536) CK_(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipEvent_t e0, e1; CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fn, grid, dim3(256), smem, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fn, grid, dim3(64 * WM * WN), smem, 0, a);
     CK_(hipDeviceSynchronize());
     const int iters = 20;
     CK_(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(fn, grid, dim3(256), smem, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(fn, grid, dim3(64 * WM * WN), smem, 0, a);
     CK_(hipEventRecord(e1, 0)); CK_(hipEventSynchronize(e1));
     float ms; CK_(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, flop = 2.0 * B * Hout * Wout * Cout * Cin * KS * KS;
+    if (ABL & 16) {
+        std::vector<long long> hd(1024 * 128); CK_(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+        for (int blk : {0, 1, 2, 300, 511}) { printf("  block %d stamps (cycles; entry, tables filled, first loads issued, first stage staged | 5 per stage: start, loads issued, mfma done, epilogue done, staged):\n   ", blk); long long t0 = hd[blk * 128];
+            for (int i = 0; i < 126 && hd[blk * 128 + i]; ++i) printf(" %lld%s", hd[blk * 128 + i] - t0, (i % 5 == 3) ? " |" : ""); printf("\n"); }
+    }
     printf("%-46s abl=%2d wg/cu=%d grid=%5u smem=%6zu  %8.1f us  %6.1f TF\n", name, ABL, wg_per_cu, grid.x, smem, us, flop / us / 1e6);
     hipFree(in); hipFree(w); hipFree(out); hipFree(res); hipFree(gamma); hipFree(beta); hipFree(bias); hipFree(st); hipFree(sto);
 }
 
 int main(int argc, char** argv) {
     const int B = 64;
+    if (argc > 1 && argv[1][0] == 'n') {  // nontemporal-store experiment (ABL 64 = plain stores)
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) nt", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 64>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) plain", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) nt", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 64>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) plain", B, 64, 64, 32, 32, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_NONE, 0>("1x1 64->64 @64^2 (8x16,NT64) nt", B, 64, 64, 64, 64, 2);
+        run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_NONE, 64>("1x1 64->64 @64^2 (8x16,NT64) plain", B, 64, 64, 64, 64, 2);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_NONE, 0>("3x3 64->64 @64^2 (16x16,NT64,8w) nt", B, 64, 64, 64, 64, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_NONE, 64>("3x3 64->64 @64^2 (16x16,NT64,8w) plain", B, 64, 64, 64, 64, 1);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 's') {  // stamp mode
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 16>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) 1wg", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 30>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) 1wg", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 30>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w)", B, 64, 64, 32, 32, 1);
+        return 0;
+    }
+    if (argc > 1) {  // PMC mode: few kernels, distinct template instantiations
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 14>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0>("3x3 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
+        run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64)", B, 64, 64, 64, 64, 2);
+        return 0;
+    }
     run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, 2);
     run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 14>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, 2);
+    run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w)", B, 64, 64, 32, 32, 1);
+    run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 14>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w)", B, 64, 64, 32, 32, 1);
     run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (8x16,NT32)", B, 32, 32, 64, 64, 2);
-    run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, EPI_RES>("3x3 gn_silu 64->64 @32^2 +res (8x16,NT32)", B, 32, 32, 64, 64, 2);
+    run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (16x16,NT32,8w)", B, 32, 32, 64, 64, 1);
+    run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (16x16,NT64,8w)", B, 32, 32, 64, 64, 1);
     run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0>("3x3 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
+    run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0>("3x3 64->64 @64^2 (16x16,NT32,8w)", B, 64, 64, 64, 64, 1);
+    run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_NONE, 0>("3x3 64->64 @64^2 (16x16,NT64,8w)", B, 64, 64, 64, 64, 1);
     run<3, 1, 0, 8, 8, 16, 2, 2, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 128->128 @8^2 (8x8,NT64)", B, 8, 8, 128, 128, 2);
     run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @16^2 (8x16,NT32)", B, 16, 16, 64, 64, 2);
-    run<3, 1, 0, 8, 8, 16, 2, 2, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @16^2 (8x8,NT64)", B, 16, 16, 64, 64, 2);
-    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_NONE, 0>("1x1 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
     run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_NONE, 0>("1x1 64->64 @64^2 (8x16,NT64)", B, 64, 64, 64, 64, 2);
-    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_GN_DW, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
     run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64)", B, 64, 64, 64, 64, 2);
-    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64) 1wg", B, 64, 64, 64, 64, 1);
-    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_GN_DW, 0>("1x1 gn_dw 128->128 @32^2 (8x16,NT32)", B, 32, 32, 128, 128, 2);
     run<1, 1, 0, 8, 16, 32, 4, 1, 1, 4, PRO_GN_DW, 0>("1x1 gn_dw 128->128 @32^2 (8x16,NT128)", B, 32, 32, 128, 128, 1);
-    run<1, 1, 0, 8, 8, 32, 2, 2, 1, 2, PRO_GN_DW, 0>("1x1 gn_dw 128->128 @32^2 (8x8,NT128)", B, 32, 32, 128, 128, 2);
-    run<1, 1, 0, 8, 16, 32, 4, 1, 1, 1, PRO_GN_SILU, 0>("1x1 gn_silu 256->128 @32^2 (8x16,NT32)", B, 32, 32, 256, 128, 2);
     run<1, 1, 0, 8, 16, 32, 4, 1, 1, 4, PRO_GN_SILU, 0>("1x1 gn_silu 256->128 @32^2 (8x16,NT128)", B, 32, 32, 256, 128, 2);
     return 0;
 }
