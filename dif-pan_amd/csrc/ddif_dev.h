@@ -8,6 +8,7 @@ typedef hipemu_f32x4 f32x4;
 #define DDIF_MFMA_32x32x2(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
 #define DDIF_MFMA_16x16x4(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
 #define DDIF_DYN_SMEM(name) char* name = hipemu::tctx().dyn_smem
+#define DDIF_SCHED_FENCE() ((void)0)
 #else
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -15,6 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DDIF_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define DDIF_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define DDIF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define DDIF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // instruction-scheduling fence (no code)
 #endif
 
 #define DDIF_WAVE 64

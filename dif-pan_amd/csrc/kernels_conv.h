@@ -514,23 +514,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         // (3) contraction over taps x chunk channels: both fragments from LDS, no global load in here.  Weights are
         //     the MFMA's FIRST operand: D[cout][pixel] (see the header comment).
         const float* Wc = Ws + cur * WBUF + (wn * NB) * (NF * 256) + h * 128 + j * 4;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
+        //     Fragments are double-buffered in registers: the ds_reads of step f+1 are issued BEFORE the MFMAs of step f
+        //     (an in-order wave otherwise issues them only after the last MFMA of step f has issued, and the LDS
+        //     latency beyond that MFMA's 64 cycles is a bubble in the matrix pipe).
+        float4 af[2][MB], bf[2][NB];
+        auto load_frags = [&](int f, int slot) {
             const int tap = f / K8, k8 = f % K8;
             const int aoff = ((tap / KS) * IW + (tap % KS)) * LDA;
-            float4 af[MB], bf[NB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + k8 * 8]);
+            for (int mb = 0; mb < MB; ++mb) af[slot][mb] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + k8 * 8]);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(&Wc[nb * (NF * 256) + f * 256]);
+            for (int nb = 0; nb < NB; ++nb) bf[slot][nb] = *reinterpret_cast<const float4*>(&Wc[nb * (NF * 256) + f * 256]);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (f + 1 < NF) load_frags(f + 1, (f + 1) & 1);
+            DDIF_SCHED_FENCE();  // keep the reads above the MFMAs (the scheduler otherwise sinks them to their first use)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        if (ABL & 1) acc[mb][nb][i] += (&af[mb].x)[i] * (&bf[nb].x)[i];
-                        else acc[mb][nb] = DDIF_MFMA_32x32x2((&bf[nb].x)[i], (&af[mb].x)[i], acc[mb][nb]);
+                        if (ABL & 1) acc[mb][nb][i] += (&af[f & 1][mb].x)[i] * (&bf[f & 1][nb].x)[i];
+                        else acc[mb][nb] = DDIF_MFMA_32x32x2((&bf[f & 1][nb].x)[i], (&af[f & 1][mb].x)[i], acc[mb][nb]);
+            DDIF_SCHED_FENCE();
         }
         stamp();
         if constexpr (LAST) {
@@ -637,6 +646,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     finish_stage(R0, 0);
     __syncthreads();
     stamp();
+#ifndef DDIF_EMU
+    if (ABL & 32) {  // experiment: start the workgroup in the odd wave slot of each SIMD half a stage late (anti-phase)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1u) {
+            if (ABL & 64) __builtin_amdgcn_s_sleep(60);
+            else __builtin_amdgcn_s_sleep(40);
+        }
+    }
+#endif
     const int npairs = nflat >> 1;
     for (int pr = 0; pr < npairs; ++pr) {
         if (bufch[0] == a.n_chunks - 1) stage(StageKind<1>{}, 0, R1, R0);

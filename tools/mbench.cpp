@@ -64,6 +64,25 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
 
 int main(int argc, char** argv) {
     const int B = 64;
+    if (argc > 1 && argv[1][0] == 'b') {  // big per-wave register tiles, one wave per SIMD
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w)", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,4w MB2)", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (16x16,NT64,8w)", B, 32, 32, 64, 64, 1);
+        run<3, 1, 0, 16, 16, 16, 4, 1, 2, 2, PRO_GN_SILU, 0>("3x3 gn_silu 64->64 @32^2 (16x16,NT64,4w MB2NB2)", B, 32, 32, 64, 64, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_NONE, 0>("3x3 64->64 @64^2 (16x16,NT64,8w)", B, 64, 64, 64, 64, 1);
+        run<3, 1, 0, 16, 16, 16, 4, 1, 2, 2, PRO_NONE, 0>("3x3 64->64 @64^2 (16x16,NT64,4w MB2NB2)", B, 64, 64, 64, 64, 1);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'd') {  // delayed-start (anti-phase) experiment
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (8x16,NT32)", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 32>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) delay40", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 96>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) delay60", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 48>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) delay40 stamps", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0>("3x3 64->64 @64^2 (8x16,NT32)", B, 64, 64, 64, 64, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 32>("3x3 64->64 @64^2 (8x16,NT32) delay40", B, 64, 64, 64, 64, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 96>("3x3 64->64 @64^2 (8x16,NT32) delay60", B, 64, 64, 64, 64, 2);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'n') {  // nontemporal-store experiment (ABL 64 = plain stores)
         run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) nt", B, 64, 64, 32, 32, 2);
         run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 64>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) plain", B, 64, 64, 32, 32, 2);
