@@ -257,6 +257,11 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
                 s.ups, c0, c1, pc.cout, Hout, Wout, s.pro, epi, cfg, nwork, grid.x, smem);
     Op op;
     op.name = var.name;
+    {
+        char lb[160];
+        snprintf(lb, sizeof lb, "%s %dx%d %d+%d->%d @%dx%d cfg%d", s.name, pc.ks, pc.ks, c0, c1, pc.cout, Hout, Wout, cfg);
+        op.label = lb;
+    }
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
     op.timed = (pc.ks == 3);
@@ -782,6 +787,29 @@ int Plan::time_rows(const float* t_host, int rows, hipStream_t s) {
 }
 
 void Plan::run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof) {
+    static const char* op_timing = getenv("DDIF_OP_TIMING");
+    if (op_timing && prof && !op_timing_done) {  // development aid: every op of ONE step between its own pair of events
+        op_timing_done = true;
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            if (FILE* f = fopen(op_timing, "w")) {
+                fprintf(f, "op,kernel,us,gflop,mbytes\n");
+                for (auto& op : prog) {
+                    (void)hipEventRecord(e0, s);
+                    op.run(s, ctx);
+                    (void)hipEventRecord(e1, s);
+                    (void)hipEventSynchronize(e1);
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    fprintf(f, "\"%s\",%s,%.2f,%.4f,%.3f\n", op.label.empty() ? op.name : op.label.c_str(), op.name, ms * 1e3, op.flop / 1e9, op.bytes / 1e6);
+                }
+                fclose(f);
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                return;
+            }
+        }
+    }
     for (auto& op : prog) {
         const bool t = prof && op.timed && ev_used < (int)ev0.size();
         if (t) (void)hipEventRecord(ev0[ev_used], s);

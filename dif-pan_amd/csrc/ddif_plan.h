@@ -1,5 +1,6 @@
 // Plan: per-(B,H,W) workspaces, the cond-only caches and the launch program of one denoising step.
 #pragma once
+#include <string>
 #include "ddif_net.h"
 
 namespace ddif {
@@ -27,6 +28,7 @@ struct Op {
     double flop = 0, bytes = 0;
     bool timed = false;  // member of the profiled kernel class (3x3 implicit-GEMM convs)
     const char* name = "";
+    std::string label;   // layer + shape, for the DDIF_OP_TIMING dump
 };
 
 typedef void (*ConvKernelFn)(ConvArgs);
@@ -107,6 +109,7 @@ struct Plan {
     int ensure_tb(int rows);
     int time_rows(const float* t_host, int rows, hipStream_t s);
     void run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof);
+    bool op_timing_done = false;  // DDIF_OP_TIMING=<csv path>: one profiled step is timed op by op (development aid)
 
     int set_cond(const float* cond, hipStream_t s);
     int forward(const float* x, const float* t_host, const float* sc, float* out, hipStream_t s);

@@ -98,20 +98,26 @@ __global__ void softmax_stats_kernel(const float* in, int ld, int coff, int C, i
                                      float* mx, float* sm) {
     const int keep = axis == 0 ? W : H, red = axis == 0 ? H : W;
     const size_t n = (size_t)B * keep * C;
+    const size_t rstride = (size_t)(axis == 0 ? W : 1) * ld;  // floats between consecutive elements of the reduced axis
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int k = (int)((i / C) % keep);
         const int b = (int)(i / ((size_t)C * keep));
-        const size_t base = (size_t)b * H * W;
-        float m = -INFINITY;
-        for (int r = 0; r < red; ++r) {
-            const size_t pix = base + (axis == 0 ? (size_t)r * W + k : (size_t)k * W + r);
-            m = fmaxf(m, in[pix * ld + coff + c]);
-        }
-        float s = 0.f;
-        for (int r = 0; r < red; ++r) {
-            const size_t pix = base + (axis == 0 ? (size_t)r * W + k : (size_t)k * W + r);
-            s += dd_exp(in[pix * ld + coff + c] - m);
+        const float* p0 = in + ((size_t)b * H * W + (axis == 0 ? (size_t)k : (size_t)k * W)) * ld + coff + c;
+        float m = -INFINITY, s = 0.f;
+        if (red <= 64) {
+            // the whole line lives in registers: ONE pass over memory, same two-pass arithmetic (and order) as below
+            float v[64];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) v[r] = p0[(size_t)(r < red ? r : red - 1) * rstride];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) m = fmaxf(m, v[r]);  // the clamped tail repeats the last element: max unchanged
+#pragma unroll
+            for (int r = 0; r < 64; ++r)
+                if (r < red) s += dd_exp(v[r] - m);
+        } else {
+            for (int r = 0; r < red; ++r) m = fmaxf(m, p0[(size_t)r * rstride]);
+            for (int r = 0; r < red; ++r) s += dd_exp(p0[(size_t)r * rstride] - m);
         }
         mx[i] = m;
         sm[i] = s;
