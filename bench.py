@@ -34,6 +34,7 @@ def log(msg):
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix (= vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3  # dense bf16 MFMA (2.5 PF); the bf16x3 path issues 6 bf16 products per fp32 product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -137,6 +138,8 @@ def main():
     ach_tflops = prof["total_flop"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] > 0 else 0.0
     step_flop_total = cost["step_flop"] * T + cost["cond_flop"]
     traffic, traffic_src = committed_traffic()
+    x3 = "bf16x3" in prof["kernel"]
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_F32_MFMA_TFLOPS
     result = {
         "metric": "fused megapixels/sec at T=%d, WV3 64x64x8 tiles" % T,
         "value": value,
@@ -151,13 +154,18 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "WV3 pansharpening, batch %d of %dx%dx8 tiles per GPU, T=%d DDPM p_sample, fp32" % (B, H, H, T),
-                   "tiles_per_gpu": B, "tile": [H, H, C], "T": T, "sampler": "ddpm", "parallelism": "tile-shard x%d" % world},
+                   "tiles_per_gpu": B, "tile": [H, H, C], "T": T, "sampler": "ddpm", "parallelism": "tile-shard x%d" % world,
+                   "conv_math": "bf16x3 (3x3 convs) + exact fp32 MFMA (1x1, attention)" if x3 else "exact fp32 MFMA"},
         "roofline": {
             "bound": "mfma",
             "achieved": ach_tflops,
-            "peak": PEAK_F32_MFMA_TFLOPS,
+            "peak": peak,
             "unit": "TFLOP/s",
-            "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS,
+            "frac": ach_tflops / peak,
+            "peak_note": ("fp32-equivalent: dense bf16 MFMA peak 2516.8 TF / 6 split products per fp32 product (bf16x3: hi/mid/lo "
+                          "operand split, fp32 accumulate, fp32-class accuracy); achieved counts ALGORITHMIC fp32 flops"
+                          if x3 else "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+            "frac_of_f32_mfma_peak": ach_tflops / PEAK_F32_MFMA_TFLOPS,
             "traffic": traffic,
             "traffic_unit": "bytes of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)",
             "traffic_source": traffic_src,

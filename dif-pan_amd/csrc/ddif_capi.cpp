@@ -152,7 +152,10 @@ int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
         out->total_flop += p.ev_flop[i];
         out->total_bytes += p.ev_bytes[i];
     }
-    std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions)");
+    if (p.n_conv3_x3 > 0)
+        std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions; bf16x3 split products on %d of %d)", p.n_conv3_x3, p.n_conv3);
+    else
+        std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions; exact fp32 MFMA)");
     p.prof_every = 0;
     p.ev_used = 0;
     return DDIF_OK;

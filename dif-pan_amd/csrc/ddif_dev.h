@@ -7,6 +7,13 @@ typedef hipemu_f32x16 f32x16;
 typedef hipemu_f32x4 f32x4;
 #define DDIF_MFMA_32x32x2(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
 #define DDIF_MFMA_16x16x4(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
+static inline f32x16 ddif_mfma_bf16_emu(float4 a, float4 b, f32x16 c) {
+    hipemu_u32x4 ua, ub;
+    __builtin_memcpy(&ua, &a, 16);
+    __builtin_memcpy(&ub, &b, 16);
+    return hipemu_mfma_32x32x16_bf16(ua, ub, c);
+}
+#define DDIF_MFMA_32x32x16_BF16(a, b, c) ddif_mfma_bf16_emu((a), (b), (c))
 #define DDIF_DYN_SMEM(name) char* name = hipemu::tctx().dyn_smem
 #define DDIF_SCHED_FENCE() ((void)0)
 #else
@@ -15,6 +22,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // exact-fp32 matrix FMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32): bitwise an fmaf chain over k
 #define DDIF_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define DDIF_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_32x32x16_bf16 on operands carried as float4 (8 bf16 = 16 bytes per lane: A[i][k = 8*(lane>>5) + t])
+typedef __bf16 ddif_bf16x8 __attribute__((ext_vector_type(8)));
+#define DDIF_MFMA_32x32x16_BF16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ddif_bf16x8, (a)), __builtin_bit_cast(ddif_bf16x8, (b)), (c), 0, 0, 0)
 #define DDIF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define DDIF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // instruction-scheduling fence (no code)
 #endif
@@ -51,6 +62,49 @@ __device__ __forceinline__ float dd_rcp_fast(float x) {
     return 1.0f / x;
 #else
     return __builtin_amdgcn_rcpf(x);
+#endif
+}
+
+// ---- 3-way bf16 split of an fp32 value: x = hi + mid + lo exactly to ~2^-24 |x| (each part 8 significant bits, round
+// to nearest even; the remainders x - hi and x - hi - mid are exact in fp32).  Six cross products hi*hi, hi*mid, mid*hi,
+// mid*mid, hi*lo, lo*hi on the bf16 matrix instruction (exact products, fp32 accumulate) reproduce the fp32 product to
+// ~2^-23 relative (measured: tools/probes/bf16x3.cpp, 1.6e-7 vs 1.0e-7 of the exact-fp32 MFMA, relative to sum |a b|).
+__device__ __forceinline__ unsigned dd_bf16_bits(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float dd_bf16_val(unsigned b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ void dd_split3(float x, unsigned* hi, unsigned* mid, unsigned* lo) {
+    const unsigned h = dd_bf16_bits(x);
+    const float r1 = x - dd_bf16_val(h);
+    const unsigned m = dd_bf16_bits(r1);
+    const float r2 = r1 - dd_bf16_val(m);
+    *hi = h;
+    *mid = m;
+    *lo = dd_bf16_bits(r2);
+}
+
+// the same split for two values at once, results packed (a in the low half): v_cvt_pk_bf16_f32 does the RNE rounding
+// of both in one instruction (5.5 VALU ops per value instead of ~20 with integer rounding)
+__device__ __forceinline__ void dd_split3_pair(float a, float b, unsigned* hi, unsigned* mid, unsigned* lo) {
+#ifdef DDIF_EMU
+    unsigned ha, ma, la, hb, mb, lb;
+    dd_split3(a, &ha, &ma, &la);
+    dd_split3(b, &hb, &mb, &lb);
+    *hi = ha | (hb << 16);
+    *mid = ma | (mb << 16);
+    *lo = la | (lb << 16);
+#else
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+    const v2f v = {a, b};
+    const unsigned H = __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b));
+    const v2f r1 = {a - __builtin_bit_cast(float, H << 16), b - __builtin_bit_cast(float, H & 0xffff0000u)};
+    const unsigned M = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, v2b));
+    const v2f r2 = {r1.x - __builtin_bit_cast(float, M << 16), r1.y - __builtin_bit_cast(float, M & 0xffff0000u)};
+    *hi = H;
+    *mid = M;
+    *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2b));
 #endif
 }
 

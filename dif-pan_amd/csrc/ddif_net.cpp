@@ -1,6 +1,7 @@
 // Network construction and weight repacking (host side).
 // Layer list = UNetSR3.__init__ (reference models/sr3_dwt.py:69-163); checkpoint keys = SURVEY.md appendix C.
 #include "ddif_net.h"
+#include <cstdint>
 
 namespace ddif {
 
@@ -173,11 +174,54 @@ size_t pack_conv(Blob& b, const float* w, int cout, int cin, int ks, int ck, int
     return off;
 }
 
+// bf16x3 order (kernels_conv.h, MATH = 1; 3x3 convs, 16-channel chunks):
+//   [n-block of 32 couts][chunk][tap][plane: hi, mid, lo][half h][cout j][8 bf16: cin = chunk*16 + 8*h + t]
+// = 1 KiB per (tap, plane) in exactly the per-lane A-operand order of v_mfma_f32_32x32x16_bf16.  The split is the same
+// round-to-nearest-even three-way split the kernel applies to the activations (ddif_dev.h dd_split3).
+inline unsigned bf16_bits_host(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+inline float bf16_val_host(unsigned b) {
+    const unsigned u = b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+size_t pack_conv_x3(Blob& b, const float* w, int cout, int cin) {
+    const int ck = 16, taps = 9;
+    const int n_chunks = (cin + ck - 1) / ck, nb = (cout + 31) / 32, nb_pad = (nb + 3) & ~3;
+    const size_t per = (size_t)taps * 3 * 256;  // floats per (n-block, chunk)
+    const size_t off = b.add(nullptr, (size_t)nb_pad * n_chunks * per);
+    uint16_t* o = reinterpret_cast<uint16_t*>(b.v.data() + off);
+    for (int nbi = 0; nbi < nb; ++nbi)
+        for (int ch = 0; ch < n_chunks; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int h = 0; h < 2; ++h)
+                    for (int j = 0; j < 32; ++j)
+                        for (int t = 0; t < 8; ++t) {
+                            const int ci = ch * ck + 8 * h + t, co = nbi * 32 + j;
+                            float val = 0.f;
+                            if (co < cout && ci < cin) val = w[((size_t)co * cin + ci) * taps + tap];
+                            unsigned q[3];
+                            q[0] = bf16_bits_host(val);
+                            const float r1 = val - bf16_val_host(q[0]);
+                            q[1] = bf16_bits_host(r1);
+                            q[2] = bf16_bits_host(r1 - bf16_val_host(q[1]));
+                            for (int pl = 0; pl < 3; ++pl) {
+                                const size_t fl = ((((size_t)nbi * n_chunks + ch) * taps + tap) * 3 + pl) * 256 + (size_t)(h * 32 + j) * 4;  // float index of the lane's 16 bytes
+                                o[fl * 2 + t] = (uint16_t)q[pl];
+                            }
+                        }
+    return off;
+}
+
 }  // namespace
 
 int Net::commit(hipStream_t stream) {
     Blob b;
-    struct PendConv { std::string name; size_t w_off; long bias_off; int cin, cout, ks, ck, n_chunks; };
+    struct PendConv { std::string name; size_t w_off; long bias_off; int cin, cout, ks, ck, n_chunks; long x3_off = -1; };
     std::vector<PendConv> pend;
     std::map<std::string, size_t> vec_off;
     std::string missing;
@@ -199,6 +243,7 @@ int Net::commit(hipStream_t stream) {
         p.ks = (int)w->shape[2];
         p.ck = (p.ks == 3 || p.cin <= 16) ? 16 : 32;  // 3x3: 16-channel chunks (A + W double-buffered = 65 KB of LDS)
         p.w_off = pack_conv(b, w->v.data(), p.cout, p.cin, p.ks, p.ck, &p.n_chunks);
+        if (p.ks == 3) p.x3_off = (long)pack_conv_x3(b, w->v.data(), p.cout, p.cin);
         p.bias_off = bs ? (long)b.add(bs->v.data(), bs->v.size()) : -1;
         pend.push_back(p);
     };
@@ -346,6 +391,7 @@ int Net::commit(hipStream_t stream) {
     for (auto& p : pend) {
         PackedConv pc;
         pc.w = blob + p.w_off;
+        pc.w_x3 = p.x3_off >= 0 ? blob + p.x3_off : nullptr;
         pc.bias = p.bias_off >= 0 ? blob + p.bias_off : nullptr;
         pc.cin = p.cin;
         pc.cout = p.cout;

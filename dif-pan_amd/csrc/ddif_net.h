@@ -42,6 +42,7 @@ struct Layer {
 // A convolution's weights in kernel order (see pack_conv in ddif_net.cpp) + its bias, both device pointers.
 struct PackedConv {
     const float* w = nullptr;
+    const float* w_x3 = nullptr;  // 3x3 convs: the same weights as three bf16 planes (kernels_conv.h MATH = 1)
     const float* bias = nullptr;
     int cin = 0, cout = 0, ks = 1, ck = 32, n_chunks = 0;
 };

@@ -29,6 +29,15 @@ ConvVariant variant_for_cfg(int cfg) {
             default: break;
         }
     }
+    if constexpr (KS == 3 && S == 1 && VEC == 1) {
+        switch (cfg) {
+            // bf16x3 (MATH = 1): 7 = 16x16 x 32 on eight waves, 8 = 8x16 x 32 on four, 9 = 8x8 x 64 on four
+            case 7: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 1>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = true; break;
+            case 8: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
+            case 9: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = true; break;
+            default: break;
+        }
+    }
     if constexpr (KS == 3 && S == 1 && U == 0 && VEC == 1) {
         switch (cfg) {
             case 5: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; break;
@@ -100,6 +109,12 @@ static int pick_cfg(int ks, int vec, int stride, int ups_, int Hout, int Wout, i
         return Cout > 64 ? 4 : 2;
     }
     static const int big3 = [] { const char* e = getenv("DDIF_CONV3_BIG"); return e ? atoi(e) : 1; }();  // A/B switch
+    static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();  // 0: exact-fp32 MFMA everywhere
+    if (ks == 3 && vec == 1 && stride == 1 && x3) {
+        if (wide && Hout >= 32 && Wout >= 32) return 7;
+        if (wide || Cout <= 32) return 8;
+        return 9;
+    }
     if (ks == 3 && vec == 1 && wide && big3 && !ups_) {
         const long items32 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
         if (Hout >= 32 && Wout >= 32 && items32 >= 2L * num_cus()) return (Cout % 64 == 0 && items32 >= 4L * num_cus()) ? 6 : 5;
@@ -198,7 +213,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.Hout = Hout;
     a.Wout = Wout;
     a.Cout = pc.cout;
-    a.w = s.w_override ? s.w_override : pc.w;
+    a.w = s.w_override ? s.w_override : (var.x3 ? pc.w_x3 : pc.w);
+    if (var.x3 && !pc.w_x3) return fail(DDIF_ERR_STATE, "%s: bf16x3 variant without split weights", s.name);
     a.w_bstride = s.w_bstride;
     a.cs_mx = s.cs_mx;
     a.cs_sm = s.cs_sm;
@@ -265,6 +281,10 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
     op.timed = (pc.ks == 3);
+    if (pc.ks == 3 && &prog == &step) {
+        ++n_conv3;
+        if (var.x3) ++n_conv3_x3;
+    }
     op.run = [a, var, fn_tbs, grid, block, smem, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
         ConvArgs aa = a;
         if (dyn) {

@@ -36,6 +36,7 @@ struct ConvVariant {
     ConvKernelFn fn = nullptr;
     size_t smem = 0;
     int th = 0, tw = 0, nt = 0, nthr = 256;
+    bool x3 = false;  // bf16x3 instantiation: wants PackedConv::w_x3
     const char* name = "";
 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi);
@@ -109,6 +110,7 @@ struct Plan {
     int ensure_tb(int rows);
     int time_rows(const float* t_host, int rows, hipStream_t s);
     void run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof);
+    int n_conv3 = 0, n_conv3_x3 = 0;  // 3x3 conv ops of the step program / of them on the bf16x3 path (reported by prof_collect)
     bool op_timing_done = false;  // DDIF_OP_TIMING=<csv path>: one profiled step is timed op by op (development aid)
 
     int set_cond(const float* cond, hipStream_t s);

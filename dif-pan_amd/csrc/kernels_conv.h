@@ -96,16 +96,24 @@ enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16 };
 // the levers are (a) fewer non-MFMA instructions per stage (32-bit offsets off uniform bases, no per-item branches),
 // (b) more MFMAs per staged byte (8-wave workgroups: a 16x16-pixel tile shares one weight chunk, 64-cout tiles share
 // one input chunk).
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0>
+// MATH: 0 = exact fp32 on v_mfma_f32_32x32x2_f32;  1 = "bf16x3": both operands split three ways into bf16 (hi, mid, lo --
+// ddif_dev.h), six cross products per 16-channel slab on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  fp32-class
+// result (not bitwise the fmaf chain), 198 instead of 512 matrix cycles per slab, and the matrix core runs beside the
+// VALU instead of on it.  LDS holds three bf16 planes per operand (96 B per pixel and 16-channel chunk + 16 B pad).
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0, int MATH = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    constexpr int LDA = CK + 4;
+    constexpr bool X3 = MATH >= 1;
+    constexpr bool WSB = MATH == 2;  // ONE weight buffer (an extra barrier per stage): 69 KB of LDS -> two workgroups per CU, whose VALU
+                                     // staging and bf16 MFMAs then overlap (different pipes)
+    constexpr int NWB = WSB ? 1 : 2;
+    constexpr int LDA = X3 ? 28 : CK + 4;                 // floats per staged pixel (X3: 3 planes x 32 B + 16 B pad)
     constexpr int TAPS = KS * KS;
     constexpr int K8 = CK / 8;
     constexpr int C4 = CK / 4;
-    constexpr int NF = TAPS * K8;                         // (tap, k8) steps per chunk
+    constexpr int NF = X3 ? TAPS : TAPS * K8;             // MFMA steps per chunk: (tap, k8), or tap with all 16 channels
     constexpr int ABUF = IH * IW * LDA;                   // floats per LDS buffer
     // PRO_GN_DW (1x1 conv over depthwise3x3(GroupNorm(x))): the LOAD tile has a one-pixel halo and goes to a scratch
     // LDS region; the depthwise conv turns it into the A tile of the 1x1 contraction.
@@ -120,19 +128,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int DWMAX = DWM ? 9 * 256 : 0;                       // depthwise weights of up to 256 channels
     constexpr int DITEMS = (TH * TW * C4 + NTHR - 1) / NTHR;
     constexpr int NITEMS = (LH * LW * C4 + NTHR - 1) / NTHR;  // float4 input-staging items per thread and chunk
-    constexpr int WBUF = NB * WN * NF * 256;              // floats of one weight chunk (all n-blocks of the cout tile)
+    constexpr int WCHUNK = X3 ? TAPS * 3 * 256 : NF * 256;  // floats per (32-cout block, chunk): X3 = 3 bf16 planes of 1 KiB per tap
+    constexpr int WBUF = NB * WN * WCHUNK;                // floats of one weight chunk (all n-blocks of the cout tile)
     constexpr int WITEMS = (WBUF / 4 + NTHR - 1) / NTHR;  // float4 weight-staging items per thread and chunk
-    constexpr int DUMMY = CK;                             // pad slot of pixel 0 of an A buffer: staging items past the end write here
+    constexpr int DUMMY = X3 ? 24 : CK;                   // pad slot of pixel 0 of an A buffer: staging items past the end write here
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per workgroup");
+    static_assert(!X3 || (CK == 16 && !DWM && VEC == 1), "bf16x3 path: 16-channel chunks, float4 staging, no depthwise prologue");
     static_assert(TH * TW == 32 * MB * WM, "pixel tile must match the wave layout");
     static_assert(CK % 8 == 0 && NTHR % C4 == 0, "chunk size");
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
 
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
-    float* Ws = As + 2 * ABUF;                    // [2][WBUF]  weight chunk in B-fragment order
-    double* red = reinterpret_cast<double*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float));  // [2][2 * NW]
-    float* Hs = reinterpret_cast<float*>(smem + (size_t)2 * (ABUF + WBUF) * sizeof(float) + 4 * NW * sizeof(double));  // [HBUF]
+    float* Ws = As + 2 * ABUF;                    // [NWB][WBUF]  weight chunk in B-fragment order
+    double* red = reinterpret_cast<double*>(smem + (size_t)(2 * ABUF + NWB * WBUF) * sizeof(float));  // [2][2 * NW]
+    float* Hs = reinterpret_cast<float*>(smem + (size_t)(2 * ABUF + NWB * WBUF) * sizeof(float) + 4 * NW * sizeof(double));  // [HBUF]
     float* DWs = Hs + HBUF;                       // [9][Ctot]
     float* GBs = DWs + DWMAX;                     // GroupNorm gamma | beta, [2][n_chunks * CK] (host adds the bytes)
     float* BTs = GBs + (GNP ? 2 * a.n_chunks * CK : 0);  // bias (+ the step's time-bias row) of all n_ct * NT couts
@@ -168,7 +178,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         e_off[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * a.Cout + 4 * h) * 4);
         e_foff[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * 2 * a.Cout + 4 * h) * 4);
     }
-    constexpr int WCHUNK = NF * 256;  // floats per (n-block, chunk)
 
     // ---- per-thread staging geometry: constant for the whole kernel (no divisions inside the stage loop) ----
     int a_py[NITEMS], a_px[NITEMS], a_lds[NITEMS];
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         const int pix = in ? pixr : LH * LW - 1;
         a_py[it] = pix / LW;
         a_px[it] = pix % LW;
-        a_lds[it] = in ? pix * LDA + c4 * 4 : DUMMY;
+        a_lds[it] = in ? pix * LDA + (X3 ? c4 * 2 : c4 * 4) : DUMMY;
         a_in |= (in ? 1u : 0u) << it;
     }
     unsigned w_boff[WITEMS];
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         const int qr = tid + it * NTHR;
         const bool in = qr < WBUF / 4;
         const int q = in ? qr : WBUF / 4 - 1;
-        w_boff[it] = (unsigned)(((q / (NF * 64)) * (a.n_chunks * WCHUNK) + (q % (NF * 64)) * 4) * 4);
+        w_boff[it] = (unsigned)(((q / (WCHUNK / 4)) * (a.n_chunks * WCHUNK) + (q % (WCHUNK / 4)) * 4) * 4);
         w_lds[it] = in ? q * 4 : -1;
     }
 
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     };
     auto finish_stage = [&](StageRegs& R, int buf) {
         float* dst = As + buf * ABUF;
-        float* wdst = Ws + buf * WBUF;
+        float* wdst = Ws + (WSB ? 0 : buf) * WBUF;
         float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
         if (GNP) {
             if (R.pos.b != gn_b) {  // workgroup-uniform; every wavefront reduces the partials itself (no barrier)
@@ -382,6 +391,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                 if (a.out_xn && ok && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
                     *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cb + c4 * 4) =
                         make_float4(v[0], v[1], v[2], v[3]);
+            } else if constexpr (X3) {
+                unsigned h01, m01, l01, h23, m23, l23;
+                dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
+                dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
+                const int ps = ((a_in >> it) & 1u) ? 8 : 0;  // plane stride in floats (the dummy slot takes all three)
+                *reinterpret_cast<uint2*>(&dst[a_lds[it]]) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(&dst[a_lds[it] + ps]) = make_uint2(m01, m23);
+                *reinterpret_cast<uint2*>(&dst[a_lds[it] + 2 * ps]) = make_uint2(l01, l23);
             } else {
                 *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -513,7 +530,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         }
         // (3) contraction over taps x chunk channels: both fragments from LDS, no global load in here.  Weights are
         //     the MFMA's FIRST operand: D[cout][pixel] (see the header comment).
-        const float* Wc = Ws + cur * WBUF + (wn * NB) * (NF * 256) + h * 128 + j * 4;
+        const float* Wc = Ws + (WSB ? 0 : cur) * WBUF + (wn * NB) * WCHUNK + h * 128 + j * 4;
+        if constexpr (X3) {
+            //     bf16x3: per tap one 16-channel slab; three planes per operand, six cross products, small terms first;
+            //     the fragments of tap t+1 are read before the MFMAs of tap t (register double buffer)
+            float4 xa[2][MB][3], wb[2][NB][3];
+            auto load_frags3 = [&](int tap, int slot) {
+                const int aoff = ((tap / KS) * IW + (tap % KS)) * LDA;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) xa[slot][mb][q] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + q * 8]);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) wb[slot][nb][q] = *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + (tap * 3 + q) * 256]);
+                }
+            };
+            load_frags3(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 1 < TAPS) load_frags3(tap + 1, (tap + 1) & 1);
+                DDIF_SCHED_FENCE();
+                const int sl = tap & 1;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        f32x16 c = acc[mb][nb];
+                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][2], xa[sl][mb][0], c);  // lo * hi
+                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][2], c);  // hi * lo
+                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][1], xa[sl][mb][1], c);  // mid * mid
+                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][1], xa[sl][mb][0], c);  // mid * hi
+                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][1], c);  // hi * mid
+                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][0], c);  // hi * hi
+                        acc[mb][nb] = c;
+                    }
+                DDIF_SCHED_FENCE();
+            }
+        } else {
         //     Fragments are double-buffered in registers: the ds_reads of step f+1 are issued BEFORE the MFMAs of step f
         //     (an in-order wave otherwise issues them only after the last MFMA of step f has issued, and the LDS
         //     latency beyond that MFMA's 64 cycles is a bubble in the matrix pipe).
@@ -524,7 +577,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) af[slot][mb] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + k8 * 8]);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bf[slot][nb] = *reinterpret_cast<const float4*>(&Wc[nb * (NF * 256) + f * 256]);
+            for (int nb = 0; nb < NB; ++nb) bf[slot][nb] = *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + f * 256]);
         };
         load_frags(0, 0);
 #pragma unroll
@@ -541,6 +594,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                         else acc[mb][nb] = DDIF_MFMA_32x32x2((&bf[f & 1][nb].x)[i], (&af[f & 1][mb].x)[i], acc[mb][nb]);
             DDIF_SCHED_FENCE();
         }
+        }
+        if constexpr (WSB && !TAIL) __syncthreads();  // every wave is done reading the single weight buffer
         stamp();
         if constexpr (LAST) {
             // (4) epilogue of work item Cp: lane (j, h) owns pixel j of each 32-pixel block and, per accumulator quad g,
@@ -672,11 +727,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 }
 
 
-template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO = 0, int NW = 4>
+template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO = 0, int NW = 4, int MATH = 0>
 constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN; + conv_smem_extra() at launch
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
-    return (size_t)(2 * (IH * IW * (CK + 4) + NBT * KS * KS * (CK / 8) * 256) + dw) * sizeof(float) + 4 * NW * sizeof(double);
+    constexpr int lda = MATH >= 1 ? 28 : CK + 4, wchunk = MATH >= 1 ? KS * KS * 3 * 256 : KS * KS * (CK / 8) * 256;
+    return (size_t)(2 * IH * IW * lda + (MATH == 2 ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
 }
 // GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts
 inline size_t conv_smem_extra(int pro, int n_chunks, int ck, int cout_pad) {

@@ -35,6 +35,7 @@ struct int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) double2 { double x, y; };
 struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
@@ -106,6 +107,33 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x2(float a, float b, hipemu_f32x16 
         int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float acc = d[r];
         for (int k = 0; k < 2; ++k) acc = fmaf(g[(row + 32 * k) * 2 + 0], g[(col + 32 * k) * 2 + 1], acc);
+        d[r] = acc;
+    }
+    hipemu::wave_release();
+    return d;
+}
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+t], B[k=8*(l>>5)+t][j=l&31], t = 0..7 (8 bf16 = 4 dwords per lane);
+// same D layout as 32x32x2.  Products are exact in fp32; the accumulation order of the hardware is not documented, so
+// this model (k ascending, fp32 adds) agrees with the GPU to fp32 rounding, not bitwise.
+struct hipemu_u32x4 { unsigned v[4]; };
+static inline float hipemu_bf16_to_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; __builtin_memcpy(&f, &u, 4); return f; }
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x16 c) {
+    unsigned ab[8];
+    for (int i = 0; i < 4; ++i) { ab[i] = a.v[i]; ab[4 + i] = b.v[i]; }
+    const unsigned* g = (const unsigned*)hipemu::wave_gather(ab, sizeof(ab));
+    int l = hipemu::tctx().lane;
+    int col = l & 31, hi = l >> 5;
+    hipemu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = d[r];
+        for (int k = 0; k < 16; ++k) {
+            const int half = k >> 3, t = k & 7;
+            const unsigned aw = g[(row + 32 * half) * 8 + (t >> 1)], bw = g[(col + 32 * half) * 8 + 4 + (t >> 1)];
+            const float av = hipemu_bf16_to_f32((unsigned short)((t & 1) ? (aw >> 16) : (aw & 0xffffu)));
+            const float bv = hipemu_bf16_to_f32((unsigned short)((t & 1) ? (bw >> 16) : (bw & 0xffffu)));
+            acc += av * bv;  // exact product (8 x 8 significant bits), one fp32 rounding per add
+        }
         d[r] = acc;
     }
     hipemu::wave_release();

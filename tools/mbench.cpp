@@ -11,12 +11,12 @@ namespace ddif { thread_local std::string g_err; int fail(int c, const char*, ..
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int KS, int S, int U, int TH, int TW, int CKc, int WM, int WN, int MB, int NB, int PRO, int ABL, int EPI = 0>
+template <int KS, int S, int U, int TH, int TW, int CKc, int WM, int WN, int MB, int NB, int PRO, int ABL, int EPI = 0, int MATH = 0>
 void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu) {
     const int Hout = S == 2 ? (H - 1) / 2 + 1 : (U ? 2 * H : H), Wout = S == 2 ? (W - 1) / 2 + 1 : (U ? 2 * W : W);
     const int n_chunks = (Cin + CKc - 1) / CKc, nb = (Cout + 31) / 32, nb_pad = (nb + 3) & ~3;
     const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Hout * Wout * Cout;
-    const size_t nw = (size_t)nb_pad * n_chunks * KS * KS * (CKc / 8) * 256;
+    const size_t nw = (size_t)nb_pad * n_chunks * (MATH >= 1 ? KS * KS * 3 * 256 : KS * KS * (CKc / 8) * 256);
     float *in, *w, *out, *gamma, *beta, *bias, *res; double *st, *sto;
     CK_(hipMalloc(&in, nin * 4)); CK_(hipMalloc(&w, nw * 4)); CK_(hipMalloc(&out, nout * 4)); CK_(hipMalloc(&res, nout * 4));
     CK_(hipMalloc(&gamma, Cin * 4)); CK_(hipMalloc(&beta, Cin * 4)); CK_(hipMalloc(&bias, Cout * 4));
@@ -41,8 +41,8 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
     const long nwork = (long)B * a.tiles_x * a.tiles_y * a.n_ct;
     const long cap = 256L * wg_per_cu;
     dim3 grid((unsigned)(nwork < cap ? nwork : cap));
-    auto fn = conv_mfma_kernel<KS, S, U, TH, TW, CKc, WM, WN, MB, NB, PRO, 1, EPI, ABL>;
-    const size_t smem = conv_smem_bytes<KS, S, U, TH, TW, CKc, NB * WN, PRO, WM * WN>() + conv_smem_extra(PRO, n_chunks, CKc, a.n_ct * NT);
+    auto fn = conv_mfma_kernel<KS, S, U, TH, TW, CKc, WM, WN, MB, NB, PRO, 1, EPI, ABL, MATH>;
+    const size_t smem = conv_smem_bytes<KS, S, U, TH, TW, CKc, NB * WN, PRO, WM * WN, MATH>() + conv_smem_extra(PRO, n_chunks, CKc, a.n_ct * NT);
     if (smem > 65536) CK_(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipEvent_t e0, e1; CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fn, grid, dim3(64 * WM * WN), smem, 0, a);
@@ -64,6 +64,23 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
 
 int main(int argc, char** argv) {
     const int B = 64;
+    if (argc > 1 && argv[1][0] == 'x') {  // bf16x3 (MATH = 1) against the exact-fp32 MFMA
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) f32", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 14, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (8x16,NT32,4w) bf16x3", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 64->64 @32^2 (16x16,NT32,8w) bf16x3", B, 32, 32, 64, 64, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_NONE, 0>("3x3 64->64 @64^2 (16x16,NT64,8w) f32", B, 64, 64, 64, 64, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0, 0, 1>("3x3 64->64 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 64, 64, 1);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 2>("3x3 gn_silu 32->32 @64^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 14, 0, 2>("3x3 gn_silu 32->32 @64^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 2>("3x3 gn_silu 64->64 @32^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 32, 32, 64, 64, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0, 0, 2>("3x3 64->64 @64^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 64, 64, 64, 64, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 2>("3x3 gn_silu 64->64 @16^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 16, 16, 64, 64, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 64->64 @16^2 (8x16,NT32,4w) bf16x3", B, 16, 16, 64, 64, 1);
+        run<3, 1, 0, 8, 8, 16, 2, 2, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 128->128 @8^2 (8x8,NT64,4w) bf16x3", B, 8, 8, 128, 128, 1);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'b') {  // big per-wave register tiles, one wave per SIMD
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w)", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 4, 1, 2, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,4w MB2)", B, 64, 64, 32, 32, 1);
