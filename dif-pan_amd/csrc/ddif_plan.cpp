@@ -3,6 +3,7 @@
 // 624-666; solver/dpm_solver.py:1179-1221).
 #include "ddif_plan.h"
 #include "kernels_conv.h"
+#include "kernels_conv_ws.h"
 #include "kernels_misc.h"
 
 namespace ddif {
@@ -47,6 +48,31 @@ ConvVariant variant_for_cfg(int cfg) {
     }
     return v;
 }
+// cfg 11: the wave-specialised bf16x3 kernel (kernels_conv_ws.h), 16x16 pixels x 32 couts, 4 consumer + 4 producer waves
+template <int U, int PRO, int EPI>
+ConvVariant ws_variant(const char* name) {
+    ConvVariant v;
+    v.fn = conv3_ws_kernel<U, PRO, EPI>;
+    v.smem = conv3_ws_smem_bytes();
+    v.th = 16;
+    v.tw = 16;
+    v.nt = 32;
+    v.nthr = 512;
+    v.x3 = true;
+    v.name = name;
+    return v;
+}
+ConvVariant get_ws_variant(int ups, int pro, int epi) {
+    if (!ups && pro == PRO_GN_SILU && epi == 0) return ws_variant<0, PRO_GN_SILU, 0>("conv3x3_ws_gn_silu");
+    if (!ups && pro == PRO_GN_SILU && epi == EPI_RES) return ws_variant<0, PRO_GN_SILU, EPI_RES>("conv3x3_ws_gn_silu_res");
+    if (!ups && pro == PRO_GN_SILU && epi == EPI_TBS) return ws_variant<0, PRO_GN_SILU, EPI_TBS>("conv3x3_ws_gn_silu_tbs");
+    if (!ups && pro == PRO_NONE && epi == 0) return ws_variant<0, PRO_NONE, 0>("conv3x3_ws");
+    if (!ups && pro == PRO_NONE && epi == EPI_RES) return ws_variant<0, PRO_NONE, EPI_RES>("conv3x3_ws_res");
+    if (!ups && pro == PRO_NONE && epi == EPI_SILU) return ws_variant<0, PRO_NONE, EPI_SILU>("conv3x3_ws_silu");
+    if (ups && pro == PRO_NONE && epi == 0) return ws_variant<1, PRO_NONE, 0>("conv3x3_ws_up2");
+    return ConvVariant();
+}
+
 template <int KS, int S, int U, int CK, int PRO, int VEC>
 ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not fit comfortably in LDS
     return (cfg >= 2) ? variant_for_cfg<KS, S, U, CK, PRO, VEC>(cfg) : ConvVariant();
@@ -60,6 +86,7 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 // Only the combinations the network uses are instantiated.
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi) {
     ConvVariant v;
+    if (cfg == 11) return (ks == 3 && ck == 16 && stride == 1 && vec == 1) ? get_ws_variant(ups, pro, epi) : v;
     const bool plain = stride == 1 && !ups;
     if (epi == EPI_FILM) {
         if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
@@ -111,7 +138,10 @@ static int pick_cfg(int ks, int vec, int stride, int ups_, int Hout, int Wout, i
     static const int big3 = [] { const char* e = getenv("DDIF_CONV3_BIG"); return e ? atoi(e) : 1; }();  // A/B switch
     static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();  // 0: exact-fp32 MFMA everywhere
     if (ks == 3 && vec == 1 && stride == 1 && x3) {
-        if (wide && Hout >= 32 && Wout >= 32) return 7;
+        // 1: wave-specialised kernel (kernels_conv_ws.h).  Measured on MI355X: 43.5 vs 41.9 us (32->32 @64^2), 134 vs 124 us
+        // (64->64 @64^2) -- faster without memory traffic (27.9 vs 30.4 us), slower with it; off by default.
+        static const int ws = [] { const char* e = getenv("DDIF_WS"); return e ? atoi(e) : 0; }();
+        if (wide && Hout >= 32 && Wout >= 32) return ws ? 11 : 7;
         if (wide || Cout <= 32) return 8;
         return 9;
     }
@@ -195,9 +225,13 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 != 0 || c1 % 4 != 0) ? 0 : ((c1 == 0 || c0 % pc.ck == 0) ? 1 : 2);
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
-    const int cfg = pick_cfg(pc.ks, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
+    int cfg = pick_cfg(pc.ks, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0);
-    const ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    if (!var.fn && cfg == 11) {  // epilogue / prologue combination the wave-specialised kernel does not carry
+        cfg = 7;
+        var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    }
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
