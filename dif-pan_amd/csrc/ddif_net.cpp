@@ -174,8 +174,8 @@ size_t pack_conv(Blob& b, const float* w, int cout, int cin, int ks, int ck, int
     return off;
 }
 
-// bf16x3 order (kernels_conv.h, MATH = 1; 3x3 convs, 16-channel chunks):
-//   [n-block of 32 couts][chunk][tap][plane: hi, mid, lo][half h][cout j][8 bf16: cin = chunk*16 + 8*h + t]
+// bf16x3 order (kernels_conv.h, MATH = 1; 3x3 convs with 16-channel chunks, 1x1 convs with 32-channel chunks):
+//   [n-block of 32 couts][chunk][tap][16-channel slab k16][plane: hi, mid, lo][half h][cout j][8 bf16: cin = chunk*ck + 16*k16 + 8*h + t]
 // = 1 KiB per (tap, plane) in exactly the per-lane A-operand order of v_mfma_f32_32x32x16_bf16.  The split is the same
 // round-to-nearest-even three-way split the kernel applies to the activations (ddif_dev.h dd_split3).
 inline unsigned bf16_bits_host(float x) {
@@ -189,19 +189,20 @@ inline float bf16_val_host(unsigned b) {
     std::memcpy(&f, &u, 4);
     return f;
 }
-size_t pack_conv_x3(Blob& b, const float* w, int cout, int cin) {
-    const int ck = 16, taps = 9;
+size_t pack_conv_x3(Blob& b, const float* w, int cout, int cin, int ks, int ck) {
+    const int taps = ks * ks, K16 = ck / 16;
     const int n_chunks = (cin + ck - 1) / ck, nb = (cout + 31) / 32, nb_pad = (nb + 3) & ~3;
-    const size_t per = (size_t)taps * 3 * 256;  // floats per (n-block, chunk)
+    const size_t per = (size_t)taps * K16 * 3 * 256;  // floats per (n-block, chunk)
     const size_t off = b.add(nullptr, (size_t)nb_pad * n_chunks * per);
     uint16_t* o = reinterpret_cast<uint16_t*>(b.v.data() + off);
     for (int nbi = 0; nbi < nb; ++nbi)
         for (int ch = 0; ch < n_chunks; ++ch)
             for (int tap = 0; tap < taps; ++tap)
+              for (int k16 = 0; k16 < K16; ++k16)
                 for (int h = 0; h < 2; ++h)
                     for (int j = 0; j < 32; ++j)
                         for (int t = 0; t < 8; ++t) {
-                            const int ci = ch * ck + 8 * h + t, co = nbi * 32 + j;
+                            const int ci = ch * ck + 16 * k16 + 8 * h + t, co = nbi * 32 + j;
                             float val = 0.f;
                             if (co < cout && ci < cin) val = w[((size_t)co * cin + ci) * taps + tap];
                             unsigned q[3];
@@ -210,7 +211,7 @@ size_t pack_conv_x3(Blob& b, const float* w, int cout, int cin) {
                             q[1] = bf16_bits_host(r1);
                             q[2] = bf16_bits_host(r1 - bf16_val_host(q[1]));
                             for (int pl = 0; pl < 3; ++pl) {
-                                const size_t fl = ((((size_t)nbi * n_chunks + ch) * taps + tap) * 3 + pl) * 256 + (size_t)(h * 32 + j) * 4;  // float index of the lane's 16 bytes
+                                const size_t fl = (((((size_t)nbi * n_chunks + ch) * taps + tap) * K16 + k16) * 3 + pl) * 256 + (size_t)(h * 32 + j) * 4;  // float index of the lane's 16 bytes
                                 o[fl * 2 + t] = (uint16_t)q[pl];
                             }
                         }
@@ -243,7 +244,7 @@ int Net::commit(hipStream_t stream) {
         p.ks = (int)w->shape[2];
         p.ck = (p.ks == 3 || p.cin <= 16) ? 16 : 32;  // 3x3: 16-channel chunks (A + W double-buffered = 65 KB of LDS)
         p.w_off = pack_conv(b, w->v.data(), p.cout, p.cin, p.ks, p.ck, &p.n_chunks);
-        if (p.ks == 3) p.x3_off = (long)pack_conv_x3(b, w->v.data(), p.cout, p.cin);
+        if (p.ck % 16 == 0 && (p.ks == 3 || p.ck == 32)) p.x3_off = (long)pack_conv_x3(b, w->v.data(), p.cout, p.cin, p.ks, p.ck);
         p.bias_off = bs ? (long)b.add(bs->v.data(), bs->v.size()) : -1;
         pend.push_back(p);
     };

@@ -29,6 +29,16 @@ ConvVariant variant_for_cfg(int cfg) {
             case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO>(); v.th = 8; v.tw = 8; v.nt = 128; break;
             default: break;
         }
+        if constexpr (CK == 32 && PRO != PRO_COLSM) {  // bf16x3 instantiations of the same five tilings (cfg + 12)
+            switch (cfg) {
+                case 12: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
+                case 13: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 64; v.x3 = true; break;
+                case 15: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 4, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 4, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 128; v.x3 = true; break;
+                case 14: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = true; break;
+                case 16: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 128; v.x3 = true; break;
+                default: break;
+            }
+        }
     }
     if constexpr (KS == 3 && S == 1 && VEC == 1) {
         switch (cfg) {
@@ -128,12 +138,15 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
 }
 
 static int num_cus();
-static int pick_cfg(int ks, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B) {
+static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B) {
     static const int wide1 = [] { const char* e = getenv("DDIF_CONV1_WIDE"); return e ? atoi(e) : 1; }();  // A/B switch
     const bool wide = (Wout >= 16) && stride == 1;
+    static const int x3_1 = [] { const char* e = getenv("DDIF_X3_1X1"); return e ? atoi(e) : 1; }();  // bf16x3 for the 1x1 convs too
     if (ks == 1 && vec == 1 && wide1) {
-        if (wide) return Cout > 64 ? 3 : (Cout > 32 ? 1 : 0);
-        return Cout > 64 ? 4 : 2;
+        const int base = wide ? (Cout > 64 ? 3 : (Cout > 32 ? 1 : 0)) : (Cout > 64 ? 4 : 2);
+        static const int x3on = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();
+        if (x3on && x3_1 && ck == 32 && pro != PRO_COLSM) return base + 12;  // 0,1,3,2,4 -> 12,13,15,14,16
+        return base;
     }
     static const int big3 = [] { const char* e = getenv("DDIF_CONV3_BIG"); return e ? atoi(e) : 1; }();  // A/B switch
     static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();  // 0: exact-fp32 MFMA everywhere
@@ -225,7 +238,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 != 0 || c1 % 4 != 0) ? 0 : ((c1 == 0 || c0 % pc.ck == 0) ? 1 : 2);
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
-    int cfg = pick_cfg(pc.ks, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
+    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0);
     ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if (!var.fn && cfg == 11) {  // epilogue / prologue combination the wave-specialised kernel does not carry

@@ -109,11 +109,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr bool WSB = MATH == 2;  // ONE weight buffer (an extra barrier per stage): 69 KB of LDS -> two workgroups per CU, whose VALU
                                      // staging and bf16 MFMAs then overlap (different pipes)
     constexpr int NWB = WSB ? 1 : 2;
-    constexpr int LDA = X3 ? 28 : CK + 4;                 // floats per staged pixel (X3: 3 planes x 32 B + 16 B pad)
+    constexpr int PS = CK / 2;                            // X3: floats per bf16 plane of one staged pixel (CK x 2 B)
+    constexpr int LDA = X3 ? 3 * PS + 4 : CK + 4;         // floats per staged pixel (X3: 3 planes + 16 B pad)
+    constexpr int LDH = CK + 4;                           // row of the fp32 scratch tile of the depthwise prologue
     constexpr int TAPS = KS * KS;
     constexpr int K8 = CK / 8;
+    constexpr int K16 = CK / 16;
     constexpr int C4 = CK / 4;
-    constexpr int NF = X3 ? TAPS : TAPS * K8;             // MFMA steps per chunk: (tap, k8), or tap with all 16 channels
+    constexpr int NF = X3 ? TAPS * K16 : TAPS * K8;       // MFMA steps per chunk: (tap, k8), or (tap, 16-channel slab)
     constexpr int ABUF = IH * IW * LDA;                   // floats per LDS buffer
     // PRO_GN_DW (1x1 conv over depthwise3x3(GroupNorm(x))): the LOAD tile has a one-pixel halo and goes to a scratch
     // LDS region; the depthwise conv turns it into the A tile of the 1x1 contraction.
@@ -124,16 +127,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     static_assert(PRO != PRO_COLSM || VEC == 1, "column-softmax prologue needs uniform-source float4 staging");
     constexpr int LPAD = DWM ? 1 : PAD;
     constexpr int LH = DWM ? TH + 2 : IH, LW = DWM ? TW + 2 : IW;   // extent of the loaded tile
-    constexpr int HBUF = DWM ? LH * LW * LDA : 0;                  // scratch for the normalised halo tile
+    constexpr int HBUF = DWM ? LH * LW * LDH : 0;                  // scratch for the normalised halo tile (fp32)
     constexpr int DWMAX = DWM ? 9 * 256 : 0;                       // depthwise weights of up to 256 channels
     constexpr int DITEMS = (TH * TW * C4 + NTHR - 1) / NTHR;
     constexpr int NITEMS = (LH * LW * C4 + NTHR - 1) / NTHR;  // float4 input-staging items per thread and chunk
-    constexpr int WCHUNK = X3 ? TAPS * 3 * 256 : NF * 256;  // floats per (32-cout block, chunk): X3 = 3 bf16 planes of 1 KiB per tap
+    constexpr int WCHUNK = X3 ? NF * 3 * 256 : NF * 256;  // floats per (32-cout block, chunk): X3 = 3 bf16 planes of 1 KiB per step
     constexpr int WBUF = NB * WN * WCHUNK;                // floats of one weight chunk (all n-blocks of the cout tile)
     constexpr int WITEMS = (WBUF / 4 + NTHR - 1) / NTHR;  // float4 weight-staging items per thread and chunk
-    constexpr int DUMMY = X3 ? 24 : CK;                   // pad slot of pixel 0 of an A buffer: staging items past the end write here
+    constexpr int DUMMY = DWM ? CK : (X3 ? 3 * PS : CK);  // pad slot of pixel 0 of the buffer the staging items go to (Hs for the
+                                                          // depthwise prologue, else the A buffer): items past the end write here
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per workgroup");
-    static_assert(!X3 || (CK == 16 && !DWM && VEC == 1), "bf16x3 path: 16-channel chunks, float4 staging, no depthwise prologue");
+    static_assert(!X3 || (CK % 16 == 0 && VEC == 1), "bf16x3 path: 16-channel slabs, float4 staging");
     static_assert(TH * TW == 32 * MB * WM, "pixel tile must match the wave layout");
     static_assert(CK % 8 == 0 && NTHR % C4 == 0, "chunk size");
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         const int pix = in ? pixr : LH * LW - 1;
         a_py[it] = pix / LW;
         a_px[it] = pix % LW;
-        a_lds[it] = in ? pix * LDA + (X3 ? c4 * 2 : c4 * 4) : DUMMY;
+        a_lds[it] = in ? (DWM ? pix * LDH + c4 * 4 : (X3 ? pix * LDA + c4 * 2 : pix * LDA + c4 * 4)) : DUMMY;
         a_in |= (in ? 1u : 0u) << it;
     }
     unsigned w_boff[WITEMS];
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                 unsigned h01, m01, l01, h23, m23, l23;
                 dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
                 dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
-                const int ps = ((a_in >> it) & 1u) ? 8 : 0;  // plane stride in floats (the dummy slot takes all three)
+                const int ps = ((a_in >> it) & 1u) ? PS : 0;  // plane stride in floats (the dummy slot takes all three)
                 *reinterpret_cast<uint2*>(&dst[a_lds[it]]) = make_uint2(h01, h23);
                 *reinterpret_cast<uint2*>(&dst[a_lds[it] + ps]) = make_uint2(m01, m23);
                 *reinterpret_cast<uint2*>(&dst[a_lds[it] + 2 * ps]) = make_uint2(l01, l23);
@@ -414,14 +418,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
-                        const float4 hv = *reinterpret_cast<const float4*>(&Hs[((ty + k / 3) * LW + tx + k % 3) * LDA + c4 * 4]);
+                        const float4 hv = *reinterpret_cast<const float4*>(&Hs[((ty + k / 3) * LW + tx + k % 3) * LDH + c4 * 4]);
                         const float4 wk = *reinterpret_cast<const float4*>(&DWs[k * Ctot + R.cb + c4 * 4]);
                         s0 = fmaf(hv.x, wk.x, s0);
                         s1 = fmaf(hv.y, wk.y, s1);
                         s2 = fmaf(hv.z, wk.z, s2);
                         s3 = fmaf(hv.w, wk.w, s3);
                     }
-                    *reinterpret_cast<float4*>(&dst[p * LDA + c4 * 4]) = make_float4(s0, s1, s2, s3);
+                    if constexpr (X3) {
+                        unsigned h01, m01, l01, h23, m23, l23;
+                        dd_split3_pair(s0, s1, &h01, &m01, &l01);
+                        dd_split3_pair(s2, s3, &h23, &m23, &l23);
+                        *reinterpret_cast<uint2*>(&dst[p * LDA + c4 * 2]) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(&dst[p * LDA + PS + c4 * 2]) = make_uint2(m01, m23);
+                        *reinterpret_cast<uint2*>(&dst[p * LDA + 2 * PS + c4 * 2]) = make_uint2(l01, l23);
+                    } else {
+                        *reinterpret_cast<float4*>(&dst[p * LDA + c4 * 4]) = make_float4(s0, s1, s2, s3);
+                    }
                 }
             }
         }
@@ -534,23 +547,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         if constexpr (X3) {
             //     bf16x3: per tap one 16-channel slab; three planes per operand, six cross products, small terms first;
             //     the fragments of tap t+1 are read before the MFMAs of tap t (register double buffer)
-            float4 xa[2][MB][3], wb[2][NB][3];
-            auto load_frags3 = [&](int tap, int slot) {
-                const int aoff = ((tap / KS) * IW + (tap % KS)) * LDA;
+            constexpr int FB = (MB * NB >= 2) ? 1 : 2;  // register double buffer only for the single-tile shapes (wide cout tiles would spill)
+            float4 xa[FB][MB][3], wb[FB][NB][3];
+            auto load_frags3 = [&](int f, int slot) {  // step f = (tap, 16-channel slab)
+                const int tap = f / K16, k16 = f % K16;
+                const int aoff = ((tap / KS) * IW + (tap % KS)) * LDA + k16 * 8;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) xa[slot][mb][q] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + q * 8]);
+                    for (int mb = 0; mb < MB; ++mb) xa[slot][mb][q] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + q * PS]);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) wb[slot][nb][q] = *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + (tap * 3 + q) * 256]);
+                    for (int nb = 0; nb < NB; ++nb) wb[slot][nb][q] = *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + (f * 3 + q) * 256]);
                 }
             };
-            load_frags3(0, 0);
+            if (FB == 2) load_frags3(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                if (tap + 1 < TAPS) load_frags3(tap + 1, (tap + 1) & 1);
+            for (int tap = 0; tap < NF; ++tap) {
+                if (FB == 2) {
+                    if (tap + 1 < NF) load_frags3(tap + 1, (tap + 1) & 1);
+                } else {
+                    load_frags3(tap, 0);
+                }
                 DDIF_SCHED_FENCE();
-                const int sl = tap & 1;
+                const int sl = FB == 2 ? (tap & 1) : 0;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -731,7 +750,7 @@ template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO 
 constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN; + conv_smem_extra() at launch
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
-    constexpr int lda = MATH >= 1 ? 28 : CK + 4, wchunk = MATH >= 1 ? KS * KS * 3 * 256 : KS * KS * (CK / 8) * 256;
+    constexpr int lda = MATH >= 1 ? 3 * CK / 2 + 4 : CK + 4, wchunk = MATH >= 1 ? KS * KS * (CK / 16) * 3 * 256 : KS * KS * (CK / 8) * 256;
     return (size_t)(2 * IH * IW * lda + (MATH == 2 ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
 }
 // GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts
