@@ -155,7 +155,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "WV3 pansharpening, batch %d of %dx%dx8 tiles per GPU, T=%d DDPM p_sample, fp32" % (B, H, H, T),
                    "tiles_per_gpu": B, "tile": [H, H, C], "T": T, "sampler": "ddpm", "parallelism": "tile-shard x%d" % world,
-                   "conv_math": "bf16x3 (3x3 convs) + exact fp32 MFMA (1x1, attention)" if x3 else "exact fp32 MFMA"},
+                   "conv_math": "bf16x3 split products (3x3 and 32-channel-chunk 1x1 convs) + exact fp32 MFMA (remaining convs, attention)" if x3 else "exact fp32 MFMA"},
         "roofline": {
             "bound": "mfma",
             "achieved": ach_tflops,
