@@ -721,13 +721,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     __syncthreads();
     stamp();
 #ifndef DDIF_EMU
-    if (ABL & 32) {  // experiment: start the workgroup in the odd wave slot of each SIMD half a stage late (anti-phase)
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (hwid & 1u) {
-            if (ABL & 64) __builtin_amdgcn_s_sleep(60);
-            else __builtin_amdgcn_s_sleep(40);
-        }
+    if (ABL & 32) {  // experiment: stagger the workgroups of a launch in time so that their memory phases do not coincide
+        const int k = (ABL & 64) ? (blockIdx.x & 15) : (blockIdx.x & 7);
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep((ABL & 64) ? 4 : 8);
     }
 #endif
     const int npairs = nflat >> 1;

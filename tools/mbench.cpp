@@ -67,6 +67,13 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
 
 int main(int argc, char** argv) {
     const int B = 64;
+    if (argc > 1 && argv[1][0] == 'm') {  // which memory stream costs what (bf16x3, 16x16 x 32, 8 waves)
+#define RUNM(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, ABLV, 0, 1>("3x3 gn_silu 32->32 @64^2 x3 8w", B, 64, 64, 32, 32, 1)
+        RUNM(0); RUNM(32); RUNM(96); RUNM(14); RUNM(46);
+#define RUNM2(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, ABLV, 0, 1>("3x3 64->64 @64^2 x3 8w", B, 64, 64, 64, 64, 1)
+        RUNM2(0); RUNM2(32); RUNM2(96);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'x') {  // bf16x3 (MATH = 1) against the exact-fp32 MFMA
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) f32", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
