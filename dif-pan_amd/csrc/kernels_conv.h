@@ -693,6 +693,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         //     `has_next` branch, whose skip path would leave Rn pending at the loop-head merge)
         if constexpr (!TAIL) finish_stage(Rn, cur ^ 1);
         stamp();
+#ifndef DDIF_EMU
+        // keep the tails of stage<LAST> and stage<!LAST> distinct: the optimiser otherwise sinks their common last LDS
+        // writes below the join of the two, where the merged wait-count state degrades to vmcnt(0) (= waits for the prefetch)
+        asm volatile("; end of stage kind %0" ::"n"(LAST ? 1 : 0));
+#endif
     };
 
     stamp();
