@@ -118,21 +118,23 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x2(float a, float b, hipemu_f32x16 
 struct hipemu_u32x4 { unsigned v[4]; };
 static inline float hipemu_bf16_to_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; __builtin_memcpy(&f, &u, 4); return f; }
 static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x16 c) {
-    unsigned ab[8];
-    for (int i = 0; i < 4; ++i) { ab[i] = a.v[i]; ab[4 + i] = b.v[i]; }
-    const unsigned* g = (const unsigned*)hipemu::wave_gather(ab, sizeof(ab));
+    float ab[16];  // this lane's 8 A values then its 8 B values, already widened (exactly) to fp32
+    for (int t = 0; t < 8; ++t) {
+        const unsigned aw = a.v[t >> 1], bw = b.v[t >> 1];
+        ab[t] = hipemu_bf16_to_f32((unsigned short)((t & 1) ? (aw >> 16) : (aw & 0xffffu)));
+        ab[8 + t] = hipemu_bf16_to_f32((unsigned short)((t & 1) ? (bw >> 16) : (bw & 0xffffu)));
+    }
+    const float* g = (const float*)hipemu::wave_gather(ab, sizeof(ab));
     int l = hipemu::tctx().lane;
     int col = l & 31, hi = l >> 5;
     hipemu_f32x16 d = c;
     for (int r = 0; r < 16; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float acc = d[r];
-        for (int k = 0; k < 16; ++k) {
-            const int half = k >> 3, t = k & 7;
-            const unsigned aw = g[(row + 32 * half) * 8 + (t >> 1)], bw = g[(col + 32 * half) * 8 + 4 + (t >> 1)];
-            const float av = hipemu_bf16_to_f32((unsigned short)((t & 1) ? (aw >> 16) : (aw & 0xffffu)));
-            const float bv = hipemu_bf16_to_f32((unsigned short)((t & 1) ? (bw >> 16) : (bw & 0xffffu)));
-            acc += av * bv;  // exact product (8 x 8 significant bits), one fp32 rounding per add
+        for (int half = 0; half < 2; ++half) {
+            const float* ar = g + (row + 32 * half) * 16;
+            const float* bc = g + (col + 32 * half) * 16 + 8;
+            for (int t = 0; t < 8; ++t) acc += ar[t] * bc[t];  // exact product (8 x 8 significant bits), one fp32 rounding per add
         }
         d[r] = acc;
     }

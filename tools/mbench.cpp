@@ -67,6 +67,18 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
 
 int main(int argc, char** argv) {
     const int B = 64;
+    if (argc > 1 && argv[1][0] == 'q') {  // the fused q conv (GN + depthwise 3x3 + 1x1): 4 vs 8 waves, f32 vs bf16x3
+        run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0, 0, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,4w) f32", B, 64, 64, 64, 64, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0, 0, 1>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,4w) x3", B, 64, 64, 64, 64, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 2, 1, 1, PRO_GN_DW, 0, 0, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,8w) f32", B, 64, 64, 64, 64, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 2, 1, 1, PRO_GN_DW, 0, 0, 1>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,8w) x3", B, 64, 64, 64, 64, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 1, 1, 4, PRO_GN_DW, 0, 0, 1>("1x1 gn_dw 128->128 @32^2 (8x16,NT128,4w) x3", B, 32, 32, 128, 128, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 2, 1, 2, PRO_GN_DW, 0, 0, 1>("1x1 gn_dw 128->128 @32^2 (8x16,NT128,8w) x3", B, 32, 32, 128, 128, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 2, 1, 2, PRO_GN_DW, 0, 0, 0>("1x1 gn_dw 128->128 @32^2 (8x16,NT128,8w) f32", B, 32, 32, 128, 128, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 2, 1, 1, PRO_NONE, 0, 0, 1>("1x1 64->64 @64^2 (8x16,NT64,8w) x3", B, 64, 64, 64, 64, 1);
+        run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_NONE, 0, 0, 1>("1x1 64->64 @64^2 (8x16,NT64,4w) x3", B, 64, 64, 64, 64, 2);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'm') {  // which memory stream costs what (bf16x3, 16x16 x 32, 8 waves)
 #define RUNM(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, ABLV, 0, 1>("3x3 gn_silu 32->32 @64^2 x3 8w", B, 64, 64, 32, 32, 1)
         RUNM(0); RUNM(32); RUNM(96); RUNM(14); RUNM(46);
