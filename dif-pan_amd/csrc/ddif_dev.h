@@ -136,6 +136,31 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+// fp64 sum over the 64 lanes with the same DPP sequence as wave_sum_fast (two 32-bit DPP moves per step instead of
+// two ds_bpermute round trips): every lane returns the total (read from lane 63).
+__device__ __forceinline__ double wave_sum_fast_f64(double v) {
+#ifdef DDIF_EMU
+    return wave_sum(v);
+#else
+#define DDIF_DPP_ADD_F64(ctrl, rmask)                                                                              \
+    {                                                                                                              \
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);                                    \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, rmask, 0xf, false);                   \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, rmask, 0xf, false);           \
+        v += __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo); \
+    }
+    DDIF_DPP_ADD_F64(0xB1, 0xf)   // quad_perm [1,0,3,2]
+    DDIF_DPP_ADD_F64(0x4E, 0xf)   // quad_perm [2,3,0,1]
+    DDIF_DPP_ADD_F64(0x124, 0xf)  // row_ror:4
+    DDIF_DPP_ADD_F64(0x128, 0xf)  // row_ror:8
+    DDIF_DPP_ADD_F64(0x142, 0xa)  // row_bcast:15
+    DDIF_DPP_ADD_F64(0x143, 0xc)  // row_bcast:31
+#undef DDIF_DPP_ADD_F64
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
@@ -145,28 +170,66 @@ __device__ __forceinline__ float wave_max(float v) {
 // GroupNorm(1 group) statistics travel with a tensor as per-producer-workgroup partials:
 //   st[(b * np + i) * 2 + {0,1}] = {sum, sum of squares} over the elements workgroup i wrote for sample b.
 // Called by ALL 64 lanes of a wavefront; returns mean / rstd for sample b over the concatenation of up to two
-// tensors.  Deterministic (fixed summation order), fp64 combine.
-__device__ __forceinline__ void gn_finalize_wave(const double* st0, int np0, const double* st1, int np1, int b,
-                                                  double count, float* mean_out, float* rstd_out) {
+// tensors.  Deterministic (fixed summation order), fp64 combine.  Split in two so that a kernel prologue can put the
+// loads (gn_load_partials: up to 4 pairs per lane and tensor in registers, no arithmetic on them) in flight together
+// with its other prologue loads and pay ONE memory latency before gn_reduce_partials.
+struct GnPartials {
+    double v[2][4][2];  // [tensor][k: partial lane + 64 k][sum | sum of squares]
+};
+__device__ __forceinline__ void gn_load_partials(const double* st0, int np0, const double* st1, int np1, int b, GnPartials* p) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        const int i0 = i < np0 ? i : np0 - 1;
+        p->v[0][k][0] = st0[((size_t)b * np0 + i0) * 2 + 0];
+        p->v[0][k][1] = st0[((size_t)b * np0 + i0) * 2 + 1];
+        if (st1 != nullptr) {
+            const int i1 = i < np1 ? i : np1 - 1;
+            p->v[1][k][0] = st1[((size_t)b * np1 + i1) * 2 + 0];
+            p->v[1][k][1] = st1[((size_t)b * np1 + i1) * 2 + 1];
+        }
+    }
+}
+__device__ __forceinline__ void gn_reduce_partials(const GnPartials& p, const double* st0, int np0, const double* st1, int np1, int b,
+                                                    double count, float* mean_out, float* rstd_out) {
     const int lane = threadIdx.x & 63;
     double s = 0.0, ss = 0.0;
-    for (int i = lane; i < np0; i += 64) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (lane + 64 * k < np0) {
+            s += p.v[0][k][0];
+            ss += p.v[0][k][1];
+        }
+    for (int i = lane + 256; i < np0; i += 64) {  // more than 256 producer workgroups per sample (images beyond 128x128)
         s += st0[((size_t)b * np0 + i) * 2 + 0];
         ss += st0[((size_t)b * np0 + i) * 2 + 1];
     }
     if (st1 != nullptr) {
-        for (int i = lane; i < np1; i += 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane + 64 * k < np1) {
+                s += p.v[1][k][0];
+                ss += p.v[1][k][1];
+            }
+        for (int i = lane + 256; i < np1; i += 64) {
             s += st1[((size_t)b * np1 + i) * 2 + 0];
             ss += st1[((size_t)b * np1 + i) * 2 + 1];
         }
     }
-    s = wave_sum(s);
-    ss = wave_sum(ss);
+    s = wave_sum_fast_f64(s);
+    ss = wave_sum_fast_f64(ss);
     const double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0.0) var = 0.0;
     *mean_out = (float)mean;
     *rstd_out = (float)(1.0 / sqrt(var + DDIF_GN_EPS));
+}
+__device__ __forceinline__ void gn_finalize_wave(const double* st0, int np0, const double* st1, int np1, int b,
+                                                  double count, float* mean_out, float* rstd_out) {
+    GnPartials p;
+    gn_load_partials(st0, np0, st1, np1, b, &p);
+    gn_reduce_partials(p, st0, np0, st1, np1, b, count, mean_out, rstd_out);
 }
 
 }  // namespace ddif

@@ -706,19 +706,73 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     issue_loads(R0);
     issue_loads(R1);
     stamp();
-    if (DWM) {
-        for (int i = tid; i < 9 * Ctot; i += NTHR) DWs[i] = a.dw_w[i];
-    }
+    // Every prologue load is issued before any of them is used (fixed unroll counts, clamped indices): the tables, the
+    // GroupNorm partials of the first sample and the two stage loads above share ONE memory latency.
+    constexpr int TBL = 512 / NTHR > 0 ? 512 / NTHR : 1;  // 512 table entries per pass of the unrolled part
+    constexpr int DWI = DWM ? (9 * 256 + NTHR - 1) / NTHR : 1;
+    [[maybe_unused]] float t_g[TBL], t_b[TBL], t_dw[DWI];
+    float t_bias[TBL], t_tb[TBL];
+    [[maybe_unused]] GnPartials gp;
     if (GNP) {
-        for (int i = tid; i < GBN; i += NTHR) {
+#pragma unroll
+        for (int k = 0; k < TBL; ++k) {
+            const int i = tid + k * NTHR, c = i < Ctot ? i : Ctot - 1;
+            t_g[k] = a.gamma[c];
+            t_b[k] = a.beta[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TBL; ++k) {
+        const int i = tid + k * NTHR, c = i < a.Cout ? i : a.Cout - 1;
+        t_bias[k] = a.bias[c];
+        t_tb[k] = TBS ? 0.f : tbrow[c];
+    }
+    if (DWM) {
+#pragma unroll
+        for (int k = 0; k < DWI; ++k) {
+            const int i = tid + k * NTHR;
+            t_dw[k] = a.dw_w[i < 9 * Ctot ? i : 9 * Ctot - 1];
+        }
+    }
+    if (GNP) gn_load_partials(a.st0, a.np0, a.st1, a.np1, R0.pos.b, &gp);
+    // ... and now the uses
+    if (GNP) {
+#pragma unroll
+        for (int k = 0; k < TBL; ++k) {
+            const int i = tid + k * NTHR;
+            if (i < GBN) {
+                GBs[i] = t_g[k];
+                GBs[GBN + i] = t_b[k];
+            }
+        }
+        for (int i = tid + TBL * NTHR; i < GBN; i += NTHR) {  // more than 512 input channels
             const int c = i < Ctot ? i : Ctot - 1;
             GBs[i] = a.gamma[c];
             GBs[GBN + i] = a.beta[c];
         }
     }
-    for (int i = tid; i < a.n_ct * (32 * NB * WN); i += NTHR) {
-        const int c = i < a.Cout ? i : a.Cout - 1;
-        BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
+    {
+        const int nbt = a.n_ct * (32 * NB * WN);
+#pragma unroll
+        for (int k = 0; k < TBL; ++k) {
+            const int i = tid + k * NTHR;
+            if (i < nbt) BTs[i] = t_bias[k] + t_tb[k];
+        }
+        for (int i = tid + TBL * NTHR; i < nbt; i += NTHR) {
+            const int c = i < a.Cout ? i : a.Cout - 1;
+            BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
+        }
+    }
+    if (DWM) {
+#pragma unroll
+        for (int k = 0; k < DWI; ++k) {
+            const int i = tid + k * NTHR;
+            if (i < 9 * Ctot) DWs[i] = t_dw[k];
+        }
+    }
+    if (GNP) {
+        gn_reduce_partials(gp, a.st0, a.np0, a.st1, a.np1, R0.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
+        gn_b = R0.pos.b;
     }
     __syncthreads();
     stamp();

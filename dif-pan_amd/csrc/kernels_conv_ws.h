@@ -98,6 +98,14 @@ __global__ __launch_bounds__(512) void conv3_ws_kernel(ConvArgs a) {
         BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
     }
 
+#ifndef DDIF_EMU
+    if (ABL & 32) {  // experiment: issue priority for one role
+        if (!consumer) __builtin_amdgcn_s_setprio(3);
+    }
+    if (ABL & 64) {
+        if (consumer) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     if (!consumer) {
         // =================================================================================== PRODUCER (waves 4..7)
         const int ptid = tid - 256;

@@ -67,6 +67,11 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
 
 int main(int argc, char** argv) {
     const int B = 64;
+    if (argc > 1 && argv[1][0] == 'w') {  // wave-specialised kernel: issue priority per role
+#define RUNW(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, ABLV, 0, 1, 1>("3x3 gn_silu 32->32 @64^2 WS", B, 64, 64, 32, 32, 1)
+        RUNW(0); RUNW(32); RUNW(64); RUNW(14); RUNW(46); RUNW(78);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'q') {  // the fused q conv (GN + depthwise 3x3 + 1x1): 4 vs 8 waves, f32 vs bf16x3
         run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0, 0, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,4w) f32", B, 64, 64, 64, 64, 1);
         run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0, 0, 1>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,4w) x3", B, 64, 64, 64, 64, 1);
@@ -138,9 +143,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (argc > 1 && argv[1][0] == 's') {  // stamp mode
-        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 16>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) 1wg", B, 64, 64, 32, 32, 1);
-        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 30>("3x3 gn_silu 32->32 @64^2 (8x16,NT32) 1wg", B, 64, 64, 32, 32, 1);
-        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 30>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w)", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 16, 0, 1>("3x3 gn_silu 32->32 @64^2 x3 8w", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 30, 0, 1>("3x3 gn_silu 32->32 @64^2 x3 8w", B, 64, 64, 32, 32, 1);
         return 0;
     }
     if (argc > 1) {  // PMC mode: few kernels, distinct template instantiations
