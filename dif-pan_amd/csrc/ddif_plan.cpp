@@ -29,7 +29,7 @@ ConvVariant variant_for_cfg(int cfg) {
             case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO>(); v.th = 8; v.tw = 8; v.nt = 128; break;
             default: break;
         }
-        if constexpr (CK == 32 && PRO != PRO_COLSM) {  // bf16x3 instantiations of the same five tilings (cfg + 12)
+        if constexpr (CK == 32) {  // bf16x3 instantiations of the same five tilings (cfg + 12)
             switch (cfg) {
                 case 12: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
                 case 13: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 64; v.x3 = true; break;
@@ -145,7 +145,10 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
     if (ks == 1 && vec == 1 && wide1) {
         const int base = wide ? (Cout > 64 ? 3 : (Cout > 32 ? 1 : 0)) : (Cout > 64 ? 4 : 2);
         static const int x3on = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();
-        if (x3on && x3_1 && ck == 32 && pro != PRO_COLSM) return base + 12;  // 0,1,3,2,4 -> 12,13,15,14,16
+        (void)pro;
+        // 32-cout tiles stay on the exact instruction: with 12 MFMAs per stage the split only adds staging work
+        // (measured: softmax_H(q).ctx.attn_out 64+64->32 @64^2 72 vs 58 us)
+        if (x3on && x3_1 && ck == 32 && base != 0) return base + 12;  // 1,3,2,4 -> 13,15,14,16
         return base;
     }
     static const int big3 = [] { const char* e = getenv("DDIF_CONV3_BIG"); return e ? atoi(e) : 1; }();  // A/B switch
@@ -261,7 +264,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.Wout = Wout;
     a.Cout = pc.cout;
     a.w = s.w_override ? s.w_override : (var.x3 ? pc.w_x3 : pc.w);
-    if (var.x3 && !pc.w_x3) return fail(DDIF_ERR_STATE, "%s: bf16x3 variant without split weights", s.name);
+    if (var.x3 && !s.w_override && !pc.w_x3) return fail(DDIF_ERR_STATE, "%s: bf16x3 variant without split weights", s.name);
     a.w_bstride = s.w_bstride;
     a.cs_mx = s.cs_mx;
     a.cs_sm = s.cs_sm;
@@ -727,7 +730,9 @@ int Plan::build() {
         if (fold) {
             // cond-only: M_b = scale * W_out . blockdiag(ctx_b^T), packed per sample next to W_res
             const int nb_pad = (((pmix->cout + 31) / 32) + 3) & ~3;
-            const size_t per = (size_t)nb_pad * pmix->n_chunks * (pmix->ck / 8) * 256;
+            // the layout follows the instantiation add_conv() will pick for this conv (bf16x3 planes or fp32 fragments)
+            const bool mix_x3 = pick_cfg(1, pmix->ck, PRO_COLSM, 1, 1, 0, Hl, Wl, pmix->cout, B) >= 12;
+            const size_t per = mix_x3 ? (size_t)nb_pad * pmix->n_chunks * (pmix->ck / 16) * 3 * 256 : (size_t)nb_pad * pmix->n_chunks * (pmix->ck / 8) * 256;
             float* wmix = nullptr;
             DDIF_TRY(dalloc(&wmix, per * B));
             const float* wo = V(ci + ".attn_out.weight");
@@ -739,8 +744,11 @@ int Plan::build() {
                 const float scale = 1.0f / std::sqrt((float)d);
                 const int co_n = pmix->cout, ck = pmix->ck, nch = pmix->n_chunks;
                 op.flop = 2.0 * B * co_n * (double)fea * d;
-                op.run = [wo, wr, ctx, wmix, BB, co_n, fea, d, scale, ck, nch, nb_pad, per](hipStream_t s, const StepCtx&) {
-                    hipLaunchKernelGGL(pack_mix_weights_kernel, ew_grid(per * BB), dim3(256), 0, s, wo, wr, (const float*)ctx, BB, co_n, fea, d, scale, ck, nch, nb_pad, wmix);
+                op.run = [wo, wr, ctx, wmix, BB, co_n, fea, d, scale, ck, nch, nb_pad, per, mix_x3](hipStream_t s, const StepCtx&) {
+                    if (mix_x3)
+                        hipLaunchKernelGGL(pack_mix_weights_x3_kernel, ew_grid(per * BB), dim3(256), 0, s, wo, wr, (const float*)ctx, BB, co_n, fea, d, scale, ck, nch, nb_pad, wmix);
+                    else
+                        hipLaunchKernelGGL(pack_mix_weights_kernel, ew_grid(per * BB), dim3(256), 0, s, wo, wr, (const float*)ctx, BB, co_n, fea, d, scale, ck, nch, nb_pad, wmix);
                 };
                 pre.push_back(std::move(op));
             }

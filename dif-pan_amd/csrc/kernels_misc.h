@@ -303,6 +303,46 @@ __global__ void pack_mix_weights_kernel(const float* wo, const float* wr, const 
     }
 }
 
+// The same fold, written as the three bf16 planes of the bf16x3 conv path (kernels_conv.h MATH = 1):
+//   [n-block][chunk][16-channel slab][plane hi|mid|lo][half h][cout j][8 bf16: cin = chunk*ck + 16*k16 + 8*h + t]
+__global__ void pack_mix_weights_x3_kernel(const float* wo, const float* wr, const float* ctx, int B, int co_n, int fea, int d,
+                                           float scale, int ck, int n_chunks, int nb_pad, float* out) {
+    const int K16 = ck / 16;
+    const size_t per = (size_t)nb_pad * n_chunks * K16 * 3 * 256;  // floats per sample
+    const size_t nel = (size_t)nb_pad * n_chunks * K16 * 2 * 32 * 8;  // weights per sample
+    const int cin_n = wr ? 2 * fea : fea;
+    unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nel * B; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / nel);
+        size_t r = idx % nel;
+        const int t = (int)(r % 8); r /= 8;
+        const int j = (int)(r % 32); r /= 32;
+        const int h = (int)(r % 2); r /= 2;
+        const int k16 = (int)(r % K16); r /= K16;
+        const int ch = (int)(r % n_chunks); r /= n_chunks;
+        const int nbi = (int)r;
+        const int ci = ch * ck + 16 * k16 + 8 * h + t, co = nbi * 32 + j;
+        float v = 0.f;
+        if (co < co_n && ci < cin_n) {
+            if (ci < fea) {
+                const int hd = ci / d, ii = ci % d;
+                const float* cx = ctx + (((size_t)b * (fea / d) + hd) * d + ii) * d;
+                float s = 0.f;
+                for (int e = 0; e < d; ++e) s = fmaf(wo[(size_t)co * fea + hd * d + e], cx[e], s);
+                v = s * scale;
+            } else {
+                v = wr[(size_t)co * fea + (ci - fea)];
+            }
+        }
+        unsigned q0, q1, q2;
+        dd_split3(v, &q0, &q1, &q2);
+        const size_t fl = (size_t)b * per + ((((size_t)nbi * n_chunks + ch) * K16 + k16) * 3) * 256 + (size_t)(h * 32 + j) * 4;  // float index, plane 0
+        o16[fl * 2 + t] = (unsigned short)q0;
+        o16[(fl + 256) * 2 + t] = (unsigned short)q1;
+        o16[(fl + 512) * 2 + t] = (unsigned short)q2;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // bottleneck self-attention on the matrix cores (the ONE place the north star asks for MFMA): exact-fp32
 // v_mfma_f32_16x16x4_f32.  One wavefront = 64 queries of one (tile, head); D = 16.
