@@ -8,6 +8,33 @@ struct ddif_plan {
     ddif::Plan p;
 };
 
+namespace ddif {
+extern int g_debug_grid_cap;
+}
+
+// Every entry point runs with the handle's device current and restores the caller's device afterwards: a process
+// that drives several GPUs (test_fn(device="cuda:1") without torch.cuda.set_device) must not have the lazily
+// allocated sampler state land on whatever device happened to be current.
+struct DeviceScope {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+#define DDIF_PLAN_ENTER(plan, what)                                                                                   \
+    if (!(plan)) return ddif::fail(DDIF_ERR_INVALID, what ": NULL plan");                                             \
+    DeviceScope dscope__((plan)->p.net->device);                                                                      \
+    if (!dscope__.ok) return ddif::fail(DDIF_ERR_HIP, what ": hipSetDevice(%d) failed", (plan)->p.net->device);      \
+    if ((plan)->p.generation != (plan)->p.net->generation)                                                            \
+        return ddif::fail(DDIF_ERR_STATE, what ": the network's weights were re-committed after this plan was built " \
+                                               "(its launch program points into the old weight blob); create a new plan")
+
 #define DDIF_GUARD_BEGIN try {
 #define DDIF_GUARD_END                                                                    \
     }                                                                                     \
@@ -24,7 +51,8 @@ int ddif_net_create(ddif_net_t* out, const ddif_net_cfg* cfg, int device) {
     DDIF_GUARD_BEGIN
     if (!out || !cfg) return ddif::fail(DDIF_ERR_INVALID, "ddif_net_create: NULL argument");
     *out = nullptr;
-    DDIF_HIPCHK(hipSetDevice(device));
+    DeviceScope ds(device);
+    if (!ds.ok) return ddif::fail(DDIF_ERR_HIP, "ddif_net_create: hipSetDevice(%d) failed", device);
     std::unique_ptr<ddif_net> h(new ddif_net());
     h->n.cfg = *cfg;
     h->n.device = device;
@@ -46,7 +74,8 @@ int ddif_net_load(ddif_net_t net, const char* key, const float* data, const int6
 int ddif_net_commit(ddif_net_t net, void* stream) {
     DDIF_GUARD_BEGIN
     if (!net) return ddif::fail(DDIF_ERR_INVALID, "ddif_net_commit: NULL net");
-    DDIF_HIPCHK(hipSetDevice(net->n.device));
+    DeviceScope ds(net->n.device);
+    if (!ds.ok) return ddif::fail(DDIF_ERR_HIP, "ddif_net_commit: hipSetDevice(%d) failed", net->n.device);
     return net->n.commit((hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -57,9 +86,11 @@ int ddif_plan_create(ddif_plan_t* out, ddif_net_t net, int B, int H, int W) {
     DDIF_GUARD_BEGIN
     if (!out || !net) return ddif::fail(DDIF_ERR_INVALID, "ddif_plan_create: NULL argument");
     *out = nullptr;
-    DDIF_HIPCHK(hipSetDevice(net->n.device));
+    DeviceScope ds(net->n.device);
+    if (!ds.ok) return ddif::fail(DDIF_ERR_HIP, "ddif_plan_create: hipSetDevice(%d) failed", net->n.device);
     std::unique_ptr<ddif_plan> h(new ddif_plan());
     h->p.net = &net->n;
+    h->p.generation = net->n.generation;
     h->p.B = B;
     h->p.H = H;
     h->p.W = W;
@@ -73,14 +104,14 @@ void ddif_plan_destroy(ddif_plan_t plan) { delete plan; }
 
 int ddif_plan_set_cond(ddif_plan_t plan, const float* cond, void* stream) {
     DDIF_GUARD_BEGIN
-    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    DDIF_PLAN_ENTER(plan, "ddif_plan call");
     return plan->p.set_cond(cond, (hipStream_t)stream);
     DDIF_GUARD_END
 }
 
 int ddif_plan_forward(ddif_plan_t plan, const float* x, const float* time_host, const float* self_cond, float* out, void* stream) {
     DDIF_GUARD_BEGIN
-    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    DDIF_PLAN_ENTER(plan, "ddif_plan call");
     return plan->p.forward(x, time_host, self_cond, out, (hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -88,7 +119,7 @@ int ddif_plan_forward(ddif_plan_t plan, const float* x, const float* time_host, 
 int ddif_plan_sample_ddpm(ddif_plan_t plan, const ddif_ddpm_tables* tabs, const float* x_T, const float* noise, uint64_t seed,
                           uint64_t tile0, float clamp_lo, float clamp_hi, int do_clamp, float* out, void* stream) {
     DDIF_GUARD_BEGIN
-    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    DDIF_PLAN_ENTER(plan, "ddif_plan call");
     return plan->p.sample_ddpm(tabs, x_T, noise, seed, tile0, clamp_lo, clamp_hi, do_clamp, out, (hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -96,7 +127,7 @@ int ddif_plan_sample_ddpm(ddif_plan_t plan, const ddif_ddpm_tables* tabs, const 
 int ddif_plan_sample_ddim(ddif_plan_t plan, const ddif_ddim_tables* tabs, const float* x_T, const float* noise, uint64_t seed,
                           uint64_t tile0, float clamp_lo, float clamp_hi, int do_clamp, float* out, void* stream) {
     DDIF_GUARD_BEGIN
-    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    DDIF_PLAN_ENTER(plan, "ddif_plan call");
     return plan->p.sample_ddim(tabs, x_T, noise, seed, tile0, clamp_lo, clamp_hi, do_clamp, out, (hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -104,7 +135,7 @@ int ddif_plan_sample_ddim(ddif_plan_t plan, const ddif_ddim_tables* tabs, const 
 int ddif_plan_sample_dpmpp(ddif_plan_t plan, const ddif_dpm_tables* tabs, const float* x_T, float clamp_lo, float clamp_hi,
                            int do_clamp, float* out, void* stream) {
     DDIF_GUARD_BEGIN
-    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    DDIF_PLAN_ENTER(plan, "ddif_plan call");
     return plan->p.sample_dpmpp(tabs, x_T, clamp_lo, clamp_hi, do_clamp, out, (hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -113,7 +144,7 @@ int ddif_plan_q_sample_forward(ddif_plan_t plan, const float* x0, const float* n
                                const float* sqrt_1mac_host, const float* time_host, const float* self_cond, float* pred,
                                void* stream) {
     DDIF_GUARD_BEGIN
-    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    DDIF_PLAN_ENTER(plan, "ddif_plan call");
     return plan->p.q_sample_forward(x0, noise, sqrt_ac_host, sqrt_1mac_host, time_host, self_cond, pred, (hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -163,7 +194,7 @@ int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
 }
 
 int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes) {
-    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    DDIF_PLAN_ENTER(plan, "ddif_plan call");
     double sf = 0, sb = 0, cf = 0, cb = 0;
     for (auto& op : plan->p.step) {
         sf += op.flop;
@@ -177,6 +208,11 @@ int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, doub
     if (step_bytes) *step_bytes = sb;
     if (cond_flop) *cond_flop = cf;
     if (cond_bytes) *cond_bytes = cb;
+    return DDIF_OK;
+}
+
+int ddif_debug_set_grid_cap(int max_workgroups) {
+    ddif::g_debug_grid_cap = max_workgroups > 0 ? max_workgroups : 0;
     return DDIF_OK;
 }
 

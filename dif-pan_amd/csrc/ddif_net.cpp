@@ -410,6 +410,7 @@ int Net::commit(hipStream_t stream) {
     wall = blob + o_wall;
     ball = blob + o_ball;
     committed = true;
+    ++generation;
     return 0;
 }
 

@@ -59,6 +59,7 @@ struct Net {
     int final_in = 0;
     std::map<std::string, HostTensor> host;
     bool committed = false;
+    unsigned long long generation = 0;  // bumped by every commit(): plans built against an older blob are refused
 
     float* blob = nullptr;  // one device allocation holding every repacked tensor
     size_t blob_floats = 0;

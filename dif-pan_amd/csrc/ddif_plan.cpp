@@ -3,7 +3,6 @@
 // 624-666; solver/dpm_solver.py:1179-1221).
 #include "ddif_plan.h"
 #include "kernels_conv.h"
-#include "kernels_conv_ws.h"
 #include "kernels_misc.h"
 
 namespace ddif {
@@ -58,31 +57,6 @@ ConvVariant variant_for_cfg(int cfg) {
     }
     return v;
 }
-// cfg 11: the wave-specialised bf16x3 kernel (kernels_conv_ws.h), 16x16 pixels x 32 couts, 4 consumer + 4 producer waves
-template <int U, int PRO, int EPI>
-ConvVariant ws_variant(const char* name) {
-    ConvVariant v;
-    v.fn = conv3_ws_kernel<U, PRO, EPI>;
-    v.smem = conv3_ws_smem_bytes();
-    v.th = 16;
-    v.tw = 16;
-    v.nt = 32;
-    v.nthr = 512;
-    v.x3 = true;
-    v.name = name;
-    return v;
-}
-ConvVariant get_ws_variant(int ups, int pro, int epi) {
-    if (!ups && pro == PRO_GN_SILU && epi == 0) return ws_variant<0, PRO_GN_SILU, 0>("conv3x3_ws_gn_silu");
-    if (!ups && pro == PRO_GN_SILU && epi == EPI_RES) return ws_variant<0, PRO_GN_SILU, EPI_RES>("conv3x3_ws_gn_silu_res");
-    if (!ups && pro == PRO_GN_SILU && epi == EPI_TBS) return ws_variant<0, PRO_GN_SILU, EPI_TBS>("conv3x3_ws_gn_silu_tbs");
-    if (!ups && pro == PRO_NONE && epi == 0) return ws_variant<0, PRO_NONE, 0>("conv3x3_ws");
-    if (!ups && pro == PRO_NONE && epi == EPI_RES) return ws_variant<0, PRO_NONE, EPI_RES>("conv3x3_ws_res");
-    if (!ups && pro == PRO_NONE && epi == EPI_SILU) return ws_variant<0, PRO_NONE, EPI_SILU>("conv3x3_ws_silu");
-    if (ups && pro == PRO_NONE && epi == 0) return ws_variant<1, PRO_NONE, 0>("conv3x3_ws_up2");
-    return ConvVariant();
-}
-
 template <int KS, int S, int U, int CK, int PRO, int VEC>
 ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not fit comfortably in LDS
     return (cfg >= 2) ? variant_for_cfg<KS, S, U, CK, PRO, VEC>(cfg) : ConvVariant();
@@ -96,7 +70,6 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 // Only the combinations the network uses are instantiated.
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi) {
     ConvVariant v;
-    if (cfg == 11) return (ks == 3 && ck == 16 && stride == 1 && vec == 1) ? get_ws_variant(ups, pro, epi) : v;
     const bool plain = stride == 1 && !ups;
     if (epi == EPI_FILM) {
         if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
@@ -138,30 +111,26 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
 }
 
 static int num_cus();
+static int x3_enabled() {  // DDIF_X3=0: the exact-fp32 MFMA instantiation everywhere (bitwise an fmaf chain); covered by tests/test_env_switches.py
+    static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();
+    return x3;
+}
 static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B) {
-    static const int wide1 = [] { const char* e = getenv("DDIF_CONV1_WIDE"); return e ? atoi(e) : 1; }();  // A/B switch
     const bool wide = (Wout >= 16) && stride == 1;
-    static const int x3_1 = [] { const char* e = getenv("DDIF_X3_1X1"); return e ? atoi(e) : 1; }();  // bf16x3 for the 1x1 convs too
-    if (ks == 1 && vec == 1 && wide1) {
+    (void)pro;
+    if (ks == 1 && vec == 1) {
         const int base = wide ? (Cout > 64 ? 3 : (Cout > 32 ? 1 : 0)) : (Cout > 64 ? 4 : 2);
-        static const int x3on = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();
-        (void)pro;
         // 32-cout tiles stay on the exact instruction: with 12 MFMAs per stage the split only adds staging work
         // (measured: softmax_H(q).ctx.attn_out 64+64->32 @64^2 72 vs 58 us)
-        if (x3on && x3_1 && ck == 32 && base != 0) return base + 12;  // 1,3,2,4 -> 13,15,14,16
+        if (x3_enabled() && ck == 32 && base != 0) return base + 12;  // 1,3,2,4 -> 13,15,14,16
         return base;
     }
-    static const int big3 = [] { const char* e = getenv("DDIF_CONV3_BIG"); return e ? atoi(e) : 1; }();  // A/B switch
-    static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();  // 0: exact-fp32 MFMA everywhere
-    if (ks == 3 && vec == 1 && stride == 1 && x3) {
-        // 1: wave-specialised kernel (kernels_conv_ws.h).  Measured on MI355X: 43.5 vs 41.9 us (32->32 @64^2), 134 vs 124 us
-        // (64->64 @64^2) -- faster without memory traffic (27.9 vs 30.4 us), slower with it; off by default.
-        static const int ws = [] { const char* e = getenv("DDIF_WS"); return e ? atoi(e) : 0; }();
-        if (wide && Hout >= 32 && Wout >= 32) return ws ? 11 : 7;
+    if (ks == 3 && vec == 1 && stride == 1 && x3_enabled()) {
+        if (wide && Hout >= 32 && Wout >= 32) return 7;
         if (wide || Cout <= 32) return 8;
         return 9;
     }
-    if (ks == 3 && vec == 1 && wide && big3 && !ups_) {
+    if (ks == 3 && vec == 1 && wide && !ups_) {
         const long items32 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
         if (Hout >= 32 && Wout >= 32 && items32 >= 2L * num_cus()) return (Cout % 64 == 0 && items32 >= 4L * num_cus()) ? 6 : 5;
     }
@@ -170,26 +139,24 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
     return 2;
 }
 
-static int num_cus() {
-    static int n = [] {
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu = v;
-        }
-        return cu;
-    }();
-    return n;
+static int num_cus() {  // of the CURRENT device (plan entry points make the net's device current), cached per device
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cache[dev] == 0) {
+        int v = 0;
+        cache[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cache[dev];
 }
+// Test hook (ddif_debug_set_grid_cap, include/ddif.h): caps the persistent grid of every conv launch of plans built
+// afterwards, so that small parity cases walk several work items per workgroup across sample boundaries -- the
+// regime the B=64 benchmark runs in.  0 = no cap.
+int g_debug_grid_cap = 0;
 static int wg_per_cu(size_t smem) {
-    static int forced = [] {
-        const char* e = getenv("DDIF_WG_PER_CU");
-        return e ? atoi(e) : 0;
-    }();
     int byl = (int)((160 * 1024) / (smem ? smem : 1));
     if (byl < 1) byl = 1;
-    int want = forced > 0 ? forced : 2;
-    return want < byl ? want : byl;
+    return 2 < byl ? 2 : byl;
 }
 
 static inline dim3 ew_grid(size_t n) {
@@ -241,13 +208,9 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 != 0 || c1 % 4 != 0) ? 0 : ((c1 == 0 || c0 % pc.ck == 0) ? 1 : 2);
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
-    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
+    const int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0);
     ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
-    if (!var.fn && cfg == 11) {  // epilogue / prologue combination the wave-specialised kernel does not carry
-        cfg = 7;
-        var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
-    }
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
@@ -297,7 +260,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const long nwork = (long)B * a.tiles_x * a.tiles_y * gy;
     const int gy0 = (pc.cout + var.nt - 1) / var.nt;
     const size_t smem = var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
-    const long cap = (long)num_cus() * wg_per_cu(smem);
+    long cap = (long)num_cus() * wg_per_cu(smem);
+    if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
     const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
     const dim3 block((unsigned)var.nthr);
     if (var.smem + 8192 > 64 * 1024) {  // the attribute is per kernel function: set it to the variant's maximum
@@ -475,13 +439,8 @@ int Plan::build() {
             const float scale = 1.0f / std::sqrt((float)Cc);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)
             op.flop = 4.0 * B * 8 * (double)n * n * 16;
             op.bytes = 4.0 * B * n * 4.0 * Cc;
-            static const bool valu_attn = getenv("DDIF_ATTN_VALU") != nullptr;  // A/B switch: the pre-MFMA kernel
             op.run = [qkv, o, n, Cc, BB, scale](hipStream_t s, const StepCtx&) {
-                if (valu_attn)
-                    hipLaunchKernelGGL((self_attn_kernel<16>), dim3((n + 63) / 64, 8, BB), dim3(64), 2 * 64 * 16 * sizeof(float), s,
-                                       (const float*)qkv.p, n, Cc, scale, o.p);
-                else
-                    hipLaunchKernelGGL(self_attn_mfma_kernel, dim3((n + 63) / 64, 8, BB), dim3(64), 0, s, (const float*)qkv.p, n, Cc, scale, o.p);
+                hipLaunchKernelGGL(self_attn_mfma_kernel, dim3((n + 63) / 64, 8, BB), dim3(64), 0, s, (const float*)qkv.p, n, Cc, scale, o.p);
             };
             step.push_back(std::move(op));
         }
@@ -652,16 +611,16 @@ int Plan::build() {
             }
         }
         // ---- per step
-        Tensor dwq, xn, q, o, amix, f1, f2, f3;
+        Tensor xn, q, amix, f1, f2, f3;
         DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl));
         const PackedConv* pq1 = PC(ci + ".q.1");
         if (!pq1) return fail(DDIF_ERR_MISSING, "%s.q.1 missing", ci.c_str());
         if (!cur.st || !skip.st) return fail(DDIF_ERR_STATE, "%s: prenorm without producer statistics", ci.c_str());
         const float *pn_g = V(ci + ".prenorm_x.weight"), *pn_b = V(ci + ".prenorm_x.bias"), *q0w = V(ci + ".q.0.weight");
         if (!pn_g || !pn_b || !q0w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
-        static const bool no_dw_fuse = getenv("DDIF_NO_DW_FUSE") != nullptr;
-        const bool dwfuse = !no_dw_fuse && pq1->ck == 32 && cur.C % 4 == 0 && skip.C % 4 == 0 && fea <= 256;
-        if (dwfuse) {
+        if (pq1->ck != 32 || cur.C % 4 != 0 || skip.C % 4 != 0 || fea > 256)
+            return fail(DDIF_ERR_INVALID, "%s: the fused q = 1x1(dw3x3(GN(cat))) kernel needs 4 | channels and <= 256 of them (got %d+%d)", ci.c_str(), cur.C, skip.C);
+        {
             // q = q.1(depthwise3x3(GroupNorm(cat[h, skip]))) in ONE kernel; also emits xn (sr3_dwt.py:507-513,537,540)
             ConvSpec s;
             s.pc = pq1;
@@ -673,43 +632,6 @@ int Plan::build() {
             s.dw_w = q0w;
             s.out_xn = xn.p;
             s.name = "q = 1x1(dw3x3(GN(cat)))";
-            DDIF_TRY(add_conv(step, s, &q));
-        } else {
-            DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl));
-            {
-                DwArgs a{};
-                a.in0 = cur.p;
-                a.c0 = cur.C;
-                a.in1 = skip.p;
-                a.c1 = skip.C;
-                a.B = B;
-                a.H = Hl;
-                a.W = Wl;
-                a.st0 = cur.st;
-                a.np0 = cur.np;
-                a.st1 = skip.st;
-                a.np1 = skip.np;
-                a.gamma = pn_g;
-                a.beta = pn_b;
-                a.w = q0w;
-                a.out_dw = dwq.p;
-                a.out_xn = xn.p;
-                a.tiles_x = (Wl + 15) / 16;
-                a.tiles_y = (Hl + 7) / 8;
-                a.use_gn = 1;
-                Op op;
-                op.name = "q.gn_dw3x3";
-                op.flop = 2.0 * 9 * B * Hl * Wl * fea;
-                op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
-                op.run = [a, BB](hipStream_t s, const StepCtx&) {
-                    hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
-                };
-                step.push_back(std::move(op));
-            }
-            ConvSpec s;
-            s.pc = pq1;
-            s.in0 = dwq;
-            s.name = "q.1x1";
             DDIF_TRY(add_conv(step, s, &q));
         }
         float *qmx, *qsm;
@@ -726,8 +648,9 @@ int Plan::build() {
         }
         const PackedConv* pmix = PC(ci + ".attn_mix");
         if (!pmix) return fail(DDIF_ERR_MISSING, "%s.attn_out missing", ci.c_str());
-        const bool fold = (fea % 32 == 0) && pmix->ck == 32;  // context folded into per-sample attn_out weights
-        if (fold) {
+        // the linear-attention context is folded into per-sample attn_out weights (needs 32-channel chunks)
+        if (fea % 32 != 0 || pmix->ck != 32) return fail(DDIF_ERR_INVALID, "%s: linear attention over %d channels needs 32 | channels", ci.c_str(), fea);
+        {
             // cond-only: M_b = scale * W_out . blockdiag(ctx_b^T), packed per sample next to W_res
             const int nb_pad = (((pmix->cout + 31) / 32) + 3) & ~3;
             // the layout follows the instantiation add_conv() will pick for this conv (bf16x3 planes or fp32 fragments)
@@ -763,27 +686,6 @@ int Plan::build() {
             s.w_override = wmix;
             s.w_bstride = (long long)per;
             s.name = "softmax_H(q).ctx.attn_out+res";
-            DDIF_TRY(add_conv(step, s, &amix));
-        } else {
-            DDIF_TRY(alloc_tensor(&o, fea, Hl, Wl));
-            {
-                Op op;
-                op.name = "linattn_apply";
-                const float scale = 1.0f / std::sqrt((float)d);
-                op.flop = 2.0 * B * Hl * Wl * (double)fea * d;
-                op.bytes = 8.0 * B * Hl * Wl * fea;
-                op.run = [q, qmx, qsm, ctx, o, fea, d, BB, Hl, Wl, scale](hipStream_t s, const StepCtx&) {
-                    hipLaunchKernelGGL(linattn_apply_kernel, dim3((Hl * Wl + 15) / 16, BB), dim3(256), (size_t)(fea * d + 16 * fea) * sizeof(float), s,
-                                       (const float*)q.p, (const float*)qmx, (const float*)qsm, (const float*)ctx, BB, Hl, Wl, fea, d, scale, o.p);
-                };
-                step.push_back(std::move(op));
-            }
-            ConvSpec s;
-            s.pc = pmix;
-            s.in0 = o;
-            if (pmix->cin == 2 * fea) s.in1 = xn;
-            else s.res = xn.p;  // attn_res is Identity
-            s.name = "attn_out+res";
             DDIF_TRY(add_conv(step, s, &amix));
         }
         {

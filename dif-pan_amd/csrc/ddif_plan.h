@@ -65,6 +65,7 @@ struct ConvSpec {
 
 struct Plan {
     Net* net = nullptr;
+    unsigned long long generation = 0;  // Net::generation at build time: entry points refuse a plan that outlived a re-commit
     int B = 0, H = 0, W = 0, C = 0, P = 0, CC = 0;
     std::vector<void*> allocs;
     std::vector<Op> pre, step;

@@ -171,103 +171,6 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* kv, const
     }
 }
 
-// linear-attention apply (per step): o[b,p,hd*d+e] = sum_i ctx[b,hd,i,e] * softmax_H(q)[p,hd*d+i] * scale  (:545,561,565)
-__global__ __launch_bounds__(256) void linattn_apply_kernel(const float* q, const float* qmx, const float* qsm,
-                                                            const float* ctx, int B, int H, int W, int Cq, int d,
-                                                            float scale, float* out) {
-    DDIF_DYN_SMEM(smem);
-    constexpr int PB = 16;
-    float* cs = reinterpret_cast<float*>(smem);  // [heads*d*d]
-    float* qs = cs + Cq * d;                     // [PB][Cq]
-    const int b = blockIdx.y, tid = threadIdx.x, n = H * W;
-    const int p0 = blockIdx.x * PB;
-    for (int i = tid; i < Cq * d; i += 256) cs[i] = ctx[(size_t)b * Cq * d + i];
-    for (int it = tid; it < PB * Cq; it += 256) {
-        const int pl = it / Cq, c = it % Cq, p = p0 + pl;
-        float v = 0.f;
-        if (p < n) {
-            const int w = p % W;
-            const size_t si = ((size_t)b * W + w) * Cq + c;
-            v = dd_exp(q[((size_t)b * n + p) * Cq + c] - qmx[si]) / qsm[si] * scale;
-        }
-        qs[it] = v;
-    }
-    __syncthreads();
-    for (int it = tid; it < PB * Cq; it += 256) {
-        const int pl = it / Cq, c = it % Cq, p = p0 + pl;
-        const int hd = c / d, e = c % d;
-        float s = 0.f;
-        for (int i = 0; i < d; ++i) s = fmaf(cs[(hd * d + i) * d + e], qs[pl * Cq + hd * d + i], s);
-        if (p < n) out[((size_t)b * n + p) * Cq + c] = s;
-    }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// bottleneck self-attention (SelfAttention, :341-360): qkv [B,n,3C] with per-head [q|k|v] interleave
-// (channel = hd*3D + {0,D,2D} + c), logits scaled by 1/sqrt(C) (NOT 1/sqrt(D)), softmax over keys.
-// One wavefront = 64 queries of one (tile, head); keys/values stream through LDS in blocks of 64 with an online
-// softmax (a single block, n <= 64, is the plain max/exp/sum softmax).  Output o [B,n,C], channel = hd*D + c.
-template <int D>
-__global__ __launch_bounds__(64) void self_attn_kernel(const float* qkv, int n, int C, float scale, float* out) {
-    DDIF_DYN_SMEM(smem);
-    float* ks = reinterpret_cast<float*>(smem);  // [64][D]
-    float* vs = ks + 64 * D;                     // [64][D]
-    const int hd = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-    const int qi = blockIdx.x * 64 + lane;
-    const bool qok = qi < n;
-    float qr[D], acc[D];
-    const size_t rowq = ((size_t)b * n + (qok ? qi : 0)) * 3 * C + (size_t)hd * 3 * D;
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        qr[c] = qkv[rowq + c];
-        acc[c] = 0.f;
-    }
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < n; k0 += 64) {
-        __syncthreads();
-        {
-            const int kj = k0 + lane;
-            const size_t rowk = ((size_t)b * n + (kj < n ? kj : 0)) * 3 * C + (size_t)hd * 3 * D;
-#pragma unroll
-            for (int c = 0; c < D; ++c) {
-                ks[lane * D + c] = kj < n ? qkv[rowk + D + c] : 0.f;
-                vs[lane * D + c] = kj < n ? qkv[rowk + 2 * D + c] : 0.f;
-            }
-        }
-        __syncthreads();
-        const int nk = (n - k0) < 64 ? (n - k0) : 64;
-        float s[64];
-        float bm = -INFINITY;
-#pragma unroll
-        for (int jj = 0; jj < 64; ++jj) {
-            float d = 0.f;
-#pragma unroll
-            for (int c = 0; c < D; ++c) d = fmaf(qr[c], ks[jj * D + c], d);
-            d = jj < nk ? d * scale : -INFINITY;
-            s[jj] = d;
-            bm = fmaxf(bm, d);
-        }
-        const float mn = fmaxf(m, bm);
-        const float corr = (m == -INFINITY) ? 0.f : dd_exp(m - mn);
-        l *= corr;
-#pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] *= corr;
-#pragma unroll
-        for (int jj = 0; jj < 64; ++jj) {
-            const float p = jj < nk ? dd_exp(s[jj] - mn) : 0.f;
-            l += p;
-#pragma unroll
-            for (int c = 0; c < D; ++c) acc[c] = fmaf(p, vs[jj * D + c], acc[c]);
-        }
-        m = mn;
-    }
-    if (qok) {
-        const float inv = 1.f / l;
-#pragma unroll
-        for (int c = 0; c < D; ++c) out[((size_t)b * n + qi) * C + hd * D + c] = acc[c] * inv;
-    }
-}
-
 // Folds the cond-only linear-attention context into the attn_out weights (once per tile batch):
 //   attn_out(ctx^T (q_n * scale)) + attn_res(xn) = [M_b | W_res] . cat[q_n, xn],   M_b[co][hd*d+i] = scale * sum_e
 //   W_out[co][hd*d+e] * ctx[b,hd,i,e]       (FastAttnCondInjection, models/sr3_dwt.py:561-573)

@@ -88,15 +88,12 @@ class UNetSR3(nn.Module):
         self.self_condition = self_condition
         self.pred_var = pred_var
         self.fourier_features = fourier_features
-        for a in attn_res:  # the reference prints this from its constructor (models/sr3_dwt.py:138-139)
-            pass
         manifest = param_manifest(self.cfg)
         shapes = dict(manifest)
         for key, shape in manifest:
             _register(self, key, _default_init(key, shape, shapes))
         self._net: Optional[NetHandle] = None
         self._weights_sig = None
-        self._dropout_warned = False
 
     # ---- weights -> library -----------------------------------------------------------------------------------------
     def _signature(self):
@@ -121,19 +118,19 @@ class UNetSR3(nn.Module):
         return self._net
 
     def plan_for(self, B: int, H: int, W: int, device) -> PlanHandle:
-        p = self._ensure_net(device).plan(B, H, W)
-        p.net_out_channels = self.cfg["out_channel"]
-        return p
+        return self._ensure_net(device).plan(B, H, W)
 
     # ---- reference API ----------------------------------------------------------------------------------------------
     def forward(self, x, time, cond=None, self_cond=None):
         if cond is None:
             raise DdifError("UNetSR3.forward: cond is required (the reference indexes it unconditionally, "
                             "models/sr3_dwt.py:197)")
-        if self.training and (self.cfg["dropout"] or True) and not self._dropout_warned:
-            # Dropout / DropPath masks (train mode) are not implemented by the kernels yet: the forward below is
-            # the eval-mode network.  Training (config 5) is listed as not built in DESIGN.md.
-            self._dropout_warned = True
+        if self.training:
+            # Train mode = Dropout(p) after every Block's SiLU (models/sr3_dwt.py:295) + DropPath(0.2) on every decoder FFN
+            # (:534,576).  The kernels implement the eval network only; running it silently under .train() would change
+            # training semantics, so refuse (call .eval() for sampling / validation, as the reference engine does).
+            raise DdifError("UNetSR3.forward in train mode (Dropout / DropPath masks) is not implemented by the HIP path; "
+                            "call .eval() -- there is no silent eval-mode substitute and no PyTorch fallback")
         B, _, H, W = x.shape
         plan = self.plan_for(B, H, W, x.device)
         plan.set_cond(cond)

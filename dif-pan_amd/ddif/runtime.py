@@ -89,6 +89,7 @@ class _Lib:
         d.ddif_prof_begin.argtypes = [vp, i32, i32]
         d.ddif_prof_collect.argtypes = [vp, C.POINTER(ProfResult)]
         d.ddif_plan_cost.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
+        d.ddif_debug_set_grid_cap.argtypes = [i32]
         self.emulated = bool(d.ddif_is_emulated())
 
     def check(self, rc: int, what: str):
@@ -131,6 +132,19 @@ def _check_tensor(lib: _Lib, t: torch.Tensor, name: str):
     elif t.device.type != "cuda":
         raise DdifError(f"{name} is on {t.device}: the ddif kernels run on the GPU only; there is no CPU fallback "
                         f"(move the tensors to cuda)")
+
+
+def _check_shape(t: torch.Tensor, name: str, expected: tuple):
+    """The kernels index with the plan's shapes: a mismatched tensor would read out of bounds on the GPU (the process
+    dies with a bare 'Aborted').  The reference raises a shape error from torch in the same situation."""
+    if tuple(t.shape) != tuple(expected):
+        raise DdifError(f"{name}: expected shape {tuple(expected)}, got {tuple(t.shape)}")
+
+
+def set_debug_grid_cap(max_workgroups: int):
+    """TEST HOOK (include/ddif.h ddif_debug_set_grid_cap): cap the persistent conv grids of plans created afterwards."""
+    lib = get_lib()
+    lib.check(lib.dll.ddif_debug_set_grid_cap(int(max_workgroups)), "ddif_debug_set_grid_cap")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -181,6 +195,8 @@ class NetHandle:
         idx = self.device.index if self.device.type == "cuda" and self.device.index is not None else 0
         self.lib.check(self.lib.dll.ddif_net_create(C.byref(h), C.byref(c), idx), "ddif_net_create")
         self.h = h
+        self.in_channel, self.out_channel = int(cfg["in_channel"]), int(cfg["out_channel"])
+        self.cond_channel = 2 * int(cfg["lms_channel"]) + 4 * int(cfg["pan_channel"])
         self.plans: Dict[Tuple[int, int, int], "PlanHandle"] = {}
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], freqs: torch.Tensor):
@@ -226,6 +242,7 @@ class PlanHandle:
         self.h = h
         self._cond_ref = None
         self._cond_ver = None
+        self.net_out_channels = net.out_channel
 
     def __del__(self):
         try:
@@ -238,6 +255,7 @@ class PlanHandle:
     # -- cond ---------------------------------------------------------------------------------------------------
     def set_cond(self, cond: torch.Tensor, force: bool = False):
         _check_tensor(self.lib, cond, "cond")
+        _check_shape(cond, "cond", (self.B, self.net.cond_channel, self.H, self.W))
         cond_c = cond.contiguous()
         same = (not force and self._cond_ref is not None and self._cond_ref() is cond
                 and self._cond_ver == cond._version and cond_c is cond)
@@ -252,10 +270,12 @@ class PlanHandle:
     # -- network ------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, time: torch.Tensor, self_cond: Optional[torch.Tensor]) -> torch.Tensor:
         _check_tensor(self.lib, x, "x")
+        _check_shape(x, "x", (self.B, self.net.in_channel, self.H, self.W))
         x = x.contiguous()
         sc = None
         if self_cond is not None:
             _check_tensor(self.lib, self_cond, "self_cond")
+            _check_shape(self_cond, "self_cond", (self.B, self.net.out_channel, self.H, self.W))
             sc = self_cond.contiguous()
         t = time.detach().to("cpu", torch.float32).contiguous()
         if t.numel() != self.B:
@@ -265,16 +285,22 @@ class PlanHandle:
                                                       _stream(self.lib, x.device)), "ddif_plan_forward")
         return out
 
-    net_out_channels = 0  # set by the owner
+    def _check_sampler_inputs(self, x_T, noise, n_steps):
+        img = (self.B, self.net.out_channel, self.H, self.W)
+        if x_T is not None:
+            _check_tensor(self.lib, x_T, "x_T")
+            _check_shape(x_T, "x_T", img)
+        if noise is not None:
+            _check_tensor(self.lib, noise, "noise")
+            if noise.dim() != 5 or tuple(noise.shape[1:]) != img or noise.shape[0] < n_steps:
+                raise DdifError(f"noise: expected shape (>={n_steps},) + {img}, got {tuple(noise.shape)}")
 
     # -- samplers -----------------------------------------------------------------------------------------------
     def sample_ddpm(self, t_model, c_x0, c_xt, c_z, x_T, noise, seed, tile0, clamp, device) -> torch.Tensor:
         n = len(t_model)
         keep = [_farr(t_model), _farr(c_x0), _farr(c_xt), _farr(c_z)]
         tabs = DdpmTables(n, *[C.cast(a, _FP) for a in keep])
-        for nm, t in (("x_T", x_T), ("noise", noise)):
-            if t is not None:
-                _check_tensor(self.lib, t, nm)
+        self._check_sampler_inputs(x_T, noise, n)
         x_T = None if x_T is None else x_T.contiguous()
         noise = None if noise is None else noise.contiguous()
         out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=device)
@@ -289,9 +315,7 @@ class PlanHandle:
         n = len(t_model)
         keep = [_farr(v) for v in (t_model, sqrt_recip, sqrt_recipm1, sqrt_ap, dir_coef, sigma)]
         tabs = DdimTables(n, *[C.cast(a, _FP) for a in keep])
-        for nm, t in (("x_T", x_T), ("noise", noise)):
-            if t is not None:
-                _check_tensor(self.lib, t, nm)
+        self._check_sampler_inputs(x_T, noise, n)
         x_T = None if x_T is None else x_T.contiguous()
         noise = None if noise is None else noise.contiguous()
         out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=device)
@@ -302,7 +326,7 @@ class PlanHandle:
         return out
 
     def sample_dpmpp(self, tabs: dict, x_T: torch.Tensor, clamp) -> torch.Tensor:
-        _check_tensor(self.lib, x_T, "x_T")
+        self._check_sampler_inputs(x_T, None, 0)
         x_T = x_T.contiguous()
         keep = {k: (_iarr(v) if k == "ord" else _farr(v)) for k, v in tabs.items() if k not in ("n_evals", "order")}
         t = DpmTables()
@@ -316,8 +340,10 @@ class PlanHandle:
         return out
 
     def q_sample_forward(self, x0, noise, a, s, time, self_cond) -> torch.Tensor:
-        for nm, t in (("x_start", x0), ("noise", noise)):
+        img = (self.B, self.net.out_channel, self.H, self.W)
+        for nm, t in (("x_start", x0), ("noise", noise)) + ((("self_cond", self_cond),) if self_cond is not None else ()):
             _check_tensor(self.lib, t, nm)
+            _check_shape(t, nm, img)
         x0, noise = x0.contiguous(), noise.contiguous()
         sc = None if self_cond is None else self_cond.contiguous()
         a = a.detach().to("cpu", torch.float32).contiguous()

@@ -168,6 +168,12 @@ DDIF_API int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out);
 /* flops / bytes of one denoising step and of set_cond for this plan (algorithmic, SURVEY.md 8d accounting) */
 DDIF_API int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes);
 
+/* TEST HOOK: cap the persistent grid (workgroups per conv launch) of plans created afterwards; 0 removes the cap.
+ * Results do not depend on the cap (work items are walked in a fixed order per workgroup and every reduction has a
+ * fixed order); tests use it to make small cases walk many work items per workgroup, across sample boundaries,
+ * which is the regime the B=64 benchmark configuration runs in. */
+DDIF_API int ddif_debug_set_grid_cap(int max_workgroups);
+
 DDIF_API const char* ddif_last_error(void);
 DDIF_API const char* ddif_version(void);
 /* 1 when built for the test-only host emulator (never shipped), 0 for the gfx950 build */

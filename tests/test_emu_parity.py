@@ -103,6 +103,9 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(DdifError):
         UNetSR3(fourier_features=True)
     net = UNetSR3(in_channel=8, out_channel=8, norm_groups=32, channel_mults=(1, 2), image_size=16)  # reference defaults
+    with pytest.raises(DdifError, match="train mode"):  # .train() is torch's default: never a silent eval-mode forward
+        net(torch.zeros(1, 8, 16, 16), torch.zeros(1), torch.zeros(1, 20, 16, 16))
+    net.eval()
     with pytest.raises(DdifError, match="norm_groups"):
         net(torch.zeros(1, 8, 16, 16), torch.zeros(1), torch.zeros(1, 20, 16, 16))
 
@@ -124,3 +127,28 @@ def test_emulated_dpm_solver_matches_oracle():
         ref = O.dpmpp_multistep_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, O.schedule_tables(O.cosine_betas(T))["betas"],
                                        xT, steps, order)
     assert float((out - ref).abs().max()) <= 2e-5
+
+
+def test_emulated_grid_cap_hook_gives_identical_results():
+    """ddif_debug_set_grid_cap (the hook the -m gpu multi-item tests rely on): one workgroup walking every work item
+    of every conv launch, across the sample boundaries of a B=3 batch, reproduces the uncapped result bit for bit."""
+    from ddif import runtime
+
+    ds, B, H = "gf2", 3, 8
+    C, cond, g = _tiny(ds, B, H, H, 9)
+    x = torch.randn(B, C, H, H, generator=g)
+    t = torch.tensor([3, 500, 999])
+    net = net_for(ds)
+    net._net and net._net.plans.clear()
+    want = net(x, t, cond).clone()
+    try:
+        runtime.set_debug_grid_cap(1)
+        net._net.plans.clear()
+        got = net(x, t, cond)
+    finally:
+        runtime.set_debug_grid_cap(0)
+        net._net.plans.clear()
+    assert torch.equal(got, want)
+    with torch.no_grad():
+        ref = O.unet_forward(gc.weights_for(ds), gc.cfg_for(ds), x, t, cond, None)
+    assert float((got - ref).abs().max()) <= 2e-5

@@ -1,0 +1,158 @@
+"""Parity of the code path the headline benchmark runs (-m gpu): persistent workgroups that walk SEVERAL work items
+each, across sample boundaries.
+
+Every conv launch is persistent (grid = min(work items, CUs x workgroups-per-CU), csrc/ddif_plan.cpp add_conv); the
+small golden cases give every workgroup exactly one item, so `next_pos`, the prefetch across item boundaries, the
+deferred `flush_stats` and the per-sample GroupNorm re-finalisation (csrc/kernels_conv.h) only run when a batch is
+large.  These tests run BASELINE.json configs[1] itself (batch 64 of 64x64x8 WV3 tiles) and, through the
+`ddif_debug_set_grid_cap` test hook, small cases squeezed onto a handful of workgroups:
+  * a tile of the batch must be BIT-equal to the same tile run alone (tiles are independent, every reduction has a fixed
+    order that does not depend on the batch or on the grid);
+  * spot tiles (first, last, two in the middle) must match the pinned CPU oracle within the north-star tolerances.
+Reference loop: diffusion/diffusion_ddpm_pan.py:445-507; network: models/sr3_dwt.py:169-219.
+"""
+import pytest
+import torch
+
+import golden_cases as gc
+from ddif_testlib import make_diffusion, make_net, use_gpu_library
+from oracle import ddif_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SPOT = (0, 21, 42, 63)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    return use_gpu_library()
+
+
+@pytest.fixture(scope="module")
+def net():
+    return make_net("wv3", DEV)
+
+
+@pytest.fixture()
+def grid_cap():
+    """Set the persistent-grid cap for plans built inside the test; always removed afterwards."""
+    from ddif import runtime
+
+    def set_cap(n):
+        runtime.set_debug_grid_cap(n)
+
+    yield set_cap
+    runtime.set_debug_grid_cap(0)
+
+
+def _fresh_plans(net):
+    """Plans are cached per (B, H, W): drop them so that the next call builds its launch program under the current cap."""
+    if net._net is not None:
+        net._net.plans.clear()
+
+
+def _inputs(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 8, H, W, generator=g)
+    sc = torch.randn(B, 8, H, W, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    cond = gc.tiles_for("wv3", B, H, W, seed=seed)["cond"]
+    return x, t, cond, sc
+
+
+def test_forward_batch64_tiles_equal_single_tile_runs_and_oracle(net):
+    """BASELINE config 2 shape: 1024-2048 work items per launch on 256-512 workgroups (4-16 items each)."""
+    B, H = 64, 64
+    x, t, cond, sc = _inputs(B, H, H, 640)
+    y = net(x.to(DEV), t.to(DEV), cond.to(DEV), sc.to(DEV))
+    y2 = net(x.to(DEV), t.to(DEV), cond.to(DEV), sc.to(DEV))
+    assert torch.equal(y, y2)  # run-to-run bitwise determinism of the multi-item path
+    for b in SPOT:
+        yb = net(x[b:b + 1].to(DEV), t[b:b + 1].to(DEV), cond[b:b + 1].to(DEV).contiguous(), sc[b:b + 1].to(DEV))
+        assert torch.equal(yb[0], y[b]), f"tile {b} of the batch differs from the same tile run alone"
+        with torch.no_grad():
+            ref = O.unet_forward(gc.weights_for("wv3"), gc.cfg_for("wv3"), x[b:b + 1], t[b:b + 1], cond[b:b + 1], sc[b:b + 1])
+        assert float((y[b:b + 1].cpu() - ref).abs().max()) <= 2e-5
+
+
+def test_ddpm_batch64_reference_noise_vs_single_tiles_and_oracle(net):
+    """B=64 DDPM, T=20 (all 20 steps of a 20-step cosine schedule), noise uploaded in the reference's draw order."""
+    B, H, T = 64, 64, 20
+    cond = gc.tiles_for("wv3", B, H, H, seed=641)["cond"]
+    g = torch.Generator().manual_seed(642)
+    xT = torch.randn(B, 8, H, H, generator=g)
+    noise = torch.randn(T, B, 8, H, H, generator=g)
+    d = make_diffusion(net, 8, T, H, DEV)
+    out = d(cond.to(DEV), mode="ddpm_sample", x_T=xT.to(DEV), noise=noise.to(DEV))
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    for k, b in enumerate(SPOT):
+        one = d(cond[b:b + 1].to(DEV).contiguous(), mode="ddpm_sample", x_T=xT[b:b + 1].to(DEV),
+                noise=noise[:, b:b + 1].to(DEV).contiguous())
+        assert torch.equal(one[0], out[b]), f"tile {b}: batch-64 sampler differs from the single-tile run"
+        if k in (0, 3):  # first and last tile against the oracle (20 CPU steps each)
+            it = iter([xT[b:b + 1]] + [noise[s, b:b + 1] for s in range(T)])
+            with torch.no_grad():
+                ref = O.ddpm_sample(gc.weights_for("wv3"), gc.cfg_for("wv3"), cond[b:b + 1], tabs, noise_fn=lambda s: next(it))
+            assert float((out[b:b + 1].cpu() - ref).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("cap", [1, 3, 7])
+def test_capped_grid_small_case_walks_many_items_with_mixed_samples(net, grid_cap, cap):
+    """16x16, B=8 on `cap` workgroups: every conv launch walks >= 4 items per workgroup and every workgroup crosses
+    sample boundaries (7 and 3 do not divide the item counts, so the boundaries fall mid-range)."""
+    B, H = 8, 16
+    x, t, cond, sc = _inputs(B, H, H, 160 + cap)
+    _fresh_plans(net)
+    want = net(x.to(DEV), t.to(DEV), cond.to(DEV), sc.to(DEV)).clone()  # uncapped: one item per workgroup
+    grid_cap(cap)
+    _fresh_plans(net)
+    got = net(x.to(DEV), t.to(DEV), cond.to(DEV), sc.to(DEV))
+    assert torch.equal(got, want)
+    with torch.no_grad():
+        ref = O.unet_forward(gc.weights_for("wv3"), gc.cfg_for("wv3"), x, t, cond, sc)
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5
+    _fresh_plans(net)
+
+
+def test_capped_grid_sampler_matches_uncapped(net, grid_cap):
+    B, H, T = 6, 16, 8
+    cond = gc.tiles_for("wv3", B, H, H, seed=77)["cond"].to(DEV)
+    g = torch.Generator().manual_seed(78)
+    xT = torch.randn(B, 8, H, H, generator=g).to(DEV)
+    noise = torch.randn(T, B, 8, H, H, generator=g).to(DEV)
+    d = make_diffusion(net, 8, T, H, DEV)
+    _fresh_plans(net)
+    want = d(cond, mode="ddpm_sample", x_T=xT, noise=noise).clone()
+    grid_cap(5)
+    _fresh_plans(net)
+    got = d(cond, mode="ddpm_sample", x_T=xT, noise=noise)
+    assert torch.equal(got, want)
+    _fresh_plans(net)
+
+
+def test_mismatched_shapes_raise_instead_of_faulting(net):
+    from ddif import DdifError
+
+    x, t, cond, sc = _inputs(2, 16, 16, 5)
+    with pytest.raises(DdifError, match="cond"):
+        net(x.to(DEV), t.to(DEV), cond[:, :19].to(DEV).contiguous())
+    with pytest.raises(DdifError, match="x"):
+        net(x[:, :7].to(DEV).contiguous(), t.to(DEV), cond.to(DEV))
+    d = make_diffusion(net, 8, 10, 16, DEV)
+    with pytest.raises(DdifError, match="noise"):
+        d(cond.to(DEV), mode="ddpm_sample", x_T=x.to(DEV), noise=torch.zeros(3, 2, 8, 16, 16, device=DEV))
+
+
+def test_stale_plan_is_refused_after_recommit(net):
+    """A PlanHandle kept across a weight change points into the freed blob: the library must refuse it (DDIF_ERR_STATE)."""
+    from ddif import DdifError
+
+    x, t, cond, sc = _inputs(1, 16, 16, 6)
+    plan = net.plan_for(1, 16, 16, torch.device(DEV))
+    plan.set_cond(cond.to(DEV))
+    with torch.no_grad():
+        p = next(net.parameters())
+        p.add_(0.0)  # bumps the version counter -> next use reloads and re-commits the weights
+    net(x.to(DEV), t.to(DEV), cond.to(DEV))  # re-commit happens here, with a new plan
+    with pytest.raises(DdifError, match="re-committed"):
+        plan.forward(x.to(DEV), t, None)

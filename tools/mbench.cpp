@@ -6,14 +6,13 @@
 #include <cstdlib>
 #include "ddif_net.h"
 #include "kernels_conv.h"
-#include "kernels_conv_ws.h"
 using namespace ddif;
 typedef void (*ConvKernelFnT)(ConvArgs);
 namespace ddif { thread_local std::string g_err; int fail(int c, const char*, ...) { return c; } }
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int KS, int S, int U, int TH, int TW, int CKc, int WM, int WN, int MB, int NB, int PRO, int ABL, int EPI = 0, int MATH = 0, int WS = 0>
+template <int KS, int S, int U, int TH, int TW, int CKc, int WM, int WN, int MB, int NB, int PRO, int ABL, int EPI = 0, int MATH = 0>
 void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu) {
     const int Hout = S == 2 ? (H - 1) / 2 + 1 : (U ? 2 * H : H), Wout = S == 2 ? (W - 1) / 2 + 1 : (U ? 2 * W : W);
     const int n_chunks = (Cin + CKc - 1) / CKc, nb = (Cout + 31) / 32, nb_pad = (nb + 3) & ~3;
@@ -44,7 +43,6 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
     const long cap = 256L * wg_per_cu;
     dim3 grid((unsigned)(nwork < cap ? nwork : cap));
     ConvKernelFnT fn = conv_mfma_kernel<KS, S, U, TH, TW, CKc, WM, WN, MB, NB, PRO, 1, EPI, ABL, MATH>;
-    if constexpr (WS == 1) fn = conv3_ws_kernel<U, PRO, EPI, ABL>;
     const size_t smem = conv_smem_bytes<KS, S, U, TH, TW, CKc, NB * WN, PRO, WM * WN, MATH>() + conv_smem_extra(PRO, n_chunks, CKc, a.n_ct * NT);
     if (smem > 65536) CK_(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipEvent_t e0, e1; CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
@@ -67,11 +65,6 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
 
 int main(int argc, char** argv) {
     const int B = 64;
-    if (argc > 1 && argv[1][0] == 'w') {  // wave-specialised kernel: issue priority per role
-#define RUNW(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, ABLV, 0, 1, 1>("3x3 gn_silu 32->32 @64^2 WS", B, 64, 64, 32, 32, 1)
-        RUNW(0); RUNW(32); RUNW(64); RUNW(14); RUNW(46); RUNW(78);
-        return 0;
-    }
     if (argc > 1 && argv[1][0] == 'q') {  // the fused q conv (GN + depthwise 3x3 + 1x1): 4 vs 8 waves, f32 vs bf16x3
         run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0, 0, 0>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,4w) f32", B, 64, 64, 64, 64, 1);
         run<1, 1, 0, 8, 16, 32, 4, 1, 1, 2, PRO_GN_DW, 0, 0, 1>("1x1 gn_dw 64->64 @64^2 (8x16,NT64,4w) x3", B, 64, 64, 64, 64, 1);
@@ -95,19 +88,10 @@ int main(int argc, char** argv) {
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) f32", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 14, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
-        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1, 1>("3x3 gn_silu 32->32 @64^2 WS bf16x3", B, 64, 64, 32, 32, 1);
-        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 14, 0, 1, 1>("3x3 gn_silu 32->32 @64^2 WS bf16x3", B, 64, 64, 32, 32, 1);
-        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, EPI_RES, 1, 1>("3x3 gn_silu 64->64 @32^2 +res WS bf16x3", B, 32, 32, 64, 64, 1);
-        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0, 0, 1, 1>("3x3 64->64 @64^2 WS bf16x3", B, 64, 64, 64, 64, 1);
         run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (8x16,NT32,4w) bf16x3", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 64->64 @32^2 (16x16,NT32,8w) bf16x3", B, 32, 32, 64, 64, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_NONE, 0>("3x3 64->64 @64^2 (16x16,NT64,8w) f32", B, 64, 64, 64, 64, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0, 0, 1>("3x3 64->64 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 64, 64, 1);
-        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 2>("3x3 gn_silu 32->32 @64^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 64, 64, 32, 32, 2);
-        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 14, 0, 2>("3x3 gn_silu 32->32 @64^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 64, 64, 32, 32, 2);
-        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 2>("3x3 gn_silu 64->64 @32^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 32, 32, 64, 64, 2);
-        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0, 0, 2>("3x3 64->64 @64^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 64, 64, 64, 64, 2);
-        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 2>("3x3 gn_silu 64->64 @16^2 (8x16,NT32,4w) bf16x3 WSB 2wg", B, 16, 16, 64, 64, 2);
         run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 64->64 @16^2 (8x16,NT32,4w) bf16x3", B, 16, 16, 64, 64, 1);
         run<3, 1, 0, 8, 8, 16, 2, 2, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 128->128 @8^2 (8x8,NT64,4w) bf16x3", B, 8, 8, 128, 128, 1);
         return 0;
