@@ -1,0 +1,50 @@
+// Instantiations of the low-resolution conv kernel (kernels_lr.h) -- a translation unit of its own so that it builds
+// in parallel with the main conv kernel family (ddif_plan.cpp).
+#include "ddif_plan.h"
+#include "kernels_lr.h"
+
+namespace ddif {
+
+namespace {
+template <int KS, int MB, int PRO, int EPI>
+ConvVariant lr_variant(const char* name) {
+    ConvVariant v;
+    v.fn = conv_lr_kernel<KS, MB, PRO, EPI>;
+    v.smem = LrGeom<KS, MB, PRO>::smem;
+    v.th = LrGeom<KS, MB, PRO>::TH;
+    v.tw = LrGeom<KS, MB, PRO>::TW;
+    v.nt = 32;
+    v.nthr = 256;
+    v.x3 = true;
+    v.lr = true;
+    v.name = name;
+    return v;
+}
+template <int MB>
+ConvVariant lr_for(int ks, int pro, int epi) {
+    if (ks == 3) {
+        if (pro == PRO_GN_SILU && epi == 0) return lr_variant<3, MB, PRO_GN_SILU, 0>("lr3x3_gn_silu");
+        if (pro == PRO_GN_SILU && epi == EPI_RES) return lr_variant<3, MB, PRO_GN_SILU, EPI_RES>("lr3x3_gn_silu_res");
+        if (pro == PRO_NONE && epi == EPI_SILU) return lr_variant<3, MB, PRO_NONE, EPI_SILU>("lr3x3_silu");
+        if (pro == PRO_NONE && epi == 0) return lr_variant<3, MB, PRO_NONE, 0>("lr3x3");
+    } else if (ks == 1) {
+        if (pro == PRO_NONE && epi == EPI_FILM) return lr_variant<1, MB, PRO_NONE, EPI_FILM>("lr1x1_film");
+        if (pro == PRO_NONE && epi == EPI_RES) return lr_variant<1, MB, PRO_NONE, EPI_RES>("lr1x1_res");
+        if (pro == PRO_NONE && epi == 0) return lr_variant<1, MB, PRO_NONE, 0>("lr1x1");
+        if (pro == PRO_GN && epi == 0) return lr_variant<1, MB, PRO_GN, 0>("lr1x1_gn");
+        if (pro == PRO_GN_SILU && epi == 0) return lr_variant<1, MB, PRO_GN_SILU, 0>("lr1x1_gn_silu");
+        if (pro == PRO_COLSM && epi == 0) return lr_variant<1, MB, PRO_COLSM, 0>("lr1x1_colsoftmax");
+        if (pro == PRO_GN_DW && epi == 0) return lr_variant<1, MB, PRO_GN_DW, 0>("lr1x1_gn_dw3x3");
+    }
+    return ConvVariant();
+}
+}  // namespace
+
+// mb = 2: 8x8 pixel tiles, mb = 4: 8x16.  The per-sample time bias needs no variant of its own here (the epilogue reads
+// bias and time-bias rows straight from memory), so EPI_TBS is accepted and ignored.
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi) {
+    epi &= ~EPI_TBS;
+    return mb == 2 ? lr_for<2>(ks, pro, epi) : lr_for<4>(ks, pro, epi);
+}
+
+}  // namespace ddif

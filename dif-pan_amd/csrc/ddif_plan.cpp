@@ -70,6 +70,7 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 // Only the combinations the network uses are instantiated.
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi) {
     ConvVariant v;
+    if (cfg == 20 || cfg == 21) return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi) : v;
     const bool plain = stride == 1 && !ups;
     if (epi == EPI_FILM) {
         if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
@@ -115,9 +116,18 @@ static int x3_enabled() {  // DDIF_X3=0: the exact-fp32 MFMA instantiation every
     static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();
     return x3;
 }
-static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B) {
+static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) as well; covered by tests/test_env_switches.py
+    static const int lr = [] { const char* e = getenv("DDIF_LR"); return e ? atoi(e) : 1; }();
+    return lr;
+}
+// cfg 20 / 21: the low-resolution kernel (kernels_lr.h) with 8x8 / 8x16 pixel tiles -- samples of <= 256 pixels whose
+// channel counts fit its 16-channel slabs
+static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B, int cin, int c0, bool allow_lr = true) {
     const bool wide = (Wout >= 16) && stride == 1;
     (void)pro;
+    if (allow_lr && x3_enabled() && lr_enabled() && vec == 1 && stride == 1 && !ups_ && Hout * Wout <= 256 && Cout % 4 == 0 && cin % 16 == 0 && c0 % 16 == 0 &&
+        ck == (ks == 3 ? 16 : 32))
+        return (Hout <= 8 && Wout <= 8) ? 20 : 21;
     if (ks == 1 && vec == 1) {
         const int base = wide ? (Cout > 64 ? 3 : (Cout > 32 ? 1 : 0)) : (Cout > 64 ? 4 : 2);
         // 32-cout tiles stay on the exact instruction: with 12 MFMAs per stage the split only adds staging work
@@ -208,9 +218,13 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 != 0 || c1 % 4 != 0) ? 0 : ((c1 == 0 || c0 % pc.ck == 0) ? 1 : 2);
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
-    const int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B);
+    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0);
     ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    if (!var.fn && cfg >= 20) {  // prologue / epilogue combination the low-resolution kernel does not carry
+        cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false);
+        var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    }
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
@@ -259,7 +273,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     // persistent launch: a few workgroups per CU, each walking a contiguous range of (cout tile, pixel tile) items
     const long nwork = (long)B * a.tiles_x * a.tiles_y * gy;
     const int gy0 = (pc.cout + var.nt - 1) / var.nt;
-    const size_t smem = var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
+    const size_t smem = var.lr ? var.smem : var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
     long cap = (long)num_cus() * wg_per_cu(smem);
     if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
     const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
@@ -654,7 +668,7 @@ int Plan::build() {
             // cond-only: M_b = scale * W_out . blockdiag(ctx_b^T), packed per sample next to W_res
             const int nb_pad = (((pmix->cout + 31) / 32) + 3) & ~3;
             // the layout follows the instantiation add_conv() will pick for this conv (bf16x3 planes or fp32 fragments)
-            const bool mix_x3 = pick_cfg(1, pmix->ck, PRO_COLSM, 1, 1, 0, Hl, Wl, pmix->cout, B) >= 12;
+            const bool mix_x3 = pick_cfg(1, pmix->ck, PRO_COLSM, 1, 1, 0, Hl, Wl, pmix->cout, B, pmix->cin, pmix->cin == 2 * fea ? fea : pmix->cin) >= 12;
             const size_t per = mix_x3 ? (size_t)nb_pad * pmix->n_chunks * (pmix->ck / 16) * 3 * 256 : (size_t)nb_pad * pmix->n_chunks * (pmix->ck / 8) * 256;
             float* wmix = nullptr;
             DDIF_TRY(dalloc(&wmix, per * B));

@@ -37,9 +37,11 @@ struct ConvVariant {
     size_t smem = 0;
     int th = 0, tw = 0, nt = 0, nthr = 256;
     bool x3 = false;  // bf16x3 instantiation: wants PackedConv::w_x3
+    bool lr = false;  // low-resolution kernel (kernels_lr.h): smem is the whole requirement, nothing is added per launch
     const char* name = "";
 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi);
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi);  // ddif_lr.cpp
 
 struct ConvSpec {
     const PackedConv* pc = nullptr;

@@ -1,9 +1,12 @@
-"""The two build-time-independent switches libddif reads from the environment, each run against the reference goldens
+"""The three build-time-independent switches libddif reads from the environment, each run against the reference goldens
 (-m gpu).  The library reads them once per process, so every case runs a slice of the parity suite in a child process:
 
   DDIF_X3=0     every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) instead of the bf16x3
                 split products -- INTEGRATION.md advertises it as the "bitwise-fmaf build";
-  DDIF_GRAPH=0  the sampler loop as plain stream launches instead of hipGraph replay of step pairs.
+  DDIF_GRAPH=0  the sampler loop as plain stream launches instead of hipGraph replay of step pairs;
+  DDIF_LR=0     the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) instead of the low-resolution
+                split-K kernel (kernels_lr.h) -- the golden cases at 16x16 / 32x32 otherwise run almost entirely on the
+                latter, so this is what keeps the general kernel's small-tile instantiations covered.
 
 All other A/B switches of round 1 (wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides) were
 deleted together with their code."""
@@ -21,8 +24,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
          "or test_forward_matches_oracle_other_sizes and 8x8")
 
 
-@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0"])
+@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
@@ -33,10 +36,11 @@ def test_parity_slice_under_switch(env):
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
 
 
-def test_multi_item_path_under_exact_fp32():
-    """The capped-grid / batch tests once more with DDIF_X3=0 (other kernel instantiations, other tile shapes)."""
+@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_LR": "0"}], ids=["X3=0", "LR=0"])
+def test_multi_item_path_under_switch(env):
+    """The capped-grid tests once more with DDIF_X3=0 / DDIF_LR=0 (other kernel instantiations, other tile shapes)."""
     e = dict(os.environ)
-    e["DDIF_X3"] = "0"
+    e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_batch64.py"), "-m", "gpu", "-x", "-q",
                         "-k", "capped_grid", "-p", "no:cacheprovider"], env=e, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-3000:]
