@@ -34,7 +34,6 @@ ConvVariant lr_for(int ks, int pro, int epi) {
         if (pro == PRO_GN && epi == 0) return lr_variant<1, MB, PRO_GN, 0>("lr1x1_gn");
         if (pro == PRO_GN_SILU && epi == 0) return lr_variant<1, MB, PRO_GN_SILU, 0>("lr1x1_gn_silu");
         if (pro == PRO_COLSM && epi == 0) return lr_variant<1, MB, PRO_COLSM, 0>("lr1x1_colsoftmax");
-        if (pro == PRO_GN_DW && epi == 0) return lr_variant<1, MB, PRO_GN_DW, 0>("lr1x1_gn_dw3x3");
     }
     return ConvVariant();
 }

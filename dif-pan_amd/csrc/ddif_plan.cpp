@@ -634,7 +634,51 @@ int Plan::build() {
         if (!pn_g || !pn_b || !q0w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
         if (pq1->ck != 32 || cur.C % 4 != 0 || skip.C % 4 != 0 || fea > 256)
             return fail(DDIF_ERR_INVALID, "%s: the fused q = 1x1(dw3x3(GN(cat))) kernel needs 4 | channels and <= 256 of them (got %d+%d)", ci.c_str(), cur.C, skip.C);
-        {
+        if (pick_cfg(1, 32, PRO_NONE, 1, 1, 0, Hl, Wl, pq1->cout, B, fea, fea) >= 20) {
+            // low-resolution levels: xn = GN(cat), dwq = depthwise3x3(xn) from ONE small kernel (whole sample per workgroup),
+            // then q = q.1(dwq) on the split-K kernel -- fused into the 1x1 conv the depthwise pass would be recomputed by
+            // every 32-cout tile (sr3_dwt.py:507-513,537,540)
+            Tensor dwq;
+            DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl));
+            DwArgs a{};
+            a.in0 = cur.p;
+            a.c0 = cur.C;
+            a.in1 = skip.p;
+            a.c1 = skip.C;
+            a.B = B;
+            a.H = Hl;
+            a.W = Wl;
+            a.st0 = cur.st;
+            a.np0 = cur.np;
+            a.st1 = skip.st;
+            a.np1 = skip.np;
+            a.gamma = pn_g;
+            a.beta = pn_b;
+            a.w = q0w;
+            a.out_dw = dwq.p;
+            a.out_xn = xn.p;
+            a.use_gn = 1;
+            Op op;
+            op.name = "q.gn_dw3x3";
+            {
+                char lb[160];
+                snprintf(lb, sizeof lb, "q.gn_dw3x3 %d+%d @%dx%d", cur.C, skip.C, Hl, Wl);
+                op.label = lb;
+            }
+            op.flop = 2.0 * 9 * B * Hl * Wl * fea;
+            op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
+            const size_t sm = (size_t)(Hl + 2) * (Wl + 2) * 36 * sizeof(float);
+            if (sm > 64 * 1024) DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_dw3x3_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+            op.run = [a, BB, fea, sm](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL(gn_dw3x3_small_kernel, dim3((fea + 31) / 32, BB), dim3(256), sm, s, a);
+            };
+            step.push_back(std::move(op));
+            ConvSpec s;
+            s.pc = pq1;
+            s.in0 = dwq;
+            s.name = "q.1x1";
+            DDIF_TRY(add_conv(step, s, &q));
+        } else {
             // q = q.1(depthwise3x3(GroupNorm(cat[h, skip]))) in ONE kernel; also emits xn (sr3_dwt.py:507-513,537,540)
             ConvSpec s;
             s.pc = pq1;

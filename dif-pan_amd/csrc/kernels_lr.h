@@ -13,9 +13,17 @@
 //   accumulator blocks of 32 pixels x 32 couts).  Consequences:
 //     * weights are not shared between waves, so they never touch LDS: each wave reads its own B-fragment stream
 //       (pre-packed per-lane order, 1 KiB per (tap, plane), perfectly coalesced) straight from L2 into the MFMA operand
-//       registers through a small register ring that runs 1-3 steps ahead (counted vmcnt, in-order retirement);
+//       registers.  The ring holds one slab of a 3x3 conv (9 taps x 3 planes = 108 VGPRs) and is filled BEFORE the
+//       activation tile is staged, so the weight stream's L2 latency hides behind the staging; each slot is refilled
+//       with the step 9 ahead (1.4 us of MFMAs) as soon as its own MFMAs have issued (counted vmcnt, in-order
+//       retirement).  A 3-step ring measured 19.8 us per 128->128 conv at 8x8 with 3 us of matrix work (six exposed L2
+//       round trips); a whole-phase ring (216 VGPRs) spills;
+//     * every other load of a work item (GroupNorm partials, bias / time-bias / residual / FiLM operands of the epilogue,
+//       the first phase's activation tile) is issued in the same burst, before anything is waited on: one memory
+//       latency per work item instead of four; the next phase's tile is fetched before the current phase's MFMAs;
 //     * the activation tile (whole sample at 8x8) is staged ONCE per <=128-channel phase with the producer-side
-//       GroupNorm / SiLU / column-softmax / depthwise prologue applied, as three bf16 planes;
+//       GroupNorm / SiLU / column-softmax prologue applied, as three bf16 planes (the depthwise branch of the q conv is
+//       a kernel of its own at these levels, gn_dw3x3_small_kernel: fused here it would be recomputed by every cout tile);
 //     * the four K-partials meet in LDS (fixed order: (w0 + w1) + (w2 + w3)) and wave g runs the epilogue of accumulator
 //       quad g (bias + time bias, FiLM, SiLU, residual, float4 NHWC stores, GroupNorm partial of the output).
 //   Arithmetic is the bf16x3 scheme of kernels_conv.h (operands split hi/mid/lo, six exact bf16 products per fp32
@@ -28,43 +36,36 @@ namespace ddif {
 template <int KS, int MB, int PRO>
 struct LrGeom {
     static constexpr int TH = 8, TW = MB == 2 ? 8 : 16;
-    static constexpr bool DWM = PRO == PRO_GN_DW;
-    static constexpr int PAD = KS / 2, LP = DWM ? 1 : PAD;
-    static constexpr int LH = TH + 2 * LP, LW = TW + 2 * LP;   // loaded tile (halo of the 3x3 / depthwise taps)
-    static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD; // tile the MFMAs read
-    static constexpr int PC = (MB == 4 && (KS == 3 || DWM)) ? 64 : 128;  // channels staged per phase
+    static constexpr int PAD = KS / 2;
+    static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD; // staged tile (halo of the 3x3 taps)
+    static constexpr int PC = (MB == 4 && KS == 3) ? 64 : 128; // channels staged per phase
     static constexpr int SP = PC / 16;                         // 16-channel slabs per phase
     static constexpr int APIX = SP * 24 + 4;                   // floats per staged pixel: SP x (3 planes x 32 B) + 16 B pad
-    static constexpr int HPIX = PC + 4;                        // DWM: floats per pixel of the fp32 scratch tile
     static constexpr int AFL = IH * IW * APIX;
     static constexpr int RFL = 4 * MB * 4 * 64 * 4;            // K-partials: [wave][mb][quad g][lane] float4
-    static constexpr int HFL = DWM ? LH * LW * HPIX : 0;
-    static constexpr size_t smem = (size_t)((AFL > RFL ? AFL : RFL) + HFL + 16) * sizeof(float);
+    static constexpr size_t smem = (size_t)((AFL > RFL ? AFL : RFL) + 16) * sizeof(float);
     static constexpr int SPW = SP / 4;                         // slabs per wave and phase
     static constexpr int TAPS = KS * KS;
-    static constexpr int U = (SPW * TAPS) % 3 == 0 ? 3 : ((SPW * TAPS) % 2 == 0 ? 2 : 1);  // weight ring depth (steps)
+    static constexpr int U = KS == 3 ? TAPS : SPW;             // weight ring (steps): one slab of a 3x3 conv (9 taps), one phase of a 1x1
 };
 
 template <int KS, int MB, int PRO, int EPI>
 __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     using G = LrGeom<KS, MB, PRO>;
-    constexpr int TH = G::TH, TW = G::TW, LP = G::LP, LH = G::LH, LW = G::LW, IW = G::IW, PC = G::PC, SP = G::SP;
-    constexpr int APIX = G::APIX, HPIX = G::HPIX, TAPS = G::TAPS, U = G::U, SPW = G::SPW;
-    constexpr bool DWM = G::DWM;
-    constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW);
+    constexpr int TH = G::TH, TW = G::TW, LP = G::PAD, LH = G::IH, LW = G::IW, IW = G::IW, PC = G::PC, SP = G::SP;
+    constexpr int APIX = G::APIX, TAPS = G::TAPS, U = G::U, SPW = G::SPW;
+    constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU);
+    static_assert(PRO == PRO_NONE || PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_COLSM, "prologues of the low-resolution kernel");
     constexpr bool FILM = (EPI & EPI_FILM) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0;
     constexpr int C4 = PC / 4;                          // float4 channel groups per staged pixel
     constexpr int PSTEP = 256 / C4;                     // pixels covered by one pass of the 256 threads
     constexpr int NIT = (LH * LW + PSTEP - 1) / PSTEP;  // staging items per thread and phase
-    constexpr int DIT = (TH * TW) / PSTEP;              // depthwise output items per thread and phase
-    static_assert(256 % C4 == 0 && (TH * TW) % PSTEP == 0, "staging geometry");
-    static_assert((SPW * TAPS) % U == 0, "weight ring depth must divide the steps of a phase");
+    static_assert(256 % C4 == 0, "staging geometry");
 
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);
     float* Red = As;  // reused after the last phase (barrier in between)
-    float* Hs = As + (G::AFL > G::RFL ? G::AFL : G::RFL);
-    float* Sst = Hs + G::HFL;  // [4 waves][2] statistics partials
+    float* Sst = As + (G::AFL > G::RFL ? G::AFL : G::RFL);  // [4 waves][2] statistics partials
 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef DDIF_EMU
@@ -78,12 +79,8 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     const int w0 = (int)((long long)blockIdx.x * nwork / gridDim.x);
     const int w1 = (int)((long long)(blockIdx.x + 1) * nwork / gridDim.x);
     const int Ctot = a.c0 + a.c1;
-    // K extent in 16-channel slabs, rounded up so that every wave runs whole groups of U steps in every phase (1x1 convs
-    // with a 2-step ring: a multiple of 8).  Slabs past the data stage ZERO activations; their weight reads are clamped to
-    // a real slab (finite x 0), so the padding only costs the few MFMAs of a ragged tail.
-    constexpr int SQ = 4 * (TAPS == 1 ? U : 1);
-    const int NS = (((Ctot + 15) / 16) + SQ - 1) / SQ * SQ;
-    const int NSW = a.n_chunks * (KS == 3 ? 1 : 2);  // slabs in the packed weights
+    const int NS = (Ctot + 15) / 16;                 // 16-channel slabs (channels past the end of the last one stage zeros)
+    const int NSW = a.n_chunks * (KS == 3 ? 1 : 2);  // slabs in the packed weights (>= NS)
     const int NP = (NS + SP - 1) / SP;               // phases
     const int c4 = tid % C4, p0 = tid / C4;
     const float* tbrow = a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0);
@@ -103,181 +100,13 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
         const int pt = work / a.n_ct, ct = work - pt * a.n_ct;  // cout tile fastest: neighbours re-read the same input from L2
         const int b = pt / tiles, t = pt - b * tiles;
         const int oy0 = (t / a.tiles_x) * TH, ox0 = (t % a.tiles_x) * TW;
-        if (GNP && b != gn_b) {  // workgroup-uniform; every wavefront reduces the producer's partials itself
-            gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
-            gn_b = b;
-        }
-        // ---- weight stream of this wave: slabs wave, wave+4, ... ; steps = (slab, tap); ring of U steps in registers
-        const char* wbase = reinterpret_cast<const char*>(a.w + (size_t)b * a.w_bstride) + ((size_t)ct * NSW * TAPS) * 3072 + (size_t)lane * 16;
-        const int nslab_w = NS > wave ? (NS - wave + 3) / 4 : 0;
-        const int nstep_w = nslab_w * TAPS;
-        int pf_slab = wave, pf_tap = 0, pf_n = 0;  // prefetch cursor
-        float4 wr[U][3];
-        auto ring_load = [&](int slot) {
-            // past the end the cursor re-reads the last real step (never consumed): a constant number of loads in flight
-            const int se = pf_n < nstep_w ? pf_slab : wave;
-            const int s = se < NSW ? se : 0;
-            const int tp = pf_n < nstep_w ? pf_tap : 0;
-            const char* p = wbase + ((size_t)s * TAPS + tp) * 3072;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) wr[slot][q] = *reinterpret_cast<const float4*>(p + q * 1024);
-            ++pf_n;
-            if (++pf_tap == TAPS) {
-                pf_tap = 0;
-                pf_slab += 4;
-            }
-        };
-#pragma unroll
-        for (int u = 0; u < U; ++u) ring_load(u);
 
-        f32x16 acc[MB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+        // ================= (1) every load of the work item that does not depend on another one, in one burst ==========
+        [[maybe_unused]] GnPartials gp;
+        const bool new_b = GNP && b != gn_b;  // workgroup-uniform
+        if (new_b) gn_load_partials(a.st0, a.np0, a.st1, a.np1, b, &gp);
 
-        int cs_slab = wave;  // consume cursor (slab of the next step to run)
-        for (int ph = 0; ph < NP; ++ph) {
-            const int cb = ph * PC;
-            // ---- stage PC channels of the (haloed) tile: loads first, then prologue + LDS writes
-            const int c = cb + c4 * 4;            // first of this thread's 4 channels
-            const bool cok = c < Ctot;            // channels past the end stage zeros
-            const bool s0 = !cok || c < a.c0;    // (padding channels read source 0, channel 0: always valid)
-            const float* src = s0 ? a.in0 + (cok ? c : 0) : a.in1 + (c - a.c0);
-            const int cs = s0 ? a.c0 : a.c1;
-            float4 sv[NIT];
-            [[maybe_unused]] float4 mxv[PRO == PRO_COLSM ? NIT : 1], smv[PRO == PRO_COLSM ? NIT : 1];
-            unsigned okm = 0;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int pix = p0 + it * PSTEP;
-                const int py = pix / LW, px = pix - py * LW;
-                const int iy = oy0 - LP + py, ix = ox0 - LP + px;
-                const bool ok = (pix < LH * LW) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win) & cok;
-                okm |= (ok ? 1u : 0u) << it;
-                const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
-                const size_t sp = ((size_t)b * a.Hin + iyc) * a.Win + ixc;
-                sv[it] = *reinterpret_cast<const float4*>(src + sp * cs);
-                if constexpr (PRO == PRO_COLSM) {
-                    const size_t so = ((size_t)b * a.Win + ixc) * a.c0 + ((s0 && cok) ? c : 0);
-                    mxv[it] = *reinterpret_cast<const float4*>(a.cs_mx + so);
-                    smv[it] = *reinterpret_cast<const float4*>(a.cs_sm + so);
-                }
-            }
-            float ga[4] = {1.f, 1.f, 1.f, 1.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (GNP) {
-                const float4 gq = *reinterpret_cast<const float4*>(a.gamma + (cok ? c : 0));
-                const float4 bq = *reinterpret_cast<const float4*>(a.beta + (cok ? c : 0));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ga[i] = (&gq.x)[i] * rstd;
-                    gb[i] = (&bq.x)[i] - mean * ga[i];
-                }
-            }
-            [[maybe_unused]] float4 dwv[DWM ? 9 : 1];
-            if constexpr (DWM) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) dwv[k] = *reinterpret_cast<const float4*>(a.dw_w + (size_t)k * Ctot + (cok ? c : 0));
-            }
-            if (ph > 0) __syncthreads();  // every wave is done reading the previous phase's tile
-            const bool colsm = (PRO == PRO_COLSM) && s0 && cok;
-            const int slab_l = (c4 * 4) / 16, cin_slab = (c4 * 4) % 16;  // slab within the phase, channel within the slab
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int pix = p0 + it * PSTEP;
-                const bool ok = (okm >> it) & 1u;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x = (&sv[it].x)[i];
-                    if constexpr (GNP) {
-                        x = fmaf(x, ga[i], gb[i]);
-                        if constexpr (PRO == PRO_GN_SILU) x = dd_silu(x);
-                    }
-                    if constexpr (PRO == PRO_COLSM) {
-                        if (colsm) x = dd_exp2_fast((x - (&mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&smv[it].x)[i]);
-                    }
-                    v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation (and channels past the end are zero)
-                }
-                if (pix < LH * LW) {
-                    if constexpr (DWM) {
-                        *reinterpret_cast<float4*>(&Hs[pix * HPIX + c4 * 4]) = make_float4(v[0], v[1], v[2], v[3]);
-                        const int py = pix / LW, px = pix - py * LW;
-                        // centre pixels inside the image: this IS xn = GroupNorm(cat[h, skip]) (attn_res input); one cout tile writes it
-                        if (a.out_xn && ok && ct == 0 && py >= 1 && py <= TH && px >= 1 && px <= TW)
-                            *reinterpret_cast<float4*>(a.out_xn + (((size_t)b * a.Hin + oy0 + py - 1) * a.Win + ox0 + px - 1) * Ctot + c) =
-                                make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        unsigned h01, m01, l01, h23, m23, l23;
-                        dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
-                        dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
-                        float* d = &As[pix * APIX + slab_l * 24 + cin_slab / 2];
-                        *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
-                        *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
-                        *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
-                    }
-                }
-            }
-            if constexpr (DWM) {
-                __syncthreads();  // normalised halo tile complete in Hs
-#pragma unroll
-                for (int it = 0; it < DIT; ++it) {
-                    const int m = p0 + it * PSTEP;
-                    const int ty = m / TW, tx = m - ty * TW;
-                    float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const float4 hv = *reinterpret_cast<const float4*>(&Hs[((ty + k / 3) * LW + tx + k % 3) * HPIX + c4 * 4]);
-                        s[0] = fmaf(hv.x, dwv[k].x, s[0]);
-                        s[1] = fmaf(hv.y, dwv[k].y, s[1]);
-                        s[2] = fmaf(hv.z, dwv[k].z, s[2]);
-                        s[3] = fmaf(hv.w, dwv[k].w, s[3]);
-                    }
-                    if (!cok) s[0] = s[1] = s[2] = s[3] = 0.f;
-                    unsigned h01, m01, l01, h23, m23, l23;
-                    dd_split3_pair(s[0], s[1], &h01, &m01, &l01);
-                    dd_split3_pair(s[2], s[3], &h23, &m23, &l23);
-                    float* d = &As[m * APIX + slab_l * 24 + cin_slab / 2];
-                    *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
-                    *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
-                    *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
-                }
-            }
-            __syncthreads();
-            // ---- this wave's K steps of the phase: slabs cb/16 + wave, + 4, ...
-            const int s_end = (ph + 1) * SP < NS ? (ph + 1) * SP : NS;
-            const int ngrp = cs_slab < s_end ? ((s_end - cs_slab + 3) / 4) * TAPS / U : 0;
-            int st_tap = 0;
-            for (int gI = 0; gI < ngrp; ++gI) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int sl = cs_slab - ph * SP;  // slab within the phase
-                    const int aoff = ((st_tap / KS) * IW + (st_tap % KS)) * APIX + sl * 24;
-                    float4 xa[MB][3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[abase[mb] + aoff + q * 8]);
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        f32x16 cacc = acc[mb];
-                        cacc = DDIF_MFMA_32x32x16_BF16(wr[u][2], xa[mb][0], cacc);  // lo * hi
-                        cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][2], cacc);  // hi * lo
-                        cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][1], cacc);  // mid * mid
-                        cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][0], cacc);  // mid * hi
-                        cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][1], cacc);  // hi * mid
-                        cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][0], cacc);  // hi * hi
-                        acc[mb] = cacc;
-                    }
-                    ring_load(u);  // refill the slot just consumed with the step U ahead
-                    if (++st_tap == TAPS) {
-                        st_tap = 0;
-                        cs_slab += 4;
-                    }
-                }
-            }
-        }
-        // ---- epilogue operands of this wave's quad g = wave: couts ct*32 + 8*wave + 4h .. +3 of pixel (mb, j)
+        // epilogue operands of this wave's quad g = wave: couts ct*32 + 8*wave + 4h .. +3 of pixel (mb, j)
         const int co = ct * 32 + 8 * wave + 4 * h;
         const bool cok_o = co < a.Cout;  // Cout is a multiple of 4
         const int coc = cok_o ? co : 0;
@@ -296,6 +125,149 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             if constexpr (FILM) {
                 e_fs[mb] = *reinterpret_cast<const float4*>(a.film + opix[mb] * 2 * a.Cout + coc);
                 e_fh[mb] = *reinterpret_cast<const float4*>(a.film + opix[mb] * 2 * a.Cout + a.Cout + coc);
+            }
+        }
+
+        // weight stream of this wave: slabs wave, wave+4, ... ; steps = (slab, tap) in order; ring slot = step within the phase
+        const char* wbase = reinterpret_cast<const char*>(a.w + (size_t)b * a.w_bstride) + ((size_t)ct * NSW * TAPS) * 3072 + (size_t)lane * 16;
+        int pf_slab = wave, pf_tap = 0;  // prefetch cursor
+        float4 wr[U][3];
+        auto ring_load = [&](int slot) {
+            const int s = pf_slab < NS ? pf_slab : 0;  // (the initial fill of a wave without slabs re-reads slab 0; never consumed)
+            const char* p = wbase + ((size_t)s * TAPS + pf_tap) * 3072;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wr[slot][q] = *reinterpret_cast<const float4*>(p + q * 1024);
+            if (++pf_tap == TAPS) {
+                pf_tap = 0;
+                pf_slab += 4;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) ring_load(u);
+
+        // activation tile of one phase: loads (stage_load) and prologue + LDS writes (stage_write) are separate so that the
+        // next phase's loads fly during the current phase's MFMAs
+        float4 sv[NIT];
+        [[maybe_unused]] float4 mxv[PRO == PRO_COLSM ? NIT : 1], smv[PRO == PRO_COLSM ? NIT : 1];
+        [[maybe_unused]] float4 gq4, bq4;
+        unsigned okm = 0;
+        auto stage_load = [&](int ph) {
+            const int c = ph * PC + c4 * 4;      // first of this thread's 4 channels
+            const bool cok = c < Ctot;           // channels past the end stage zeros
+            const bool s0 = !cok || c < a.c0;    // (padding channels read source 0, channel 0: always valid)
+            const float* src = s0 ? a.in0 + (cok ? c : 0) : a.in1 + (c - a.c0);
+            const int cs = s0 ? a.c0 : a.c1;
+            okm = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = p0 + it * PSTEP;
+                const int py = pix / LW, px = pix - py * LW;
+                const int iy = oy0 - LP + py, ix = ox0 - LP + px;
+                const bool ok = (pix < LH * LW) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win) & cok;
+                okm |= (ok ? 1u : 0u) << it;
+                const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
+                const size_t sp = ((size_t)b * a.Hin + iyc) * a.Win + ixc;
+                sv[it] = *reinterpret_cast<const float4*>(src + sp * cs);
+                if constexpr (PRO == PRO_COLSM) {
+                    const size_t so = ((size_t)b * a.Win + ixc) * a.c0 + ((s0 && cok) ? c : 0);
+                    mxv[it] = *reinterpret_cast<const float4*>(a.cs_mx + so);
+                    smv[it] = *reinterpret_cast<const float4*>(a.cs_sm + so);
+                }
+            }
+            if constexpr (GNP) {
+                gq4 = *reinterpret_cast<const float4*>(a.gamma + (cok ? c : 0));
+                bq4 = *reinterpret_cast<const float4*>(a.beta + (cok ? c : 0));
+            }
+        };
+        auto stage_write = [&](int ph) {
+            const int c = ph * PC + c4 * 4;
+            const bool cok = c < Ctot;
+            const bool colsm = (PRO == PRO_COLSM) && cok && c < a.c0;
+            const int slab_l = (c4 * 4) / 16, cin_slab = (c4 * 4) % 16;  // slab within the phase, channel within the slab
+            float ga[4] = {1.f, 1.f, 1.f, 1.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (GNP) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ga[i] = (&gq4.x)[i] * rstd;
+                    gb[i] = (&bq4.x)[i] - mean * ga[i];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = p0 + it * PSTEP;
+                const bool ok = (okm >> it) & 1u;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = (&sv[it].x)[i];
+                    if constexpr (GNP) {
+                        x = fmaf(x, ga[i], gb[i]);
+                        if constexpr (PRO == PRO_GN_SILU) x = dd_silu(x);
+                    }
+                    if constexpr (PRO == PRO_COLSM) {
+                        if (colsm) x = dd_exp2_fast((x - (&mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&smv[it].x)[i]);
+                    }
+                    v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation (and channels past the end are zero)
+                }
+                if (pix < LH * LW) {
+                    unsigned h01, m01, l01, h23, m23, l23;
+                    dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
+                    dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
+                    float* d = &As[pix * APIX + slab_l * 24 + cin_slab / 2];
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
+                    *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
+                }
+            }
+        };
+        stage_load(0);
+
+        // ================= (2) first uses =================
+        if (new_b) {  // every wavefront reduces the producer's partials itself (no barrier)
+            gn_reduce_partials(gp, a.st0, a.np0, a.st1, a.np1, b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
+            gn_b = b;
+        }
+        f32x16 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+        for (int ph = 0; ph < NP; ++ph) {
+            if (ph > 0) __syncthreads();  // every wave is done reading the previous phase's tile
+            stage_write(ph);
+            if (ph + 1 < NP) stage_load(ph + 1);  // in flight during this phase's MFMAs
+            __syncthreads();
+            // ---- this wave's K steps of the phase: slabs ph*SP + wave, + 4, ... (ring slot = tap for 3x3, slab-in-phase for 1x1)
+            const int s_end = (ph + 1) * SP < NS ? (ph + 1) * SP : NS;
+#pragma unroll
+            for (int k = 0; k < SPW; ++k) {
+                const int sl = wave + 4 * k;  // slab within the phase
+                if (ph * SP + sl < s_end) {   // wave-uniform; only the last phase can be ragged
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        constexpr int UU = U;
+                        const int u = (k * TAPS + tap) % UU;
+                        const int aoff = ((tap / KS) * IW + (tap % KS)) * APIX + sl * 24;
+                        float4 xa[MB][3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[abase[mb] + aoff + q * 8]);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            f32x16 cacc = acc[mb];
+                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][2], xa[mb][0], cacc);  // lo * hi
+                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][2], cacc);  // hi * lo
+                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][1], cacc);  // mid * mid
+                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][0], cacc);  // mid * hi
+                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][1], cacc);  // hi * mid
+                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][0], cacc);  // hi * hi
+                            acc[mb] = cacc;
+                        }
+                        if (pf_slab < NS) ring_load(u);  // the step U ahead of this one (wave-uniform branch)
+                    }
+                }
             }
         }
         __syncthreads();  // the activation tile is dead: its LDS becomes the K-partial exchange

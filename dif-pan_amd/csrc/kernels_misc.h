@@ -91,6 +91,82 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// The same op for samples of <= 256 pixels (the 8x8 / 16x16 levels): one workgroup per (32-channel chunk, sample) holds
+// the WHOLE normalised image of its chunk (+ zero border) in LDS, float4 channel groups, one pass.  Emits dw3x3(xn) and
+// xn = GroupNorm(cat[in0, in1]); channel counts are multiples of 4.
+__global__ __launch_bounds__(256) void gn_dw3x3_small_kernel(DwArgs a) {
+    constexpr int CK = 32, HP = CK + 4;  // floats per staged pixel (16 B pad: conflict-free float4 rows)
+    DDIF_DYN_SMEM(smem);
+    float* Hs = reinterpret_cast<float*>(smem);  // [(H+2)*(W+2)][HP]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, cb = blockIdx.x * CK;
+    const int C = a.c0 + a.c1, IW = a.W + 2, n = a.H * a.W, nh = (a.H + 2) * IW;
+    const int c4 = tid & 7, c = cb + c4 * 4;
+    const bool cok = c < C;
+    const bool s0 = !cok || c < a.c0;
+    const float* src = s0 ? a.in0 + (cok ? c : 0) : a.in1 + (c - a.c0);
+    const int cs = s0 ? a.c0 : a.c1;
+    // loads first: the tile rows of this thread (<= 8 pixels), affine parameters, taps -- then the statistics
+    float4 v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int p = (tid >> 3) + it * 32;
+        const int pc = p < n ? p : n - 1;
+        v[it] = *reinterpret_cast<const float4*>(src + ((size_t)b * n + pc) * cs);
+    }
+    const float4 gq = *reinterpret_cast<const float4*>(a.gamma + (cok ? c : 0));
+    const float4 bq = *reinterpret_cast<const float4*>(a.beta + (cok ? c : 0));
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(a.w + (size_t)k * C + (cok ? c : 0));
+    float mean, rstd;
+    gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, b, (double)C * a.H * a.W, &mean, &rstd);  // every wavefront for itself
+    for (int i = tid; i < nh; i += 256) {  // zero border (and interior, overwritten below after the barrier)
+        const int y = i / IW, x = i - y * IW;
+        if (y == 0 || y == a.H + 1 || x == 0 || x == a.W + 1)
+            for (int k = 0; k < CK / 4; ++k) *reinterpret_cast<float4*>(&Hs[i * HP + k * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float ga[4], gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ga[i] = (&gq.x)[i] * rstd;
+        gb[i] = (&bq.x)[i] - mean * ga[i];
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int p = (tid >> 3) + it * 32;
+        if (p < n) {
+            const int y = p / a.W, x = p - y * a.W;
+            float4 xn;
+            xn.x = cok ? fmaf(v[it].x, ga[0], gb[0]) : 0.f;
+            xn.y = cok ? fmaf(v[it].y, ga[1], gb[1]) : 0.f;
+            xn.z = cok ? fmaf(v[it].z, ga[2], gb[2]) : 0.f;
+            xn.w = cok ? fmaf(v[it].w, ga[3], gb[3]) : 0.f;
+            *reinterpret_cast<float4*>(&Hs[((y + 1) * IW + x + 1) * HP + c4 * 4]) = xn;
+            if (cok && a.out_xn) *reinterpret_cast<float4*>(a.out_xn + ((size_t)b * n + p) * C + c) = xn;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int p = (tid >> 3) + it * 32;
+        if (p < n && cok) {
+            const int y = p / a.W, x = p - y * a.W;
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float4 hv = *reinterpret_cast<const float4*>(&Hs[((y + k / 3) * IW + x + k % 3) * HP + c4 * 4]);
+                s[0] = fmaf(hv.x, wk[k].x, s[0]);
+                s[1] = fmaf(hv.y, wk[k].y, s[1]);
+                s[2] = fmaf(hv.z, wk[k].z, s[2]);
+                s[3] = fmaf(hv.w, wk[k].w, s[3]);
+            }
+            *reinterpret_cast<float4*>(a.out_dw + ((size_t)b * n + p) * C + c) = make_float4(s[0], s[1], s[2], s[3]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // softmax statistics along one image axis for channels [coff, coff+C) of an NHWC tensor with row stride ld:
 //   axis 0: over H (q.softmax(dim=-2), :545) -> mx/sm indexed [b][w][c];  axis 1: over W (k.softmax(dim=-1), :546)
 //   -> [b][h][c].  Two passes (max, then sum of exp(x - max)) like torch.softmax.

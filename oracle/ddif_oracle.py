@@ -306,17 +306,18 @@ def _default_noise(shape):
 
 def ddpm_sample(sd, cfg, cond: Tensor, tabs: Dict[str, Tensor], clamp=(0.0, 1.0),
                 noise_fn: NoiseFn = _default_noise, record: Optional[Dict[int, Tensor]] = None,
-                max_steps: Optional[int] = None) -> Tensor:
+                max_steps: Optional[int] = None, timesteps: Optional[Sequence[int]] = None) -> Tensor:
     """p_sample_loop / p_sample / p_mean_variance / q_posterior for pred_mode="x_start"
     (diffusion/diffusion_ddpm_pan.py:445-507,418-442,346-415,316-325).  RNG draw order: x_T, then one
-    tensor per step (also at i=0).  `record` maps "steps done" -> img snapshot; `max_steps` truncates."""
+    tensor per step (also at i=0).  `record` maps "steps done" -> img snapshot; `max_steps` truncates;
+    `timesteps` replaces reversed(range(T)) (truncated fixtures: the first / last n steps of a long schedule)."""
     B, _, H, W = cond.shape
     C = cfg["out_channel"]
     T = tabs["betas"].numel()
     lms = cond[:, :C]
     img = noise_fn((B, C, H, W))
     done = 0
-    for i in reversed(range(T)):
+    for i in (reversed(range(T)) if timesteps is None else timesteps):
         t = torch.full((B,), i, dtype=torch.long)
         x0 = unet_forward(sd, cfg, img, t, cond, img)  # self-cond == current img (:491,502; sr3_dwt.py:173)
         if clamp is not None:
@@ -358,6 +359,16 @@ def ddim_sample(sd, cfg, cond: Tensor, tabs: Dict[str, Tensor], section_counts: 
     return img, nt
 
 
+def _interp1(x: Tensor, xp: Tensor, yp: Tensor) -> Tensor:
+    """interpolate_fn (solver/dpm_solver.py:1261-1300) for one query point: the query is sorted (stably, so BEFORE an
+    equal keypoint) into the keypoints, the segment is [idx-1, idx] with linear extrapolation from the outermost segment."""
+    K = xp.numel()
+    x_idx = int((xp < x).sum())
+    lo = 0 if x_idx == 0 else (K - 2 if x_idx == K else x_idx - 1)
+    x0, x1, y0, y1 = xp[lo], xp[lo + 1], yp[lo], yp[lo + 1]
+    return (y0 + (x - x0) * (y1 - y0) / (x1 - x0)).reshape(())
+
+
 class VPDiscrete:
     """NoiseScheduleVP('discrete', betas=...) (solver/dpm_solver.py:100-109,126-157,1261-1300): fp32 tables,
     piecewise-linear log-alpha with linear extrapolation outside [1/N, 1]."""
@@ -382,6 +393,13 @@ class VPDiscrete:
         x0, x1, y0, y1 = xp[lo], xp[lo + 1], yp[lo], yp[lo + 1]
         return (y0 + (t - x0) * (y1 - y0) / (x1 - x0)).reshape(())
 
+    def inverse_lambda(self, lamb: Tensor) -> Tensor:
+        """NoiseScheduleVP.inverse_lambda for the discrete schedule (solver/dpm_solver.py:163-175): log_alpha from the
+        half-logSNR, then the piecewise-linear map log_alpha -> t through the FLIPPED tables (ascending log_alpha)."""
+        log_alpha = -0.5 * torch.logaddexp(torch.zeros(1), -2.0 * lamb)
+        xp, yp = torch.flip(self.log_alpha, [0]), torch.flip(self.t, [0])
+        return torch.stack([_interp1(v, xp, yp) for v in log_alpha.reshape(-1)])
+
     def alpha(self, t):
         return torch.exp(self.log_alpha_at(t))
 
@@ -394,7 +412,7 @@ class VPDiscrete:
 
 
 def dpmpp_multistep_sample(sd, cfg, cond: Tensor, betas32: Tensor, x_T: Tensor, steps: int = 50, order: int = 2,
-                           clamp=(0.0, 1.0)) -> Tensor:
+                           clamp=(0.0, 1.0), skip_type: str = "time_uniform") -> Tensor:
     """DPM_Solver(algorithm_type="dpmsolver++").sample(method="multistep", skip_type="time_uniform",
     solver_type="dpmsolver") around model_wrapper(model_type="x_start", guidance_type="classifier-free",
     guidance_scale=1) (solver/dpm_solver.py:279-300,441-459,555-588,804-845,862-912,1167-1221).
@@ -415,7 +433,12 @@ def dpmpp_multistep_sample(sd, cfg, cond: Tensor, betas32: Tensor, x_T: Tensor, 
             x0 = (x0 + lms).clamp(clamp[0], clamp[1]) - lms
         return x0
 
-    ts = torch.linspace(1.0, 1.0 / ns.N, steps + 1)
+    if skip_type == "logSNR":  # get_time_steps (:481-485): uniform in half-logSNR between lambda(T) and lambda(eps)
+        lt, l0 = ns.lam(torch.tensor(1.0)), ns.lam(torch.tensor(1.0 / ns.N))
+        ts = ns.inverse_lambda(torch.linspace(lt.item(), l0.item(), steps + 1))
+    else:
+        assert skip_type == "time_uniform"
+        ts = torch.linspace(1.0, 1.0 / ns.N, steps + 1)
     assert steps >= order
 
     def update(x, models, tprev, t, o):

@@ -93,6 +93,22 @@ DPM_CASES = [  # (case id, dataset, H, W, T, steps, order, seed)   (B = 1: refer
     ("dpm_wv3_16_T500_s6_o3", "wv3", 16, 16, 500, 6, 3, 34),
 ]
 
+DPM_SKIP_CASES = [  # (case id, dataset, H, W, T, steps, order, seed, skip_type)
+    ("dpm_wv3_16_T500_s10_o2_logsnr", "wv3", 16, 16, 500, 10, 2, 35, "logSNR"),
+]
+
+# BASELINE config 4 (CAVE, T = 2000): truncated DDPM runs -- the first / last `n` steps of the T-step loop
+# (case id, dataset, B, H, W, T, which, n, seed)
+DDPM_TRUNC_CASES = [
+    ("ddpm_cave_64_T2000_first20", "cave", 1, 64, 64, 2000, "first", 20, 51),
+    ("ddpm_cave_64_T2000_last20", "cave", 1, 64, 64, 2000, "last", 20, 52),
+]
+
+# big forward case of config 4's shape (multi-tile stem with scalar staging, C = 31 scalar-output epilogue, 256 tokens)
+FORWARD_BIG_CASES = [
+    ("fwd_cave_128", "cave", 1, 128, 128, [1500], False, True),
+]
+
 LOSS_CASES = [  # (case id, dataset, B, H, W, T, t values, self-cond branch, seed)
     ("loss_wv3_16_sc0", "wv3", 2, 16, 16, 500, [3, 444], False, 41),
     ("loss_wv3_16_sc1", "wv3", 2, 16, 16, 500, [100, 7], True, 42),

@@ -165,6 +165,48 @@ def test_dpm_solver_matches_reference_golden(case):
     assert _maxerr(out, torch.from_numpy(g["out"])) <= 1e-4
 
 
+@pytest.mark.parametrize("case", gc.DPM_SKIP_CASES, ids=lambda c: c[0])
+def test_dpm_solver_logsnr_matches_reference_golden(case):
+    cid, ds, H, W, T, steps, order, seed, skip = case
+    g = _load(cid)
+    C = gc.DATASETS[ds][0]
+    cond = gc.tiles_for(ds, 1, H, W, seed=seed)["cond"].to(DEV)
+    xT = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    slv = _dpm_solver(ds, cond, T)
+    out = slv.sample(xT, steps=steps, order=order, skip_type=skip, method="multistep")
+    assert _maxerr(out, torch.from_numpy(g["out"])) <= 1e-4
+
+
+@pytest.mark.parametrize("case", gc.DDPM_TRUNC_CASES, ids=lambda c: c[0])
+def test_ddpm_cave_T2000_truncated_matches_reference_golden(case):
+    """BASELINE config 4: CAVE (31 + 3 bands), T = 2000 schedule; the first / last 20 steps of the reference's loop."""
+    cid, ds, B, H, W, T, which, n, seed = case
+    g = _load(cid)
+    C = gc.DATASETS[ds][0]
+    cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+    d = make_diffusion(net_for(ds), C, T, H, DEV)
+    xT, noise = reference_noise_stream(seed, (B, C, H, W), n)
+    plan = d._plan(cond.to(DEV))
+    c1, c2 = d.posterior_mean_coef1.cpu(), d.posterior_mean_coef2.cpu()
+    cz = (0.5 * d.posterior_log_variance_clipped.cpu()).exp()
+    order = list(reversed(range(T)))
+    order = order[:n] if which == "first" else order[-n:]
+    out = plan.sample_ddpm([float(i) for i in order], [float(c1[i]) for i in order], [float(c2[i]) for i in order],
+                           [0.0 if i == 0 else float(cz[i]) for i in order], xT.to(DEV), noise.to(DEV).contiguous(), 0, 0,
+                           (0.0, 1.0), DEV)
+    assert _maxerr(out, torch.from_numpy(g["out"])) <= 1e-4
+
+
+@pytest.mark.parametrize("case", gc.FORWARD_BIG_CASES, ids=lambda c: c[0])
+def test_forward_cave_128_matches_reference_golden(case):
+    """CAVE at its BASELINE size: multi-tile scalar-staged stem (31 + 31 channels), the C = 31 scalar-output epilogue at
+    128x128, 256 bottleneck tokens."""
+    g = _load(case[0])
+    x, t, cond, sc = gc.forward_inputs(case)
+    y = net_for(case[1])(x.to(DEV), t.to(DEV), cond.to(DEV), sc.to(DEV))
+    assert _maxerr(y, torch.from_numpy(g["y"])) <= 2e-5
+
+
 def test_dpm_solver_generic_loop_equals_fused_path():
     """An opaque corrector closure (as the reference's clamp_fn) takes the per-evaluation loop; same result."""
     cid, ds, H, W, T, steps, order, seed = gc.DPM_CASES[0]

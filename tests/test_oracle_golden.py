@@ -124,6 +124,68 @@ def test_dpm_solver_matches_reference(case):
     assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("case", gc.DPM_SKIP_CASES, ids=lambda c: c[0])
+def test_dpm_solver_logsnr_matches_reference(case):
+    cid, ds, H, W, T, steps, order, seed, skip = case
+    g = _load(cid)
+    C = gc.DATASETS[ds][0]
+    cond = gc.tiles_for(ds, 1, H, W, seed=seed)["cond"]
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    xT = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        out = O.dpmpp_multistep_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, tabs["betas"], xT, steps, order, skip_type=skip)
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("case", gc.DDPM_TRUNC_CASES, ids=lambda c: c[0])
+def test_ddpm_cave_T2000_truncated_matches_reference(case):
+    """BASELINE config 4's schedule (T = 2000) on a CAVE-shaped tile: first / last 20 steps of the reference's own loop."""
+    cid, ds, B, H, W, T, which, n, seed = case
+    g = _load(cid)
+    cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    order = list(reversed(range(T)))
+    steps = order[:n] if which == "first" else order[-n:]
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        out = O.ddpm_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, tabs, timesteps=steps)
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("case", gc.FORWARD_BIG_CASES, ids=lambda c: c[0])
+def test_forward_cave_128_matches_reference(case):
+    g = _load(case[0])
+    x, t, cond, sc = gc.forward_inputs(case)
+    with torch.no_grad():
+        y = O.unet_forward(gc.weights_for(case[1]), gc.cfg_for(case[1]), x, t, cond, sc)
+    assert float((y - torch.from_numpy(g["y"])).abs().max()) <= 5e-6
+
+
+def test_dropin_schedule_buffers_match_reference_tables():
+    """The drop-in GaussianDiffusion's OWN schedule buffers (the ones its samplers hand to libddif), bit for bit against the
+    tables captured from the reference's set_new_noise_schedule / space_new_betas (diffusion_ddpm_pan.py:199-276,583-592)."""
+    from ddif.diffusion.diffusion_ddpm_pan import GaussianDiffusion, make_beta_schedule
+
+    class _Stub(torch.nn.Module):
+        self_condition, pred_var = True, False
+
+    g = _load("schedules")
+    for T in gc.SCHEDULE_T:
+        d = GaussianDiffusion(_Stub(), image_size=64, channels=8, pred_mode="x_start", loss_type="l1", device="cpu", clamp_range=(0, 1))
+        d.set_new_noise_schedule(betas=make_beta_schedule("cosine", T, cosine_s=8e-3), device="cpu")
+        for k in O.TABLE_NAMES:
+            assert np.array_equal(getattr(d, k).numpy(), g[f"T{T}.{k}"]), (T, k)
+    for T in gc.DDIM_FROM:
+        d = GaussianDiffusion(_Stub(), image_size=64, channels=8, pred_mode="x_start", loss_type="l1", device="cpu", clamp_range=(0, 1))
+        d.set_new_noise_schedule(betas=make_beta_schedule("cosine", T, cosine_s=8e-3), device="cpu")
+        use = d.space_timesteps(d.num_timesteps, "ddim25")
+        assert sorted(use) == list(g[f"ddim25_from_T{T}.keep"])
+        d.space_new_betas(use)
+        assert d.num_timesteps == 25
+        for k in O.TABLE_NAMES:
+            assert np.array_equal(getattr(d, k).numpy(), g[f"ddim25_from_T{T}.{k}"]), (T, k)
+
+
 @pytest.mark.parametrize("case", gc.LOSS_CASES, ids=lambda c: c[0])
 def test_p_losses_matches_reference(case):
     cid, ds, B, H, W, T, tvals, sc_branch, seed = case

@@ -94,7 +94,7 @@ def make_diffusion(D, net, C, T, size):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="manifest,fwd,sched,ddpm,ddim,dpm,loss,psnr")
+    ap.add_argument("--only", default="manifest,fwd,fwdbig,trunc,dpmskip,sched,ddpm,ddim,dpm,loss,psnr")
     ap.add_argument("--skip-long", action="store_true")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -130,6 +130,47 @@ def main():
             with torch.no_grad():
                 y = net_for(case[1])(x, t, cond, sc)
             save(case[0], y=y, x_chk=chk(x), cond_chk=chk(cond))
+
+    if "fwdbig" in only:
+        for case in gc.FORWARD_BIG_CASES:
+            x, t, cond, sc = gc.forward_inputs(case)
+            with torch.no_grad():
+                y = net_for(case[1])(x, t, cond, sc)
+            save(case[0], y=y, x_chk=chk(x), cond_chk=chk(cond))
+
+    if "trunc" in only:
+        import builtins
+
+        for cid, ds, B, H, W, T, which, n, seed in gc.DDPM_TRUNC_CASES:
+            C = gc.DATASETS[ds][0]
+            cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+            d = make_diffusion(D, net_for(ds), C, T, H)
+            # the reference loop itself, iterating only the first / last n timesteps: p_sample_loop looks `reversed` up
+            # in its module globals, so a module-level stand-in truncates the iteration without touching its code
+            D.reversed = (lambda r: iter(list(builtins.reversed(r))[:n])) if which == "first" else (lambda r: iter(list(builtins.reversed(r))[-n:]))
+            try:
+                torch.manual_seed(seed)
+                t0 = time.time()
+                out = d(cond, mode="ddpm_sample")
+            finally:
+                del D.reversed
+            print(f"  {cid}: {time.time() - t0:.1f}s")
+            save(cid, out=out, cond_chk=chk(cond))
+
+    if "dpmskip" in only:
+        for cid, ds, H, W, T, steps, order, seed, skip in gc.DPM_SKIP_CASES:
+            C = gc.DATASETS[ds][0]
+            cond = gc.tiles_for(ds, 1, H, W, seed=seed)["cond"]
+            d = make_diffusion(D, net_for(ds), C, T, H)
+            ns = S.NoiseScheduleVP("discrete", betas=d.betas)
+            lms = cond[:, :C]
+            fn = S.model_wrapper(net_for(ds), ns, model_type="x_start", guidance_type="classifier-free",
+                                 guidance_scale=1.0, condition=cond)
+            slv = S.DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=lambda x0, t, lms=lms: (x0 + lms).clamp(0, 1.0) - lms)
+            xT = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(seed))
+            with torch.no_grad():
+                out = slv.sample(xT, steps=steps, order=order, skip_type=skip, method="multistep")
+            save(cid, out=out, cond_chk=chk(cond))
 
     if "sched" in only:
         out = {}
