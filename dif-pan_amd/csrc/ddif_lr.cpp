@@ -10,9 +10,10 @@ template <int KS, int MB, int PRO, int EPI>
 ConvVariant lr_variant(const char* name) {
     ConvVariant v;
     v.fn = conv_lr_kernel<KS, MB, PRO, EPI>;
-    v.smem = LrGeom<KS, MB, PRO>::smem;
-    v.th = LrGeom<KS, MB, PRO>::TH;
-    v.tw = LrGeom<KS, MB, PRO>::TW;
+    using G = LrGeom<KS, MB, PRO, (EPI & EPI_COLST) != 0>;
+    v.smem = G::smem;
+    v.th = G::TH;
+    v.tw = G::TW;
     v.nt = 32;
     v.nthr = 256;
     v.x3 = true;
@@ -31,6 +32,7 @@ ConvVariant lr_for(int ks, int pro, int epi) {
         if (pro == PRO_NONE && epi == EPI_FILM) return lr_variant<1, MB, PRO_NONE, EPI_FILM>("lr1x1_film");
         if (pro == PRO_NONE && epi == EPI_RES) return lr_variant<1, MB, PRO_NONE, EPI_RES>("lr1x1_res");
         if (pro == PRO_NONE && epi == 0) return lr_variant<1, MB, PRO_NONE, 0>("lr1x1");
+        if (pro == PRO_NONE && epi == EPI_COLST) return lr_variant<1, MB, PRO_NONE, EPI_COLST>("lr1x1_colstats");
         if (pro == PRO_GN && epi == 0) return lr_variant<1, MB, PRO_GN, 0>("lr1x1_gn");
         if (pro == PRO_GN_SILU && epi == 0) return lr_variant<1, MB, PRO_GN_SILU, 0>("lr1x1_gn_silu");
         if (pro == PRO_COLSM && epi == 0) return lr_variant<1, MB, PRO_COLSM, 0>("lr1x1_colsoftmax");

@@ -219,7 +219,9 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
     int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1);
-    const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0);
+    const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0);
+    if (s.cso_mx && (cfg < 20 || Hout > (cfg == 20 ? 8 : 16)))
+        return fail(DDIF_ERR_INVALID, "%s: column statistics epilogue needs the low-resolution kernel and H <= 16", s.name);
     ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if (!var.fn && cfg >= 20) {  // prologue / epilogue combination the low-resolution kernel does not carry
         cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false);
@@ -247,6 +249,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.cs_sm = s.cs_sm;
     a.dw_w = s.dw_w;
     a.out_xn = s.out_xn;
+    a.cso_mx = s.cso_mx;
+    a.cso_sm = s.cso_sm;
     if (s.pro == PRO_GN_DW && (!s.dw_w || c0 + c1 > 256)) return fail(DDIF_ERR_INVALID, "%s: depthwise staging needs weights and <= 256 channels", s.name);
     if (s.pro == PRO_COLSM && (!s.cs_mx || !s.cs_sm || c0 % pc.ck != 0)) return fail(DDIF_ERR_INVALID, "%s: column-softmax prologue needs statistics and c0 %% %d == 0", s.name, pc.ck);
     a.n_chunks = pc.n_chunks;
@@ -634,6 +638,7 @@ int Plan::build() {
         if (!pn_g || !pn_b || !q0w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
         if (pq1->ck != 32 || cur.C % 4 != 0 || skip.C % 4 != 0 || fea > 256)
             return fail(DDIF_ERR_INVALID, "%s: the fused q = 1x1(dw3x3(GN(cat))) kernel needs 4 | channels and <= 256 of them (got %d+%d)", ci.c_str(), cur.C, skip.C);
+        float *qmx = nullptr, *qsm = nullptr;
         if (pick_cfg(1, 32, PRO_NONE, 1, 1, 0, Hl, Wl, pq1->cout, B, fea, fea) >= 20) {
             // low-resolution levels: xn = GN(cat), dwq = depthwise3x3(xn) from ONE small kernel (whole sample per workgroup),
             // then q = q.1(dwq) on the split-K kernel -- fused into the 1x1 conv the depthwise pass would be recomputed by
@@ -677,6 +682,13 @@ int Plan::build() {
             s.pc = pq1;
             s.in0 = dwq;
             s.name = "q.1x1";
+            if (Hl <= 16) {  // whole columns inside one tile: softmax_H statistics of q from the conv's epilogue
+                DDIF_TRY(dalloc(&qmx, (size_t)B * Wl * fea));
+                DDIF_TRY(dalloc(&qsm, (size_t)B * Wl * fea));
+                s.cso_mx = qmx;
+                s.cso_sm = qsm;
+                s.name = "q.1x1 (+softmax_H stats)";
+            }
             DDIF_TRY(add_conv(step, s, &q));
         } else {
             // q = q.1(depthwise3x3(GroupNorm(cat[h, skip]))) in ONE kernel; also emits xn (sr3_dwt.py:507-513,537,540)
@@ -692,10 +704,9 @@ int Plan::build() {
             s.name = "q = 1x1(dw3x3(GN(cat)))";
             DDIF_TRY(add_conv(step, s, &q));
         }
-        float *qmx, *qsm;
-        DDIF_TRY(dalloc(&qmx, (size_t)B * Wl * fea));
-        DDIF_TRY(dalloc(&qsm, (size_t)B * Wl * fea));
-        {
+        if (!qmx) {
+            DDIF_TRY(dalloc(&qmx, (size_t)B * Wl * fea));
+            DDIF_TRY(dalloc(&qsm, (size_t)B * Wl * fea));
             Op op;
             op.name = "q.softmax_stats";
             op.bytes = 8.0 * B * Hl * Wl * fea;

@@ -60,6 +60,8 @@ struct ConvSpec {
     const float* cs_sm = nullptr;
     const float* dw_w = nullptr;        // PRO_GN_DW: depthwise weights [9][C]
     float* out_xn = nullptr;            // PRO_GN_DW: normalised input written out
+    float* cso_mx = nullptr;            // low-resolution kernel: column-softmax statistics of the OUTPUT ([B][W][Cout]); the image
+    float* cso_sm = nullptr;            //   must fit one tile vertically (caller checks with lr_colstats_ok)
     bool silu = false;
     bool stats = false;
     const char* name = "conv";

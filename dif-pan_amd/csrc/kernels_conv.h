@@ -67,6 +67,8 @@ struct ConvArgs {
     const float* cs_sm;
     const float* dw_w;       // PRO_GN_DW: depthwise 3x3 weights [9][c0 + c1] applied to the normalised input
     float* out_xn;           // PRO_GN_DW: the normalised input itself, [B,H,W,c0+c1] (consumed by attn_res) or null
+    float* cso_mx;           // kernels_lr.h EPI_COLST: column-softmax statistics of the OUTPUT (max / sum of exp over H), [B][Wout][Cout]
+    float* cso_sm;
     long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
 };
 
@@ -84,7 +86,7 @@ struct StageKind {
 // 4 = residual add,  8 = SiLU on the output (a runtime flag gets if-converted: exp + rcp computed for every conv),
 // 16 = per-SAMPLE time-bias rows (tbias_stride != 0: forward() / p_losses with one t per sample; in the samplers every
 // sample shares the step's row and bias + time bias sit in LDS for the whole launch).
-enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16 };
+enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_COLST = 32 };
 // VEC (input staging): 0 = scalar loads, any channel counts;  1 = float4 loads, every CK-channel chunk lies in ONE source
 // (c1 == 0 or c0 % CK == 0): the source base is wave-uniform (SGPR) and a load costs one VALU add;  2 = float4 loads with
 // a per-thread source select (the stem's cat[x, x] with 8 + 8 channels).

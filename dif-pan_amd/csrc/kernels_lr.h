@@ -33,9 +33,11 @@
 
 namespace ddif {
 
-template <int KS, int MB, int PRO>
+// TALL: 16x8 instead of 8x16 pixels for MB = 4 -- whole image columns inside one tile, which is what the column-softmax
+// statistics epilogue (EPI_COLST) needs
+template <int KS, int MB, int PRO, bool TALL = false>
 struct LrGeom {
-    static constexpr int TH = 8, TW = MB == 2 ? 8 : 16;
+    static constexpr int TH = (TALL && MB == 4) ? 16 : 8, TW = (MB == 2 || TALL) ? 8 : 16;
     static constexpr int PAD = KS / 2;
     static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD; // staged tile (halo of the 3x3 taps)
     static constexpr int PC = (MB == 4 && KS == 3) ? 64 : 128; // channels staged per phase
@@ -49,9 +51,12 @@ struct LrGeom {
     static constexpr int U = KS == 3 ? TAPS : SPW;             // weight ring (steps): one slab of a 3x3 conv (9 taps), one phase of a 1x1
 };
 
-template <int KS, int MB, int PRO, int EPI>
+// ABL (tools/mbench_lr.cpp only): 1 = no weight loads, 2 = no MFMAs, 4 = no activation loads, 8 = no output stores
+template <int KS, int MB, int PRO, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
-    using G = LrGeom<KS, MB, PRO>;
+    constexpr bool COLST = (EPI & EPI_COLST) != 0;
+    static_assert(!COLST || KS == 1, "column statistics epilogue: 1x1 convs");
+    using G = LrGeom<KS, MB, PRO, COLST>;
     constexpr int TH = G::TH, TW = G::TW, LP = G::PAD, LH = G::IH, LW = G::IW, IW = G::IW, PC = G::PC, SP = G::SP;
     constexpr int APIX = G::APIX, TAPS = G::TAPS, U = G::U, SPW = G::SPW;
     constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU);
@@ -136,7 +141,10 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             const int s = pf_slab < NS ? pf_slab : 0;  // (the initial fill of a wave without slabs re-reads slab 0; never consumed)
             const char* p = wbase + ((size_t)s * TAPS + pf_tap) * 3072;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) wr[slot][q] = *reinterpret_cast<const float4*>(p + q * 1024);
+            for (int q = 0; q < 3; ++q) {
+                if (ABL & 1) wr[slot][q] = make_float4(1e-3f * (float)q, 2e-3f, 3e-3f, 4e-3f);
+                else wr[slot][q] = *reinterpret_cast<const float4*>(p + q * 1024);
+            }
             if (++pf_tap == TAPS) {
                 pf_tap = 0;
                 pf_slab += 4;
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                 okm |= (ok ? 1u : 0u) << it;
                 const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
                 const size_t sp = ((size_t)b * a.Hin + iyc) * a.Win + ixc;
-                sv[it] = *reinterpret_cast<const float4*>(src + sp * cs);
+                if (ABL & 4) sv[it] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);
+                else sv[it] = *reinterpret_cast<const float4*>(src + sp * cs);
                 if constexpr (PRO == PRO_COLSM) {
                     const size_t so = ((size_t)b * a.Win + ixc) * a.c0 + ((s0 && cok) ? c : 0);
                     mxv[it] = *reinterpret_cast<const float4*>(a.cs_mx + so);
@@ -257,6 +266,11 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
                             f32x16 cacc = acc[mb];
+                            if (ABL & 2) {
+                                cacc[0] += wr[u][0].x * xa[mb][0].x + wr[u][1].y * xa[mb][1].y + wr[u][2].z * xa[mb][2].z;
+                                acc[mb] = cacc;
+                                continue;
+                            }
                             cacc = DDIF_MFMA_32x32x16_BF16(wr[u][2], xa[mb][0], cacc);  // lo * hi
                             cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][2], cacc);  // hi * lo
                             cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][1], cacc);  // mid * mid
@@ -279,6 +293,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                     make_float4(acc[mb][4 * g + 0], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]);
         __syncthreads();
         float s1 = 0.f, s2 = 0.f;
+        [[maybe_unused]] float colv[COLST ? MB : 1][4];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             float4 pp[4];
@@ -294,10 +309,41 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                 if constexpr (RES) x += (&e_res[mb].x)[i];
                 v[i] = x;
             }
+            if constexpr (COLST) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) colv[mb][i] = pok[mb] ? v[i] : -INFINITY;
+            }
             if (pok[mb]) {
-                *reinterpret_cast<float4*>(a.out + opix[mb] * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+                if (!(ABL & 8) || v[0] == 12345.678f) *reinterpret_cast<float4*>(a.out + opix[mb] * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
                 s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+        }
+        if constexpr (COLST) {
+            // softmax_H statistics of the output (q.softmax(dim=-2), sr3_dwt.py:545): the tile holds whole columns (TW = 8:
+            // pixel m = 8 y + x, lane j <-> rows j/8 + 4 mb of column j%8), so max / sum(exp(. - max)) over H are an in-register
+            // reduction over mb and two xor-shuffles (8, 16) inside the 32-lane half; lanes j < 8 write [b][x][cout quad]
+            float cm[4], cs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float m = colv[0][i];
+#pragma unroll
+                for (int mb = 1; mb < MB; ++mb) m = fmaxf(m, colv[mb][i]);
+                m = fmaxf(m, __shfl_xor(m, 8));
+                m = fmaxf(m, __shfl_xor(m, 16));
+                float e = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) e += dd_exp(colv[mb][i] - m);  // rows outside the image: exp(-inf) = 0
+                e += __shfl_xor(e, 8);
+                e += __shfl_xor(e, 16);
+                cm[i] = m;
+                cs[i] = e;
+            }
+            const int ox = ox0 + (j & 7);
+            if (j < 8 && ox < a.Wout && cok_o) {
+                const size_t so = ((size_t)b * a.Wout + ox) * a.Cout + co;
+                *reinterpret_cast<float4*>(a.cso_mx + so) = make_float4(cm[0], cm[1], cm[2], cm[3]);
+                *reinterpret_cast<float4*>(a.cso_sm + so) = make_float4(cs[0], cs[1], cs[2], cs[3]);
             }
         }
         if (a.st_out) {
