@@ -90,6 +90,12 @@ class _Lib:
         d.ddif_prof_collect.argtypes = [vp, C.POINTER(ProfResult)]
         d.ddif_plan_cost.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
         d.ddif_debug_set_grid_cap.argtypes = [i32]
+        d.ddif_cond_assemble.argtypes = [vp, vp, f32, i32, i32, i32, i32, i32, i32, vp, vp]
+        d.ddif_metrics.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
+        d.ddif_optim_create.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32]
+        d.ddif_optim_destroy.argtypes = [vp]
+        d.ddif_optim_destroy.restype = None
+        d.ddif_optim_step.argtypes = [vp, f32, f32, f32, f32, f32, C.c_int64, f32, i32, f32, C.POINTER(C.c_float), vp]
         self.emulated = bool(d.ddif_is_emulated())
 
     def check(self, rc: int, what: str):
@@ -369,3 +375,77 @@ class PlanHandle:
         v = [C.c_double() for _ in range(4)]
         self.lib.check(self.lib.dll.ddif_plan_cost(self.h, *[C.byref(x) for x in v]), "ddif_plan_cost")
         return dict(step_flop=v[0].value, step_bytes=v[1].value, cond_flop=v[2].value, cond_bytes=v[3].value)
+
+
+# ---- kernels either side of the denoising loop (include/ddif.h, csrc/kernels_aux.h) ---------------------------------------
+def cond_assemble(lms_raw: torch.Tensor, pan_raw: torch.Tensor, division: float, wavelet_order: int = 0) -> torch.Tensor:
+    """cond = cat[lms, pan, bilinear_up2(Haar wavelets)] / division in ONE kernel (reference diffusion_engine.py:221-228 +
+    dataset/pan_dataset.py:73-81,139-142).  wavelet_order 0 = [LL,H,D,V] (pan sets), 1 = [LL,H,V,D] (CAVE / Harvard)."""
+    lib = get_lib()
+    _check_tensor(lib, lms_raw, "lms")
+    _check_tensor(lib, pan_raw, "pan")
+    B, Cc, H, W = lms_raw.shape
+    _check_shape(pan_raw, "pan", (B, pan_raw.shape[1], H, W))
+    P = pan_raw.shape[1]
+    lms_raw, pan_raw = lms_raw.contiguous(), pan_raw.contiguous()
+    out = torch.empty((B, 2 * Cc + 4 * P, H, W), dtype=torch.float32, device=lms_raw.device)
+    lib.check(lib.dll.ddif_cond_assemble(_ptr(lms_raw), _ptr(pan_raw), float(division), B, Cc, P, H, W, int(wavelet_order), _ptr(out),
+                                         _stream(lib, lms_raw.device)), "ddif_cond_assemble")
+    return out
+
+
+def metrics(gt: torch.Tensor, pred: torch.Tensor, ergas_ratio: float = 4.0) -> torch.Tensor:
+    """(B, 4) = [SAM, ERGAS, PSNR (reference sign), CC] per image (reference utils/_metric_legacy.py:299-379)."""
+    lib = get_lib()
+    _check_tensor(lib, gt, "gt")
+    _check_tensor(lib, pred, "pred")
+    _check_shape(pred, "pred", tuple(gt.shape))
+    B, Cc, H, W = gt.shape
+    gt, pred = gt.contiguous(), pred.contiguous()
+    out = torch.empty((B, 4), dtype=torch.float32, device=gt.device)
+    lib.check(lib.dll.ddif_metrics(_ptr(gt), _ptr(pred), B, Cc, H, W, float(ergas_ratio), _ptr(out), _stream(lib, gt.device)), "ddif_metrics")
+    return out
+
+
+class FusedAdamW:
+    """clip_grad_norm_ + torch.optim.AdamW.step + EmaUpdater.update as three launches (reference diffusion_engine.py:237-241).
+    `params`, `grads` (and `ema`, optional) are lists of contiguous fp32 tensors that stay alive and in place."""
+
+    def __init__(self, params, grads, ema=None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.lib = get_lib()
+        self.params, self.grads, self.ema = list(params), list(grads), (list(ema) if ema is not None else None)
+        for i, (p, g) in enumerate(zip(self.params, self.grads)):
+            _check_tensor(self.lib, p, f"param[{i}]")
+            _check_tensor(self.lib, g, f"grad[{i}]")
+            if not (p.is_contiguous() and g.is_contiguous()) or p.numel() != g.numel():
+                raise DdifError(f"param[{i}] / grad[{i}] must be contiguous and of equal size")
+        n = len(self.params)
+        sizes = (C.c_int64 * n)(*[p.numel() for p in self.params])
+        pp = (C.c_void_p * n)(*[p.data_ptr() for p in self.params])
+        gp = (C.c_void_p * n)(*[g.data_ptr() for g in self.grads])
+        ep = None
+        if self.ema is not None:
+            ep = (C.c_void_p * n)(*[e.data_ptr() for e in self.ema])
+        dev = self.params[0].device
+        idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
+        h = C.c_void_p()
+        self.lib.check(self.lib.dll.ddif_optim_create(C.byref(h), n, sizes, pp, gp, ep, idx), "ddif_optim_create")
+        self.h, self.device = h, dev
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.t = 0
+
+    def step(self, max_grad_norm: float = 0.0, ema_mode: int = 0, ema_decay: float = 0.0, return_norm: bool = False):
+        self.t += 1
+        gn = C.c_float(0.0)
+        self.lib.check(self.lib.dll.ddif_optim_step(self.h, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                                                    float(max_grad_norm), int(ema_mode), float(ema_decay),
+                                                    C.byref(gn) if return_norm else None, _stream(self.lib, self.device)), "ddif_optim_step")
+        return gn.value if return_norm else None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dll.ddif_optim_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

@@ -150,6 +150,37 @@ DDIF_API int ddif_plan_q_sample_forward(ddif_plan_t plan, const float* x0, const
                                const float* sqrt_1mac_host, const float* time_host, const float* self_cond,
                                float* pred, void* stream);
 
+/* ---- either side of the denoising loop ---------------------------------------------------------------------------- */
+
+/* Cond assembly of the engine, fused with the level-1 Haar analysis the reference does with PyWavelets on the CPU at
+ * dataset construction (dataset/pan_dataset.py:73-81,127-142; dataset/hisr.py:48-59; diffusion_engine.py:221-228,441-444):
+ *   cond = cat[lms, pan, bilinear_up2([LL(lms), details(pan)])] / division        -> (B, 2C+4P, H, W)
+ * lms_raw (B,C,H,W), pan_raw (B,P,H,W): device, raw sensor units; H, W even.
+ * wavelet_order 0 = [LL, H, D, V] (PanCollection sets), 1 = [LL, H, V, D] (CAVE / Harvard). */
+DDIF_API int ddif_cond_assemble(const float* lms_raw, const float* pan_raw, float division, int B, int C, int P, int H, int W,
+                                int wavelet_order, float* cond_out, void* stream);
+
+/* Validation metrics per image (utils/_metric_legacy.py:299-379 analysis_accu(choices=5) as called by
+ * utils/metric.py:24-98 AnalysisPanAcc): out[b] = {SAM, ERGAS, PSNR (reference sign), CC}; gt, pred (B,C,H,W) device;
+ * out: device, B*4 floats.  The reference's quirks are kept: last row / column dropped, pi = 3.14159256, SAM rounded to
+ * 6 digits, PSNR = -20 log10(1/rmse). */
+DDIF_API int ddif_metrics(const float* gt, const float* pred, int B, int C, int H, int W, float ergas_ratio, float* out, void* stream);
+
+/* Fused optimizer step of the training loop (diffusion_engine.py:237-241): global-norm gradient clipping
+ * (utils/misc.py:25-36 -> clip_grad_norm_), torch.optim.AdamW.step and EmaUpdater.update (utils/optim_utils.py:43-58) as
+ * three launches over a chunk table, whatever the number of tensors.  The handle owns the moment buffers (zero-initialised);
+ * params / grads / ema are borrowed device pointers that must stay valid for the handle's lifetime (ema or its entries may
+ * be NULL). */
+typedef struct ddif_optim* ddif_optim_t;
+DDIF_API int ddif_optim_create(ddif_optim_t* out, int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
+                               float* const* ema, int device);
+DDIF_API void ddif_optim_destroy(ddif_optim_t h);
+/* step: 1-based AdamW step count; max_grad_norm <= 0 disables clipping; ema_mode 0 = leave ema alone, 1 = ema <- p
+ * (iteration <= start_iter), 2 = ema <- ema*decay + p*(1-decay); grad_norm_host (nullable) receives the pre-clip global
+ * norm and makes the call synchronous. */
+DDIF_API int ddif_optim_step(ddif_optim_t h, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                             float max_grad_norm, int ema_mode, float ema_decay, float* grad_norm_host, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 
 /* Bracket launches of the dominant kernel class (3x3 implicit-GEMM convolutions of the denoising step) with HIP

@@ -522,3 +522,77 @@ def psnr_reference_sign(gt: Tensor, pred: Tensor) -> float:
     p = pred[:, :-1, :-1].double()
     rmse = torch.sqrt(((g - p) ** 2).reshape(g.shape[0], -1).sum(dim=1) / (g.shape[1] * g.shape[2]))
     return float(torch.mean(-20 * torch.log10(1.0 / rmse)))
+
+
+# --------------------------------------------------------------------------- either side of the loop
+
+
+def haar_dwt2(x: Tensor):
+    """pywt.wavedec2(x, "db1", level=1) as documented by PyWavelets (not installed here: pinned by the Haar identities and
+    the documented 1-D example in tests/test_engine.py -- "parity unpinned" against the library itself):
+    returns cA, (cH, cV, cD) for the 2x2 blocks [[a, b], [c, d]]."""
+    a, b = x[..., 0::2, 0::2], x[..., 0::2, 1::2]
+    c, d = x[..., 1::2, 0::2], x[..., 1::2, 1::2]
+    return (a + b + c + d) * 0.5, ((a + b - c - d) * 0.5, (a - b + c - d) * 0.5, (a - b - c + d) * 0.5)
+
+
+def assemble_cond(lms_raw: Tensor, pan_raw: Tensor, division: float, hisr_order: bool = False) -> Tensor:
+    """Dataset + engine cond assembly (dataset/pan_dataset.py:73-81,127-142 / dataset/hisr.py:48-59 wavelets on the raw data,
+    then /division; diffusion_engine.py:221-228 pack with bilinear up-sampling)."""
+    ll, _ = haar_dwt2(lms_raw)
+    _, (ph, pv, pd) = haar_dwt2(pan_raw)
+    wave = torch.cat([ll, ph, pv, pd] if hisr_order else [ll, ph, pd, pv], dim=1) / division
+    lms, pan = lms_raw / division, pan_raw / division
+    return torch.cat([lms, pan, F.interpolate(wave, size=lms.shape[-1], mode="bilinear")], dim=1)
+
+
+def analysis_accu(img_base: Tensor, img_out: Tensor, ratio: float = 4.0) -> Dict[str, float]:
+    """utils/_metric_legacy.py:299-379 with flag_cut_bounds=True, dim_cut=1, choices=5; inputs (H, W, C) as there."""
+    img_base, img_out = img_base[0:-1, 0:-1, :], img_out[0:-1, 0:-1, :]
+    h, w, ch = img_out.shape
+    sum1 = torch.sum(img_base * img_out, 2)
+    sum2 = torch.sum(img_base * img_base, 2)
+    sum3 = torch.sum(img_out * img_out, 2)
+    t = (sum2 * sum3) ** 0.5
+    num = torch.sum(torch.gt(t, 0))
+    angle = torch.acos(sum1 / t)
+    sumangle = torch.where(torch.isnan(angle), torch.zeros_like(angle), angle).sum()
+    aver = sumangle if num == 0 else sumangle / num
+    aver = (aver * 10 ** 6).round() / (10 ** 6)
+    sam = aver * 180 / 3.14159256
+    summ = 0
+    for i in range(ch):
+        a1 = torch.mean((img_base[:, :, i] - img_out[:, :, i]) ** 2)
+        m1 = torch.mean(img_base[:, :, i])
+        summ = summ + a1 / (m1 * m1)
+    ergas = 100 * (1 / ratio) * ((summ / ch) ** 0.5)
+    mse = torch.mean(torch.mean((img_base - img_out) ** 2, 0), 0)
+    psnr_ = torch.mean(-20 * (torch.log(1 / mse ** 0.5) / math.log(10)))
+    c1 = torch.sum(torch.sum(img_base * img_out, 0), 0) - h * w * (torch.mean(torch.mean(img_base, 0), 0) * torch.mean(torch.mean(img_out, 0), 0))
+    c2 = torch.sum(torch.sum(img_out ** 2, 0), 0) - h * w * (torch.mean(torch.mean(img_out, 0), 0) ** 2)
+    c3 = torch.sum(torch.sum(img_base ** 2, 0), 0) - h * w * (torch.mean(torch.mean(img_base, 0), 0) ** 2)
+    cc = torch.mean(c1 / ((c2 * c3) ** 0.5))
+    return dict(SAM=float(sam), ERGAS=float(ergas), PSNR=float(psnr_), CC=float(cc))
+
+
+def optimizer_steps(params: List[Tensor], grads_per_step: List[List[Tensor]], lr=1e-4, weight_decay=1e-4, max_norm=0.003,
+                    ema_decay=0.995, ema_start_iter=1):
+    """The reference's update sequence (diffusion_engine.py:237-241): clip_grad_norm_ (utils/misc.py:33-34),
+    torch.optim.AdamW(lr, weight_decay).step(), EmaUpdater.update(iteration) (utils/optim_utils.py:43-58: copy while
+    iteration <= start_iter, then lerp) -- with torch's own CPU implementations.  Returns (params, ema, norms)."""
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    ema = [p.detach().clone() for p in ps]
+    opt = torch.optim.AdamW(ps, lr=lr, weight_decay=weight_decay)
+    norms = []
+    for it, grads in enumerate(grads_per_step):
+        for p, g in zip(ps, grads):
+            p.grad = g.clone()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(ps, max_norm)))
+        opt.step()
+        with torch.no_grad():
+            for p, e in zip(ps, ema):
+                if it > ema_start_iter:
+                    e.copy_(e * ema_decay + p.data * (1 - ema_decay))
+                else:
+                    e.copy_(p.data)
+    return [p.detach() for p in ps], ema, norms

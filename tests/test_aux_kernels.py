@@ -1,0 +1,122 @@
+"""Kernels either side of the denoising loop (csrc/kernels_aux.h) against their CPU
+restatements in the oracle:
+  cond assembly + level-1 Haar (reference dataset/pan_dataset.py:73-81,127-142, diffusion_engine.py:221-228),
+  validation metrics SAM / ERGAS / PSNR / CC (utils/_metric_legacy.py:299-379; golden from the reference's own function),
+  fused clip + AdamW + EMA (diffusion_engine.py:237-241; torch's CPU implementations are the reference's).
+Each test runs on the CPU against the host-emulated build of the same kernel sources and, with -m gpu, on the MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from ddif_testlib import use_emulator, use_gpu_library
+from oracle import ddif_oracle as O
+
+BACKENDS = [pytest.param("emu", id="emulated"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+
+
+def _dev(backend):
+    if backend == "emu":
+        use_emulator()
+        return "cpu"
+    use_gpu_library()
+    return "cuda:0"
+
+
+def _raw_pair(B, C, P, H, W, seed, division):
+    g = torch.Generator().manual_seed(seed)
+    lms = (torch.rand(B, C, H, W, generator=g) * division).round()  # raw sensor counts
+    pan = (torch.rand(B, P, H, W, generator=g) * division).round()
+    return lms, pan
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("ds,shape", [("wv3", (2, 16, 16)), ("gf2", (1, 8, 8)), ("cave", (1, 12, 12))])  # square: the reference resizes to size=lms.shape[-1]
+def test_cond_assemble_matches_oracle(backend, ds, shape):
+    from ddif import runtime
+
+    dev = _dev(backend)
+    C, P, order = gc.DATASETS[ds]
+    B, H, W = shape
+    division = {"wv3": 2047.0, "gf2": 1023.0, "cave": 1.0}[ds]
+    lms, pan = _raw_pair(B, C, P, H, W, 11, division if division > 1 else 1.0)
+    if division == 1.0:
+        lms, pan = lms * 0 + torch.rand(lms.shape, generator=torch.Generator().manual_seed(1)), pan * 0 + torch.rand(pan.shape, generator=torch.Generator().manual_seed(2))
+    want = O.assemble_cond(lms, pan, division, hisr_order=(order == "hisr"))
+    got = runtime.cond_assemble(lms.to(dev), pan.to(dev), division, 1 if order == "hisr" else 0).cpu()
+    assert got.shape == want.shape == (B, 2 * C + 4 * P, H, W)
+    assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_cond_assemble_equals_the_fixture_generator(backend):
+    """synth_tiles() builds cond from normalised data with torch ops (what every parity fixture uses): the kernel fed with
+    the same data (division 1) reproduces it."""
+    from ddif import runtime
+    from ddif.synth import synth_tiles
+
+    dev = _dev(backend)
+    t = synth_tiles(2, 8, 1, 16, 16, seed=3)
+    got = runtime.cond_assemble(t["lms"].to(dev), t["pan"].to(dev), 1.0, 0).cpu()
+    assert float((got - t["cond"]).abs().max()) <= 1e-6
+
+
+def test_metrics_oracle_matches_reference_golden():
+    """oracle.analysis_accu against the values the reference's own analysis_accu produced (tools/make_golden.py, psnr.npz)."""
+    g = np.load(os.path.join(gc.GOLDEN_DIR, "psnr.npz"))
+    gen = torch.Generator().manual_seed(5)
+    a = torch.rand(8, 33, 35, generator=gen)
+    b = (a + 0.05 * torch.randn(8, 33, 35, generator=gen)).clamp(0, 1)
+    m = O.analysis_accu(a.permute(1, 2, 0), b.permute(1, 2, 0), 4)
+    assert abs(m["PSNR"] - float(g["ref_psnr"])) <= 1e-4
+    assert abs(m["SAM"] - float(g["sam"])) <= 1e-4
+    assert abs(m["ERGAS"] - float(g["ergas"])) <= 1e-4
+    if "cc" in g:
+        assert abs(m["CC"] - float(g["cc"])) <= 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_metrics_kernel_matches_oracle(backend):
+    from ddif import runtime
+
+    dev = _dev(backend)
+    gen = torch.Generator().manual_seed(6)
+    gt = torch.rand(3, 8, 33, 35, generator=gen)
+    pred = (gt + 0.05 * torch.randn(3, 8, 33, 35, generator=gen)).clamp(0, 1)
+    pred[2] = gt[2]  # identical pair: SAM 0, rmse 0 -> PSNR = -inf in the reference's sign, ERGAS 0
+    got = runtime.metrics(gt.to(dev), pred.to(dev), 4.0).cpu()
+    for b in range(2):
+        m = O.analysis_accu(gt[b].permute(1, 2, 0), pred[b].permute(1, 2, 0), 4)
+        want = torch.tensor([m["SAM"], m["ERGAS"], m["PSNR"], m["CC"]])
+        assert torch.allclose(got[b], want, rtol=2e-5, atol=2e-5), (got[b], want)
+    m = O.analysis_accu(gt[2].permute(1, 2, 0), pred[2].permute(1, 2, 0), 4)
+    assert abs(float(got[2, 1]) - m["ERGAS"]) <= 1e-6 and float(got[2, 2]) == m["PSNR"] == float("-inf")
+    assert abs(float(got[2, 0]) - m["SAM"]) <= 0.05  # acos near 1 amplifies fp32 rounding of the normalised dot product
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fused_adamw_clip_ema_matches_torch(backend):
+    from ddif import runtime
+
+    dev = _dev(backend)
+    gen = torch.Generator().manual_seed(7)
+    shapes = [(64, 32, 3, 3), (64,), (5000,), (3, 7), (1,)]
+    params = [torch.randn(s, generator=gen) * 0.1 for s in shapes]
+    steps = 4
+    grads = [[torch.randn(s, generator=gen) * (0.01 if k % 2 else 1e-5) for s in shapes] for k in range(steps)]  # clipped and unclipped steps
+    want_p, want_e, norms = O.optimizer_steps(params, grads, lr=1e-3, weight_decay=1e-2, max_norm=0.003, ema_decay=0.9, ema_start_iter=1)
+    p = [t.clone().to(dev) for t in params]
+    g = [torch.zeros_like(t) for t in p]
+    e = [torch.zeros_like(t) for t in p]
+    opt = runtime.FusedAdamW(p, g, e, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    for it in range(steps):
+        for gi, src in zip(g, grads[it]):
+            gi.copy_(src)
+        gn = opt.step(max_grad_norm=0.003, ema_mode=2 if it > 1 else 1, ema_decay=0.9, return_norm=True)
+        assert abs(gn - norms[it]) <= 1e-6 * max(1.0, norms[it])
+    for a, b in zip(p, want_p):
+        assert float((a.cpu() - b).abs().max()) <= 2e-7
+    for a, b in zip(e, want_e):
+        assert float((a.cpu() - b).abs().max()) <= 2e-7

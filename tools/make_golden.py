@@ -275,8 +275,8 @@ def main():
         ml = importlib.util.module_from_spec(spec)
         try:
             spec.loader.exec_module(ml)
-            acc = ml.analysis_accu(a.permute(1, 2, 0), b.permute(1, 2, 0), 4)
-            save("psnr", ref_psnr=acc["PSNR"], sam=acc["SAM"], ergas=acc["ERGAS"])
+            acc = ml.analysis_accu(a.permute(1, 2, 0), b.permute(1, 2, 0), 4, choices=5)  # what AnalysisPanAcc calls (utils/metric.py:27-29)
+            save("psnr", ref_psnr=acc["PSNR"], sam=acc["SAM"], ergas=acc["ERGAS"], cc=acc["CC"])
         except Exception as e:  # pragma: no cover
             print("  psnr fixture skipped:", repr(e))
 
