@@ -33,9 +33,32 @@ def log(msg):
     print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix (= vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_BF16_MFMA_TFLOPS = 16 * 157.3  # dense bf16 MFMA (2.5 PF); the bf16x3 path issues 6 bf16 products per fp32 product
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix (= vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2516.8  # dense bf16 MFMA (16 x the fp32 rate); the bf16x3 path issues 6 bf16 products per fp32 product
 PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on (default; what the driver runs)
+    "wv3": dict(ds="wv3", C=8, P=1, batch=64, tile=64, T=1000, sampler="ddpm",
+                metric="fused megapixels/sec at T=%d, WV3 64x64x8 tiles"),
+    # configs[2]: GF2 512x512 scene = 64 tiles of 64x64, DPM-Solver++ 2M, 50 model evaluations (per GPU: 64 tiles at N=1)
+    "gf2_dpm50": dict(ds="gf2", C=4, P=1, batch=64, tile=64, T=1000, sampler="dpmpp2m", nfe=50,
+                      metric="fused megapixels/sec, GF2 64x64x4 tiles, DPM-Solver++ 2M %d NFE"),
+    # configs[3]: CAVE 31-band HSI + 3-band MSI, 128x128 patches, T=2000 DDPM
+    "cave128_t2000": dict(ds="cave", C=31, P=3, batch=8, tile=128, T=2000, sampler="ddpm",
+                          metric="fused megapixels/sec at T=%d, CAVE 128x128x31 patches"),
+}
+
+
+def build_id():
+    """sha1 over the kernel / host sources the library is built from: ties a committed PMC profile to the build it measured."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dif-pan_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -43,11 +66,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU (BASELINE config: 64)")
-    ap.add_argument("--T", type=int, default=1000, help="diffusion steps (BASELINE config: 1000)")
-    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--config", default="wv3", choices=sorted(CONFIGS), help="wv3 = BASELINE.json's metric configuration (default)")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (0: the configuration's own)")
+    ap.add_argument("--T", type=int, default=0, help="diffusion steps (0: the configuration's own)")
+    ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget of the cpu_baseline leg (split over B=1 and B=8)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: CPUs this process may run on (sched_getaffinity)")
     args = ap.parse_args()
 
@@ -76,7 +100,10 @@ def main():
 
     lib = ddif.get_lib()
     assert not lib.emulated
-    C, P, B, H, T = 8, 1, args.batch, args.tile, args.T
+    cf = CONFIGS[args.config]
+    C, P = cf["C"], cf["P"]
+    B, H, T = args.batch or cf["batch"], args.tile or cf["tile"], args.T or cf["T"]
+    order = "hisr" if cf["ds"] == "cave" else "pan"
     cfg = engine_cfg(C, P)
     keys = ("in_channel", "out_channel", "inner_channel", "lms_channel", "pan_channel", "norm_groups", "channel_mults",
             "attn_res", "res_blocks", "dropout", "image_size", "self_condition")
@@ -89,7 +116,7 @@ def main():
     diffusion.set_new_noise_schedule(betas=make_beta_schedule("cosine", T, cosine_s=8e-3), device=dev)
 
     log("network built (%d params), generating %d synthetic tiles" % (sum(p.numel() for p in net.parameters()), B))
-    tiles = synth_tiles(B, C, P, H, H, seed=100 + rank)
+    tiles = synth_tiles(B, C, P, H, H, seed=100 + rank, order=order)
     cond = tiles["cond"].to(dev)
     lms = cond[:, :C].contiguous()
     gathered = torch.empty((world * B, C, H, H), device=dev) if world > 1 else None
@@ -98,9 +125,24 @@ def main():
     torch.cuda.synchronize()
     log("plan ready: %.3f GFLOP and %.1f MB (algorithmic) per denoising step of the batch" % (cost["step_flop"] / 1e9, cost["step_bytes"] / 1e6))
 
+    solver = None
+    n_evals = T
+    if cf["sampler"] == "dpmpp2m":
+        from ddif.solver.dpm_solver import DPM_Solver, ImageSpaceClamp, NoiseScheduleVP, model_wrapper
+
+        n_evals = cf["nfe"]
+        ns = NoiseScheduleVP("discrete", betas=diffusion.betas)
+        fn = model_wrapper(net, ns, model_type="x_start", guidance_type="classifier-free", guidance_scale=1.0, condition=cond)
+        solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(lms, 0.0, 1.0))
+        assert solver._fused_target() is not None  # the whole solver loop runs inside libddif
+
     def one_step(seed):
         plan.set_cond(cond, force=True)  # once-per-tile precompute is part of the job
-        res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=rank * B, device_rng=True)
+        if solver is not None:
+            xT = torch.randn((B, C, H, H), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+            res = solver.sample(xT, steps=n_evals, order=2, skip_type="time_uniform", method="multistep")
+        else:
+            res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=rank * B, device_rng=True)
         sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
         if world > 1:
             dist.all_gather_into_tensor(gathered, sr)  # stitch: every rank ends with the whole scene
@@ -115,7 +157,8 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    plan.prof_begin(max(1, T // 20), 16384)
+    prof_every = max(1, n_evals // 20)
+    plan.prof_begin(prof_every, 16384)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = None
@@ -136,12 +179,29 @@ def main():
     mp_per_step = world * B * H * H / 1e6
     value = mp_per_step * args.steps / dt
     ach_tflops = prof["total_flop"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] > 0 else 0.0
-    step_flop_total = cost["step_flop"] * T + cost["cond_flop"]
-    traffic, traffic_src = committed_traffic()
+    step_flop_total = cost["step_flop"] * n_evals + cost["cond_flop"]
+    traffic, traffic_info = committed_traffic()
     x3 = "bf16x3" in prof["kernel"]
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_F32_MFMA_TFLOPS
+    # per-class breakdown of the profiled denoising steps (every launch of those steps sits between two HIP events)
+    n_prof_steps = max(1, sum(1 for k in range(n_evals) if k % prof_every == 0) * args.steps)
+    classes, cls_ms_total = [], 0.0
+    for c in prof["classes"]:
+        if not c["launches"]:
+            continue
+        ms = c["total_ms"] / n_prof_steps
+        floor_ms = max(c["total_flop"] / (PEAK_F32_MFMA_TFLOPS * 1e12), c["total_bytes"] / (PEAK_HBM_GBS * 1e9)) * 1e3 / n_prof_steps
+        cls_ms_total += ms
+        classes.append({"class": c["name"], "launches_per_step": c["launches"] / n_prof_steps, "ms_per_step": ms,
+                        "tflops": c["total_flop"] / (c["total_ms"] * 1e-3) / 1e12, "algorithmic_gbytes_per_s": c["total_bytes"] / (c["total_ms"] * 1e-3) / 1e9,
+                        "floor_ms_per_step": floor_ms, "frac_of_floor": floor_ms / ms if ms > 0 else None})
+    if cf["sampler"] == "dpmpp2m":
+        metric = cf["metric"] % n_evals
+        workload = "GF2 pansharpening, batch %d of %dx%dx%d tiles per GPU, DPM-Solver++ 2M %d NFE (T=%d schedule), fp32" % (B, H, H, C, n_evals, T)
+    else:
+        metric = cf["metric"] % T
+        workload = "%s, batch %d of %dx%dx%d tiles per GPU, T=%d DDPM p_sample, fp32" % ("WV3 pansharpening" if cf["ds"] == "wv3" else "CAVE MHIF", B, H, H, C, T)
     result = {
-        "metric": "fused megapixels/sec at T=%d, WV3 64x64x8 tiles" % T,
+        "metric": metric,
         "value": value,
         "unit": "MP/s",
         "n_gpus": world,
@@ -153,37 +213,47 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "WV3 pansharpening, batch %d of %dx%dx8 tiles per GPU, T=%d DDPM p_sample, fp32" % (B, H, H, T),
-                   "tiles_per_gpu": B, "tile": [H, H, C], "T": T, "sampler": "ddpm", "parallelism": "tile-shard x%d" % world,
-                   "conv_math": "bf16x3 split products (3x3 and 32-channel-chunk 1x1 convs) + exact fp32 MFMA (remaining convs, attention)" if x3 else "exact fp32 MFMA"},
+        "config": {"workload": workload, "name": args.config, "tiles_per_gpu": B, "tile": [H, H, C], "T": T, "model_evaluations": n_evals,
+                   "sampler": cf["sampler"], "parallelism": "tile-shard x%d" % world,
+                   "conv_math": ("fp32 operands split into 3 bf16 planes, 6 exact products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (3x3 convs, "
+                                 "wide 1x1 convs, low-resolution levels); exact fp32 MFMA elsewhere") if x3 else "exact fp32 MFMA"},
         "roofline": {
             "bound": "mfma",
             "achieved": ach_tflops,
-            "peak": peak,
+            "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": ach_tflops / peak,
-            "peak_note": ("fp32-equivalent: dense bf16 MFMA peak 2516.8 TF / 6 split products per fp32 product (bf16x3: hi/mid/lo "
-                          "operand split, fp32 accumulate, fp32-class accuracy); achieved counts ALGORITHMIC fp32 flops"
-                          if x3 else "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
-            "frac_of_f32_mfma_peak": ach_tflops / PEAK_F32_MFMA_TFLOPS,
+            "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS,
+            "peak_note": "dense fp32 matrix peak (guide); `achieved` counts ALGORITHMIC fp32 flops (2*M*N*K, unpadded) of the dominant class",
+            "mfma_issued_tflops": (6.0 * ach_tflops) if x3 else ach_tflops,
+            "mfma_issued_note": ("every fp32 product is issued as 6 bf16 MFMA products: issued rate vs the dense bf16 peak %.1f TF" % PEAK_BF16_MFMA_TFLOPS) if x3 else "exact fp32 MFMA",
+            "frac_of_bf16_mfma_peak_issued": (6.0 * ach_tflops / PEAK_BF16_MFMA_TFLOPS) if x3 else None,
             "traffic": traffic,
-            "traffic_unit": "bytes of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)",
-            "traffic_source": traffic_src,
+            "traffic_unit": "bytes of HBM traffic per launch of the dominant class (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this command)",
+            **traffic_info,
             "algorithmic_bytes_per_launch": (prof["total_bytes"] / prof["launches"]) if prof["launches"] else None,
             "kernel": prof["kernel"],
             "launches_timed": prof["launches"],
             "avg_launch_us": (prof["total_ms"] * 1e3 / prof["launches"]) if prof["launches"] else None,
             "algorithmic_gflop_per_launch": (prof["total_flop"] / prof["launches"] / 1e9) if prof["launches"] else None,
-            "whole_job_tflops": step_flop_total * args.steps / dt / 1e12,
-            "whole_job_frac_of_f32_peak": step_flop_total * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "whole_job_hbm_frac": (cost["step_bytes"] * T + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
+            "whole_step": {
+                "ms_per_denoising_step": dt / args.steps * 1e3 / n_evals,
+                "tflops": step_flop_total * args.steps / dt / 1e12,
+                "frac_of_f32_mfma_peak": step_flop_total * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "hbm_frac": (cost["step_bytes"] * n_evals + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
+                "classes_note": "HIP events around every launch of one denoising step in %d; floor = max(flops / 157.3 TF, algorithmic bytes / 8 TB/s)" % prof_every,
+                "classes_ms_per_step_sum": cls_ms_total,
+                "classes": classes,
+            },
         },
+        "build_id": build_id(),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("gpu result: %s" % json.dumps({k: result[k] for k in ("value", "ms_per_step")}))
-        result["cpu_baseline"] = cpu_baseline(sd, cfg, tiles["cond"][:1].contiguous(), T, args.cpu_seconds, args.cpu_threads)
-        result["vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        cb = cpu_baseline(sd, cfg, tiles["cond"][:8].contiguous(), T, args.cpu_seconds, args.cpu_threads)
+        result["cpu_baseline"] = cb
+        result["vs_cpu_baseline"] = value / cb["value"]
+        result["vs_cpu_baseline_b1"] = value / cb["by_batch"]["1"]["value"]
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -191,19 +261,24 @@ def main():
 
 
 def committed_traffic():
-    """HBM bytes per launch of the dominant kernel class.  PMC counters need their own rocprofv3 passes (they cannot
-    be collected from inside this process), so this reads the newest summary committed under profiles/ -- produced
-    from the same `bench.py` command by tools/gpu_full.sh + tools/pmc_traffic.py -- and reports null when none exists."""
+    """HBM bytes per launch of the dominant kernel class.  PMC counters need their own rocprofv3 passes (they cannot be
+    collected from inside this process), so this reads the newest summary committed under profiles/ (tools/gpu_full.sh +
+    tools/pmc_traffic.py, same `bench.py` command) -- and ONLY reports it when that profile was taken from the build being
+    benchmarked (same sha1 over csrc/); otherwise `traffic` is null and the stale file is named."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
     if not files:
-        return None, None
+        return None, {"traffic_from_committed_profile": False}
     try:
         with open(files[-1]) as f:
-            return float(json.load(f)["class_hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
+            j = json.load(f)
+        name = "profiles/" + os.path.basename(files[-1])
+        if j.get("build_id") == build_id():
+            return float(j["class_hbm_bytes_per_launch"]), {"traffic_from_committed_profile": True, "traffic_source": name}
+        return None, {"traffic_from_committed_profile": False, "traffic_stale_profile": name}
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, {"traffic_from_committed_profile": False}
 
 
 def usable_cpus():
@@ -229,9 +304,10 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(sd, cfg, cond1, T, budget_s, threads=0):
-    """The oracle (CPU port of the reference DDPM sampler: same torch-CPU op sequence, no hoisting, no fusion) on the
-    host cores of this box: B=1 tile (BASELINE config 1), the first n of the T steps, scaled to T."""
+def cpu_baseline(sd, cfg, cond8, T, budget_s, threads=0):
+    """The oracle (CPU port of the reference DDPM sampler: same torch-CPU op sequence, no hoisting, no fusion) on the host
+    cores of this box at B=1 (BASELINE config 1) and at B=8 (the CPU's best operating point): the first n of the
+    T steps of each, scaled to T.  `value` is the BETTER of the two (the honest multiple); both are listed."""
     import torch
 
     from oracle import ddif_oracle as O
@@ -242,29 +318,34 @@ def cpu_baseline(sd, cfg, cond1, T, budget_s, threads=0):
     log("cpu baseline: %d threads (os.cpu_count() = %s)" % (threads, os.cpu_count()))
     tabs = O.schedule_tables(O.cosine_betas(T))
     g = torch.Generator().manual_seed(1)
-    shape = tuple(cond1.shape[:1]) + (cfg["out_channel"],) + tuple(cond1.shape[2:])
+    by = {}
+    for bsz, share in ((1, 0.4), (8, 0.6)):
+        cond = cond8[:bsz].contiguous()
 
-    def run(n):
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            O.ddpm_sample(sd, cfg, cond1, tabs, noise_fn=lambda s: torch.randn(s, generator=g), max_steps=n)
-        return time.perf_counter() - t0
+        def run(n):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.ddpm_sample(sd, cfg, cond, tabs, noise_fn=lambda s: torch.randn(s, generator=g), max_steps=n)
+            return time.perf_counter() - t0
 
-    tw = run(1)  # warm-up (oneDNN primitive creation)
-    log("cpu baseline warm-up step: %.2f s" % tw)
-    t_probe = run(3) / 3
-    log("cpu baseline probe: %.3f s/step" % t_probe)
-    n = int(max(3, min(T, budget_s / max(t_probe, 1e-4))))
-    dt = run(n)
-    per_step = dt / n
-    mp = cond1.shape[0] * cond1.shape[2] * cond1.shape[3] / 1e6
+        run(1)  # warm-up (oneDNN primitive creation)
+        t_probe = run(2) / 2
+        n = int(max(2, min(T, share * budget_s / max(t_probe, 1e-4))))
+        dt = run(n)
+        per_step = dt / n
+        mp = cond.shape[0] * cond.shape[2] * cond.shape[3] / 1e6
+        by[str(bsz)] = {"value": mp / (per_step * T), "seconds_per_step": per_step, "steps_timed": n, "seconds_timed": dt}
+        log("cpu baseline B=%d: %.3f s/step over %d steps -> %.3e MP/s" % (bsz, per_step, n, by[str(bsz)]["value"]))
+    best = max(by, key=lambda k: by[k]["value"])
     return {
-        "value": mp / (per_step * T),
+        "value": by[best]["value"],
         "unit": "MP/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": "oracle/ddif_oracle.ddpm_sample, B=1 tile 64x64x8, first %d of T=%d steps timed (%.2f s), scaled to T" % (n, T, dt),
-        "seconds_per_step": per_step,
+        "sample": "oracle/ddif_oracle.ddpm_sample on tiles %dx%dx%d: first %d of T=%d steps at B=1 (%.1f s) and first %d at B=8 (%.1f s), each scaled to T; value = B=%s (the better)"
+                  % (cond8.shape[2], cond8.shape[3], cfg["out_channel"], by["1"]["steps_timed"], T, by["1"]["seconds_timed"], by["8"]["steps_timed"], by["8"]["seconds_timed"], best),
+        "best_batch": int(best),
+        "by_batch": by,
         "host_cpus": os.cpu_count(),
     }
 

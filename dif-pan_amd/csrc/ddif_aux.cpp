@@ -59,7 +59,7 @@ int ddif_cond_assemble(const float* lms_raw, const float* pan_raw, float divisio
     if (B < 1 || C < 1 || P < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return ddif::fail(DDIF_ERR_INVALID, "ddif_cond_assemble: H=%d W=%d must be even and >= 2", H, W);
     if (!(division > 0.f) || wavelet_order < 0 || wavelet_order > 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_cond_assemble: bad division / wavelet_order");
     const size_t total = (size_t)B * (2 * C + 4 * P) * H * W;
-    hipLaunchKernelGGL(ddif::cond_assemble_kernel, ddif::grid_for(total), dim3(256), 0, (hipStream_t)stream, lms_raw, pan_raw, 1.0f / division, B, C, P, H, W,
+    hipLaunchKernelGGL(ddif::cond_assemble_kernel, ddif::grid_for(total), dim3(256), 0, (hipStream_t)stream, lms_raw, pan_raw, division, B, C, P, H, W,
                        wavelet_order, cond_out);
     DDIF_HIPCHK(hipGetLastError());
     return DDIF_OK;

@@ -162,7 +162,9 @@ int ddif_prof_begin(ddif_plan_t plan, int every_n_steps, int max_events) {
     }
     p.ev_flop.assign(p.ev0.size(), 0.0);
     p.ev_bytes.assign(p.ev0.size(), 0.0);
+    p.ev_cls.assign(p.ev0.size(), 5);
     p.ev_used = 0;
+    p.prof_all = true;
     p.prof_every = every_n_steps;
     p.prof_max = max_events;
     return DDIF_OK;
@@ -174,10 +176,17 @@ int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
     if (!plan || !out) return ddif::fail(DDIF_ERR_INVALID, "ddif_prof_collect: NULL argument");
     ddif::Plan& p = plan->p;
     std::memset(out, 0, sizeof(*out));
+    for (int k = 0; k < 6; ++k) p.cls_res[k] = ddif_prof_class{};
     for (int i = 0; i < p.ev_used; ++i) {
         float ms = 0.f;
         DDIF_HIPCHK(hipEventSynchronize(p.ev1[i]));
         DDIF_HIPCHK(hipEventElapsedTime(&ms, p.ev0[i], p.ev1[i]));
+        const int k = p.ev_cls[i] >= 0 && p.ev_cls[i] < 6 ? p.ev_cls[i] : 5;
+        p.cls_res[k].launches += 1;
+        p.cls_res[k].total_ms += ms;
+        p.cls_res[k].total_flop += p.ev_flop[i];
+        p.cls_res[k].total_bytes += p.ev_bytes[i];
+        if (k != 0) continue;  // the aggregate result is the dominant class (3x3 convs of the high-resolution levels)
         out->launches += 1;
         out->total_ms += ms;
         out->total_flop += p.ev_flop[i];
@@ -191,6 +200,17 @@ int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
     p.ev_used = 0;
     return DDIF_OK;
     DDIF_GUARD_END
+}
+
+int ddif_prof_classes(ddif_plan_t plan, ddif_prof_class* out6) {
+    if (!plan || !out6) return ddif::fail(DDIF_ERR_INVALID, "ddif_prof_classes: NULL argument");
+    static const char* names[6] = {"conv3x3 (> 256 px / sample)", "conv1x1 (> 256 px / sample)", "low-resolution levels (<= 256 px / sample)",
+                                   "bottleneck attention", "softmax statistics", "other"};
+    for (int k = 0; k < 6; ++k) {
+        out6[k] = plan->p.cls_res[k];
+        std::snprintf(out6[k].name, sizeof(out6[k].name), "%s", names[k]);
+    }
+    return DDIF_OK;
 }
 
 int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes) {

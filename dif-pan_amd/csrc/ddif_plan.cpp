@@ -312,7 +312,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     }
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
-    op.timed = (pc.ks == 3);
+    op.cls = (Hout * Wout <= 256) ? 2 : (pc.ks == 3 ? 0 : 1);
+    op.timed = op.cls == 0;
     if (pc.ks == 3 && &prog == &step) {
         ++n_conv3;
         if (var.x3) ++n_conv3_x3;
@@ -453,6 +454,7 @@ int Plan::build() {
         {
             Op op;
             op.name = "self_attn";
+            op.cls = 3;
             const int n = in.H * in.W, Cc = in.C, BB = B;
             const float scale = 1.0f / std::sqrt((float)Cc);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)
             op.flop = 4.0 * B * 8 * (double)n * n * 16;
@@ -665,6 +667,7 @@ int Plan::build() {
             a.use_gn = 1;
             Op op;
             op.name = "q.gn_dw3x3";
+            op.cls = 2;
             {
                 char lb[160];
                 snprintf(lb, sizeof lb, "q.gn_dw3x3 %d+%d @%dx%d", cur.C, skip.C, Hl, Wl);
@@ -709,6 +712,7 @@ int Plan::build() {
             DDIF_TRY(dalloc(&qsm, (size_t)B * Wl * fea));
             Op op;
             op.name = "q.softmax_stats";
+            op.cls = 4;
             op.bytes = 8.0 * B * Hl * Wl * fea;
             op.run = [q, qmx, qsm, fea, BB, Hl, Wl](hipStream_t s, const StepCtx&) {
                 hipLaunchKernelGGL(softmax_stats_kernel, ew_grid((size_t)BB * Wl * fea), dim3(256), 0, s, (const float*)q.p, fea, 0, fea, BB, Hl, Wl, 0, qmx, qsm);
@@ -857,13 +861,14 @@ void Plan::run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bo
         }
     }
     for (auto& op : prog) {
-        const bool t = prof && op.timed && ev_used < (int)ev0.size();
+        const bool t = prof && (op.timed || prof_all) && ev_used < (int)ev0.size();
         if (t) (void)hipEventRecord(ev0[ev_used], s);
         op.run(s, ctx);
         if (t) {
             (void)hipEventRecord(ev1[ev_used], s);
             ev_flop[ev_used] = op.flop;
             ev_bytes[ev_used] = op.bytes;
+            ev_cls[ev_used] = op.cls;
             ++ev_used;
         }
     }

@@ -26,7 +26,8 @@ struct StepCtx {
 struct Op {
     std::function<void(hipStream_t, const StepCtx&)> run;
     double flop = 0, bytes = 0;
-    bool timed = false;  // member of the profiled kernel class (3x3 implicit-GEMM convs)
+    bool timed = false;  // member of the dominant kernel class (3x3 implicit-GEMM convs at the high-resolution levels)
+    int cls = 5;         // profiling class: 0 conv3x3 (> 256 px / sample), 1 conv1x1 (> 256 px), 2 low-resolution levels, 3 attention, 4 softmax statistics, 5 other
     const char* name = "";
     std::string label;   // layer + shape, for the DDIF_OP_TIMING dump
 };
@@ -101,10 +102,13 @@ struct Plan {
 
     // profiling
     int prof_every = 0, prof_max = 0;
+    bool prof_all = false;  // time every op of a profiled step (per-class breakdown), not only the dominant class
     std::vector<hipEvent_t> ev0, ev1;
     std::vector<double> ev_flop, ev_bytes;
+    std::vector<int> ev_cls;
     int ev_used = 0;
     std::string prof_name;
+    ddif_prof_class cls_res[6] = {};  // per-class sums of the last ddif_prof_collect
 
     ~Plan();
     int build();

@@ -15,7 +15,7 @@ namespace ddif {
 // order 0 (PanCollection): [LL, H, D, V];  order 1 (CAVE / Harvard): [LL, H, V, D].
 // The bilinear x2 up-sampling is F.interpolate(mode="bilinear", align_corners=False): src = (dst + 0.5)/2 - 0.5, clamped.
 // One thread per output element of cond (B, 2C+4P, H, W); H and W even.
-__global__ void cond_assemble_kernel(const float* lms, const float* pan, float inv_div, int B, int C, int P, int H, int W,
+__global__ void cond_assemble_kernel(const float* lms, const float* pan, float div, int B, int C, int P, int H, int W,
                                      int order, float* cond) {
     const int CC = 2 * C + 4 * P, h2 = H / 2, w2 = W / 2;
     const size_t total = (size_t)B * CC * H * W;
@@ -25,9 +25,9 @@ __global__ void cond_assemble_kernel(const float* lms, const float* pan, float i
         const int b = (int)(i / ((size_t)W * H * CC));
         float v;
         if (ch < C) {
-            v = lms[(((size_t)b * C + ch) * H + y) * W + x] * inv_div;
+            v = lms[(((size_t)b * C + ch) * H + y) * W + x] / div;  // true division, as norm_func does (dataset/pan_dataset.py:127-134)
         } else if (ch < C + P) {
-            v = pan[(((size_t)b * P + (ch - C)) * H + y) * W + x] * inv_div;
+            v = pan[(((size_t)b * P + (ch - C)) * H + y) * W + x] / div;
         } else {
             const int wch = ch - C - P;  // channel of the wavelet stack: [LL x C | band1 x P | band2 x P | band3 x P]
             const float* src;
@@ -48,8 +48,8 @@ __global__ void cond_assemble_kernel(const float* lms, const float* pan, float i
             const float ly = fy - y0, lx = fx - x0;
             auto wv = [&](int yy, int xx) {
                 const float* p = src + (size_t)(2 * yy) * W + 2 * xx;
-                const float a = p[0] * inv_div, bb = p[1] * inv_div, c = p[W] * inv_div, d = p[W + 1] * inv_div;
-                return band == 0 ? (a + bb + c + d) * 0.5f : (band == 1 ? (a + bb - c - d) * 0.5f : (band == 2 ? (a - bb + c - d) * 0.5f : (a - bb - c + d) * 0.5f));
+                const float a = p[0], bb = p[1], c = p[W], d = p[W + 1];  // wavelets of the RAW data, then / division (as the datasets do)
+                return (band == 0 ? (a + bb + c + d) * 0.5f : (band == 1 ? (a + bb - c - d) * 0.5f : (band == 2 ? (a - bb + c - d) * 0.5f : (a - bb - c + d) * 0.5f))) / div;
             };
             v = (1.f - ly) * ((1.f - lx) * wv(y0, x0) + lx * wv(y0, x1)) + ly * ((1.f - lx) * wv(y1, x0) + lx * wv(y1, x1));
         }

@@ -22,9 +22,11 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import runtime as _rt
 from .diffusion.diffusion_ddpm_pan import GaussianDiffusion, make_beta_schedule
 from .models.sr3_dwt import UNetSR3
 from .runtime import DdifError
+from .sharding import cut_tiles, sample_sharded, stitch_tiles
 from .solver.dpm_solver import ImageSpaceClamp
 
 DIVISION = {"wv3": 2047.0, "gf2": 1023.0, "qb": 2047.0, "cave": 1.0, "harvard": 1.0}  # diffusion_engine.py:107
@@ -61,7 +63,12 @@ def wavelet_stack(lms: torch.Tensor, pan: torch.Tensor, dataset_name: str) -> to
 
 def assemble_cond(lms: torch.Tensor, pan: torch.Tensor, wavelets: Optional[torch.Tensor] = None,
                   dataset_name: str = "wv3") -> torch.Tensor:
-    """cond = pack[lms, pan, bilinear_up(wavelets)] (reference :221-228).  `wavelets` is computed when not given."""
+    """cond = pack[lms, pan, bilinear_up(wavelets)] (reference :221-228) from NORMALISED lms / pan.
+    Without `wavelets` (the reference's datasets precompute them on the CPU with PyWavelets) the whole assembly --
+    Haar analysis, bilinear x2, channel pack -- is ONE HIP kernel (`ddif_cond_assemble`, csrc/kernels_aux.h) when the tensors
+    live on the GPU; host tensors and dataset-provided wavelets take the torch expression the reference uses."""
+    if wavelets is None and lms.device.type == "cuda":
+        return _rt.cond_assemble(lms, pan, 1.0, 1 if dataset_name in ("cave", "harvard") else 0)
     if wavelets is None:
         wavelets = wavelet_stack(lms, pan, dataset_name)
     up = F.interpolate(wavelets, size=lms.shape[-1], mode="bilinear")
@@ -116,38 +123,70 @@ def build_model(dataset_name: str, n_steps: int, device, weight_path: Optional[s
 def test_fn(test_data_path=None, weight_path=None, schedule_type="cosine", batch_size=320, n_steps=1500, show=False,
             device="cuda:0", full_res=False, dataset_name="gf2", division=1023, *, data: Optional[dict] = None,
             state_dict: Optional[dict] = None, sampler: str = "ddim_sample", section_counts: str = "ddim25",
-            save_path: Optional[str] = None, seed: Optional[int] = None):
+            save_path: Optional[str] = None, seed: Optional[int] = None, tile: Optional[int] = None,
+            x_T: Optional[torch.Tensor] = None):
     """Reference test_fn (:352-505): same positional / keyword arguments (schedule_type is ignored there too, :408);
     keyword-only extras let it run without h5 files (`data=`), without a checkpoint file (`state_dict=`) and with the
-    DDPM sampler (`sampler="ddpm_sample"`).  Returns dict(sr=(N,C,H,W) array in raw units, psnr=[...])."""
+    DDPM sampler (`sampler="ddpm_sample"`).  Returns dict(sr=(N,C,H,W) array in raw units, psnr=[...], metrics=[...]).
+
+    `tile=t` (new; the reference feeds whole 256x256 / 512x512 scenes through the network, :373-377): cond is assembled
+    on the whole scene by the fused kernel, cut into non-overlapping t x t tiles, the tiles are sampled `batch_size` at a
+    time -- sharded over the ranks of the default process group when one is initialised, with one RCCL all-gather per
+    batch -- and stitched back.  Noise is keyed by (scene, tile) index, so the result does not depend
+    on batch_size or on the number of GPUs.  `x_T` (tiled mode only, parity tests): (N * tiles, C, t, t) initial noise."""
     if show:
         raise DdifError("show=True (matplotlib grids) is out of scope of this build")
     d = data if data is not None else _load_h5(test_data_path)
     C, P = _dataset_shape(dataset_name)
-    lms_all = torch.as_tensor(np.asarray(d["lms"]), dtype=torch.float32) / division
-    pan_all = torch.as_tensor(np.asarray(d["pan"]), dtype=torch.float32) / division
+    lms_all = torch.as_tensor(np.asarray(d["lms"]), dtype=torch.float32)  # RAW units: the cond-assembly kernel normalises
+    pan_all = torch.as_tensor(np.asarray(d["pan"]), dtype=torch.float32)
     gt_all = None if (full_res or "gt" not in d) else torch.as_tensor(np.asarray(d["gt"]), dtype=torch.float32) / division
     if lms_all.shape[1] != C or pan_all.shape[1] != P:
         raise DdifError(f"{dataset_name}: expected lms with {C} and pan with {P} channels, got {tuple(lms_all.shape)} / {tuple(pan_all.shape)}")
     _, diffusion = build_model(dataset_name, n_steps, device, weight_path, state_dict, image_size=lms_all.shape[-1])
     if seed is not None:
         torch.manual_seed(seed)
-    preds, scores = [], []
-    for i in range(0, lms_all.shape[0], batch_size):
-        lms = lms_all[i:i + batch_size].to(device)
-        pan = pan_all[i:i + batch_size].to(device)
-        cond = assemble_cond(lms, pan, None, dataset_name)
-        if diffusion.num_timesteps != n_steps:  # ddim_sample_loop respaced the schedule in place on the previous batch
-            pass  # the reference keeps sampling with the respaced schedule too (SURVEY appendix D-2)
-        if sampler == "ddim_sample":
-            sr = diffusion(cond, mode="ddim_sample", section_counts=section_counts)
-        else:
-            sr = diffusion(cond, mode="ddpm_sample")
-        sr = (sr + lms).clip(0, 1)  # reference :446-447
-        if gt_all is not None:
-            scores.append(psnr(gt_all[i:i + batch_size], sr.cpu()))
-        preds.append((sr.cpu().numpy() * division).clip(0, division))
-    out = dict(sr=np.concatenate(preds, axis=0), psnr=scores)
+    preds, scores, mets = [], [], []
+    wave_order = 1 if dataset_name in ("cave", "harvard") else 0
+    H, W = lms_all.shape[-2:]
+    if tile is not None and (H > tile or W > tile):
+        if H % tile or W % tile:
+            raise DdifError(f"scene {H}x{W} is not a multiple of tile={tile}")
+        ny, nx = H // tile, W // tile
+        mode_kw = dict(section_counts=section_counts) if sampler == "ddim_sample" else {}
+        base_seed = 0 if seed is None else seed
+        for i in range(lms_all.shape[0]):  # one scene at a time: assemble on the scene, cut, sample, stitch
+            raw_l, raw_p = lms_all[i:i + 1].to(device), pan_all[i:i + 1].to(device)
+            cond_scene = _rt.cond_assemble(raw_l, raw_p, float(division), wave_order)[0]
+            tiles = cut_tiles(cond_scene, tile)
+            out_tiles = []
+            for j in range(0, tiles.shape[0], batch_size):
+                xt = None if x_T is None else x_T[i * ny * nx + j: i * ny * nx + j + batch_size].to(device)
+                out_tiles.append(sample_sharded(diffusion, tiles[j:j + batch_size].contiguous(), mode=sampler, seed=base_seed, x_T=xt,
+                                                tile_base=i * ny * nx + j, **mode_kw))
+            sr = stitch_tiles(torch.cat(out_tiles, dim=0), ny, nx).unsqueeze(0)
+            if gt_all is not None:
+                gt = gt_all[i:i + 1].to(device)
+                scores.append(psnr(gt.cpu(), sr.cpu()))
+                mets.append(_rt.metrics(gt, sr, 4.0).cpu().numpy())  # SAM / ERGAS / PSNR / CC on the GPU (reference :449)
+            preds.append((sr.cpu().numpy() * division).clip(0, division))
+    else:
+        for i in range(0, lms_all.shape[0], batch_size):
+            raw_l, raw_p = lms_all[i:i + batch_size].to(device), pan_all[i:i + batch_size].to(device)
+            cond = _rt.cond_assemble(raw_l, raw_p, float(division), wave_order)
+            lms = cond[:, :C]
+            if sampler == "ddim_sample":
+                sr = diffusion(cond, mode="ddim_sample", section_counts=section_counts)  # respaces the schedule in place, once (SURVEY D-2)
+            else:
+                sr = diffusion(cond, mode="ddpm_sample")
+            sr = (sr + lms).clip(0, 1)  # reference :446-447
+            if gt_all is not None:
+                gt = gt_all[i:i + batch_size].to(device)
+                scores.append(psnr(gt.cpu(), sr.cpu()))
+                mets.append(_rt.metrics(gt, sr, 4.0).cpu().numpy())
+            preds.append((sr.cpu().numpy() * division).clip(0, division))
+    out = dict(sr=np.concatenate(preds, axis=0), psnr=scores,
+               metrics=(np.concatenate(mets, axis=0) if mets else np.zeros((0, 4), np.float32)))  # columns: SAM, ERGAS, PSNR (ref. sign), CC
     if save_path is not None:
         from scipy.io import savemat
 

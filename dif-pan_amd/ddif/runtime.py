@@ -56,6 +56,11 @@ class ProfResult(C.Structure):
                 ("total_bytes", C.c_double), ("kernel_name", C.c_char * 128)]
 
 
+class ProfClass(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flop", C.c_double), ("total_bytes", C.c_double),
+                ("name", C.c_char * 64)]
+
+
 class _Lib:
     def __init__(self, path: str):
         if not os.path.exists(path):
@@ -88,6 +93,7 @@ class _Lib:
         d.ddif_plan_q_sample_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
         d.ddif_prof_begin.argtypes = [vp, i32, i32]
         d.ddif_prof_collect.argtypes = [vp, C.POINTER(ProfResult)]
+        d.ddif_prof_classes.argtypes = [vp, C.POINTER(ProfClass)]
         d.ddif_plan_cost.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
         d.ddif_debug_set_grid_cap.argtypes = [i32]
         d.ddif_cond_assemble.argtypes = [vp, vp, f32, i32, i32, i32, i32, i32, i32, vp, vp]
@@ -368,8 +374,12 @@ class PlanHandle:
     def prof_collect(self) -> dict:
         r = ProfResult()
         self.lib.check(self.lib.dll.ddif_prof_collect(self.h, C.byref(r)), "ddif_prof_collect")
+        cls = (ProfClass * 6)()
+        self.lib.check(self.lib.dll.ddif_prof_classes(self.h, cls), "ddif_prof_classes")
+        classes = [dict(name=c.name.decode(), launches=c.launches, total_ms=c.total_ms, total_flop=c.total_flop, total_bytes=c.total_bytes)
+                   for c in cls]
         return dict(launches=r.launches, total_ms=r.total_ms, total_flop=r.total_flop, total_bytes=r.total_bytes,
-                    kernel=r.kernel_name.decode())
+                    kernel=r.kernel_name.decode(), classes=classes)
 
     def cost(self) -> dict:
         v = [C.c_double() for _ in range(4)]

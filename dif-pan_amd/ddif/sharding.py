@@ -38,16 +38,21 @@ def stitch_tiles(tiles: torch.Tensor, ny: int, nx: int) -> torch.Tensor:
     return tiles.reshape(ny, nx, C, h, w).permute(2, 0, 3, 1, 4).reshape(C, ny * h, nx * w).contiguous()
 
 
-def sample_sharded(diffusion, cond_all: torch.Tensor, mode: str = "ddpm_sample", seed: int = 0, **kw) -> torch.Tensor:
+def sample_sharded(diffusion, cond_all: torch.Tensor, mode: str = "ddpm_sample", seed: int = 0, x_T: torch.Tensor = None,
+                   tile_base: int = 0, **kw) -> torch.Tensor:
     """Sample every tile of `cond_all` (n_tiles, 2C+4P, h, w; the same tensor on every rank) with the tiles split over
     the ranks of the default process group, then all-gather.  Returns sr = clip(residual + lms, 0, 1) for ALL tiles on
-    every rank.  The noise stream is keyed by global tile index, so the result does not depend on the world size."""
+    every rank.  The noise stream is keyed by global tile index (`tile_base` + index in `cond_all`), so the result does
+    not depend on the world size or on how a scene's tiles are batched.  `x_T` (n_tiles, C, h, w), optional, pins the
+    initial noise (parity tests); by default it comes from the same counter-based generator."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_range(cond_all.shape[0], rank, world)
     cond = cond_all[lo:hi].contiguous()
     C = diffusion.channels
-    res = diffusion(cond, mode=mode, seed=seed, tile0=lo, device_rng=True, **kw)
+    if x_T is not None:
+        kw = dict(kw, x_T=x_T[lo:hi].contiguous())
+    res = diffusion(cond, mode=mode, seed=seed, tile0=tile_base + lo, device_rng=x_T is None, **kw)
     sr = (res + cond[:, :C]).clip(0, 1)  # diffusion_engine.py:446-447
     if world == 1:
         return sr

@@ -195,6 +195,15 @@ typedef struct ddif_prof_result {
     char kernel_name[128];
 } ddif_prof_result;
 DDIF_API int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out);
+/* Per-class breakdown of the same profiled steps (EVERY launch of a profiled step is bracketed): six entries -- 3x3 convs and
+ * 1x1 convs of the levels with more than 256 pixels per sample, everything at the low-resolution levels, bottleneck
+ * attention, softmax statistics, other.  Valid after ddif_prof_collect. */
+typedef struct ddif_prof_class {
+    int64_t launches;
+    double total_ms, total_flop, total_bytes;
+    char name[64];
+} ddif_prof_class;
+DDIF_API int ddif_prof_classes(ddif_plan_t plan, ddif_prof_class* out6);
 
 /* flops / bytes of one denoising step and of set_cond for this plan (algorithmic, SURVEY.md 8d accounting) */
 DDIF_API int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes);

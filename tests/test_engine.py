@@ -1,4 +1,6 @@
 """Host-side engine pieces (CPU) and the test_fn mirror (GPU): cond assembly, Haar identities, tiling."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -72,3 +74,44 @@ def test_test_fn_on_in_memory_set():
                                noise_fn=lambda s: next(it))
     ref_sr = ((ref + cond[:, :4]).clip(0, 1) * div).numpy()
     assert float(np.abs(out["sr"][:2] - ref_sr).max()) <= 1e-4 * div
+
+
+@pytest.mark.gpu
+def test_test_fn_tiled_scene_matches_per_tile_runs_and_oracle(tmp_path):
+    """a 64x64 GF2 scene cut into four 32x32 tiles inside test_fn (cond assembled on the whole scene by the
+    fused kernel, tiles sampled in two batches of 2, stitched, written as .mat).  Checked against (a) the oracle on every
+    tile with the same initial noise and (b) the stitching order."""
+    from scipy.io import loadmat
+
+    from ddif.sharding import cut_tiles, stitch_tiles
+    from ddif_testlib import use_gpu_library
+    from oracle import ddif_oracle as O
+
+    use_gpu_library()
+    ds, Hs, tile, div = "gf2", 64, 32, 1023.0
+    t = gc.tiles_for(ds, 1, Hs, Hs, seed=21)
+    raw = dict(lms=(t["lms"] * div).round().numpy(), pan=(t["pan"] * div).round().numpy(), gt=(t["gt"] * div).round().numpy())
+    g = torch.Generator().manual_seed(22)
+    xT = torch.randn(4, 4, tile, tile, generator=g)
+    mat = os.path.join(tmp_path, "out.mat")
+    out = E.test_fn(None, None, batch_size=2, n_steps=50, device="cuda:0", dataset_name=ds, division=div, data=raw,
+                    state_dict=gc.weights_for(ds), tile=tile, x_T=xT, save_path=mat)
+    assert out["sr"].shape == (1, 4, Hs, Hs) and out["metrics"].shape == (1, 4)
+    # oracle: cond of the whole scene (raw data / division, Haar, bilinear), cut the same way, DDIM-25 from T=50 per tile
+    cond_scene = O.assemble_cond(torch.from_numpy(raw["lms"]), torch.from_numpy(raw["pan"]), div)[0]
+    ctiles = cut_tiles(cond_scene, tile)
+    tabs = O.schedule_tables(O.cosine_betas(50))
+    refs = []
+    for k in range(4):
+        it = iter([xT[k:k + 1]] + [torch.zeros(1, 4, tile, tile)] * 25)
+        with torch.no_grad():
+            r, _ = O.ddim_sample(gc.weights_for(ds), gc.cfg_for(ds), ctiles[k:k + 1], tabs, "ddim25", noise_fn=lambda s: next(it))
+        refs.append((r + ctiles[k:k + 1, :4]).clip(0, 1))
+    ref_scene = stitch_tiles(torch.cat(refs), 2, 2).numpy() * div
+    assert float(np.abs(out["sr"][0] - ref_scene).max()) <= 1e-4 * div
+    # metrics column 2 is the reference-sign PSNR of the stitched scene (utils/_metric_legacy.py:341-346)
+    gt_n = torch.from_numpy(raw["gt"]) / div
+    m = O.analysis_accu(gt_n[0].permute(1, 2, 0), torch.from_numpy(ref_scene / div).float().permute(1, 2, 0), 4)
+    assert abs(float(out["metrics"][0, 2]) - m["PSNR"]) <= 1e-3 and abs(float(out["metrics"][0, 0]) - m["SAM"]) <= 1e-2
+    saved = loadmat(mat)
+    assert saved["sr"].shape == (1, 4, Hs, Hs) and np.allclose(saved["sr"], out["sr"])

@@ -1,11 +1,15 @@
 #!/bin/bash
-# usage: tools/gpu_full.sh <tag>   -- everything a round's profiles/ needs, in one gpurun call:
-#   gpu tests, rocprofv3 kernel stats (T=20), two PMC passes (FETCH_SIZE, WRITE_SIZE; T=4), the default bench (T=1000)
+# usage: tools/gpu_full.sh <tag> [skip-tests]  -- everything a round's profiles/ needs, in one gpurun call:
+#   gpu tests, rocprofv3 kernel stats (T=20), PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy; T=4), op-by-op timing (T=40),
+#   the default bench (T=1000, with cpu_baseline) and the two other BASELINE configurations
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-(python -m pytest tests -m gpu -q -x 2>&1 | tail -6) > $R/gpurun_out/${tag}_tests.log 2>&1
-cat $R/gpurun_out/${tag}_tests.log
+export DDIF_BUILD_ID=$(python3 -c "import bench; print(bench.build_id())")
+if [ "$1" != "skip-tests" ]; then
+  (python -m pytest tests -m gpu -q -x 2>&1 | tail -8) > $R/gpurun_out/${tag}_tests.log 2>&1
+  cat $R/gpurun_out/${tag}_tests.log
+fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python3 $R/bench.py --steps 1 --warmup 1 --T 20 --no-cpu-baseline > $R/gpurun_out/${tag}_bench_T20.json 2> /tmp/prof_$tag.log
@@ -16,6 +20,28 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 $R/tools/pmc_summary.py $(find /tmp/pmc_$c -name "*counter_collection.csv") 60 > $R/gpurun_out/${tag}_pmc_$c.csv
 done
 python3 $R/tools/pmc_traffic.py $R/gpurun_out/${tag}_pmc_FETCH_SIZE.csv $R/gpurun_out/${tag}_pmc_WRITE_SIZE.csv $R/gpurun_out/${tag}_hbm_traffic.json
+rm -rf /tmp/pmc_mfma
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --output-format csv -d /tmp/pmc_mfma -o p -- python3 $R/bench.py --steps 1 --warmup 0 --T 4 --no-cpu-baseline > /dev/null 2> /tmp/pmc_mfma.log
+f=$(find /tmp/pmc_mfma -name "*counter_collection.csv")
+if [ -n "$f" ]; then
+  python3 $R/tools/pmc_summary.py $f 60 > $R/gpurun_out/${tag}_pmc_mfma.csv
+  python3 $R/tools/pmc_mfma.py $f $R/gpurun_out/${tag}_mfma_busy.json
+else
+  tail -5 /tmp/pmc_mfma.log
+fi
 cd $R
+DDIF_OP_TIMING=$R/gpurun_out/${tag}_op_timing_T40_B64.csv python3 bench.py --steps 1 --warmup 1 --T 40 --no-cpu-baseline > /dev/null 2>&1
+cp gpurun_out/${tag}_hbm_traffic.json profiles/ 2>/dev/null   # so that the bench line below can tie its traffic to this build
 python3 bench.py > gpurun_out/${tag}_bench_T1000_B64.json 2> gpurun_out/${tag}_bench_T1000_B64.log
 cat gpurun_out/${tag}_bench_T1000_B64.json
+python3 bench.py --config gf2_dpm50 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_gf2_dpm50.json 2> gpurun_out/${tag}_bench_gf2_dpm50.log
+python3 bench.py --config cave128_t2000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${tag}_bench_cave128_t2000.json 2> gpurun_out/${tag}_bench_cave128_t2000.log
+python3 - <<PY
+import json
+for n in ("gf2_dpm50", "cave128_t2000"):
+    try:
+        r = json.load(open("gpurun_out/${tag}_bench_%s.json" % n))
+        print(n, r["value"], r["unit"], "ms/job", r["ms_per_step"], "job TF", r["roofline"]["whole_step"]["tflops"])
+    except Exception as e:
+        print(n, "failed", e)
+PY

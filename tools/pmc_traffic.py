@@ -47,6 +47,9 @@ def main():
            "class_regex": pat.pattern, "class_launches": nl,
            "class_fetch_bytes_per_launch": fb / max(nl, 1), "class_write_bytes_per_launch": wb / max(nl, 1),
            "class_hbm_bytes_per_launch": (fb + wb) / max(nl, 1), "kernels": rows[:40]}
+    import os
+    if os.environ.get("DDIF_BUILD_ID"):
+        res["build_id"] = os.environ["DDIF_BUILD_ID"]  # sha1 over csrc/ (bench.py build_id()): ties the profile to the build it measured
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "kernels"}))
 
