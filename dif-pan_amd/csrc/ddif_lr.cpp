@@ -2,6 +2,7 @@
 // in parallel with the main conv kernel family (ddif_plan.cpp).
 #include "ddif_plan.h"
 #include "kernels_lr.h"
+#include "kernels_attn.h"
 
 namespace ddif {
 
@@ -40,6 +41,16 @@ ConvVariant lr_for(int ks, int pro, int epi) {
     return ConvVariant();
 }
 }  // namespace
+
+// Fused bottleneck attention block (kernels_attn.h): launch helper (the kernel lives in this translation unit)
+size_t attn_block_smem() { return AttnBlockGeom::smem; }
+int attn_block_prepare() {
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
+    return 0;
+}
+void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(attn_block_kernel, dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
+}
 
 // mb = 2: 8x8 pixel tiles, mb = 4: 8x16.  The per-sample time bias needs no variant of its own here (the epilogue reads
 // bias and time-bias rows straight from memory), so EPI_TBS is accepted and ignored.

@@ -4,6 +4,7 @@
 #include "ddif_plan.h"
 #include "kernels_conv.h"
 #include "kernels_misc.h"
+#include "attn_args.h"
 
 namespace ddif {
 
@@ -440,6 +441,38 @@ int Plan::build() {
     auto attention = [&](const std::string& ap, Tensor in, Tensor* out) -> int {
         const PackedConv *cq = PC(ap + ".qkv"), *co = PC(ap + ".out");
         if (!cq || !co) return fail(DDIF_ERR_MISSING, "%s: conv weights missing", ap.c_str());
+        if (in.H * in.W == 64 && in.C == 128 && x3_enabled() && lr_enabled() && cq->w_x3 && co->w_x3 && cq->ck == 32 && co->ck == 32 && in.st) {
+            // 64-token tiles: GroupNorm -> qkv -> softmax(q k^T / sqrt(C)) v -> out + bias + x in ONE kernel, one workgroup per
+            // sample (kernels_attn.h); other sizes take the three-launch path below
+            DDIF_TRY(alloc_tensor(out, in.C, in.H, in.W));
+            out->np = 1;
+            DDIF_TRY(dalloc(&out->st, (size_t)B * 2));
+            DDIF_TRY(attn_block_prepare());
+            AttnBlockArgs a{};
+            a.x = in.p;
+            a.st = in.st;
+            a.np = in.np;
+            a.gamma = V(ap + ".norm.weight");
+            a.beta = V(ap + ".norm.bias");
+            a.wqkv = cq->w_x3;
+            a.wout = co->w_x3;
+            a.bout = co->bias ? co->bias : zeros;
+            a.scale = 1.0f / std::sqrt((float)in.C);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)
+            a.out = out->p;
+            a.st_out = out->st;
+            a.B = B;
+            if (!a.gamma || !a.beta) return fail(DDIF_ERR_MISSING, "%s: norm weights missing", ap.c_str());
+            Op op;
+            op.name = "attn_block";
+            op.label = "attn_block (GN + qkv + attention + out + residual) @8x8";
+            op.cls = 3;
+            op.flop = 2.0 * B * 64 * 128.0 * (384 + 128) + 4.0 * B * 8 * 64.0 * 64 * 16;
+            op.bytes = 8.0 * B * 64 * 128;
+            const int grid = B < num_cus() ? B : num_cus();
+            op.run = [a, grid](hipStream_t s, const StepCtx&) { attn_block_launch(a, grid, s); };
+            step.push_back(std::move(op));
+            return 0;
+        }
         Tensor qkv, o;
         ConvSpec s1;
         s1.pc = cq;

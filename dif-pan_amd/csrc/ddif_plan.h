@@ -43,6 +43,9 @@ struct ConvVariant {
 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi);
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi);  // ddif_lr.cpp
+struct AttnBlockArgs;
+int attn_block_prepare();                                                        // ddif_lr.cpp (kernels_attn.h)
+void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s);
 
 struct ConvSpec {
     const PackedConv* pc = nullptr;

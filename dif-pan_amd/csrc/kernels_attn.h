@@ -1,0 +1,294 @@
+// Fused bottleneck self-attention block for 64-token tiles (the 8x8 level of a 64x64 tile), gfx950.
+//
+// Reference: SelfAttention.forward (models/sr3_dwt.py:341-360) = GroupNorm(1 group) -> 1x1 conv 128 -> 384 (no bias) ->
+// per-head [q | k | v] split -> softmax(q k^T / sqrt(C)) v -> 1x1 conv 128 -> 128 + bias -> + input.
+// As three launches (qkv conv, attention core, out conv) this block costs 49 us per instance at B = 64 and there are
+// eight instances per denoising step; none of the three has more than 3 us of work.  Here ONE workgroup (4 wavefronts)
+// owns a sample and keeps everything between the input and the output on chip:
+//   1. xn = GroupNorm(x) staged into LDS as three bf16 planes (64 tokens x 128 channels);
+//   2. qkv = xn . Wqkv^T on v_mfma_f32_32x32x16_bf16 with bf16x3 split products (wave w computes cout blocks 3w..3w+2,
+//      weights straight from L2 into the MFMA operand registers, next slab prefetched), result to LDS as fp32;
+//   3. attention, two heads per wave, exact fp32 on v_mfma_f32_16x16x4_f32 -- the algorithm of self_attn_mfma_kernel
+//      (S^T = K Q^T so that the accumulator layout IS the A-operand layout of P V; max pass, then exp / sum / PV pass),
+//      reading q, k, v from LDS; head hd's 16 output channels are exactly slab hd of the next contraction and are written
+//      back to LDS as bf16 planes;
+//   4. out = o . Wout^T + bias + x (wave w computes cout block w), float4 NHWC stores, GroupNorm partial of the output.
+// Arithmetic per stage is the same as in the unfused kernels (bf16x3 for the two 1x1 convs, exact fp32 for the
+// attention core, fast exp only where they use it), so results agree to rounding-order level.
+#pragma once
+#include "kernels_conv.h"
+#include "attn_args.h"
+
+namespace ddif {
+
+struct AttnBlockGeom {
+    static constexpr int N = 64, C = 128, NSLAB = 8;
+    static constexpr int APIX = NSLAB * 24 + 4;  // floats per token of the bf16-plane tile (8 slabs x 3 planes x 32 B + 16 B pad)
+    static constexpr int QROW = 3 * C + 4;       // floats per token of the fp32 qkv tile
+    static constexpr int AFL = N * APIX, QFL = N * QROW;
+    static constexpr size_t smem = (size_t)(AFL + QFL + 16) * sizeof(float);
+};
+
+__global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
+    using G = AttnBlockGeom;
+    constexpr int N = G::N, C = G::C, NSLAB = G::NSLAB, APIX = G::APIX, QROW = G::QROW, D = 16;
+    DDIF_DYN_SMEM(smem);
+    float* As = reinterpret_cast<float*>(smem);  // bf16 planes: xn, later o
+    float* Qs = As + G::AFL;                     // fp32 qkv [token][384]
+    float* Sst = Qs + G::QFL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DDIF_EMU
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int h = lane >> 5, j = lane & 31;
+    const int c4 = tid & 31, p0 = tid >> 5;  // staging: 32 float4 channel groups x 8 tokens per pass
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        // ---- (1) loads in one burst: GroupNorm partials, the sample, affine parameters, first weight slab
+        GnPartials gp;
+        gn_load_partials(a.st, a.np, nullptr, 0, b, &gp);
+        float4 sv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) sv[it] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + p0 + it * 8) * C + c4 * 4);
+        const float4 gq = *reinterpret_cast<const float4*>(a.gamma + c4 * 4);
+        const float4 bq = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
+        // qkv weights of this wave: cout blocks 3w .. 3w+2, slab s, plane q at ((nb * 8 + s) * 3 + q) KiB
+        const char* wq = reinterpret_cast<const char*>(a.wqkv) + (size_t)lane * 16;
+        float4 wr[2][3][3];  // [ring slot][cout block][plane]
+        auto load_qkv_w = [&](int slot, int s) {
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) wr[slot][nb][q] = *reinterpret_cast<const float4*>(wq + ((((size_t)(3 * wave + nb)) * NSLAB + s) * 3 + q) * 1024);
+        };
+        load_qkv_w(0, 0);
+        float mean, rstd;
+        gn_reduce_partials(gp, a.st, a.np, nullptr, 0, b, (double)C * N, &mean, &rstd);
+        {
+            float ga[4], gb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ga[i] = (&gq.x)[i] * rstd;
+                gb[i] = (&bq.x)[i] - mean * ga[i];
+            }
+            const int slab = c4 >> 2, cin_slab = (c4 & 3) * 4;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int tok = p0 + it * 8;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaf((&sv[it].x)[i], ga[i], gb[i]);
+                unsigned h01, m01, l01, h23, m23, l23;
+                dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
+                dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
+                float* d = &As[tok * APIX + slab * 24 + cin_slab / 2];
+                *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
+                *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
+            }
+        }
+        __syncthreads();
+
+        // ---- (2) qkv = xn . Wqkv^T : 2 token blocks x 3 cout blocks per wave, K = 8 slabs
+        {
+            f32x16 acc[2][3];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NSLAB; ++s) {
+                if (s + 1 < NSLAB) load_qkv_w((s + 1) & 1, s + 1);
+                float4 xa[2][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[(mb * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
+                DDIF_SCHED_FENCE();
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        f32x16 c = acc[mb][nb];
+                        const float4* w = wr[s & 1][nb];
+                        c = DDIF_MFMA_32x32x16_BF16(w[2], xa[mb][0], c);  // lo * hi
+                        c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][2], c);  // hi * lo
+                        c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][1], c);  // mid * mid
+                        c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][0], c);  // mid * hi
+                        c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][1], c);  // hi * mid
+                        c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][0], c);  // hi * hi
+                        acc[mb][nb] = c;
+                    }
+                DDIF_SCHED_FENCE();
+            }
+            // lane (j, h) owns token mb*32 + j and, per quad g, couts nb*32 + 8g + 4h .. +3
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(&Qs[(mb * 32 + j) * QROW + (3 * wave + nb) * 32 + 8 * g + 4 * h]) =
+                            make_float4(acc[mb][nb][4 * g + 0], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]);
+        }
+        // out-projection weights of this wave (cout block `wave`): first slab, in flight during the attention core
+        const char* wo = reinterpret_cast<const char*>(a.wout) + (size_t)lane * 16;
+        float4 wo_r[2][3];
+        auto load_out_w = [&](int slot, int s) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wo_r[slot][q] = *reinterpret_cast<const float4*>(wo + ((((size_t)wave) * NSLAB + s) * 3 + q) * 1024);
+        };
+        load_out_w(0, 0);
+        __syncthreads();  // qkv complete in LDS; xn (As) is dead
+
+        // ---- (3) attention core: heads 2w, 2w+1; n = 64 keys = one key block
+        {
+            const int jj = lane & 15, g4 = lane >> 4;
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {
+                const int hd = 2 * wave + hh;
+                const float* base = Qs + hd * 3 * D;  // + token * QROW + {0, D, 2D} + d
+                float4 qf[4], kf[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    qf[t4] = *reinterpret_cast<const float4*>(base + (t4 * 16 + jj) * QROW + 4 * g4);
+                    kf[t4] = *reinterpret_cast<const float4*>(base + (t4 * 16 + jj) * QROW + D + 4 * g4);
+                }
+                f32x4 st[4][4];  // [kt][qt]: S^T tiles; value r <-> key 16 kt + 4 g4 + r, query 16 qt + jj
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) {
+                        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) c = DDIF_MFMA_16x16x4((&kf[kt].x)[kk], (&qf[qt].x)[kk], c);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c[r] *= a.scale;
+                        st[kt][qt] = c;
+                    }
+                float m[4], inv[4];
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    float bm = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bm = fmaxf(bm, st[kt][qt][r]);
+                    bm = fmaxf(bm, __shfl_xor(bm, 16));
+                    bm = fmaxf(bm, __shfl_xor(bm, 32));
+                    float ps = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ps += dd_exp(st[kt][qt][r] - bm);
+                    ps += __shfl_xor(ps, 16);
+                    ps += __shfl_xor(ps, 32);
+                    m[qt] = bm;
+                    inv[qt] = 1.f / ps;
+                }
+                f32x4 oacc[4];
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[qt][r] = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    float vf[4];  // B operand of P V: V[key 16 kt + 4 g4 + r][channel jj]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vf[r] = base[(kt * 16 + 4 * g4 + r) * QROW + 2 * D + jj];
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = dd_exp(st[kt][qt][r] - m[qt]) * inv[qt];
+                            oacc[qt] = DDIF_MFMA_16x16x4(p, vf[r], oacc[qt]);
+                        }
+                }
+                // O tile: col = jj = channel hd*16 + jj, row = 4 g4 + r = query 16 qt + 4 g4 + r  -> slab hd of the o planes
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned q0, q1, q2;
+                        dd_split3(oacc[qt][r], &q0, &q1, &q2);
+                        unsigned short* d16 = reinterpret_cast<unsigned short*>(&As[(qt * 16 + 4 * g4 + r) * APIX + hd * 24]) + jj;
+                        d16[0] = (unsigned short)q0;
+                        d16[16] = (unsigned short)q1;  // next plane: + 8 floats = 16 halves
+                        d16[32] = (unsigned short)q2;
+                    }
+            }
+        }
+        __syncthreads();  // o planes complete
+
+        // ---- (4) out = o . Wout^T + bias + x : cout block `wave`, 2 token blocks, K = 8 slabs
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+            // epilogue operands: bias and the residual rows of this lane's two tokens
+            float4 bo[4], er[2][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bo[g] = *reinterpret_cast<const float4*>(a.bout + wave * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) er[mb][g] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + mb * 32 + j) * C + wave * 32 + 8 * g + 4 * h);
+            }
+#pragma unroll
+            for (int s = 0; s < NSLAB; ++s) {
+                if (s + 1 < NSLAB) load_out_w((s + 1) & 1, s + 1);
+                float4 xa[2][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[(mb * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
+                DDIF_SCHED_FENCE();
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    f32x16 c = acc[mb];
+                    const float4* w = wo_r[s & 1];
+                    c = DDIF_MFMA_32x32x16_BF16(w[2], xa[mb][0], c);
+                    c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][2], c);
+                    c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][1], c);
+                    c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][0], c);
+                    c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][1], c);
+                    c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][0], c);
+                    acc[mb] = c;
+                }
+                DDIF_SCHED_FENCE();
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (acc[mb][4 * g + i] + (&bo[g].x)[i]) + (&er[mb][g].x)[i];
+                    *reinterpret_cast<float4*>(a.out + ((size_t)b * N + mb * 32 + j) * C + wave * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+                    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            if (a.st_out) {
+                const float t1 = wave_sum_fast(s1), t2 = wave_sum_fast(s2);  // total in lane 63
+                if (lane == 63) {
+                    Sst[wave * 2 + 0] = t1;
+                    Sst[wave * 2 + 1] = t2;
+                }
+            }
+        }
+        __syncthreads();  // (also: As / Qs are free for the next sample)
+        if (a.st_out && tid == 0) {
+            a.st_out[(size_t)b * 2 + 0] = ((double)Sst[0] + (double)Sst[2]) + ((double)Sst[4] + (double)Sst[6]);
+            a.st_out[(size_t)b * 2 + 1] = ((double)Sst[1] + (double)Sst[3]) + ((double)Sst[5] + (double)Sst[7]);
+        }
+    }
+}
+
+}  // namespace ddif
