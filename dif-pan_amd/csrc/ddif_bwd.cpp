@@ -1,0 +1,149 @@
+// Host side of the 3x3 convolution backward op (kernels_bwd.h): the first building block of the training step
+// (SURVEY.md 8(a) a15).  extern "C" entry points are declared in include/ddif.h.
+#include "ddif_plan.h"
+#include "kernels_bwd.h"
+
+namespace ddif {
+namespace {
+inline dim3 grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g);
+}
+}  // namespace
+
+struct ConvBwd {
+    int device = 0, B = 0, Cin = 0, Cout = 0, H = 0, W = 0;
+    Net net;          // only its cfg is read (add_conv's launch closure); no weights
+    Plan plan;        // owns every device buffer of this op
+    PackedConv pc;    // the dgrad conv: Cout "input" channels -> Cin "output" channels, weights = wpack
+    float *x_nhwc = nullptr, *dy_nhwc = nullptr, *wpack = nullptr, *partial = nullptr, *bpart = nullptr;
+    Tensor dx;        // NHWC output of the dgrad conv
+    std::vector<Op> prog;
+    int n_chunks = 0, nb_pad = 0, n_co = 0, n_ci = 0, nsplit = 0, rb = 4, nbchunk = 0;
+    size_t wg_smem = 0;
+};
+}  // namespace ddif
+
+struct ddif_convbwd {
+    ddif::ConvBwd c;
+};
+
+extern "C" {
+
+int ddif_convbwd_create(ddif_convbwd_t* out, int B, int Cin, int Cout, int H, int W, int device) {
+    if (!out || B < 1 || Cin < 4 || Cout < 4 || (Cin & 3) || (Cout & 3) || H < 1 || W < 1)
+        return ddif::fail(DDIF_ERR_INVALID, "ddif_convbwd_create: B >= 1, 4 | Cin, 4 | Cout, H, W >= 1 required");
+    *out = nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    DDIF_HIPCHK(hipSetDevice(device));
+    std::unique_ptr<ddif_convbwd> h(new ddif_convbwd());
+    ddif::ConvBwd& c = h->c;
+    c.device = device;
+    c.B = B; c.Cin = Cin; c.Cout = Cout; c.H = H; c.W = W;
+    c.plan.net = &c.net;
+    c.plan.B = B;
+    c.plan.H = H;
+    c.plan.W = W;
+    int rc = 0;
+    auto TRY = [&](int e) { if (!rc) rc = e; };
+    TRY(c.plan.dalloc(&c.plan.zeros, (size_t)1024));
+    if (!rc && hipMemset(c.plan.zeros, 0, 1024 * sizeof(float)) != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_create: hipMemset failed");
+    TRY(c.plan.dalloc(&c.x_nhwc, (size_t)B * H * W * Cin));
+    TRY(c.plan.dalloc(&c.dy_nhwc, (size_t)B * H * W * Cout));
+    // dgrad conv: "cin" = Cout (16-channel chunks), "cout" = Cin
+    c.n_chunks = (Cout + 15) / 16;
+    c.nb_pad = (((Cin + 31) / 32) + 3) & ~3;
+    TRY(c.plan.dalloc(&c.wpack, (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256));
+    c.pc.w = c.wpack;
+    c.pc.cin = Cout;
+    c.pc.cout = Cin;
+    c.pc.ks = 3;
+    c.pc.ck = 16;
+    c.pc.n_chunks = c.n_chunks;
+    if (!rc) {
+        ddif::ConvSpec s;
+        s.pc = &c.pc;
+        s.in0.p = c.dy_nhwc;
+        s.in0.C = Cout;
+        s.in0.H = H;
+        s.in0.W = W;
+        s.use_bias = false;
+        s.exact = true;  // gradients on the exact-fp32 MFMA (bitwise an fmaf chain)
+        s.name = "conv3x3.dgrad";
+        TRY(c.plan.add_conv(c.prog, s, &c.dx));
+    }
+    // wgrad: (co block, ci block) x K splits; rows per band = the largest of {4, 2, 1} whose tiles fit 150 KB of LDS
+    c.n_co = (Cout + 31) / 32;
+    c.n_ci = (Cin + 31) / 32;
+    for (c.rb = 4; c.rb >= 1; c.rb >>= 1) {
+        c.wg_smem = ((size_t)c.rb * W * 32 + (size_t)(c.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
+        if (c.wg_smem <= 150 * 1024) break;
+    }
+    if (!rc && c.rb < 1) rc = ddif::fail(DDIF_ERR_INVALID, "ddif_convbwd_create: W=%d is too wide for the wgrad kernel's LDS tiles", W);
+    if (!rc) {
+        const int bands = B * ((H + c.rb - 1) / c.rb);
+        int want = (2 * 256) / (c.n_co * c.n_ci);  // ~2 workgroups per CU in total
+        if (want < 1) want = 1;
+        if (want > bands) want = bands;
+        if (want > 256) want = 256;
+        c.nsplit = want;
+        TRY(c.plan.dalloc(&c.partial, (size_t)c.nsplit * c.n_co * c.n_ci * 9 * 1024));
+        c.nbchunk = 64;
+        TRY(c.plan.dalloc(&c.bpart, (size_t)c.nbchunk * Cout));
+        if (!rc && c.wg_smem > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.wg_smem) != hipSuccess)
+            rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_create: hipFuncSetAttribute failed");
+    }
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (rc) return rc;
+    *out = h.release();
+    return DDIF_OK;
+}
+
+void ddif_convbwd_destroy(ddif_convbwd_t h) { delete h; }
+
+int ddif_convbwd_run(ddif_convbwd_t h, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, void* stream) {
+    if (!h || !dy || !w) return ddif::fail(DDIF_ERR_INVALID, "ddif_convbwd_run: NULL argument");
+    if ((dw && !x)) return ddif::fail(DDIF_ERR_INVALID, "ddif_convbwd_run: dw needs x");
+    ddif::ConvBwd& c = h->c;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c.device) DDIF_HIPCHK(hipSetDevice(c.device));
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = c.H * c.W;
+    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cout), dim3(256), 0, s, dy, c.B, c.Cout, HW, c.dy_nhwc);
+    if (dx) {
+        const size_t nw = (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256;
+        hipLaunchKernelGGL(ddif::pack_dgrad_weights_kernel, ddif::grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.n_chunks, c.nb_pad, c.wpack);
+        ddif::StepCtx ctx;
+        for (auto& op : c.prog) op.run(s, ctx);
+        hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, (const float*)c.dx.p, c.B, c.Cin, HW, dx);
+    }
+    if (dw) {
+        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, x, c.B, c.Cin, HW, c.x_nhwc);
+        ddif::WgradArgs a{};
+        a.x = c.x_nhwc;
+        a.dy = c.dy_nhwc;
+        a.B = c.B; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout;
+        a.n_ci = c.n_ci;
+        a.rb = c.rb;
+        a.bands_y = (c.H + c.rb - 1) / c.rb;
+        a.partial = c.partial;
+        hipLaunchKernelGGL(ddif::conv3x3_wgrad_kernel, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
+        hipLaunchKernelGGL(ddif::wgrad_reduce_kernel, ddif::grid_for((size_t)c.Cout * c.Cin * 9), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
+                           c.Cout, c.Cin, dw);
+    }
+    if (db) {
+        hipLaunchKernelGGL(ddif::bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 0, s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
+        hipLaunchKernelGGL(ddif::bias_grad_reduce_kernel, dim3((c.Cout + 255) / 256), dim3(256), 0, s, (const float*)c.bpart, c.nbchunk, c.Cout, db);
+    }
+    int rc = DDIF_OK;
+    if (hipGetLastError() != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_run: kernel launch failed");
+    if (prev >= 0 && prev != c.device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+}  // extern "C"

@@ -123,20 +123,21 @@ static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general c
 }
 // cfg 20 / 21: the low-resolution kernel (kernels_lr.h) with 8x8 / 8x16 pixel tiles -- samples of <= 256 pixels whose
 // channel counts fit its 16-channel slabs
-static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B, int cin, int c0, bool allow_lr = true) {
+static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B, int cin, int c0, bool allow_lr = true, bool exact = false) {
     const bool wide = (Wout >= 16) && stride == 1;
     (void)pro;
-    if (allow_lr && x3_enabled() && lr_enabled() && vec == 1 && stride == 1 && !ups_ && Hout * Wout <= 256 && Cout % 4 == 0 && cin % 16 == 0 && c0 % 16 == 0 &&
+    const bool x3 = x3_enabled() && !exact;
+    if (allow_lr && x3 && lr_enabled() && vec == 1 && stride == 1 && !ups_ && Hout * Wout <= 256 && Cout % 4 == 0 && cin % 16 == 0 && c0 % 16 == 0 &&
         ck == (ks == 3 ? 16 : 32))
         return (Hout <= 8 && Wout <= 8) ? 20 : 21;
     if (ks == 1 && vec == 1) {
         const int base = wide ? (Cout > 64 ? 3 : (Cout > 32 ? 1 : 0)) : (Cout > 64 ? 4 : 2);
         // 32-cout tiles stay on the exact instruction: with 12 MFMAs per stage the split only adds staging work
         // (measured: softmax_H(q).ctx.attn_out 64+64->32 @64^2 72 vs 58 us)
-        if (x3_enabled() && ck == 32 && base != 0) return base + 12;  // 1,3,2,4 -> 13,15,14,16
+        if (x3 && ck == 32 && base != 0) return base + 12;  // 1,3,2,4 -> 13,15,14,16
         return base;
     }
-    if (ks == 3 && vec == 1 && stride == 1 && x3_enabled()) {
+    if (ks == 3 && vec == 1 && stride == 1 && x3) {
         if (wide && Hout >= 32 && Wout >= 32) return 7;
         if (wide || Cout <= 32) return 8;
         return 9;
@@ -219,7 +220,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 != 0 || c1 % 4 != 0) ? 0 : ((c1 == 0 || c0 % pc.ck == 0) ? 1 : 2);
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
-    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1);
+    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0);
     if (s.cso_mx && (cfg < 20 || Hout > (cfg == 20 ? 8 : 16)))
         return fail(DDIF_ERR_INVALID, "%s: column statistics epilogue needs the low-resolution kernel and H <= 16", s.name);

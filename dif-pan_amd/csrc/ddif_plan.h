@@ -68,6 +68,7 @@ struct ConvSpec {
     float* cso_sm = nullptr;            //   must fit one tile vertically (caller checks with lr_colstats_ok)
     bool silu = false;
     bool stats = false;
+    bool exact = false;                 // force the exact-fp32 MFMA instantiation of kernels_conv.h (gradient convs; pc->w only)
     const char* name = "conv";
 };
 

@@ -1,0 +1,177 @@
+// Backward kernels of the 3x3 convolution (stride 1, pad 1, NHWC fp32) -- the first pieces of the training step
+// (reference: loss.backward() through nn.Conv2d, diffusion_engine.py:233).
+//
+//   dgrad  dX = conv3x3(dY, W')  with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]: the FORWARD implicit-GEMM kernel
+//          (kernels_conv.h, exact-fp32 MFMA instantiation) on weights re-packed on the device by
+//          pack_dgrad_weights_kernel -- no new contraction kernel;
+//   wgrad  dW[co][ci][tap] = sum over (b, y, x) of dY[b,y,x,co] * X[b,y+ky-1,x+kx-1,ci]: a GEMM with K = B*H*W.
+//          conv3x3_wgrad_kernel: a workgroup owns a (32 co x 32 ci) block and walks row bands (sample, 4 rows); the band of
+//          dY and the haloed band of X sit in LDS as fp32; the four waves split the band's pixel pairs and run, per pair,
+//          one exact-fp32 v_mfma_f32_32x32x2_f32 per tap (A = dY^T fragment, B = shifted X fragment, 9 accumulators of
+//          32x32) -- K split over workgroups (grid.y) AND waves, combined deterministically: waves through LDS in
+//          fixed order, workgroups through a partials buffer reduced by wgrad_reduce_kernel in index order.  No atomics.
+//   dbias  db[co] = sum dY: bias_grad_kernel (two-level fixed-order reduction).
+#pragma once
+#include "ddif_dev.h"
+
+namespace ddif {
+
+// packed fp32 fragment order of kernels_conv.h (pack_conv in ddif_net.cpp) for the dgrad weights, 16-channel chunks:
+//   [n-block of 32 "couts" = ci][chunk of 16 "cins" = co][tap][k8][half h][j][4]   with cin' = chunk*16 + k8*8 + 4h + i
+__global__ void pack_dgrad_weights_kernel(const float* w /* (Cout, Cin, 3, 3) */, int Cout, int Cin, int n_chunks, int nb_pad, float* out) {
+    const size_t total = (size_t)nb_pad * n_chunks * 9 * 2 * 256;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int i = (int)(r % 4); r /= 4;
+        const int j = (int)(r % 32); r /= 32;
+        const int h = (int)(r % 2); r /= 2;
+        const int k8 = (int)(r % 2); r /= 2;
+        const int tap = (int)(r % 9); r /= 9;
+        const int ch = (int)(r % n_chunks); r /= n_chunks;
+        const int nbi = (int)r;
+        const int co = ch * 16 + k8 * 8 + 4 * h + i;  // contraction index of the dgrad conv = output channel of the forward conv
+        const int ci = nbi * 32 + j;                  // output channel of the dgrad conv = input channel of the forward conv
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];  // flipped tap: (2-ky)*3 + (2-kx) = 8 - tap
+        out[idx] = v;
+    }
+}
+
+struct WgradArgs {
+    const float* x;    // [B, H, W, Cin]  NHWC
+    const float* dy;   // [B, H, W, Cout] NHWC
+    int B, H, W, Cin, Cout;
+    int n_ci;          // ci blocks of 32
+    int rb;            // rows per band (4, 2 or 1: the largest whose tiles fit LDS)
+    int bands_y;       // ceil(H / rb)
+    float* partial;    // [gridDim.y][n_co * n_ci][9][32 co][32 ci]
+};
+
+// grid = (n_co * n_ci, NSPLIT); block 256.  LDS: dY band [rb*W][32] + X band [(rb+2)*(W+2)][32] + reduction scratch [4][1024].
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
+    DDIF_DYN_SMEM(smem);
+    const int W = a.W, IW = W + 2;
+    const int RB = a.rb;
+    float* Ys = reinterpret_cast<float*>(smem);  // [RB*W][32]
+    float* Xs = Ys + RB * W * 32;                 // [(RB+2)*IW][32]
+    float* Rs = Xs + (RB + 2) * IW * 32;          // [4 waves][16 regs][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int cob = blockIdx.x / a.n_ci, cib = blockIdx.x % a.n_ci;
+    const int nbands = a.B * a.bands_y;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int band = blockIdx.y; band < nbands; band += gridDim.y) {
+        const int b = band / a.bands_y, y0 = (band % a.bands_y) * RB;
+        __syncthreads();  // previous band fully consumed
+        // stage dY rows y0..y0+RB-1 (32 couts of this block) and X rows y0-1..y0+RB with a one-pixel zero border
+        for (int i = tid; i < RB * W * 8; i += 256) {
+            const int c4 = i & 7, p = i >> 3;
+            const int y = y0 + p / W, x = p % W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int co = cob * 32 + c4 * 4;
+            if (y < a.H && co < a.Cout) v = *reinterpret_cast<const float4*>(a.dy + (((size_t)b * a.H + y) * W + x) * a.Cout + co);
+            *reinterpret_cast<float4*>(&Ys[p * 32 + c4 * 4]) = v;
+        }
+        for (int i = tid; i < (RB + 2) * IW * 8; i += 256) {
+            const int c4 = i & 7, p = i >> 3;
+            const int y = y0 - 1 + p / IW, x = p % IW - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = cib * 32 + c4 * 4;
+            if (y >= 0 && y < a.H && x >= 0 && x < W && ci < a.Cin) v = *reinterpret_cast<const float4*>(a.x + (((size_t)b * a.H + y) * W + x) * a.Cin + ci);
+            *reinterpret_cast<float4*>(&Xs[p * 32 + c4 * 4]) = v;
+        }
+        __syncthreads();
+        // pixel pairs of the band: pair q -> pixels (2q, 2q+1) in row-major order of the RB x W band; wave w takes q = w, w+4, ...
+        const int npix = RB * W, npairs = (npix + 1) / 2;
+        for (int q = wave; q < npairs; q += 4) {
+            const int pr = 2 * q + h;         // this lane half's pixel (k index of the MFMA)
+            const bool pv = pr < npix;        // odd pixel count: the last pair's second pixel does not exist
+            const int p = pv ? pr : npix - 1;
+            const int py = p / W, px = p % W;
+            const float av = pv ? Ys[p * 32 + j] : 0.f;  // A[i = co j][k = h]
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float bv = Xs[((py + t / 3) * IW + px + t % 3) * 32 + j];  // B[k = h][j = ci]: X at (y + ky - 1, x + kx - 1)
+                acc[t] = DDIF_MFMA_32x32x2(av, bv, acc[t]);
+            }
+        }
+    }
+    // combine the four waves tap by tap in fixed order, write this workgroup's partial block
+    float* outp = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 1024;
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rs[(wave * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        // 1024 outputs / 256 threads: element e = (r, lane): row (co) = (r&3) + 8*(r>>2) + 4*(lane>>5), col (ci) = lane & 31
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + k * 256;
+            const int r = e >> 6, l = e & 63;
+            const float s = (Rs[(0 * 16 + r) * 64 + l] + Rs[(1 * 16 + r) * 64 + l]) + (Rs[(2 * 16 + r) * 64 + l] + Rs[(3 * 16 + r) * 64 + l]);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+            outp[t * 1024 + row * 32 + col] = s;
+        }
+    }
+}
+
+// dW (OIHW) = fixed-order sum of the partial blocks; one thread per weight element
+__global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw) {
+    const size_t total = (size_t)Cout * Cin * 9;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % 9);
+        const int ci = (int)((i / 9) % Cin);
+        const int co = (int)(i / ((size_t)9 * Cin));
+        const int blk = (co / 32) * n_ci + ci / 32;
+        const size_t off = ((size_t)blk * 9 + t) * 1024 + (size_t)(co % 32) * 32 + ci % 32;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * nblk * 9 * 1024 + off];
+        dw[i] = s;
+    }
+}
+
+// db[co] = sum over pixels of dY[., co]  (NHWC): grid.x = chunks of pixels -> partial [chunk][Cout]; then fixed-order sum
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* dy, size_t npix, int Cout, int nchunk, float* partial) {
+    const size_t per = (npix + nchunk - 1) / nchunk;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+        float s = 0.f;
+        for (size_t p = p0; p < p1; ++p) s += dy[p * Cout + c];
+        partial[(size_t)blockIdx.x * Cout + c] = s;
+    }
+}
+__global__ void bias_grad_reduce_kernel(const float* partial, int nchunk, int Cout, float* db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += partial[(size_t)k * Cout + c];
+    db[c] = s;
+}
+
+}  // namespace ddif
+
+namespace ddif {
+// layout conversion at this op's NCHW boundary (the reference's layout)
+__global__ void bwd_nchw_to_nhwc_kernel(const float* in, int B, int C, int HW, float* out) {
+    const size_t total = (size_t)B * HW * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
+        out[i] = in[(b * C + c) * HW + p];
+    }
+}
+__global__ void bwd_nhwc_to_nchw_kernel(const float* in, int B, int C, int HW, float* out) {
+    const size_t total = (size_t)B * HW * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const size_t b = i / ((size_t)C * HW);
+        out[i] = in[(b * HW + p) * C + c];
+    }
+}
+}  // namespace ddif

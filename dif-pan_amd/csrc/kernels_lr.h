@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                         for (int q = 0; q < 3; ++q)
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[abase[mb] + aoff + q * 8]);
-                        DDIF_SCHED_FENCE();  // keep the unrolled steps in order (hoisted LDS reads of many taps spill)
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
                             f32x16 cacc = acc[mb];
@@ -281,7 +280,10 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                             acc[mb] = cacc;
                         }
                         if (pf_slab < NS) ring_load(u);  // the step U ahead of this one (wave-uniform branch)
-                        DDIF_SCHED_FENCE();
+                        // NOTE: do not wrap the MFMA group in __builtin_amdgcn_sched_barrier here.  With fences before / after it
+                        // this kernel produced wrong results on gfx950 (3e-2 errors in every -m gpu parity test, deterministic;
+                        // the host emulator cannot see it).  The unfenced build is the one the parity suite -- including the
+                        // bit-equality tests at B = 64 -- verifies.
                     }
                 }
             }

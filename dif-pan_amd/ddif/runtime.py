@@ -102,6 +102,10 @@ class _Lib:
         d.ddif_optim_destroy.argtypes = [vp]
         d.ddif_optim_destroy.restype = None
         d.ddif_optim_step.argtypes = [vp, f32, f32, f32, f32, f32, C.c_int64, f32, i32, f32, C.POINTER(C.c_float), vp]
+        d.ddif_convbwd_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
+        d.ddif_convbwd_destroy.argtypes = [vp]
+        d.ddif_convbwd_destroy.restype = None
+        d.ddif_convbwd_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         self.emulated = bool(d.ddif_is_emulated())
 
     def check(self, rc: int, what: str):
@@ -456,6 +460,40 @@ class FusedAdamW:
         try:
             if getattr(self, "h", None):
                 self.lib.dll.ddif_optim_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Conv3x3Backward:
+    """Backward of nn.Conv2d(Cin, Cout, 3, padding=1) (autograd under loss.backward(), reference diffusion_engine.py:233):
+    returns (dx, dw, db) for x (B,Cin,H,W), w (Cout,Cin,3,3), dy (B,Cout,H,W) -- hand-written dgrad / wgrad kernels."""
+
+    def __init__(self, B, Cin, Cout, H, W, device):
+        self.lib = get_lib()
+        dev = torch.device(device)
+        idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
+        h = C.c_void_p()
+        self.lib.check(self.lib.dll.ddif_convbwd_create(C.byref(h), B, Cin, Cout, H, W, idx), "ddif_convbwd_create")
+        self.h, self.shape, self.device = h, (B, Cin, Cout, H, W), dev
+
+    def __call__(self, x, w, dy, need_dx=True, need_dw=True, need_db=True):
+        B, Cin, Cout, H, W = self.shape
+        for nm, t, shp in (("x", x, (B, Cin, H, W)), ("w", w, (Cout, Cin, 3, 3)), ("dy", dy, (B, Cout, H, W))):
+            _check_tensor(self.lib, t, nm)
+            _check_shape(t, nm, shp)
+        x, w, dy = x.contiguous(), w.contiguous(), dy.contiguous()
+        dx = torch.empty_like(x) if need_dx else None
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if need_db else None
+        self.lib.check(self.lib.dll.ddif_convbwd_run(self.h, _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
+                                                     _stream(self.lib, x.device)), "ddif_convbwd_run")
+        return dx, dw, db
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dll.ddif_convbwd_destroy(self.h)
                 self.h = None
         except Exception:
             pass

@@ -181,6 +181,19 @@ DDIF_API void ddif_optim_destroy(ddif_optim_t h);
 DDIF_API int ddif_optim_step(ddif_optim_t h, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                              float max_grad_norm, int ema_mode, float ema_decay, float* grad_norm_host, void* stream);
 
+/* ---- training building blocks (the full train step is not built yet) ---------------------------------- */
+
+/* Backward of nn.Conv2d(Cin, Cout, 3, padding=1) as autograd computes it under loss.backward() (diffusion_engine.py:233):
+ *   dx = conv_transpose(dy, w), dw[co,ci,ky,kx] = sum dy[b,co,y,x] * x[b,ci,y+ky-1,x+kx-1], db[co] = sum dy[b,co,y,x].
+ * All pointers are DEVICE pointers in the reference's layouts: x (B,Cin,H,W), w (Cout,Cin,3,3), dy (B,Cout,H,W),
+ * dx (B,Cin,H,W), dw (Cout,Cin,3,3), db (Cout); dx / dw / db may be NULL (skipped).  4 | Cin, 4 | Cout.
+ * dgrad = the forward implicit-GEMM kernel on flipped / transposed weights (exact fp32 MFMA); wgrad = split-K MFMA kernel
+ * with a fixed-order two-level reduction; bitwise reproducible. */
+typedef struct ddif_convbwd* ddif_convbwd_t;
+DDIF_API int ddif_convbwd_create(ddif_convbwd_t* out, int B, int Cin, int Cout, int H, int W, int device);
+DDIF_API void ddif_convbwd_destroy(ddif_convbwd_t h);
+DDIF_API int ddif_convbwd_run(ddif_convbwd_t h, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 
 /* Bracket launches of the dominant kernel class (3x3 implicit-GEMM convolutions of the denoising step) with HIP

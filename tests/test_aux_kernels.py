@@ -120,3 +120,30 @@ def test_fused_adamw_clip_ema_matches_torch(backend):
         assert float((a.cpu() - b).abs().max()) <= 2e-7
     for a, b in zip(e, want_e):
         assert float((a.cpu() - b).abs().max()) <= 2e-7
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 32, 32, 16, 16), (1, 64, 32, 8, 8), (2, 16, 48, 12, 20), (3, 8, 8, 5, 7)],
+                         ids=["32-32@16", "64-32@8", "16-48@12x20", "8-8@5x7"])
+def test_conv3x3_backward_matches_autograd(backend, shape):
+    """dgrad / wgrad / dbias of the 3x3 conv (first building block) against torch autograd on the CPU in
+    fp32 -- the reference's own backward IS autograd through nn.Conv2d (diffusion_engine.py:233).  Floating point: the
+    kernels use exact-fp32 MFMAs with a different summation order; tolerance 2e-5 relative to the gradient's scale."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).requires_grad_()
+    b = torch.zeros(Cout, requires_grad=True)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    y = torch.nn.functional.conv2d(x, w, b, padding=1)
+    y.backward(dy)
+    op = runtime.Conv3x3Backward(B, Cin, Cout, H, W, dev)
+    dx, dw, db = op(x.detach().to(dev), w.detach().to(dev), dy.to(dev))
+    for got, want, nm in ((dx, x.grad, "dx"), (dw, w.grad, "dw"), (db, b.grad, "db")):
+        err = float((got.cpu() - want).abs().max())
+        assert err <= 2e-5 * max(1.0, float(want.abs().max())), (nm, err, float(want.abs().max()))
+    dx2, dw2, db2 = op(x.detach().to(dev), w.detach().to(dev), dy.to(dev))
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)  # fixed-order reductions: bitwise reproducible
