@@ -100,6 +100,65 @@ int ddif_plan_create(ddif_plan_t* out, ddif_net_t net, int B, int H, int W) {
     DDIF_GUARD_END
 }
 
+int ddif_plan_create_train(ddif_plan_t* out, ddif_net_t net, int B, int H, int W) {
+    DDIF_GUARD_BEGIN
+    if (!out || !net) return ddif::fail(DDIF_ERR_INVALID, "ddif_plan_create_train: NULL argument");
+    *out = nullptr;
+    DeviceScope ds(net->n.device);
+    if (!ds.ok) return ddif::fail(DDIF_ERR_HIP, "ddif_plan_create_train: hipSetDevice(%d) failed", net->n.device);
+    std::unique_ptr<ddif_plan> h(new ddif_plan());
+    h->p.net = &net->n;
+    h->p.generation = net->n.generation;
+    h->p.B = B;
+    h->p.H = H;
+    h->p.W = W;
+    h->p.train_mode = true;
+    h->p.use_graph = false;
+    if (int e = h->p.build()) return e;
+    // identity masks until the caller provides some: a train-mode plan then computes the eval network
+    if (int e = h->p.train_random_masks(0, 0, 0.f, 0.f, nullptr)) return e;
+    *out = h.release();
+    return DDIF_OK;
+    DDIF_GUARD_END
+}
+
+int ddif_plan_train_info(ddif_plan_t plan, int* n_dropout_sites, int* n_droppath_sites) {
+    if (!plan || !plan->p.train_mode) return ddif::fail(DDIF_ERR_STATE, "ddif_plan_train_info: not a train-mode plan");
+    if (n_dropout_sites) *n_dropout_sites = (int)plan->p.drop_sites.size();
+    if (n_droppath_sites) *n_droppath_sites = (int)plan->p.path_sites.size();
+    return DDIF_OK;
+}
+
+int ddif_plan_train_site(ddif_plan_t plan, int site, int* C, int* H, int* W) {
+    if (!plan || !plan->p.train_mode || site < 0 || site >= (int)plan->p.drop_sites.size()) return ddif::fail(DDIF_ERR_INVALID, "ddif_plan_train_site: bad plan / site");
+    const auto& d = plan->p.drop_sites[site];
+    if (C) *C = d.C;
+    if (H) *H = d.H;
+    if (W) *W = d.W;
+    return DDIF_OK;
+}
+
+int ddif_plan_train_set_dropout(ddif_plan_t plan, int site, const float* mask, void* stream) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_set_dropout");
+    return plan->p.train_set_dropout(site, mask, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_train_set_droppath(ddif_plan_t plan, const float* scales_host, void* stream) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_set_droppath");
+    return plan->p.train_set_droppath(scales_host, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_train_random_masks(ddif_plan_t plan, uint64_t seed, uint64_t tile0, float p_dropout, float p_droppath, void* stream) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_random_masks");
+    return plan->p.train_random_masks(seed, tile0, p_dropout, p_droppath, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
 void ddif_plan_destroy(ddif_plan_t plan) { delete plan; }
 
 int ddif_plan_set_cond(ddif_plan_t plan, const float* cond, void* stream) {

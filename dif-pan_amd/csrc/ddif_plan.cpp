@@ -418,6 +418,49 @@ int Plan::build() {
         const PackedConv *c1 = PC(rb + ".block1.block.3"), *c2 = PC(rb + ".block2.block.3");
         if (!c1 || !c2) return fail(DDIF_ERR_MISSING, "%s: conv weights missing", rb.c_str());
         Tensor h1;
+        if (train_mode) {
+            // train mode: y = silu(GN(h1)) * dropout mask is materialised (it is also what wgrad needs), conv2 runs on it
+            auto dropped = [&](Tensor x, const float* g, const float* bt, Tensor* y) -> int {
+                if (!x.st || !g || !bt) return fail(DDIF_ERR_STATE, "%s: GroupNorm without producer statistics / affine", rb.c_str());
+                DDIF_TRY(alloc_tensor(y, x.C, x.H, x.W));
+                DropSite site{nullptr, x.C, x.H, x.W};
+                DDIF_TRY(dalloc(&site.mask, (size_t)B * x.H * x.W * x.C));
+                drop_sites.push_back(site);
+                const int HW = x.H * x.W, Cc = x.C, BB = B;
+                const int chunks = (HW * Cc / 4 + 256 * 8 - 1) / (256 * 8);
+                Tensor yy = *y;
+                Op op;
+                op.name = "gn_silu_dropout";
+                op.cls = (HW <= 256) ? 2 : 5;
+                op.bytes = 12.0 * B * HW * Cc;
+                op.run = [x, g, bt, site, yy, HW, Cc, BB, chunks](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(gn_silu_drop_kernel, dim3(chunks < 1 ? 1 : chunks, BB), dim3(256), 0, s, (const float*)x.p, (const double*)x.st, x.np, g, bt,
+                                       (const float*)site.mask, HW, Cc, yy.p);
+                };
+                step.push_back(std::move(op));
+                return 0;
+            };
+            // Dropout sits in block2 only (ResnetBlock.__init__, sr3_dwt.py:318-319): block1 keeps the fused GroupNorm + SiLU prologue
+            Tensor y2;
+            ConvSpec s1;
+            s1.pc = c1;
+            s1.in0 = in;
+            s1.pro = PRO_GN_SILU;
+            s1.gamma = V(rb + ".block1.block.0.weight");
+            s1.beta = V(rb + ".block1.block.0.bias");
+            s1.tb_off = net->slot_off.at(rb);
+            s1.stats = true;
+            s1.name = "res.conv1";
+            DDIF_TRY(add_conv(step, s1, &h1));
+            DDIF_TRY(dropped(h1, V(rb + ".block2.block.0.weight"), V(rb + ".block2.block.0.bias"), &y2));
+            ConvSpec s2;
+            s2.pc = c2;
+            s2.in0 = y2;
+            s2.res = in.p;
+            s2.stats = true;
+            s2.name = "res.conv2 (train)";
+            return add_conv(step, s2, out);
+        }
         ConvSpec s1;
         s1.pc = c1;
         s1.in0 = in;
@@ -815,10 +858,35 @@ int Plan::build() {
             s3.pc = PC(ci + ".ffn.3");
             if (!s3.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.3 missing", ci.c_str());
             s3.in0 = f2;
-            s3.res = amix.p;
-            s3.stats = true;
-            s3.name = "ffn.3";
-            DDIF_TRY(add_conv(step, s3, &f3));
+            if (train_mode) {
+                // ffn_drop_path(ffn(a)) + a  (sr3_dwt.py:576): the per-sample DropPath scale sits between the conv and the residual
+                Tensor f3c;
+                s3.name = "ffn.3 (train)";
+                DDIF_TRY(add_conv(step, s3, &f3c));
+                DDIF_TRY(alloc_tensor(&f3, f3c.C, f3c.H, f3c.W));
+                float* scale = nullptr;
+                DDIF_TRY(dalloc(&scale, (size_t)B));
+                path_sites.push_back(scale);
+                const int HW = f3c.H * f3c.W, Cc = f3c.C;
+                int chunks = (HW * Cc / 4 + 256 * 8 - 1) / (256 * 8);
+                if (chunks < 1) chunks = 1;
+                f3.np = chunks;
+                DDIF_TRY(dalloc(&f3.st, (size_t)B * chunks * 2));
+                Tensor fo = f3;
+                Op op;
+                op.name = "droppath_add";
+                op.cls = (HW <= 256) ? 2 : 5;
+                op.bytes = 12.0 * B * HW * Cc;
+                op.run = [f3c, scale, amix, fo, HW, Cc, BB, chunks](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(droppath_add_kernel, dim3(chunks, BB), dim3(256), 64, s, (const float*)f3c.p, (const float*)scale, (const float*)amix.p, HW, Cc, fo.p, fo.st);
+                };
+                step.push_back(std::move(op));
+            } else {
+                s3.res = amix.p;
+                s3.stats = true;
+                s3.name = "ffn.3";
+                DDIF_TRY(add_conv(step, s3, &f3));
+            }
         }
         DDIF_TRY(resblock(L.p + ".res_block", f3, &cur));
         if (L.attn) {
@@ -1051,6 +1119,37 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
         }
     }
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[n_steps & 1], B, C, HW, out);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- train mode: dropout / DropPath masks
+int Plan::train_set_dropout(int site, const float* mask_nchw, hipStream_t s) {
+    if (!train_mode) return fail(DDIF_ERR_STATE, "not a train-mode plan (ddif_plan_create_train)");
+    if (site < 0 || site >= (int)drop_sites.size() || !mask_nchw) return fail(DDIF_ERR_INVALID, "ddif_plan_train_set_dropout: bad site %d of %d", site, (int)drop_sites.size());
+    const DropSite& d = drop_sites[site];
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid((size_t)B * d.H * d.W * d.C), dim3(256), 0, s, mask_nchw, B, d.C, d.H * d.W, 0, d.C, d.mask);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+int Plan::train_set_droppath(const float* scales_host, hipStream_t s) {
+    if (!train_mode) return fail(DDIF_ERR_STATE, "not a train-mode plan (ddif_plan_create_train)");
+    if (!scales_host) return fail(DDIF_ERR_INVALID, "ddif_plan_train_set_droppath: NULL");
+    for (size_t k = 0; k < path_sites.size(); ++k)
+        DDIF_HIPCHK(hipMemcpyAsync(path_sites[k], scales_host + k * B, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    return 0;
+}
+int Plan::train_random_masks(uint64_t seed, uint64_t tile0, float p_drop, float p_path, hipStream_t s) {
+    if (!train_mode) return fail(DDIF_ERR_STATE, "not a train-mode plan (ddif_plan_create_train)");
+    if (!(p_drop >= 0.f && p_drop < 1.f && p_path >= 0.f && p_path < 1.f)) return fail(DDIF_ERR_INVALID, "drop probabilities must be in [0, 1)");
+    for (size_t k = 0; k < drop_sites.size(); ++k) {
+        const DropSite& d = drop_sites[k];
+        hipLaunchKernelGGL(dropout_mask_kernel, ew_grid((size_t)B * d.H * d.W * d.C), dim3(256), 0, s, d.mask, B, d.C, d.H * d.W, (unsigned long long)seed, (unsigned)k,
+                           (unsigned long long)tile0, 1.f - p_drop);
+    }
+    for (size_t k = 0; k < path_sites.size(); ++k)  // one "pixel" per sample: the same generator, site numbers after the dropout sites
+        hipLaunchKernelGGL(dropout_mask_kernel, dim3(1), dim3(64), 0, s, path_sites[k], B, 1, 1, (unsigned long long)seed, (unsigned)(drop_sites.size() + k),
+                           (unsigned long long)tile0, 1.f - p_path);
     DDIF_HIPCHK(hipGetLastError());
     return 0;
 }

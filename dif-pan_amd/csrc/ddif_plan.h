@@ -79,6 +79,11 @@ struct Plan {
     std::vector<void*> allocs;
     std::vector<Op> pre, step;
     bool cond_set = false;
+    // train mode (ddif_plan_create_train): Dropout after every ResnetBlock's SiLU and DropPath on every decoder FFN
+    bool train_mode = false;
+    struct DropSite { float* mask; int C, H, W; };
+    std::vector<DropSite> drop_sites;      // NHWC masks (0 or 1/(1-p)), one per Block with dropout, in execution order
+    std::vector<float*> path_sites;        // per-sample DropPath scales [B], one per FastAttnCondInjection, in execution order
     size_t bytes_allocated = 0;
 
     // fixed buffers
@@ -126,6 +131,9 @@ struct Plan {
     int n_conv3 = 0, n_conv3_x3 = 0;  // 3x3 conv ops of the step program / of them on the bf16x3 path (reported by prof_collect)
     bool op_timing_done = false;  // DDIF_OP_TIMING=<csv path>: one profiled step is timed op by op (development aid)
 
+    int train_set_dropout(int site, const float* mask_nchw, hipStream_t s);
+    int train_set_droppath(const float* scales_host, hipStream_t s);
+    int train_random_masks(uint64_t seed, uint64_t tile0, float p_drop, float p_path, hipStream_t s);
     int set_cond(const float* cond, hipStream_t s);
     int forward(const float* x, const float* t_host, const float* sc, float* out, hipStream_t s);
     int run_sampler(int kind, int n_steps, const float* const* tabs_host, int n_tabs, const float* t_model, const float* xT,

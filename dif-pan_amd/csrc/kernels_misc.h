@@ -441,6 +441,82 @@ __global__ __launch_bounds__(64) void self_attn_mfma_kernel(const float* qkv, in
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* o);
+// Train mode (models/sr3_dwt.py:288-300 Block with Dropout; :534,576 DropPath on the decoder FFN).  In a train-mode plan
+// the dropout sits between the GroupNorm + SiLU prologue and the conv, so the activation is materialised once:
+//   y = silu(GroupNorm(x)) * mask        gn_silu_drop_kernel   (mask holds 0 or 1/(1-p); y is also what wgrad will need)
+//   out = f * scale[b] + res             droppath_add_kernel   (scale[b] in {0, 1/(1-p)}; emits the GroupNorm partial of out)
+//   mask generation                      dropout_mask_kernel   (Philox keyed by (seed, site, NCHW element): split-invariant)
+// grid = (chunks, B), 256 threads, float4 over C (C % 4 == 0).
+__global__ __launch_bounds__(256) void gn_silu_drop_kernel(const float* x, const double* st, int np, const float* gamma, const float* beta,
+                                                           const float* mask, int HW, int C, float* y) {
+    const int b = blockIdx.y;
+    float mean, rstd;
+    gn_finalize_wave(st, np, nullptr, 0, b, (double)C * HW, &mean, &rstd);  // every wavefront for itself
+    const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const float4 v = *reinterpret_cast<const float4*>(x + base + i * 4);
+        const float4 m = *reinterpret_cast<const float4*>(mask + base + i * 4);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = dd_silu(fmaf(v.x, g.x * rstd, bt.x - mean * (g.x * rstd))) * m.x;
+        o.y = dd_silu(fmaf(v.y, g.y * rstd, bt.y - mean * (g.y * rstd))) * m.y;
+        o.z = dd_silu(fmaf(v.z, g.z * rstd, bt.z - mean * (g.z * rstd))) * m.z;
+        o.w = dd_silu(fmaf(v.w, g.w * rstd, bt.w - mean * (g.w * rstd))) * m.w;
+        *reinterpret_cast<float4*>(y + base + i * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void droppath_add_kernel(const float* f, const float* scale, const float* res, int HW, int C, float* out, double* st_out) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [2][4]
+    const int b = blockIdx.y;
+    const float sc = scale[b];
+    const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(f + base + i * 4);
+        const float4 r = *reinterpret_cast<const float4*>(res + base + i * 4);
+        float4 o;
+        o.x = v.x * sc + r.x;
+        o.y = v.y * sc + r.y;
+        o.z = v.z * sc + r.z;
+        o.w = v.w * sc + r.w;
+        *reinterpret_cast<float4*>(out + base + i * 4) = o;
+        s1 += ((double)o.x + o.y) + ((double)o.z + o.w);
+        s2 += ((double)o.x * o.x + (double)o.y * o.y) + ((double)o.z * o.z + (double)o.w * o.w);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s1;
+        red[4 + (threadIdx.x >> 6)] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st_out[((size_t)b * gridDim.x + blockIdx.x) * 2 + 0] = (red[0] + red[1]) + (red[2] + red[3]);
+        st_out[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+// mask (NHWC) of one dropout site: element index = its NCHW position in the (tile0 + b)-th tile, like the sampler noise
+__global__ void dropout_mask_kernel(float* mask, int B, int C, int HW, unsigned long long seed, unsigned site, unsigned long long tile0, float keep) {
+    const size_t total = (size_t)B * HW * C;
+    const float inv = 1.0f / keep;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
+        unsigned o[4];
+        const unsigned long long e = ((tile0 + b) * C + c) * HW + p;
+        philox4x32_10((unsigned)e, (unsigned)(e >> 32), site, 0xD0F0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+        const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        mask[i] = u < keep ? inv : 0.f;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // time embedding (PositionalEncoding + noise_level_mlp + every FeatureWiseAffine, :223-258,59-64):
 // row r: pe = [sin(t*f_j), cos(t*f_j)], temb = W3 swish(W1 pe + b1) + b3, out[r][s] = Wall[s] . temb + ball[s].
 // One workgroup (128 threads) per row.  inner = 32 only (engine configuration).

@@ -139,7 +139,7 @@ class GaussianDiffusion(nn.Module):
             self.register_buffer(k, to_torch(v))
 
     # ------------------------------------------------------------------------------------------------ helpers
-    def _plan(self, cond: torch.Tensor):
+    def _plan(self, cond: torch.Tensor, train: bool = False):
         if not self.conditional:
             raise DdifError("unconditional sampling is not implemented by the HIP path")
         if self.pred_mode != "x_start":
@@ -147,7 +147,7 @@ class GaussianDiffusion(nn.Module):
         if self.clamp_type != "abs":
             raise DdifError("clamp_type='dynamic' is not implemented by the HIP path")
         B, _, H, W = cond.shape
-        plan = self.model.plan_for(B, H, W, cond.device)
+        plan = self.model.plan_for(B, H, W, cond.device, train=train)
         plan.set_cond(cond)
         return plan
 
@@ -285,18 +285,33 @@ class GaussianDiffusion(nn.Module):
     # ------------------------------------------------------------------------------------------------ training
     def p_losses(self, x_start, noise=None, cond=None):
         """Reference :692-766, forward half: q_sample + (optional self-conditioning pass) + prediction + loss value.
-        The network runs in eval mode inside the kernels (no dropout / DropPath) and no autograd graph is built."""
+        With the model in .train() mode both passes run the train-mode launch program (Dropout in every ResnetBlock,
+        DropPath on every decoder FFN; fresh masks per pass from the library's generator seeded by torch's RNG, or the
+        masks pinned with `model.set_train_masks`).  No autograd graph is built: the backward pass is not implemented."""
         b = x_start.shape[0]
         t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
         noise = default(noise, lambda: torch.randn_like(x_start))
         if self.pred_mode != "x_start" or not self.conditional:
             raise DdifError("p_losses: only conditional pred_mode='x_start' is implemented by the HIP path")
-        plan = self._plan(cond)
+        training = bool(getattr(self.model, "training", False))
+        plan = self._plan(cond, train=training)
+
+        def masks():
+            if not training:
+                return
+            pinned = getattr(self.model, "_train_masks", None)
+            if pinned is not None:
+                plan.set_train_masks(*pinned)
+            else:
+                plan.random_train_masks(self._seed_from_torch(), 0, float(self.model.cfg["dropout"]), self.model.DROP_PATH_PROB)
+
         a = self.sqrt_alphas_cumprod.detach().cpu()[t.cpu()]
         s = self.sqrt_one_minus_alphas_cumprod.detach().cpu()[t.cpu()]
         x_self_cond = None
         if self.self_condition and random.random() < 0.5:
+            masks()
             x_self_cond = plan.q_sample_forward(x_start, noise, a, s, t, None)
+        masks()
         pred = plan.q_sample_forward(x_start, noise, a, s, t, x_self_cond)
         loss = self.loss_func(x_start, pred)
         loss = (loss * extract(self.p2_loss_weight, t, loss.shape)).mean()

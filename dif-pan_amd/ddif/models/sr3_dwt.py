@@ -117,22 +117,34 @@ class UNetSR3(nn.Module):
             self._weights_sig = sig
         return self._net
 
-    def plan_for(self, B: int, H: int, W: int, device) -> PlanHandle:
-        return self._ensure_net(device).plan(B, H, W)
+    DROP_PATH_PROB = 0.2  # FastAttnCondInjection's default drop_path_prob, never overridden by UNetSR3 (models/sr3_dwt.py:502,534)
+
+    def plan_for(self, B: int, H: int, W: int, device, train: bool = False) -> PlanHandle:
+        return self._ensure_net(device).plan(B, H, W, train=train)
+
+    def set_train_masks(self, dropout_masks, droppath_scales):
+        """Pin the masks of the NEXT train-mode forward passes (parity tests against a reference run whose masks were captured);
+        `None, None` returns to fresh masks from the library's counter-based generator seeded from torch's RNG."""
+        self._train_masks = None if dropout_masks is None else (dropout_masks, droppath_scales)
 
     # ---- reference API ----------------------------------------------------------------------------------------------
     def forward(self, x, time, cond=None, self_cond=None):
         if cond is None:
             raise DdifError("UNetSR3.forward: cond is required (the reference indexes it unconditionally, "
                             "models/sr3_dwt.py:197)")
-        if self.training:
-            # Train mode = Dropout(p) after every Block's SiLU (models/sr3_dwt.py:295) + DropPath(0.2) on every decoder FFN
-            # (:534,576).  The kernels implement the eval network only; running it silently under .train() would change
-            # training semantics, so refuse (call .eval() for sampling / validation, as the reference engine does).
-            raise DdifError("UNetSR3.forward in train mode (Dropout / DropPath masks) is not implemented by the HIP path; "
-                            "call .eval() -- there is no silent eval-mode substitute and no PyTorch fallback")
         B, _, H, W = x.shape
-        plan = self.plan_for(B, H, W, x.device)
+        if self.training:
+            # Train mode = Dropout(p) after every ResnetBlock Block's SiLU (models/sr3_dwt.py:295) + DropPath(0.2) on every decoder
+            # FFN (:534,576), applied by the train-mode launch program (csrc/ddif_plan.cpp).  No autograd graph is built: the
+            # backward pass is not implemented yet (DESIGN.md), so this serves p_losses' forward / loss value only.
+            plan = self.plan_for(B, H, W, x.device, train=True)
+            masks = getattr(self, "_train_masks", None)
+            if masks is not None:
+                plan.set_train_masks(*masks)
+            else:
+                plan.random_train_masks(int(torch.randint(0, 2 ** 62, (1,)).item()), 0, float(self.cfg["dropout"]), self.DROP_PATH_PROB)
+        else:
+            plan = self.plan_for(B, H, W, x.device)
         plan.set_cond(cond)
         if not torch.is_tensor(time):
             time = torch.tensor([float(time)] * B)

@@ -83,6 +83,12 @@ class _Lib:
         d.ddif_net_num_params.argtypes = [vp]
         d.ddif_net_num_params.restype = C.c_int64
         d.ddif_plan_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
+        d.ddif_plan_create_train.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
+        d.ddif_plan_train_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+        d.ddif_plan_train_site.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        d.ddif_plan_train_set_dropout.argtypes = [vp, i32, vp, vp]
+        d.ddif_plan_train_set_droppath.argtypes = [vp, vp, vp]
+        d.ddif_plan_train_random_masks.argtypes = [vp, u64, u64, f32, f32, vp]
         d.ddif_plan_destroy.argtypes = [vp]
         d.ddif_plan_destroy.restype = None
         d.ddif_plan_set_cond.argtypes = [vp, vp, vp]
@@ -229,11 +235,11 @@ class NetHandle:
         self.lib.check(dll.ddif_net_commit(self.h, _stream(self.lib, self.device)), "ddif_net_commit")
         self.plans.clear()  # plans hold pointers into the old weight blob
 
-    def plan(self, B: int, H: int, W: int) -> "PlanHandle":
-        key = (int(B), int(H), int(W))
+    def plan(self, B: int, H: int, W: int, train: bool = False) -> "PlanHandle":
+        key = (int(B), int(H), int(W)) + (("train",) if train else ())
         p = self.plans.get(key)
         if p is None:
-            p = PlanHandle(self, *key)
+            p = PlanHandle(self, int(B), int(H), int(W), train=train)
             self.plans[key] = p
         return p
 
@@ -250,11 +256,15 @@ class NetHandle:
 class PlanHandle:
     """ddif_plan_t for batches of B tiles of H x W."""
 
-    def __init__(self, net: NetHandle, B: int, H: int, W: int):
+    def __init__(self, net: NetHandle, B: int, H: int, W: int, train: bool = False):
         self.net, self.lib = net, net.lib
         self.B, self.H, self.W = B, H, W
+        self.train = train
         h = C.c_void_p()
-        self.lib.check(self.lib.dll.ddif_plan_create(C.byref(h), net.h, B, H, W), "ddif_plan_create")
+        if train:
+            self.lib.check(self.lib.dll.ddif_plan_create_train(C.byref(h), net.h, B, H, W), "ddif_plan_create_train")
+        else:
+            self.lib.check(self.lib.dll.ddif_plan_create(C.byref(h), net.h, B, H, W), "ddif_plan_create")
         self.h = h
         self._cond_ref = None
         self._cond_ver = None
@@ -267,6 +277,36 @@ class PlanHandle:
                 self.h = None
         except Exception:
             pass
+
+    # -- train mode: dropout / DropPath masks ----------------------------------------------------------------------------
+    def train_sites(self):
+        """[(C, H, W)] of every dropout site and the number of DropPath sites (execution order, as in the reference)."""
+        nd, npth = C.c_int(), C.c_int()
+        self.lib.check(self.lib.dll.ddif_plan_train_info(self.h, C.byref(nd), C.byref(npth)), "ddif_plan_train_info")
+        shapes = []
+        for k in range(nd.value):
+            c, hh, ww = C.c_int(), C.c_int(), C.c_int()
+            self.lib.check(self.lib.dll.ddif_plan_train_site(self.h, k, C.byref(c), C.byref(hh), C.byref(ww)), "ddif_plan_train_site")
+            shapes.append((c.value, hh.value, ww.value))
+        return shapes, npth.value
+
+    def set_train_masks(self, dropout_masks, droppath_scales):
+        """Explicit masks: dropout_masks[k] (B,C,H,W) holding 0 or 1/(1-p); droppath_scales (n_sites, B) holding 0 or 1/(1-p)."""
+        shapes, npth = self.train_sites()
+        if len(dropout_masks) != len(shapes) or tuple(droppath_scales.shape) != (npth, self.B):
+            raise DdifError(f"expected {len(shapes)} dropout masks and DropPath scales of shape {(npth, self.B)}")
+        for k, (m, shp) in enumerate(zip(dropout_masks, shapes)):
+            _check_tensor(self.lib, m, f"dropout_masks[{k}]")
+            _check_shape(m, f"dropout_masks[{k}]", (self.B,) + shp)
+            m = m.contiguous()
+            self.lib.check(self.lib.dll.ddif_plan_train_set_dropout(self.h, k, _ptr(m), _stream(self.lib, m.device)), "ddif_plan_train_set_dropout")
+            self._keep_mask = m
+        sc = droppath_scales.detach().to("cpu", torch.float32).contiguous()
+        self.lib.check(self.lib.dll.ddif_plan_train_set_droppath(self.h, C.c_void_p(sc.data_ptr()), _stream(self.lib, self.net.device)), "ddif_plan_train_set_droppath")
+
+    def random_train_masks(self, seed: int, tile0: int, p_dropout: float, p_droppath: float):
+        self.lib.check(self.lib.dll.ddif_plan_train_random_masks(self.h, int(seed), int(tile0), float(p_dropout), float(p_droppath),
+                                                                 _stream(self.lib, self.net.device)), "ddif_plan_train_random_masks")
 
     # -- cond ---------------------------------------------------------------------------------------------------
     def set_cond(self, cond: torch.Tensor, force: bool = False):

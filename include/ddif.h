@@ -183,6 +183,19 @@ DDIF_API int ddif_optim_step(ddif_optim_t h, float lr, float beta1, float beta2,
 
 /* ---- training building blocks (the full train step is not built yet) ---------------------------------- */
 
+/* Train-mode network (UNetSR3 under .train(): nn.Dropout(p) between SiLU and conv of every ResnetBlock Block,
+ * models/sr3_dwt.py:295, and DropPath(0.2) on every decoder FFN, :534,576).  A train-mode plan runs the same entry points
+ * (ddif_plan_set_cond / ddif_plan_forward / ddif_plan_q_sample_forward) with the masks below applied; it starts with identity
+ * masks.  Masks hold 0 or 1/(1-p) (what nn.Dropout multiplies by) / per-sample DropPath scales in {0, 1/(1-p)}. */
+DDIF_API int ddif_plan_create_train(ddif_plan_t* out, ddif_net_t net, int B, int H, int W);
+DDIF_API int ddif_plan_train_info(ddif_plan_t plan, int* n_dropout_sites, int* n_droppath_sites);  /* sites in execution order */
+DDIF_API int ddif_plan_train_site(ddif_plan_t plan, int site, int* C, int* H, int* W);             /* mask shape (B, C, H, W) */
+/* explicit masks (parity with a reference run whose masks were captured): mask (B,C,H,W) device; scales HOST [n_droppath][B] */
+DDIF_API int ddif_plan_train_set_dropout(ddif_plan_t plan, int site, const float* mask, void* stream);
+DDIF_API int ddif_plan_train_set_droppath(ddif_plan_t plan, const float* scales_host, void* stream);
+/* fresh masks from the counter-based generator, keyed by (seed, site, tile0 + sample, element): independent of the batch split */
+DDIF_API int ddif_plan_train_random_masks(ddif_plan_t plan, uint64_t seed, uint64_t tile0, float p_dropout, float p_droppath, void* stream);
+
 /* Backward of nn.Conv2d(Cin, Cout, 3, padding=1) as autograd computes it under loss.backward() (diffusion_engine.py:233):
  *   dx = conv_transpose(dy, w), dw[co,ci,ky,kx] = sum dy[b,co,y,x] * x[b,ci,y+ky-1,x+kx-1], db[co] = sum dy[b,co,y,x].
  * All pointers are DEVICE pointers in the reference's layouts: x (B,Cin,H,W), w (Cout,Cin,3,3), dy (B,Cout,H,W),

@@ -109,6 +109,11 @@ FORWARD_BIG_CASES = [
     ("fwd_cave_128", "cave", 1, 128, 128, [1500], False, True),
 ]
 
+# train-mode forward (Dropout 0.2 + DropPath 0.2 live) with the reference's own masks captured: (case id, dataset, B, H, W, t values, seed)
+TRAIN_FWD_CASES = [
+    ("trainfwd_wv3_16", "wv3", 2, 16, 16, [7, 431], 61),
+]
+
 LOSS_CASES = [  # (case id, dataset, B, H, W, T, t values, self-cond branch, seed)
     ("loss_wv3_16_sc0", "wv3", 2, 16, 16, 500, [3, 444], False, 41),
     ("loss_wv3_16_sc1", "wv3", 2, 16, 16, 500, [100, 7], True, 42),

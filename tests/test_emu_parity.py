@@ -103,7 +103,7 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(DdifError):
         UNetSR3(fourier_features=True)
     net = UNetSR3(in_channel=8, out_channel=8, norm_groups=32, channel_mults=(1, 2), image_size=16)  # reference defaults
-    with pytest.raises(DdifError, match="train mode"):  # .train() is torch's default: never a silent eval-mode forward
+    with pytest.raises(DdifError, match="norm_groups"):  # (.train() is torch's default; the train-mode plan refuses the same way)
         net(torch.zeros(1, 8, 16, 16), torch.zeros(1), torch.zeros(1, 20, 16, 16))
     net.eval()
     with pytest.raises(DdifError, match="norm_groups"):
@@ -152,3 +152,47 @@ def test_emulated_grid_cap_hook_gives_identical_results():
     with torch.no_grad():
         ref = O.unet_forward(gc.weights_for(ds), gc.cfg_for(ds), x, t, cond, None)
     assert float((got - ref).abs().max()) <= 2e-5
+
+
+def test_emulated_train_mode_forward_matches_reference_masks():
+    """UNetSR3 under .train(): Dropout(0.2) in every ResnetBlock's block2 and DropPath(0.2) on every decoder FFN, with the masks the
+    REFERENCE drew (captured by tools/make_golden.py through forward hooks) uploaded into the train-mode plan."""
+    import os
+
+    from ddif import DdifError
+
+    cid, ds, B, H, W, tvals, seed = gc.TRAIN_FWD_CASES[0]
+    g = np.load(os.path.join(gc.GOLDEN_DIR, cid + ".npz"))
+    C = gc.DATASETS[ds][0]
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=gen)
+    sc = torch.randn(B, C, H, W, generator=gen)
+    cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+    t = torch.tensor(tvals, dtype=torch.long)
+    masks = []
+    for k in range(int(g["n_drop"])):
+        shp = tuple(int(v) for v in g[f"drop_{k}_shape"])
+        bits = np.unpackbits(g[f"drop_{k}"])[: int(np.prod(shp))].reshape(shp)
+        masks.append(torch.from_numpy(bits.astype(np.float32)) / (1.0 - float(g["p_drop"])))
+    net = make_net(ds, "cpu")
+    try:
+        net.train()
+        net.set_train_masks(masks, torch.from_numpy(g["paths"]))
+        y = net(x, t, cond, sc)
+        assert float((y - torch.from_numpy(g["y"])).abs().max()) <= 2e-5
+        # fresh masks from the library's generator: a different, finite result; identity masks reproduce the eval network
+        net.set_train_masks(None, None)
+        y2 = net(x, t, cond, sc)
+        assert torch.isfinite(y2).all() and float((y2 - y).abs().max()) > 1e-3
+        ones = [torch.ones_like(m) for m in masks]
+        net.set_train_masks(ones, torch.ones_like(torch.from_numpy(g["paths"])))
+        y3 = net(x, t, cond, sc)
+        net.eval()
+        assert float((y3 - net(x, t, cond, sc)).abs().max()) <= 2e-6
+        with pytest.raises(DdifError):
+            net.train()
+            net.set_train_masks(masks[:3], torch.from_numpy(g["paths"]))
+            net(x, t, cond, sc)
+    finally:
+        net.eval()
+        net.set_train_masks(None, None)

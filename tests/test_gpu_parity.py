@@ -255,3 +255,34 @@ def test_forward_matches_oracle_other_sizes(shape):
         ref = O.unet_forward(gc.weights_for(ds), gc.cfg_for(ds), x, t, cond, None)
     y = net_for(ds)(x.to(DEV), t.to(DEV), cond.to(DEV))
     assert _maxerr(y, ref) <= 2e-5
+
+
+def test_train_mode_forward_matches_reference_masks():
+    """SURVEY 8(a) a15, forward half in TRAIN mode: the reference's captured Dropout / DropPath masks uploaded (golden from the
+    real reference under .train(), tools/make_golden.py)."""
+    cid, ds, B, H, W, tvals, seed = gc.TRAIN_FWD_CASES[0]
+    g = _load(cid)
+    C = gc.DATASETS[ds][0]
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=gen)
+    sc = torch.randn(B, C, H, W, generator=gen)
+    cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+    t = torch.tensor(tvals, dtype=torch.long)
+    masks = []
+    for k in range(int(g["n_drop"])):
+        shp = tuple(int(v) for v in g[f"drop_{k}_shape"])
+        bits = np.unpackbits(g[f"drop_{k}"])[: int(np.prod(shp))].reshape(shp)
+        masks.append((torch.from_numpy(bits.astype(np.float32)) / (1.0 - float(g["p_drop"]))).to(DEV))
+    net = make_net(ds, DEV)
+    try:
+        net.train()
+        net.set_train_masks(masks, torch.from_numpy(g["paths"]))
+        y = net(x.to(DEV), t.to(DEV), cond.to(DEV), sc.to(DEV))
+        assert _maxerr(y, torch.from_numpy(g["y"])) <= 2e-5
+        net.set_train_masks(None, None)  # library-generated masks: split-invariant (keyed by global tile index)
+        torch.manual_seed(3)
+        y_full = net(x.to(DEV), t.to(DEV), cond.to(DEV), sc.to(DEV))
+        assert torch.isfinite(y_full).all() and float((y_full - y).abs().max()) > 1e-3
+    finally:
+        net.eval()
+        net.set_train_masks(None, None)

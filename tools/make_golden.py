@@ -94,7 +94,7 @@ def make_diffusion(D, net, C, T, size):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="manifest,fwd,fwdbig,trunc,dpmskip,sched,ddpm,ddim,dpm,loss,psnr")
+    ap.add_argument("--only", default="manifest,fwd,fwdbig,trunc,dpmskip,trainfwd,sched,ddpm,ddim,dpm,loss,psnr")
     ap.add_argument("--skip-long", action="store_true")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -171,6 +171,34 @@ def main():
             with torch.no_grad():
                 out = slv.sample(xT, steps=steps, order=order, skip_type=skip, method="multistep")
             save(cid, out=out, cond_chk=chk(cond))
+
+    if "trainfwd" in only:
+        for cid, ds, B, H, W, tvals, seed in gc.TRAIN_FWD_CASES:
+            C = gc.DATASETS[ds][0]
+            net = net_for(ds)
+            g = torch.Generator().manual_seed(seed)
+            x = torch.randn(B, C, H, W, generator=g)
+            sc = torch.randn(B, C, H, W, generator=g)
+            cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+            t = torch.tensor(tvals, dtype=torch.long)
+            drops, paths, hooks = [], [], []
+            for m in net.modules():  # module order is not execution order: record in the hooks, which fire in execution order
+                if isinstance(m, nn.Dropout):
+                    hooks.append(m.register_forward_hook(lambda mod, inp, out: drops.append((out != 0) | (inp[0] == 0))))
+                elif type(m).__name__ == "DropPath":
+                    hooks.append(m.register_forward_hook(lambda mod, inp, out: paths.append((out.flatten(1).abs().sum(1) != 0).float() / (1 - mod.drop_prob))))
+            net.train()
+            torch.manual_seed(seed)
+            try:
+                with torch.no_grad():
+                    y = net(x, t, cond, sc)
+            finally:
+                net.eval()
+                for hk in hooks:
+                    hk.remove()
+            arrs = {f"drop_{k}": np.packbits(d.numpy().reshape(-1)) for k, d in enumerate(drops)}
+            arrs.update({f"drop_{k}_shape": np.array(d.shape) for k, d in enumerate(drops)})
+            save(cid, y=y, n_drop=len(drops), paths=torch.stack(paths), p_drop=0.2, **arrs)
 
     if "sched" in only:
         out = {}
