@@ -2,6 +2,7 @@
 // branches hoisted into set_cond) and the sampling loops (reference diffusion/diffusion_ddpm_pan.py:445-507,
 // 624-666; solver/dpm_solver.py:1179-1221).
 #include "ddif_plan.h"
+#include <algorithm>
 #include "kernels_conv.h"
 #include "kernels_misc.h"
 #include "attn_args.h"
@@ -165,11 +166,11 @@ static int num_cus() {  // of the CURRENT device (plan entry points make the net
 // afterwards, so that small parity cases walk several work items per workgroup across sample boundaries -- the
 // regime the B=64 benchmark runs in.  0 = no cap.
 int g_debug_grid_cap = 0;
-static int wg_per_cu(size_t smem) {
-    // (3 or 4 persistent workgroups per CU measured slower for the 1x1 class: 1.56 vs 1.46 ms per step)
+static int wg_per_cu(size_t smem, int cap = 2) {
+    // (3 or 4 persistent workgroups per CU measured slower for the 1x1 class of kernels_conv.h: 1.56 vs 1.46 ms per step)
     int byl = (int)((160 * 1024) / (smem ? smem : 1));
     if (byl < 1) byl = 1;
-    return 2 < byl ? 2 : byl;
+    return cap < byl ? cap : byl;
 }
 
 static inline dim3 ew_grid(size_t n) {
@@ -194,6 +195,11 @@ template <typename T>
 int Plan::dalloc(T** p, size_t n) {
     void* q = nullptr;
     const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    if (dry) {  // fake, never dereferenced
+        *p = reinterpret_cast<T*>((uintptr_t)0x100000000000ull + dry_next);
+        dry_next += bytes;
+        return 0;
+    }
     DDIF_HIPCHK(hipMalloc(&q, bytes));
     allocs.push_back(q);
     bytes_allocated += bytes;
@@ -201,13 +207,92 @@ int Plan::dalloc(T** p, size_t n) {
     return 0;
 }
 
-int Plan::alloc_tensor(Tensor* t, int C_, int H_, int W_) {
+int Plan::alloc_tensor(Tensor* t, int C_, int H_, int W_, bool step_act) {
     t->C = C_;
     t->H = H_;
     t->W = W_;
     t->st = nullptr;
     t->np = 0;
-    return dalloc(&t->p, (size_t)B * H_ * W_ * C_);
+    if (!step_act) return dalloc(&t->p, (size_t)B * H_ * W_ * C_);
+    // activation of the step program: lives in the arena between its first and its last launch
+    const size_t bytes = ((size_t)B * H_ * W_ * C_ * sizeof(float) + 255) & ~(size_t)255;
+    if (dry) {
+        if (int e = dalloc(&t->p, (size_t)B * H_ * W_ * C_)) return e;
+        fake2id[t->p] = (int)lives.size();
+        lives.push_back(Live{bytes, (int)step.size(), (int)step.size(), 0});
+        return 0;
+    }
+    if (arena_next >= (int)lives.size() || lives[arena_next].bytes != bytes) return fail(DDIF_ERR_STATE, "plan arena: the two build passes disagree");
+    t->p = reinterpret_cast<float*>(arena + lives[arena_next++].off);
+    return 0;
+}
+
+void Plan::use(const void* p) {
+    if (!dry || !p) return;
+    auto it = fake2id.find(p);
+    if (it == fake2id.end()) return;
+    Live& l = lives[it->second];
+    const int idx = (int)step.size();  // index of the launch being created
+    if (idx > l.last) l.last = idx;
+    if (idx < l.first) l.first = idx;
+}
+
+// Two passes over the same builder: the dry pass only records shapes and liveness, the real pass allocates.
+int Plan::build() {
+    dry = true;
+    if (int e = build_impl()) return e;
+    // the network output is read by the sampler update / layout conversion AFTER the last launch of the program
+    {
+        auto it = fake2id.find(net_out.p);
+        if (it != fake2id.end()) lives[it->second].last = 1 << 30;
+    }
+    // first-fit interval colouring in order of first use
+    std::vector<int> order(lives.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lives[x].first < lives[y].first; });
+    std::vector<int> placed;
+    arena_bytes = 0;
+    unaliased_bytes = 0;
+    for (int id : order) {
+        Live& l = lives[id];
+        unaliased_bytes += l.bytes;
+        std::vector<std::pair<size_t, size_t>> busy;  // address ranges of tensors alive at the same time
+        for (int o : placed)
+            if (!(lives[o].last < l.first || l.last < lives[o].first)) busy.emplace_back(lives[o].off, lives[o].off + lives[o].bytes);
+        std::sort(busy.begin(), busy.end());
+        size_t off = 0;
+        for (auto& r : busy) {
+            if (off + l.bytes <= r.first) break;
+            if (r.second > off) off = r.second;
+        }
+        l.off = off;
+        if (off + l.bytes > arena_bytes) arena_bytes = off + l.bytes;
+        placed.push_back(id);
+    }
+    // reset everything the dry pass produced, then build for real
+    dry = false;
+    dry_next = 0;
+    fake2id.clear();
+    pre.clear();
+    step.clear();
+    cenc.clear();
+    cdec.clear();
+    drop_sites.clear();
+    path_sites.clear();
+    n_conv3 = n_conv3_x3 = 0;
+    tb_rows = 0;
+    tb = tvals = nullptr;
+    arena_next = 0;
+    if (arena_bytes) {
+        void* q = nullptr;
+        DDIF_HIPCHK(hipMalloc(&q, arena_bytes));
+        allocs.push_back(q);
+        bytes_allocated += arena_bytes;
+        arena = reinterpret_cast<char*>(q);
+    }
+    if (int e = build_impl()) return e;
+    if (arena_next != (int)lives.size()) return fail(DDIF_ERR_STATE, "plan arena: the two build passes disagree");
+    return 0;
 }
 
 int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
@@ -233,7 +318,18 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
-    if (int e = alloc_tensor(out, pc.cout, Hout, Wout)) return e;
+    if (&prog == &step) {  // liveness of everything this launch touches (dry pass)
+        use(s.in0.p);
+        use(s.in1.p);
+        use(s.res);
+        use(s.film);
+        use(s.cs_mx);
+        use(s.cs_sm);
+        use(s.out_xn);
+        use(s.cso_mx);
+        use(s.cso_sm);
+    }
+    if (int e = alloc_tensor(out, pc.cout, Hout, Wout, &prog == &step)) return e;
     ConvArgs a{};
     a.in0 = s.in0.p;
     a.in1 = s.in1.p;
@@ -281,7 +377,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const long nwork = (long)B * a.tiles_x * a.tiles_y * gy;
     const int gy0 = (pc.cout + var.nt - 1) / var.nt;
     const size_t smem = var.lr ? var.smem : var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
-    long cap = (long)num_cus() * wg_per_cu(smem);
+    long cap = (long)num_cus() * wg_per_cu(smem, var.wg_cap);
     if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
     const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
     const dim3 block((unsigned)var.nthr);
@@ -344,7 +440,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
 }
 
 // ------------------------------------------------------------------------------------------------ program
-int Plan::build() {
+int Plan::build_impl() {
     const ddif_net_cfg& c = net->cfg;
     if (!net->committed) return fail(DDIF_ERR_STATE, "ddif_plan_create: ddif_net_commit has not been called");
     C = c.out_channel;
@@ -373,7 +469,7 @@ int Plan::build() {
 
     // ---- boundary staging + sampler state
     DDIF_TRY(dalloc(&zeros, (size_t)1024));
-    DDIF_HIPCHK(hipMemset(zeros, 0, 1024 * sizeof(float)));
+    if (!dry) DDIF_HIPCHK(hipMemset(zeros, 0, 1024 * sizeof(float)));
     DDIF_TRY(alloc_tensor(&x_in, c.in_channel, H, W));
     DDIF_TRY(alloc_tensor(&sc_in, c.out_channel, H, W));
     DDIF_TRY(alloc_tensor(&lms, C, H, W));
@@ -423,7 +519,8 @@ int Plan::build() {
             // train mode: y = silu(GN(h1)) * dropout mask is materialised (it is also what wgrad needs), conv2 runs on it
             auto dropped = [&](Tensor x, const float* g, const float* bt, Tensor* y) -> int {
                 if (!x.st || !g || !bt) return fail(DDIF_ERR_STATE, "%s: GroupNorm without producer statistics / affine", rb.c_str());
-                DDIF_TRY(alloc_tensor(y, x.C, x.H, x.W));
+                use(x.p);
+                DDIF_TRY(alloc_tensor(y, x.C, x.H, x.W, true));
                 DropSite site{nullptr, x.C, x.H, x.W};
                 DDIF_TRY(dalloc(&site.mask, (size_t)B * x.H * x.W * x.C));
                 drop_sites.push_back(site);
@@ -489,7 +586,8 @@ int Plan::build() {
         if (in.H * in.W == 64 && in.C == 128 && x3_enabled() && lr_enabled() && cq->w_x3 && co->w_x3 && cq->ck == 32 && co->ck == 32 && in.st) {
             // 64-token tiles: GroupNorm -> qkv -> softmax(q k^T / sqrt(C)) v -> out + bias + x in ONE kernel, one workgroup per
             // sample (kernels_attn.h); other sizes take the three-launch path below
-            DDIF_TRY(alloc_tensor(out, in.C, in.H, in.W));
+            use(in.p);
+            DDIF_TRY(alloc_tensor(out, in.C, in.H, in.W, true));
             out->np = 1;
             DDIF_TRY(dalloc(&out->st, (size_t)B * 2));
             DDIF_TRY(attn_block_prepare());
@@ -528,7 +626,8 @@ int Plan::build() {
         s1.use_bias = false;
         s1.name = "attn.qkv";
         DDIF_TRY(add_conv(step, s1, &qkv));
-        DDIF_TRY(alloc_tensor(&o, in.C, in.H, in.W));
+        DDIF_TRY(alloc_tensor(&o, in.C, in.H, in.W, true));
+        use(qkv.p);
         {
             Op op;
             op.name = "self_attn";
@@ -710,7 +809,7 @@ int Plan::build() {
         }
         // ---- per step
         Tensor xn, q, amix, f1, f2, f3;
-        DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl));
+        DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl, true));
         const PackedConv* pq1 = PC(ci + ".q.1");
         if (!pq1) return fail(DDIF_ERR_MISSING, "%s.q.1 missing", ci.c_str());
         if (!cur.st || !skip.st) return fail(DDIF_ERR_STATE, "%s: prenorm without producer statistics", ci.c_str());
@@ -724,7 +823,10 @@ int Plan::build() {
             // then q = q.1(dwq) on the split-K kernel -- fused into the 1x1 conv the depthwise pass would be recomputed by
             // every 32-cout tile (sr3_dwt.py:507-513,537,540)
             Tensor dwq;
-            DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl));
+            DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl, true));
+            use(cur.p);
+            use(skip.p);
+            use(xn.p);
             DwArgs a{};
             a.in0 = cur.p;
             a.c0 = cur.C;
@@ -788,6 +890,7 @@ int Plan::build() {
         if (!qmx) {
             DDIF_TRY(dalloc(&qmx, (size_t)B * Wl * fea));
             DDIF_TRY(dalloc(&qsm, (size_t)B * Wl * fea));
+            use(q.p);
             Op op;
             op.name = "q.softmax_stats";
             op.cls = 4;
@@ -864,7 +967,9 @@ int Plan::build() {
                 Tensor f3c;
                 s3.name = "ffn.3 (train)";
                 DDIF_TRY(add_conv(step, s3, &f3c));
-                DDIF_TRY(alloc_tensor(&f3, f3c.C, f3c.H, f3c.W));
+                DDIF_TRY(alloc_tensor(&f3, f3c.C, f3c.H, f3c.W, true));
+                use(f3c.p);
+                use(amix.p);
                 float* scale = nullptr;
                 DDIF_TRY(dalloc(&scale, (size_t)B));
                 path_sites.push_back(scale);

@@ -38,6 +38,7 @@ struct ConvVariant {
     size_t smem = 0;
     int th = 0, tw = 0, nt = 0, nthr = 256;
     bool x3 = false;  // bf16x3 instantiation: wants PackedConv::w_x3
+    int wg_cap = 2;   // persistent workgroups per CU (upper bound; LDS may allow fewer)
     bool lr = false;  // low-resolution kernel (kernels_lr.h): smem is the whole requirement, nothing is added per launch
     const char* name = "";
 };
@@ -119,11 +120,24 @@ struct Plan {
     std::string prof_name;
     ddif_prof_class cls_res[6] = {};  // per-class sums of the last ddif_prof_collect
 
+    // ---- liveness-based arena for the activations of the step program (built in two passes: a dry pass records, for every
+    //      step tensor, the first / last launch that touches it; the real pass places them with first-fit interval colouring)
+    struct Live { size_t bytes; int first, last; size_t off; };
+    std::vector<Live> lives;
+    std::map<const void*, int> fake2id;   // dry pass: fake address -> allocation index
+    bool dry = false;                     // dry pass: no device allocation, no device work
+    size_t dry_next = 0;                  // dry pass: next fake address offset
+    int arena_next = 0;                   // real pass: index of the next step tensor
+    char* arena = nullptr;
+    size_t arena_bytes = 0, unaliased_bytes = 0;
+    void use(const void* p);              // dry pass: the launch being created reads or writes p
+
     ~Plan();
     int build();
+    int build_impl();
     template <typename T>
     int dalloc(T** p, size_t n);
-    int alloc_tensor(Tensor* t, int C, int H, int W);
+    int alloc_tensor(Tensor* t, int C, int H, int W, bool step_act = false);
     int add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out);
     int ensure_tb(int rows);
     int time_rows(const float* t_host, int rows, hipStream_t s);
