@@ -122,6 +122,7 @@ def main():
     gathered = torch.empty((world * B, C, H, H), device=dev) if world > 1 else None
     plan = diffusion._plan(cond)  # builds workspaces + runs set_cond once (not timed)
     cost = plan.cost()
+    mem = plan.memory()
     torch.cuda.synchronize()
     log("plan ready: %.3f GFLOP and %.1f MB (algorithmic) per denoising step of the batch" % (cost["step_flop"] / 1e9, cost["step_bytes"] / 1e6))
 
@@ -215,6 +216,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "name": args.config, "tiles_per_gpu": B, "tile": [H, H, C], "T": T, "model_evaluations": n_evals,
                    "sampler": cf["sampler"], "parallelism": "tile-shard x%d" % world,
+                   "plan_memory_mb": {"total": mem["total_bytes"] / 1e6, "step_activation_arena": mem["arena_bytes"] / 1e6,
+                                      "same_activations_unaliased": mem["unaliased_bytes"] / 1e6},
                    "conv_math": ("fp32 operands split into 3 bf16 planes, 6 exact products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (3x3 convs, "
                                  "wide 1x1 convs, low-resolution levels); exact fp32 MFMA elsewhere") if x3 else "exact fp32 MFMA"},
         "roofline": {

@@ -290,6 +290,14 @@ int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, doub
     return DDIF_OK;
 }
 
+int ddif_plan_memory(ddif_plan_t plan, int64_t* total_bytes, int64_t* arena_bytes, int64_t* unaliased_bytes) {
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    if (total_bytes) *total_bytes = (int64_t)plan->p.bytes_allocated;
+    if (arena_bytes) *arena_bytes = (int64_t)plan->p.arena_bytes;
+    if (unaliased_bytes) *unaliased_bytes = (int64_t)plan->p.unaliased_bytes;
+    return DDIF_OK;
+}
+
 int ddif_debug_set_grid_cap(int max_workgroups) {
     ddif::g_debug_grid_cap = max_workgroups > 0 ? max_workgroups : 0;
     return DDIF_OK;

@@ -102,6 +102,7 @@ class _Lib:
         d.ddif_prof_classes.argtypes = [vp, C.POINTER(ProfClass)]
         d.ddif_plan_cost.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
         d.ddif_debug_set_grid_cap.argtypes = [i32]
+        d.ddif_plan_memory.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         d.ddif_cond_assemble.argtypes = [vp, vp, f32, i32, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_metrics.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
         d.ddif_optim_create.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32]
@@ -424,6 +425,11 @@ class PlanHandle:
                    for c in cls]
         return dict(launches=r.launches, total_ms=r.total_ms, total_flop=r.total_flop, total_bytes=r.total_bytes,
                     kernel=r.kernel_name.decode(), classes=classes)
+
+    def memory(self) -> dict:
+        v = [C.c_int64() for _ in range(3)]
+        self.lib.check(self.lib.dll.ddif_plan_memory(self.h, *[C.byref(x) for x in v]), "ddif_plan_memory")
+        return dict(total_bytes=v[0].value, arena_bytes=v[1].value, unaliased_bytes=v[2].value)
 
     def cost(self) -> dict:
         v = [C.c_double() for _ in range(4)]

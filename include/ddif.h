@@ -234,6 +234,11 @@ DDIF_API int ddif_prof_classes(ddif_plan_t plan, ddif_prof_class* out6);
 /* flops / bytes of one denoising step and of set_cond for this plan (algorithmic, SURVEY.md 8d accounting) */
 DDIF_API int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes);
 
+/* Device memory of a plan: everything it allocated, of which `arena_bytes` hold the activations of the denoising-step program
+ * (placed by liveness: a buffer is reused as soon as the last launch that touches its tensor has been enqueued); `unaliased_bytes`
+ * is what the same activations would take with one buffer per tensor. */
+DDIF_API int ddif_plan_memory(ddif_plan_t plan, int64_t* total_bytes, int64_t* arena_bytes, int64_t* unaliased_bytes);
+
 /* TEST HOOK: cap the persistent grid (workgroups per conv launch) of plans created afterwards; 0 removes the cap.
  * Results do not depend on the cap (work items are walked in a fixed order per workgroup and every reduction has a
  * fixed order); tests use it to make small cases walk many work items per workgroup, across sample boundaries,

@@ -196,3 +196,13 @@ def test_emulated_train_mode_forward_matches_reference_masks():
     finally:
         net.eval()
         net.set_train_masks(None, None)
+
+
+def test_emulated_plan_arena_reuses_activation_buffers():
+    """The step program's activations live in a liveness-based arena (csrc/ddif_plan.cpp Plan::build): far smaller than one
+    buffer per tensor, and -- the real check -- every parity test in this file and in -m gpu runs on the aliased buffers."""
+    net = net_for("wv3")
+    plan = net.plan_for(2, 16, 16, torch.device("cpu"))
+    m = plan.memory()
+    assert 0 < m["arena_bytes"] < 0.45 * m["unaliased_bytes"]
+    assert m["arena_bytes"] <= m["total_bytes"]
