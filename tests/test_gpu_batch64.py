@@ -156,3 +156,35 @@ def test_stale_plan_is_refused_after_recommit(net):
     net(x.to(DEV), t.to(DEV), cond.to(DEV))  # re-commit happens here, with a new plan
     with pytest.raises(DdifError, match="re-committed"):
         plan.forward(x.to(DEV), t, None)
+
+
+def test_ddpm_T1000_batch64_every_tile_matches_the_reference_golden(net):
+    """BASELINE configs[1] end to end against the REAL reference: the 64x64 tile of the T = 1000 golden (tests/golden/
+    ddpm_wv3_64_T1000.npz, produced by the reference's own p_sample_loop) replicated into a batch of 64 with the reference's
+    noise stream for every tile.  Every tile must reproduce the golden within the north-star tolerances and be bit-identical
+    to tile 0 -- 1000 steps x 184 launches through multi-item persistent workgroups, hipGraph replay and the activation arena."""
+    import os
+
+    import numpy as np
+
+    from ddif_testlib import reference_noise_stream
+
+    cid, ds, B1, H, W, T, seed = [c for c in gc.DDPM_CASES if c[0] == "ddpm_wv3_64_T1000"][0]
+    g = np.load(os.path.join(gc.GOLDEN_DIR, cid + ".npz"))
+    B = 64
+    tiles = gc.tiles_for(ds, B1, H, W, seed=seed)
+    cond = tiles["cond"].to(DEV).expand(B, -1, -1, -1).contiguous()
+    xT1, noise1 = reference_noise_stream(seed, (B1, 8, H, W), T)
+    xT = xT1.to(DEV).expand(B, -1, -1, -1).contiguous()
+    noise = noise1.to(DEV).expand(T, B, -1, -1, -1).contiguous()  # 8.6 GB of HBM: the same reference draws for every tile
+    d = make_diffusion(net, 8, T, H, DEV)
+    out = d(cond, mode="ddpm_sample", x_T=xT, noise=noise)
+    del noise
+    ref = torch.from_numpy(g["out"])
+    assert float((out[:1].cpu() - ref).abs().max()) <= 1e-4  # north-star per-pixel atol
+    for b in range(1, B):
+        assert torch.equal(out[b], out[0]), f"tile {b} differs from tile 0"
+    lms = tiles["cond"][:, :8]
+    sr_hip, sr_ref = (out[:1].cpu() + lms).clip(0, 1), (ref + lms).clip(0, 1)
+    assert abs(O.psnr(sr_hip, tiles["gt"]) - O.psnr(sr_ref, tiles["gt"])) <= 1e-3  # north-star PSNR tolerance (dB)
+    torch.cuda.empty_cache()
