@@ -158,7 +158,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    prof_every = max(1, n_evals // 20)
+    prof_every = max(10, n_evals // 20)  # a profiled step has an event pair around every launch: keep it to <= 1 step in 10
     plan.prof_begin(prof_every, 16384)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
