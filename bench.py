@@ -181,7 +181,8 @@ def main():
     value = mp_per_step * args.steps / dt
     ach_tflops = prof["total_flop"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] > 0 else 0.0
     step_flop_total = cost["step_flop"] * n_evals + cost["cond_flop"]
-    traffic, traffic_info = committed_traffic()
+    # the committed PMC passes are of the default (wv3, B = 64) command: other configurations report no traffic
+    traffic, traffic_info = committed_traffic() if (args.config == "wv3" and B == 64) else (None, {"traffic_from_committed_profile": False})
     x3 = "bf16x3" in prof["kernel"]
     # per-class breakdown of the profiled denoising steps (every launch of those steps sits between two HIP events)
     n_prof_steps = max(1, sum(1 for k in range(n_evals) if k % prof_every == 0) * args.steps)
