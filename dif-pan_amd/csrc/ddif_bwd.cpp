@@ -4,14 +4,12 @@
 #include "kernels_bwd.h"
 
 namespace ddif {
-namespace {
-inline dim3 grid_for(size_t n) {
+static inline dim3 grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     if (g > 8192) g = 8192;
     if (g < 1) g = 1;
     return dim3((unsigned)g);
 }
-}  // namespace
 
 struct ConvBwd {
     int device = 0, B = 0, Cin = 0, Cout = 0, H = 0, W = 0;
@@ -24,6 +22,8 @@ struct ConvBwd {
     int n_chunks = 0, nb_pad = 0, n_co = 0, n_ci = 0, nsplit = 0, rb = 4, nbchunk = 0;
     size_t wg_smem = 0;
 };
+int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device);
+void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float* dw, float* db);
 }  // namespace ddif
 
 struct ddif_convbwd {
@@ -40,7 +40,17 @@ int ddif_convbwd_create(ddif_convbwd_t* out, int B, int Cin, int Cout, int H, in
     (void)hipGetDevice(&prev);
     DDIF_HIPCHK(hipSetDevice(device));
     std::unique_ptr<ddif_convbwd> h(new ddif_convbwd());
-    ddif::ConvBwd& c = h->c;
+    const int rc = ddif::convbwd_init(h->c, B, Cin, Cout, H, W, device);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (rc) return rc;
+    *out = h.release();
+    return DDIF_OK;
+}
+}  // extern "C"
+
+namespace ddif {
+// the caller has made `device` current
+int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device) {
     c.device = device;
     c.B = B; c.Cin = Cin; c.Cout = Cout; c.H = H; c.W = W;
     c.plan.net = &c.net;
@@ -97,11 +107,39 @@ int ddif_convbwd_create(ddif_convbwd_t* out, int B, int Cin, int Cout, int H, in
             hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.wg_smem) != hipSuccess)
             rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_create: hipFuncSetAttribute failed");
     }
-    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
-    if (rc) return rc;
-    *out = h.release();
-    return DDIF_OK;
+    return rc;
 }
+
+// x_nhwc / dy_nhwc hold the op's inputs; dX is left in c.dx (NHWC) when want_dx
+void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float* dw, float* db) {
+    const int HW = c.H * c.W;
+    if (want_dx) {
+        const size_t nw = (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256;
+        hipLaunchKernelGGL(pack_dgrad_weights_kernel, grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.n_chunks, c.nb_pad, c.wpack);
+        StepCtx ctx;
+        for (auto& op : c.prog) op.run(s, ctx);
+    }
+    if (dw) {
+        WgradArgs a{};
+        a.x = c.x_nhwc;
+        a.dy = c.dy_nhwc;
+        a.B = c.B; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout;
+        a.n_ci = c.n_ci;
+        a.rb = c.rb;
+        a.bands_y = (c.H + c.rb - 1) / c.rb;
+        a.partial = c.partial;
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)c.Cout * c.Cin * 9), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
+                           c.Cout, c.Cin, dw);
+    }
+    if (db) {
+        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 0, s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
+        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((c.Cout + 255) / 256), dim3(256), 0, s, (const float*)c.bpart, c.nbchunk, c.Cout, db);
+    }
+}
+}  // namespace ddif
+
+extern "C" {
 
 void ddif_convbwd_destroy(ddif_convbwd_t h) { delete h; }
 
@@ -115,33 +153,99 @@ int ddif_convbwd_run(ddif_convbwd_t h, const float* x, const float* w, const flo
     hipStream_t s = (hipStream_t)stream;
     const int HW = c.H * c.W;
     hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cout), dim3(256), 0, s, dy, c.B, c.Cout, HW, c.dy_nhwc);
-    if (dx) {
-        const size_t nw = (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256;
-        hipLaunchKernelGGL(ddif::pack_dgrad_weights_kernel, ddif::grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.n_chunks, c.nb_pad, c.wpack);
-        ddif::StepCtx ctx;
-        for (auto& op : c.prog) op.run(s, ctx);
-        hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, (const float*)c.dx.p, c.B, c.Cin, HW, dx);
-    }
-    if (dw) {
-        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, x, c.B, c.Cin, HW, c.x_nhwc);
-        ddif::WgradArgs a{};
-        a.x = c.x_nhwc;
-        a.dy = c.dy_nhwc;
-        a.B = c.B; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout;
-        a.n_ci = c.n_ci;
-        a.rb = c.rb;
-        a.bands_y = (c.H + c.rb - 1) / c.rb;
-        a.partial = c.partial;
-        hipLaunchKernelGGL(ddif::conv3x3_wgrad_kernel, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
-        hipLaunchKernelGGL(ddif::wgrad_reduce_kernel, ddif::grid_for((size_t)c.Cout * c.Cin * 9), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
-                           c.Cout, c.Cin, dw);
-    }
-    if (db) {
-        hipLaunchKernelGGL(ddif::bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 0, s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
-        hipLaunchKernelGGL(ddif::bias_grad_reduce_kernel, dim3((c.Cout + 255) / 256), dim3(256), 0, s, (const float*)c.bpart, c.nbchunk, c.Cout, db);
-    }
+    if (dw) hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, x, c.B, c.Cin, HW, c.x_nhwc);
+    ddif::convbwd_core(c, s, w, dx != nullptr, dw, db);
+    if (dx) hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, (const float*)c.dx.p, c.B, c.Cin, HW, dx);
     int rc = DDIF_OK;
     if (hipGetLastError() != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_run: kernel launch failed");
+    if (prev >= 0 && prev != c.device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------- Block backward
+namespace ddif {
+struct BlockBwd {
+    ConvBwd conv;      // owns the NHWC staging buffers: conv.x_nhwc = a (the conv's input), conv.dy_nhwc = dY, conv.dx = dA
+    float *x_nhwc = nullptr, *mask_nhwc = nullptr, *dx_nhwc = nullptr, *ms = nullptr, *S = nullptr;
+    double *spart = nullptr, *cpart = nullptr, *planes = nullptr;
+    int nchunk = 32;
+};
+}  // namespace ddif
+struct ddif_blockbwd {
+    ddif::BlockBwd b;
+};
+
+extern "C" {
+
+int ddif_blockbwd_create(ddif_blockbwd_t* out, int B, int Cin, int Cout, int H, int W, int device) {
+    if (!out || B < 1 || Cin < 4 || Cout < 4 || (Cin & 3) || (Cout & 3) || H < 1 || W < 1)
+        return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_create: B >= 1, 4 | Cin, 4 | Cout, H, W >= 1 required");
+    *out = nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    DDIF_HIPCHK(hipSetDevice(device));
+    std::unique_ptr<ddif_blockbwd> h(new ddif_blockbwd());
+    ddif::BlockBwd& k = h->b;
+    int rc = ddif::convbwd_init(k.conv, B, Cin, Cout, H, W, device);
+    auto TRY = [&](int e) { if (!rc) rc = e; };
+    const size_t n = (size_t)B * H * W * Cin;
+    k.nchunk = H * W < 32 ? H * W : 32;
+    ddif::Plan& pl = k.conv.plan;
+    TRY(pl.dalloc(&k.x_nhwc, n));
+    TRY(pl.dalloc(&k.mask_nhwc, n));
+    TRY(pl.dalloc(&k.dx_nhwc, n));
+    TRY(pl.dalloc(&k.ms, (size_t)B * 2));
+    TRY(pl.dalloc(&k.S, (size_t)B * 2));
+    TRY(pl.dalloc(&k.spart, (size_t)B * k.nchunk * 2));
+    TRY(pl.dalloc(&k.cpart, (size_t)B * k.nchunk * Cin * 2));
+    TRY(pl.dalloc(&k.planes, (size_t)B * Cin * 2));
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (rc) return rc;
+    *out = h.release();
+    return DDIF_OK;
+}
+
+void ddif_blockbwd_destroy(ddif_blockbwd_t h) { delete h; }
+
+int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, const float* beta, const float* mask, const float* w, const float* dy, float* dx,
+                      float* dgamma, float* dbeta, float* dw, float* db, float* dy_plane_sums, void* stream) {
+    if (!h || !x || !gamma || !beta || !w || !dy) return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_run: NULL argument");
+    ddif::BlockBwd& k = h->b;
+    ddif::ConvBwd& c = k.conv;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c.device) DDIF_HIPCHK(hipSetDevice(c.device));
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = c.H * c.W, B = c.B, Ci = c.Cin;
+    const size_t n = (size_t)B * HW * Ci;
+    const dim3 ew((unsigned)((size_t)HW * Ci / 4 + 255) / 256 > 64 ? 64u : (unsigned)(((size_t)HW * Ci / 4 + 255) / 256), (unsigned)B);
+    const float* m = mask ? k.mask_nhwc : nullptr;
+    // boundary layout -> NHWC
+    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), 0, s, x, B, Ci, HW, k.x_nhwc);
+    if (mask) hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), 0, s, mask, B, Ci, HW, k.mask_nhwc);
+    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)B * HW * c.Cout), dim3(256), 0, s, dy, B, c.Cout, HW, c.dy_nhwc);
+    // forward recompute: GroupNorm statistics of x, then a = Dropout(SiLU(GroupNorm(x))) -- the conv's input, needed by wgrad
+    hipLaunchKernelGGL(ddif::gnb_stats_kernel, dim3(k.nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, (const float*)k.x_nhwc, (size_t)HW * Ci, k.nchunk, k.spart);
+    hipLaunchKernelGGL(ddif::gnb_finalize_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)k.spart, k.nchunk, (double)HW * Ci, B, k.ms);
+    hipLaunchKernelGGL(ddif::gnb_act_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, (const float*)k.ms, gamma, beta, m, HW, Ci, c.x_nhwc);
+    // conv backward: dA (always needed), dW, db
+    ddif::convbwd_core(c, s, w, true, dw, db);
+    if (dy_plane_sums) hipLaunchKernelGGL(ddif::plane_sum_nchw_kernel, dim3(B * c.Cout), dim3(256), 256 * sizeof(double), s, dy, HW, dy_plane_sums);
+    // GroupNorm + SiLU + dropout backward
+    const float* da = c.dx.p;
+    hipLaunchKernelGGL(ddif::gnb_bwd_partial_kernel, dim3(k.nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, (const float*)k.x_nhwc, da, m, (const float*)k.ms, gamma,
+                       beta, HW, Ci, k.nchunk, k.cpart);
+    hipLaunchKernelGGL(ddif::gnb_bwd_planes_kernel, ddif::grid_for((size_t)B * Ci), dim3(256), 0, s, (const double*)k.cpart, B, k.nchunk, Ci, k.planes);
+    hipLaunchKernelGGL(ddif::gnb_bwd_finalize_kernel, dim3((Ci + B + 255) / 256), dim3(256), 0, s, (const double*)k.planes, gamma, B, Ci, dgamma, dbeta, k.S);
+    if (dx) {
+        hipLaunchKernelGGL(ddif::gnb_bwd_dx_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, da, m, (const float*)k.ms, gamma, beta, (const float*)k.S, HW, Ci,
+                           k.dx_nhwc);
+        hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
+    }
+    int rc = DDIF_OK;
+    if (hipGetLastError() != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_blockbwd_run: kernel launch failed");
     if (prev >= 0 && prev != c.device) (void)hipSetDevice(prev);
     return rc;
 }

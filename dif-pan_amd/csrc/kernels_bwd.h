@@ -175,3 +175,193 @@ __global__ void bwd_nhwc_to_nchw_kernel(const float* in, int B, int C, int HW, f
     }
 }
 }  // namespace ddif
+
+namespace ddif {
+// ----------------------------------------------------------------------------------------------------------------
+// Backward of the part of `Block` in front of its convolution (models/sr3_dwt.py:288-300):
+//     a = Dropout(SiLU(GroupNorm_1group(x)))       x_hat = (x - mean_b) * rstd_b,  y = gamma_c x_hat + beta_c,  a = silu(y) * m
+// (m = 0 or 1/(1-p): the train-mode plan's dropout-site mask; NULL = eval).  Given dA (from the conv's dgrad):
+//     dy = dA * m * silu'(y)            silu'(y) = s (1 + y (1 - s)),  s = sigmoid(y)
+//     dgamma_c = sum_{b,p} dy x_hat     dbeta_c = sum_{b,p} dy
+//     dx = rstd_b (gamma_c dy - S1_b / N - x_hat S2_b / N),   S1_b = sum_{c,p} gamma_c dy,  S2_b = sum_{c,p} gamma_c dy x_hat,  N = C H W
+// Everything NHWC, C % 4 == 0.  Reductions: fp64, fixed order (thread-strided partials -> LDS tree in index order ->
+// per-chunk partials in memory -> serial sums), no atomics: bitwise reproducible.
+__global__ __launch_bounds__(256) void gnb_stats_kernel(const float* x, size_t per_sample, int nchunk, double* part /* [B][nchunk][2] */) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [2][256]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const size_t per = (per_sample / 4 + nchunk - 1) / nchunk;
+    const size_t i0 = (size_t)blockIdx.x * per, i1 = i0 + per < per_sample / 4 ? i0 + per : per_sample / 4;
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = i0 + tid; i < i1; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)b * per_sample + i * 4);
+        s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+    red[tid] = s1;
+    red[256 + tid] = s2;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) {
+            red[tid] += red[tid + st];
+            red[256 + tid] += red[256 + tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[((size_t)b * nchunk + blockIdx.x) * 2 + 0] = red[0];
+        part[((size_t)b * nchunk + blockIdx.x) * 2 + 1] = red[256];
+    }
+}
+__global__ void gnb_finalize_stats_kernel(const double* part, int nchunk, double n, int B, float* ms /* [B][2]: mean, rstd */) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += part[((size_t)b * nchunk + k) * 2 + 0];
+        s2 += part[((size_t)b * nchunk + k) * 2 + 1];
+    }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    ms[b * 2 + 0] = (float)mean;
+    ms[b * 2 + 1] = (float)(1.0 / sqrt(var + DDIF_GN_EPS));
+}
+// a = silu(gamma x_hat + beta) * mask     grid = (chunks, B)
+__global__ __launch_bounds__(256) void gnb_act_kernel(const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int HW, int C,
+                                                      float* out) {
+    const int b = blockIdx.y;
+    const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
+    const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const float4 v = *reinterpret_cast<const float4*>(x + base + i * 4);
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float y = fmaf(((&v.x)[k] - mean) * rstd, gamma[c + k], beta[c + k]);
+            o[k] = dd_silu(y);
+            if (mask) o[k] *= mask[base + i * 4 + k];
+        }
+        *reinterpret_cast<float4*>(out + base + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+__device__ __forceinline__ float gnb_dy(float xh, float g, float bt, float da, float m) {
+    const float y = fmaf(xh, g, bt);
+    const float s = dd_sigmoid(y);
+    return da * m * (s * (1.f + y * (1.f - s)));
+}
+// per (sample, pixel chunk, channel): {sum dy, sum dy x_hat}.  grid = (nchunk, B); thread = (pixel row r, channel quad q)
+__global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma,
+                                                              const float* beta, int HW, int C, int nchunk, double* cpart /* [B][nchunk][C][2] */) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [256][8]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int C4 = C / 4, rows = 256 / C4 > 0 ? 256 / C4 : 1;
+    const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int p0 = blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
+    for (int q0 = 0; q0 < C4; q0 += 256) {  // C > 1024: several passes over channel quads
+        const int q = q0 + tid % (C4 < 256 ? C4 : 256), r = tid / (C4 < 256 ? C4 : 256);
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q < C4 && r < rows) {
+            for (int p = p0 + r; p < p1; p += rows) {
+                const size_t e = ((size_t)b * HW + p) * C + q * 4;
+                const float4 xv = *reinterpret_cast<const float4*>(x + e);
+                const float4 dv = *reinterpret_cast<const float4*>(da + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = ((&xv.x)[k] - mean) * rstd;
+                    const float dy = gnb_dy(xh, gamma[q * 4 + k], beta[q * 4 + k], (&dv.x)[k], mask ? mask[e + k] : 1.f);
+                    acc[2 * k] += (double)dy;
+                    acc[2 * k + 1] += (double)dy * (double)xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = acc[k];
+        __syncthreads();
+        if (q < C4 && r == 0) {  // fixed order over the pixel rows
+            const int stride = C4 < 256 ? C4 : 256;
+            for (int k = 0; k < 8; ++k) {
+                double s = 0.0;
+                for (int rr = 0; rr < rows; ++rr) s += red[(rr * stride + tid) * 8 + k];
+                cpart[(((size_t)b * nchunk + blockIdx.x) * C + q * 4 + k / 2) * 2 + (k & 1)] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+// plane sums pl[b][c][2] = sum over chunks; one thread per (b, c)
+__global__ void gnb_bwd_planes_kernel(const double* cpart, int B, int nchunk, int C, double* pl) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * C) return;
+    const size_t b = i / C, c = i % C;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s0 += cpart[((b * nchunk + k) * C + c) * 2 + 0];
+        s1 += cpart[((b * nchunk + k) * C + c) * 2 + 1];
+    }
+    pl[i * 2 + 0] = s0;
+    pl[i * 2 + 1] = s1;
+}
+// threads [0, C): dgamma / dbeta (sum over samples);  threads [C, C + B): S1_b, S2_b (sum over channels, weighted by gamma)
+__global__ void gnb_bwd_finalize_kernel(const double* pl, const float* gamma, int B, int C, float* dgamma, float* dbeta, float* S /* [B][2] */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {
+        double g = 0.0, bt = 0.0;
+        for (int b = 0; b < B; ++b) {
+            bt += pl[((size_t)b * C + i) * 2 + 0];
+            g += pl[((size_t)b * C + i) * 2 + 1];
+        }
+        if (dgamma) dgamma[i] = (float)g;
+        if (dbeta) dbeta[i] = (float)bt;
+    } else if (i < C + B) {
+        const int b = i - C;
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            s1 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 0];
+            s2 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 1];
+        }
+        S[b * 2 + 0] = (float)(s1 / ((double)C));  // divided by HW in the consumer (N = C * HW)
+        S[b * 2 + 1] = (float)(s2 / ((double)C));
+    }
+}
+__global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta,
+                                                         const float* S, int HW, int C, float* dx) {
+    const int b = blockIdx.y;
+    const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
+    const float m1 = S[b * 2] / (float)HW, m2 = S[b * 2 + 1] / (float)HW;
+    const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const float4 xv = *reinterpret_cast<const float4*>(x + base + i * 4);
+        const float4 dv = *reinterpret_cast<const float4*>(da + base + i * 4);
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = ((&xv.x)[k] - mean) * rstd;
+            const float dy = gnb_dy(xh, gamma[c + k], beta[c + k], (&dv.x)[k], mask ? mask[base + i * 4 + k] : 1.f);
+            o[k] = rstd * (gamma[c + k] * dy - m1 - xh * m2);
+        }
+        *reinterpret_cast<float4*>(dx + base + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+// out[b * C + c] = sum over pixels of in[b, c, :] (NCHW planes; fixed-order tree): the FeatureWiseAffine gradient d(noise_func output)
+// of a ResnetBlock (models/sr3_dwt.py:241-258, 322) is this row sum of block1's output gradient
+__global__ __launch_bounds__(256) void plane_sum_nchw_kernel(const float* in, int HW, float* out) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [256]
+    const int tid = threadIdx.x;
+    const float* p = in + (size_t)blockIdx.x * HW;
+    double s = 0.0;
+    for (int i = tid; i < HW; i += 256) s += (double)p[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = (float)red[0];
+}
+}  // namespace ddif

@@ -113,6 +113,10 @@ class _Lib:
         d.ddif_convbwd_destroy.argtypes = [vp]
         d.ddif_convbwd_destroy.restype = None
         d.ddif_convbwd_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        d.ddif_blockbwd_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
+        d.ddif_blockbwd_destroy.argtypes = [vp]
+        d.ddif_blockbwd_destroy.restype = None
+        d.ddif_blockbwd_run.argtypes = [vp] + [vp] * 13
         self.emulated = bool(d.ddif_is_emulated())
 
     def check(self, rc: int, what: str):
@@ -540,6 +544,47 @@ class Conv3x3Backward:
         try:
             if getattr(self, "h", None):
                 self.lib.dll.ddif_convbwd_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class BlockBackward:
+    """Backward of one `Block` of the denoiser (reference models/sr3_dwt.py:288-300: GroupNorm(1 group) -> Swish -> Dropout ->
+    conv3x3) as autograd runs it under loss.backward() (diffusion_engine.py:233).  `mask` is the dropout site's mask (0 or
+    1/(1-p), what `PlanHandle.train_sites` / `set_train_masks` carry), None in eval mode.  Returns a dict with dx, dgamma,
+    dbeta, dw, db and dy_plane_sums (B, Cout) -- the gradient of the time bias FeatureWiseAffine adds behind block1."""
+
+    def __init__(self, B, Cin, Cout, H, W, device):
+        self.lib = get_lib()
+        dev = torch.device(device)
+        idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
+        h = C.c_void_p()
+        self.lib.check(self.lib.dll.ddif_blockbwd_create(C.byref(h), B, Cin, Cout, H, W, idx), "ddif_blockbwd_create")
+        self.h, self.shape, self.device = h, (B, Cin, Cout, H, W), dev
+
+    def __call__(self, x, gamma, beta, w, dy, mask=None, need_dx=True):
+        B, Cin, Cout, H, W = self.shape
+        named = [("x", x, (B, Cin, H, W)), ("gamma", gamma, (Cin,)), ("beta", beta, (Cin,)), ("w", w, (Cout, Cin, 3, 3)), ("dy", dy, (B, Cout, H, W))]
+        if mask is not None:
+            named.append(("mask", mask, (B, Cin, H, W)))
+        for nm, t, shp in named:
+            _check_tensor(self.lib, t, nm)
+            _check_shape(t, nm, shp)
+        x, gamma, beta, w, dy = x.contiguous(), gamma.contiguous(), beta.contiguous(), w.contiguous(), dy.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        f = dict(dtype=torch.float32, device=x.device)
+        out = {"dx": torch.empty_like(x) if need_dx else None, "dgamma": torch.empty((Cin,), **f), "dbeta": torch.empty((Cin,), **f),
+               "dw": torch.empty_like(w), "db": torch.empty((Cout,), **f), "dy_plane_sums": torch.empty((B, Cout), **f)}
+        self.lib.check(self.lib.dll.ddif_blockbwd_run(self.h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mask), _ptr(w), _ptr(dy), _ptr(out["dx"]),
+                                                      _ptr(out["dgamma"]), _ptr(out["dbeta"]), _ptr(out["dw"]), _ptr(out["db"]),
+                                                      _ptr(out["dy_plane_sums"]), _stream(self.lib, x.device)), "ddif_blockbwd_run")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dll.ddif_blockbwd_destroy(self.h)
                 self.h = None
         except Exception:
             pass

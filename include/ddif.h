@@ -207,6 +207,20 @@ DDIF_API int ddif_convbwd_create(ddif_convbwd_t* out, int B, int Cin, int Cout, 
 DDIF_API void ddif_convbwd_destroy(ddif_convbwd_t h);
 DDIF_API int ddif_convbwd_run(ddif_convbwd_t h, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, void* stream);
 
+/* Backward of one `Block` (models/sr3_dwt.py:288-300: GroupNorm(1 group, eps 1e-5, affine) -> x*sigmoid(x) -> Dropout -> conv3x3 pad 1 + bias),
+ * i.e. what autograd does for it inside `loss.backward()` (diffusion_engine.py:233).  NCHW fp32 device pointers:
+ *   x (B,Cin,H,W) the Block's input; gamma, beta (Cin); mask (B,Cin,H,W) = the dropout site's mask holding 0 or 1/(1-p)
+ *   (ddif_plan_train_site / _set_dropout), NULL in eval mode; w (Cout,Cin,3,3); dy (B,Cout,H,W) the gradient of the Block's output.
+ * Outputs (each nullable): dx (B,Cin,H,W), dgamma, dbeta (Cin), dw (Cout,Cin,3,3), db (Cout), and dy_plane_sums (B,Cout) =
+ * sum over pixels of dy -- the gradient of the per-sample time bias FeatureWiseAffine adds to block1's output
+ * (models/sr3_dwt.py:241-258, 322).  The activation in front of the conv is recomputed from x (nothing but x is kept
+ * from the forward pass).  fp64 fixed-order reductions; bitwise reproducible. */
+typedef struct ddif_blockbwd* ddif_blockbwd_t;
+DDIF_API int ddif_blockbwd_create(ddif_blockbwd_t* out, int B, int Cin, int Cout, int H, int W, int device);
+DDIF_API void ddif_blockbwd_destroy(ddif_blockbwd_t h);
+DDIF_API int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, const float* beta, const float* mask, const float* w, const float* dy,
+                               float* dx, float* dgamma, float* dbeta, float* dw, float* db, float* dy_plane_sums, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 
 /* Bracket launches of the dominant kernel class (3x3 implicit-GEMM convolutions of the denoising step) with HIP

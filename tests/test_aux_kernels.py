@@ -147,3 +147,80 @@ def test_conv3x3_backward_matches_autograd(backend, shape):
         assert err <= 2e-5 * max(1.0, float(want.abs().max())), (nm, err, float(want.abs().max()))
     dx2, dw2, db2 = op(x.detach().to(dev), w.detach().to(dev), dy.to(dev))
     assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)  # fixed-order reductions: bitwise reproducible
+
+
+def _block_forward(x, gamma, beta, mask, w, b):
+    """`Block.forward` of the reference (models/sr3_dwt.py:288-300) with the Dropout mask made explicit."""
+    a = torch.nn.functional.silu(torch.nn.functional.group_norm(x, 1, gamma, beta, eps=1e-5))
+    if mask is not None:
+        a = a * mask
+    return torch.nn.functional.conv2d(a, w, b, padding=1)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape,drop", [((2, 32, 32, 16, 16), 0.2), ((1, 64, 32, 8, 8), 0.0), ((2, 16, 48, 12, 20), 0.2), ((3, 8, 8, 5, 7), 0.2)],
+                         ids=["32-32@16-drop", "64-32@8-eval", "16-48@12x20-drop", "8-8@5x7-drop"])
+def test_block_backward_matches_autograd(backend, shape, drop):
+    """Backward of a whole `Block` (GroupNorm(1) -> Swish -> Dropout -> conv3x3; SURVEY 8(a) a4 under a15) against torch autograd
+    on the CPU in fp32, with the dropout mask pinned.  Tolerance 3e-5 relative to each gradient's scale (fp32, different
+    summation order; the GroupNorm sums here are fp64)."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = (torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.3).requires_grad_()
+    gamma = (1.0 + 0.2 * torch.randn(Cin, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(Cin, generator=g)).requires_grad_()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).requires_grad_()
+    b = torch.zeros(Cout, requires_grad=True)
+    mask = None
+    if drop > 0:
+        mask = (torch.rand(B, Cin, H, W, generator=g) >= drop).float() / (1.0 - drop)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    _block_forward(x, gamma, beta, mask, w, b).backward(dy)
+    op = runtime.BlockBackward(B, Cin, Cout, H, W, dev)
+    args = [t.detach().to(dev) for t in (x, gamma, beta, w, dy)]
+    got = op(*args, mask=None if mask is None else mask.to(dev))
+    want = {"dx": x.grad, "dgamma": gamma.grad, "dbeta": beta.grad, "dw": w.grad, "db": b.grad, "dy_plane_sums": dy.sum(dim=(2, 3))}
+    for nm, ref in want.items():
+        err = float((got[nm].cpu() - ref).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (nm, err, float(ref.abs().max()))
+    again = op(*args, mask=None if mask is None else mask.to(dev))
+    assert all(torch.equal(got[k], again[k]) for k in want)  # fixed-order reductions: bitwise reproducible
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_resnet_block_backward_composed_from_block_backwards(backend):
+    """`ResnetBlock` (models/sr3_dwt.py:303-327; res_conv = Identity in the engine configuration): out = block2(block1(x) + tb) + x with
+    tb = FeatureWiseAffine's per-sample time bias.  Its backward is two Block backwards chained: d(block1 output) = dx of block2,
+    d(tb) = its plane sums, d(x) = dx of block1 + d(out).  Checked against autograd through the same composition."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cc, H, W = 2, 32, 16, 16
+    g = torch.Generator().manual_seed(99)
+    leaf = lambda t: t.requires_grad_()
+    x = leaf(torch.randn(B, Cc, H, W, generator=g))
+    tb = leaf(0.3 * torch.randn(B, Cc, generator=g))
+    p = []
+    for _ in range(2):
+        p.append(dict(gamma=leaf(1.0 + 0.2 * torch.randn(Cc, generator=g)), beta=leaf(0.1 * torch.randn(Cc, generator=g)),
+                      w=leaf(torch.randn(Cc, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5)), b=leaf(0.05 * torch.randn(Cc, generator=g))))
+    mask2 = (torch.rand(B, Cc, H, W, generator=g) >= 0.2).float() / 0.8  # Dropout sits in block2 only (dropout=0 in block1, :318-319)
+    h1 = _block_forward(x, p[0]["gamma"], p[0]["beta"], None, p[0]["w"], p[0]["b"]) + tb[:, :, None, None]
+    out = _block_forward(h1, p[1]["gamma"], p[1]["beta"], mask2, p[1]["w"], p[1]["b"]) + x
+    dout = torch.randn(B, Cc, H, W, generator=g)
+    out.backward(dout)
+    op = runtime.BlockBackward(B, Cc, Cc, H, W, dev)
+    d = lambda t: t.detach().to(dev)
+    g2 = op(d(h1), d(p[1]["gamma"]), d(p[1]["beta"]), d(p[1]["w"]), d(dout), mask=mask2.to(dev))
+    g1 = op(d(x), d(p[0]["gamma"]), d(p[0]["beta"]), d(p[0]["w"]), g2["dx"])
+    dx = g1["dx"] + d(dout)
+    checks = [("dx", dx, x.grad), ("dtb", g1["dy_plane_sums"], tb.grad)]
+    for k, gk in ((0, g1), (1, g2)):
+        checks += [(f"block{k + 1}.dgamma", gk["dgamma"], p[k]["gamma"].grad), (f"block{k + 1}.dbeta", gk["dbeta"], p[k]["beta"].grad),
+                   (f"block{k + 1}.dw", gk["dw"], p[k]["w"].grad), (f"block{k + 1}.db", gk["db"], p[k]["b"].grad)]
+    for nm, got, ref in checks:
+        err = float((got.cpu() - ref).abs().max())
+        assert err <= 5e-5 * max(1.0, float(ref.abs().max())), (nm, err, float(ref.abs().max()))
