@@ -170,7 +170,9 @@ struct BlockBwd {
     ConvBwd conv;      // owns the NHWC staging buffers: conv.x_nhwc = a (the conv's input), conv.dy_nhwc = dY, conv.dx = dA
     float *x_nhwc = nullptr, *mask_nhwc = nullptr, *dx_nhwc = nullptr, *ms = nullptr, *S = nullptr;
     double *spart = nullptr, *cpart = nullptr, *planes = nullptr;
-    int nchunk = 32;
+    float *w3 = nullptr, *dw3 = nullptr;  // ks == 1: the 1x1 weights / weight gradient embedded in 3x3 tensors
+    int nchunk = 32, ks = 3, pro = DDIF_BWD_PRO_GN_SILU, resample = DDIF_BWD_PLAIN;
+    int H = 0, W = 0;  // of the op's INPUT x (the conv runs at 2H x 2W under DDIF_BWD_UP2)
 };
 }  // namespace ddif
 struct ddif_blockbwd {
@@ -180,19 +182,37 @@ struct ddif_blockbwd {
 extern "C" {
 
 int ddif_blockbwd_create(ddif_blockbwd_t* out, int B, int Cin, int Cout, int H, int W, int device) {
+    return ddif_blockbwd_create_ex(out, B, Cin, Cout, H, W, 3, DDIF_BWD_PRO_GN_SILU, DDIF_BWD_PLAIN, device);
+}
+
+int ddif_blockbwd_create_ex(ddif_blockbwd_t* out, int B, int Cin, int Cout, int H, int W, int ks, int pro, int resample, int device) {
     if (!out || B < 1 || Cin < 4 || Cout < 4 || (Cin & 3) || (Cout & 3) || H < 1 || W < 1)
         return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_create: B >= 1, 4 | Cin, 4 | Cout, H, W >= 1 required");
+    if ((ks != 1 && ks != 3) || pro < DDIF_BWD_PRO_NONE || pro > DDIF_BWD_PRO_SILU || resample < DDIF_BWD_PLAIN || resample > DDIF_BWD_UP2)
+        return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_create_ex: ks must be 1 or 3, pro one of DDIF_BWD_PRO_*, resample one of DDIF_BWD_PLAIN / _DOWN2 / _UP2");
+    if (resample != DDIF_BWD_PLAIN && (ks != 3 || pro != DDIF_BWD_PRO_NONE))
+        return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_create_ex: Downsample / Upsample are plain 3x3 convs in the reference");
     *out = nullptr;
     int prev = -1;
     (void)hipGetDevice(&prev);
     DDIF_HIPCHK(hipSetDevice(device));
     std::unique_ptr<ddif_blockbwd> h(new ddif_blockbwd());
     ddif::BlockBwd& k = h->b;
-    int rc = ddif::convbwd_init(k.conv, B, Cin, Cout, H, W, device);
+    const int up = resample == DDIF_BWD_UP2 ? 2 : 1;
+    int rc = ddif::convbwd_init(k.conv, B, Cin, Cout, H * up, W * up, device);
     auto TRY = [&](int e) { if (!rc) rc = e; };
     const size_t n = (size_t)B * H * W * Cin;
+    k.H = H;
+    k.W = W;
+    k.resample = resample;
     k.nchunk = H * W < 32 ? H * W : 32;
+    k.ks = ks;
+    k.pro = pro;
     ddif::Plan& pl = k.conv.plan;
+    if (ks == 1) {
+        TRY(pl.dalloc(&k.w3, (size_t)Cout * Cin * 9));
+        TRY(pl.dalloc(&k.dw3, (size_t)Cout * Cin * 9));
+    }
     TRY(pl.dalloc(&k.x_nhwc, n));
     TRY(pl.dalloc(&k.mask_nhwc, n));
     TRY(pl.dalloc(&k.dx_nhwc, n));
@@ -211,38 +231,75 @@ void ddif_blockbwd_destroy(ddif_blockbwd_t h) { delete h; }
 
 int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, const float* beta, const float* mask, const float* w, const float* dy, float* dx,
                       float* dgamma, float* dbeta, float* dw, float* db, float* dy_plane_sums, void* stream) {
-    if (!h || !x || !gamma || !beta || !w || !dy) return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_run: NULL argument");
+    if (!h || !x || !w || !dy) return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_run: NULL argument");
     ddif::BlockBwd& k = h->b;
+    const bool gn = k.pro == DDIF_BWD_PRO_GN || k.pro == DDIF_BWD_PRO_GN_SILU;
+    const bool act = k.pro == DDIF_BWD_PRO_SILU;
+    const int silu = k.pro == DDIF_BWD_PRO_GN_SILU;
+    if (gn && (!gamma || !beta)) return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_run: GroupNorm prologue without gamma / beta");
+    if (!gn && mask) return ddif::fail(DDIF_ERR_INVALID, "ddif_blockbwd_run: a dropout mask needs the GroupNorm prologue (Dropout only follows Swish in the reference)");
     ddif::ConvBwd& c = k.conv;
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != c.device) DDIF_HIPCHK(hipSetDevice(c.device));
     hipStream_t s = (hipStream_t)stream;
-    const int HW = c.H * c.W, B = c.B, Ci = c.Cin;
+    const int HW = k.H * k.W, B = c.B, Ci = c.Cin;  // of x
     const size_t n = (size_t)B * HW * Ci;
-    const dim3 ew((unsigned)((size_t)HW * Ci / 4 + 255) / 256 > 64 ? 64u : (unsigned)(((size_t)HW * Ci / 4 + 255) / 256), (unsigned)B);
+    const size_t nq = ((size_t)HW * Ci / 4 + 255) / 256;
+    const dim3 ew((unsigned)(nq > 64 ? 64 : nq), (unsigned)B);
     const float* m = mask ? k.mask_nhwc : nullptr;
+    const bool pre = gn || act;  // something sits between x and the conv's input
     // boundary layout -> NHWC
-    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), 0, s, x, B, Ci, HW, k.x_nhwc);
+    const int Ho = k.resample == DDIF_BWD_DOWN2 ? (k.H - 1) / 2 + 1 : c.H, Wo = k.resample == DDIF_BWD_DOWN2 ? (k.W - 1) / 2 + 1 : c.W;  // of dy
+    if (k.resample == DDIF_BWD_UP2)
+        hipLaunchKernelGGL(ddif::upsample2_nchw_to_nhwc_kernel, ddif::grid_for(n * 4), dim3(256), 0, s, x, B, Ci, k.H, k.W, c.x_nhwc);
+    else
+        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), 0, s, x, B, Ci, HW, pre ? k.x_nhwc : c.x_nhwc);
     if (mask) hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), 0, s, mask, B, Ci, HW, k.mask_nhwc);
-    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)B * HW * c.Cout), dim3(256), 0, s, dy, B, c.Cout, HW, c.dy_nhwc);
-    // forward recompute: GroupNorm statistics of x, then a = Dropout(SiLU(GroupNorm(x))) -- the conv's input, needed by wgrad
-    hipLaunchKernelGGL(ddif::gnb_stats_kernel, dim3(k.nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, (const float*)k.x_nhwc, (size_t)HW * Ci, k.nchunk, k.spart);
-    hipLaunchKernelGGL(ddif::gnb_finalize_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)k.spart, k.nchunk, (double)HW * Ci, B, k.ms);
-    hipLaunchKernelGGL(ddif::gnb_act_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, (const float*)k.ms, gamma, beta, m, HW, Ci, c.x_nhwc);
-    // conv backward: dA (always needed), dW, db
-    ddif::convbwd_core(c, s, w, true, dw, db);
-    if (dy_plane_sums) hipLaunchKernelGGL(ddif::plane_sum_nchw_kernel, dim3(B * c.Cout), dim3(256), 256 * sizeof(double), s, dy, HW, dy_plane_sums);
-    // GroupNorm + SiLU + dropout backward
+    if (k.resample == DDIF_BWD_DOWN2)
+        hipLaunchKernelGGL(ddif::zero_stuff_nchw_to_nhwc_kernel, ddif::grid_for((size_t)B * c.H * c.W * c.Cout), dim3(256), 0, s, dy, B, c.Cout, Ho, Wo, c.H, c.W, c.dy_nhwc);
+    else
+        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)B * c.H * c.W * c.Cout), dim3(256), 0, s, dy, B, c.Cout, c.H * c.W, c.dy_nhwc);
+    if (gn) {
+        // forward recompute: GroupNorm statistics of x, then a = Dropout(SiLU(GroupNorm(x))) -- the conv's input, needed by wgrad
+        hipLaunchKernelGGL(ddif::gnb_stats_kernel, dim3(k.nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, (const float*)k.x_nhwc, (size_t)HW * Ci, k.nchunk, k.spart);
+        hipLaunchKernelGGL(ddif::gnb_finalize_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)k.spart, k.nchunk, (double)HW * Ci, B, k.ms);
+        hipLaunchKernelGGL(ddif::gnb_act_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, (const float*)k.ms, gamma, beta, m, HW, Ci, silu, c.x_nhwc);
+    } else if (act) {
+        hipLaunchKernelGGL(ddif::silu_fwd_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.x_nhwc, n, c.x_nhwc);
+    }
+    // conv backward: dA (needed whenever anything in front of the conv wants a gradient), dW, db
+    const bool want_da = gn || dx;
+    const size_t nw1 = (size_t)c.Cout * Ci;
+    if (k.ks == 1) {
+        hipLaunchKernelGGL(ddif::embed_1x1_kernel, ddif::grid_for(nw1 * 9), dim3(256), 0, s, w, nw1, k.w3);
+        ddif::convbwd_core(c, s, k.w3, want_da, dw ? k.dw3 : nullptr, db);
+        if (dw) hipLaunchKernelGGL(ddif::extract_centre_kernel, ddif::grid_for(nw1), dim3(256), 0, s, (const float*)k.dw3, nw1, dw);
+    } else {
+        ddif::convbwd_core(c, s, w, want_da, dw, db);
+    }
+    if (dy_plane_sums) hipLaunchKernelGGL(ddif::plane_sum_nchw_kernel, dim3(B * c.Cout), dim3(256), 256 * sizeof(double), s, dy, Ho * Wo, dy_plane_sums);
     const float* da = c.dx.p;
-    hipLaunchKernelGGL(ddif::gnb_bwd_partial_kernel, dim3(k.nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, (const float*)k.x_nhwc, da, m, (const float*)k.ms, gamma,
-                       beta, HW, Ci, k.nchunk, k.cpart);
-    hipLaunchKernelGGL(ddif::gnb_bwd_planes_kernel, ddif::grid_for((size_t)B * Ci), dim3(256), 0, s, (const double*)k.cpart, B, k.nchunk, Ci, k.planes);
-    hipLaunchKernelGGL(ddif::gnb_bwd_finalize_kernel, dim3((Ci + B + 255) / 256), dim3(256), 0, s, (const double*)k.planes, gamma, B, Ci, dgamma, dbeta, k.S);
-    if (dx) {
-        hipLaunchKernelGGL(ddif::gnb_bwd_dx_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, da, m, (const float*)k.ms, gamma, beta, (const float*)k.S, HW, Ci,
-                           k.dx_nhwc);
-        hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
+    if (gn) {
+        // GroupNorm (+ SiLU + dropout) backward
+        hipLaunchKernelGGL(ddif::gnb_bwd_partial_kernel, dim3(k.nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, (const float*)k.x_nhwc, da, m, (const float*)k.ms,
+                           gamma, beta, HW, Ci, k.nchunk, silu, k.cpart);
+        hipLaunchKernelGGL(ddif::gnb_bwd_planes_kernel, ddif::grid_for((size_t)B * Ci), dim3(256), 0, s, (const double*)k.cpart, B, k.nchunk, Ci, k.planes);
+        hipLaunchKernelGGL(ddif::gnb_bwd_finalize_kernel, dim3((Ci + B + 255) / 256), dim3(256), 0, s, (const double*)k.planes, gamma, B, Ci, dgamma, dbeta, k.S);
+        if (dx) {
+            hipLaunchKernelGGL(ddif::gnb_bwd_dx_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, da, m, (const float*)k.ms, gamma, beta, (const float*)k.S, HW, Ci,
+                               silu, k.dx_nhwc);
+            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
+        }
+    } else if (dx) {
+        if (act) {
+            hipLaunchKernelGGL(ddif::silu_bwd_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.x_nhwc, da, n, k.dx_nhwc);
+            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
+        } else if (k.resample == DDIF_BWD_UP2) {
+            hipLaunchKernelGGL(ddif::sumpool2_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, da, B, Ci, k.H, k.W, dx);
+        } else {
+            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, da, B, Ci, HW, dx);
+        }
     }
     int rc = DDIF_OK;
     if (hipGetLastError() != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_blockbwd_run: kernel launch failed");

@@ -229,7 +229,7 @@ __global__ void gnb_finalize_stats_kernel(const double* part, int nchunk, double
 }
 // a = silu(gamma x_hat + beta) * mask     grid = (chunks, B)
 __global__ __launch_bounds__(256) void gnb_act_kernel(const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int HW, int C,
-                                                      float* out) {
+                                                      int silu, float* out) {
     const int b = blockIdx.y;
     const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
     const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
@@ -240,20 +240,21 @@ __global__ __launch_bounds__(256) void gnb_act_kernel(const float* x, const floa
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float y = fmaf(((&v.x)[k] - mean) * rstd, gamma[c + k], beta[c + k]);
-            o[k] = dd_silu(y);
+            o[k] = silu ? dd_silu(y) : y;
             if (mask) o[k] *= mask[base + i * 4 + k];
         }
         *reinterpret_cast<float4*>(out + base + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
-__device__ __forceinline__ float gnb_dy(float xh, float g, float bt, float da, float m) {
+__device__ __forceinline__ float gnb_dy(float xh, float g, float bt, float da, float m, int silu) {
+    if (!silu) return da * m;  // GroupNorm alone (SelfAttention.norm, the attention prenorms)
     const float y = fmaf(xh, g, bt);
     const float s = dd_sigmoid(y);
     return da * m * (s * (1.f + y * (1.f - s)));
 }
 // per (sample, pixel chunk, channel): {sum dy, sum dy x_hat}.  grid = (nchunk, B); thread = (pixel row r, channel quad q)
 __global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma,
-                                                              const float* beta, int HW, int C, int nchunk, double* cpart /* [B][nchunk][C][2] */) {
+                                                              const float* beta, int HW, int C, int nchunk, int silu, double* cpart /* [B][nchunk][C][2] */) {
     DDIF_DYN_SMEM(smem_);
     double* red = reinterpret_cast<double*>(smem_);  // [256][8]
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, co
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float xh = ((&xv.x)[k] - mean) * rstd;
-                    const float dy = gnb_dy(xh, gamma[q * 4 + k], beta[q * 4 + k], (&dv.x)[k], mask ? mask[e + k] : 1.f);
+                    const float dy = gnb_dy(xh, gamma[q * 4 + k], beta[q * 4 + k], (&dv.x)[k], mask ? mask[e + k] : 1.f, silu);
                     acc[2 * k] += (double)dy;
                     acc[2 * k + 1] += (double)dy * (double)xh;
                 }
@@ -328,7 +329,7 @@ __global__ void gnb_bwd_finalize_kernel(const double* pl, const float* gamma, in
     }
 }
 __global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta,
-                                                         const float* S, int HW, int C, float* dx) {
+                                                         const float* S, int HW, int C, int silu, float* dx) {
     const int b = blockIdx.y;
     const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
     const float m1 = S[b * 2] / (float)HW, m2 = S[b * 2 + 1] / (float)HW;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const f
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float xh = ((&xv.x)[k] - mean) * rstd;
-            const float dy = gnb_dy(xh, gamma[c + k], beta[c + k], (&dv.x)[k], mask ? mask[base + i * 4 + k] : 1.f);
+            const float dy = gnb_dy(xh, gamma[c + k], beta[c + k], (&dv.x)[k], mask ? mask[base + i * 4 + k] : 1.f, silu);
             o[k] = rstd * (gamma[c + k] * dy - m1 - xh * m2);
         }
         *reinterpret_cast<float4*>(dx + base + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -363,5 +364,56 @@ __global__ __launch_bounds__(256) void plane_sum_nchw_kernel(const float* in, in
         __syncthreads();
     }
     if (tid == 0) out[blockIdx.x] = (float)red[0];
+}
+// 1x1 convolutions ride the 3x3 backward kernels for now (correctness first): the (Cout, Cin) weights become the centre tap of a
+// zero 3x3 kernel -- its dgrad IS the 1x1 dgrad, and the centre tap of its wgrad IS the 1x1 wgrad (the other taps are never read)
+__global__ void embed_1x1_kernel(const float* w1, size_t n /* Cout * Cin */, float* w3) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 9; i += (size_t)gridDim.x * blockDim.x) w3[i] = (i % 9 == 4) ? w1[i / 9] : 0.f;
+}
+__global__ void extract_centre_kernel(const float* dw3, size_t n, float* dw1) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dw1[i] = dw3[i * 9 + 4];
+}
+// ---- SiLU alone in front of a conv (FastAttnCondInjection.ffn: conv3x3 -> SiLU -> conv3x3, models/sr3_dwt.py:528-533)
+__global__ void silu_fwd_kernel(const float* x, size_t n, float* a) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = dd_silu(x[i]);
+}
+__global__ void silu_bwd_kernel(const float* x, const float* da, size_t n, float* dx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float y = x[i], s = dd_sigmoid(y);
+        dx[i] = da[i] * (s * (1.f + y * (1.f - s)));
+    }
+}
+// ---- Downsample = conv3x3 stride 2 pad 1 (:276-282): its backward is the stride-1 backward on dY with zeros inserted
+//      (dYu[2oy][2ox] = dY[oy][ox]): dX[i] = sum_k dYu[i + 1 - k] w[k] and dW[k] = sum_i dYu[i] x[i + k - 1] are exactly the strided sums
+__global__ void zero_stuff_nchw_to_nhwc_kernel(const float* dy, int B, int C, int Ho, int Wo, int H, int W, float* out /* (B,H,W,C) */) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % W), y = (int)((i / ((size_t)C * W)) % H);
+        const size_t b = i / ((size_t)C * W * H);
+        float v = 0.f;
+        if (!(x & 1) && !(y & 1) && (y >> 1) < Ho && (x >> 1) < Wo) v = dy[((b * C + c) * Ho + (y >> 1)) * Wo + (x >> 1)];
+        out[i] = v;
+    }
+}
+// ---- Upsample = nearest x2 then conv3x3 (:266-273): the conv sees x_up; dX = 2x2 sum pooling of d(x_up)
+__global__ void upsample2_nchw_to_nhwc_kernel(const float* x, int B, int C, int H, int W, float* out /* (B,2H,2W,C) */) {
+    const size_t total = (size_t)B * 4 * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int xx = (int)((i / C) % (2 * W)), yy = (int)((i / ((size_t)C * 2 * W)) % (2 * H));
+        const size_t b = i / ((size_t)C * 4 * W * H);
+        out[i] = x[((b * C + c) * H + (yy >> 1)) * W + (xx >> 1)];
+    }
+}
+__global__ void sumpool2_nhwc_to_nchw_kernel(const float* dxu /* (B,2H,2W,C) */, int B, int C, int H, int W, float* dx /* (B,C,H,W) */) {
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((size_t)W * H)) % C);
+        const size_t b = i / ((size_t)W * H * C);
+        const float* p = dxu + ((b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+        dx[i] = (p[0] + p[C]) + (p[(size_t)2 * W * C] + p[(size_t)2 * W * C + C]);
+    }
 }
 }  // namespace ddif

@@ -114,6 +114,7 @@ class _Lib:
         d.ddif_convbwd_destroy.restype = None
         d.ddif_convbwd_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         d.ddif_blockbwd_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
+        d.ddif_blockbwd_create_ex.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32, i32, i32]
         d.ddif_blockbwd_destroy.argtypes = [vp]
         d.ddif_blockbwd_destroy.restype = None
         d.ddif_blockbwd_run.argtypes = [vp] + [vp] * 13
@@ -555,26 +556,39 @@ class BlockBackward:
     1/(1-p), what `PlanHandle.train_sites` / `set_train_masks` carry), None in eval mode.  Returns a dict with dx, dgamma,
     dbeta, dw, db and dy_plane_sums (B, Cout) -- the gradient of the time bias FeatureWiseAffine adds behind block1."""
 
-    def __init__(self, B, Cin, Cout, H, W, device):
+    PRO = {"none": 0, "gn": 1, "gn_silu": 2, "silu": 3}
+    RESAMPLE = {"plain": 0, "down2": 1, "up2": 2}
+
+    def __init__(self, B, Cin, Cout, H, W, device, ks=3, pro="gn_silu", resample="plain"):
         self.lib = get_lib()
         dev = torch.device(device)
         idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
         h = C.c_void_p()
-        self.lib.check(self.lib.dll.ddif_blockbwd_create(C.byref(h), B, Cin, Cout, H, W, idx), "ddif_blockbwd_create")
-        self.h, self.shape, self.device = h, (B, Cin, Cout, H, W), dev
+        self.lib.check(self.lib.dll.ddif_blockbwd_create_ex(C.byref(h), B, Cin, Cout, H, W, ks, self.PRO[pro], self.RESAMPLE[resample], idx),
+                       "ddif_blockbwd_create_ex")
+        self.h, self.shape, self.device, self.ks, self.pro = h, (B, Cin, Cout, H, W), dev, ks, pro
+        self.out_hw = {"plain": (H, W), "down2": ((H - 1) // 2 + 1, (W - 1) // 2 + 1), "up2": (2 * H, 2 * W)}[resample]
 
     def __call__(self, x, gamma, beta, w, dy, mask=None, need_dx=True):
         B, Cin, Cout, H, W = self.shape
-        named = [("x", x, (B, Cin, H, W)), ("gamma", gamma, (Cin,)), ("beta", beta, (Cin,)), ("w", w, (Cout, Cin, 3, 3)), ("dy", dy, (B, Cout, H, W))]
+        named = [("x", x, (B, Cin, H, W)), ("w", w, (Cout, Cin, self.ks, self.ks)), ("dy", dy, (B, Cout) + self.out_hw)]
+        if self.pro in ("gn", "gn_silu"):
+            named += [("gamma", gamma, (Cin,)), ("beta", beta, (Cin,))]
+        else:
+            gamma = beta = None
         if mask is not None:
             named.append(("mask", mask, (B, Cin, H, W)))
         for nm, t, shp in named:
             _check_tensor(self.lib, t, nm)
             _check_shape(t, nm, shp)
-        x, gamma, beta, w, dy = x.contiguous(), gamma.contiguous(), beta.contiguous(), w.contiguous(), dy.contiguous()
+        x, w, dy = x.contiguous(), w.contiguous(), dy.contiguous()
+        gamma = gamma.contiguous() if gamma is not None else None
+        beta = beta.contiguous() if beta is not None else None
         mask = mask.contiguous() if mask is not None else None
         f = dict(dtype=torch.float32, device=x.device)
-        out = {"dx": torch.empty_like(x) if need_dx else None, "dgamma": torch.empty((Cin,), **f), "dbeta": torch.empty((Cin,), **f),
+        gn = self.pro in ("gn", "gn_silu")
+        out = {"dx": torch.empty_like(x) if need_dx else None, "dgamma": torch.empty((Cin,), **f) if gn else None,
+               "dbeta": torch.empty((Cin,), **f) if gn else None,
                "dw": torch.empty_like(w), "db": torch.empty((Cout,), **f), "dy_plane_sums": torch.empty((B, Cout), **f)}
         self.lib.check(self.lib.dll.ddif_blockbwd_run(self.h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mask), _ptr(w), _ptr(dy), _ptr(out["dx"]),
                                                       _ptr(out["dgamma"]), _ptr(out["dbeta"]), _ptr(out["dw"]), _ptr(out["db"]),

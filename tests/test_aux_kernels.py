@@ -224,3 +224,45 @@ def test_resnet_block_backward_composed_from_block_backwards(backend):
     for nm, got, ref in checks:
         err = float((got.cpu() - ref).abs().max())
         assert err <= 5e-5 * max(1.0, float(ref.abs().max())), (nm, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("ks,pro,resample,shape", [(1, "none", "plain", (2, 32, 64, 16, 16)), (3, "none", "plain", (2, 32, 64, 8, 8)),
+                                                   (1, "gn", "plain", (2, 128, 384, 8, 8)), (1, "gn_silu", "plain", (2, 128, 64, 16, 16)),
+                                                   (3, "silu", "plain", (2, 64, 32, 16, 16)), (3, "none", "down2", (2, 32, 32, 16, 16)),
+                                                   (3, "none", "down2", (1, 16, 24, 9, 13)), (3, "none", "up2", (2, 64, 64, 8, 8))],
+                         ids=["x_conv-1x1", "ffn0-3x3", "attn-norm-qkv", "cond-body-1x1", "ffn2-silu-3x3", "downsample", "downsample-odd", "upsample"])
+def test_conv_op_backward_variants_match_autograd(backend, ks, pro, resample, shape):
+    """The other conv-with-prologue shapes of the network through the same op: plain 1x1 (CondInjection.x_conv, ffn.3, attention
+    output convs; models/sr3_dwt.py:385-396,528-533), plain 3x3 (ffn.0), GroupNorm -> 1x1 (SelfAttention.norm -> qkv, :338-339,349),
+    GroupNorm -> Swish -> 1x1 (CondInjection.body tail, :380-384), SiLU -> 3x3 (ffn.2), Downsample (:276-282, also at odd sizes),
+    Upsample (:266-273)."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + ks)
+    x = (torch.randn(B, Cin, H, W, generator=g) * 1.2 - 0.2).requires_grad_()
+    gamma = (1.0 + 0.2 * torch.randn(Cin, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(Cin, generator=g)).requires_grad_()
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (ks * Cin ** 0.5)).requires_grad_()
+    b = torch.zeros(Cout, requires_grad=True)
+    a = x
+    if pro in ("gn", "gn_silu"):
+        a = torch.nn.functional.group_norm(a, 1, gamma, beta, eps=1e-5)
+    if pro in ("gn_silu", "silu"):
+        a = torch.nn.functional.silu(a)
+    if resample == "up2":
+        a = torch.nn.functional.interpolate(a, scale_factor=2, mode="nearest")
+    y = torch.nn.functional.conv2d(a, w, b, padding=ks // 2, stride=2 if resample == "down2" else 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    op = runtime.BlockBackward(B, Cin, Cout, H, W, dev, ks=ks, pro=pro, resample=resample)
+    d = lambda t: t.detach().to(dev)
+    got = op(d(x), d(gamma), d(beta), d(w), d(dy))
+    want = {"dx": x.grad, "dw": w.grad, "db": b.grad, "dy_plane_sums": dy.sum(dim=(2, 3))}
+    if pro in ("gn", "gn_silu"):
+        want.update(dgamma=gamma.grad, dbeta=beta.grad)
+    for nm, ref in want.items():
+        err = float((got[nm].cpu() - ref).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (nm, err, float(ref.abs().max()))
