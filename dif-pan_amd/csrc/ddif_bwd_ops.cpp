@@ -1,0 +1,93 @@
+// Host side of the stateless backward ops (kernels_bwd_ops.h): thin launch wrappers behind the C ABI (include/ddif.h).  They run on
+// the CURRENT device (the one the pointers live on) and on the given stream; no workspace, no handles.
+#include "ddif_plan.h"
+#include "kernels_bwd_ops.h"
+
+namespace ddif {
+static inline dim3 ops_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g);
+}
+static int ops_done(const char* what) {
+    if (hipGetLastError() != hipSuccess) return fail(DDIF_ERR_HIP, "%s: kernel launch failed", what);
+    return DDIF_OK;
+}
+}  // namespace ddif
+
+extern "C" {
+
+int ddif_dwconv3x3_bwd(const float* x, const float* w, const float* dy, int B, int C, int H, int W, float* dx, float* dw, void* stream) {
+    if (!w || !dy || B < 1 || C < 1 || H < 1 || W < 1 || (dw && !x)) return ddif::fail(DDIF_ERR_INVALID, "ddif_dwconv3x3_bwd: bad argument");
+    [[maybe_unused]] hipStream_t s = (hipStream_t)stream;
+    if (dx) hipLaunchKernelGGL(ddif::dwconv3x3_bwd_dx_kernel, ddif::ops_grid((size_t)B * C * H * W), dim3(256), 0, s, dy, w, B, C, H, W, dx);
+    if (dw) hipLaunchKernelGGL(ddif::dwconv3x3_bwd_dw_kernel, dim3(C), dim3(256), 9 * 256 * sizeof(double), s, x, dy, B, C, H, W, dw);
+    return ddif::ops_done("ddif_dwconv3x3_bwd");
+}
+
+int ddif_film_bwd(const float* xc, const float* scale_shift, const float* dout, int B, int C, int H, int W, float* dxc, float* dscale_shift, void* stream) {
+    if (!xc || !scale_shift || !dout || B < 1 || C < 1 || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_film_bwd: bad argument");
+    hipLaunchKernelGGL(ddif::film_bwd_kernel, ddif::ops_grid((size_t)B * C * H * W), dim3(256), 0, (hipStream_t)stream, xc, scale_shift, dout, B, C, H * W, dxc,
+                       dscale_shift);
+    return ddif::ops_done("ddif_film_bwd");
+}
+
+int ddif_selfattn_core_bwd(const float* qkv, const float* dout, int B, int C, int H, int W, int heads, float* dqkv, void* stream) {
+    if (!qkv || !dout || !dqkv || B < 1 || heads < 1 || C < heads || C % heads) return ddif::fail(DDIF_ERR_INVALID, "ddif_selfattn_core_bwd: bad argument");
+    const int d = C / heads, n = H * W;
+    if (n > 64 || d > 32) return ddif::fail(DDIF_ERR_INVALID, "ddif_selfattn_core_bwd: n = H*W <= 64 and head dim <= 32 (the engine's bottleneck attention) only");
+    const size_t smem = ((size_t)4 * d * n + (size_t)2 * n * n + n) * sizeof(float);
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::selfattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return ddif::fail(DDIF_ERR_HIP, "ddif_selfattn_core_bwd: hipFuncSetAttribute failed");
+    // scale 1/sqrt(C), not 1/sqrt(d): models/sr3_dwt.py:352
+    hipLaunchKernelGGL(ddif::selfattn_bwd_kernel, dim3(B * heads), dim3(256), smem, (hipStream_t)stream, qkv, dout, heads, d, n, 1.0f / sqrtf((float)C), dqkv);
+    return ddif::ops_done("ddif_selfattn_core_bwd");
+}
+
+int ddif_linattn_core_bwd(const float* q_pre, const float* kv_pre, const float* dout, int B, int qd, int H, int W, int heads, float* dq_pre, float* dkv_pre,
+                          void* stream) {
+    if (!q_pre || !kv_pre || !dout || !dq_pre || !dkv_pre || B < 1 || heads < 1 || qd < heads || qd % heads)
+        return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_bwd: bad argument");
+    const int d = qd / heads;
+    if (d > 32 || W > 64 || H < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_bwd: head dim <= 32 and W <= 64 only");
+    const size_t smem = ((size_t)8 * d * W + (size_t)2 * d * d + d) * sizeof(float);
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::linattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return ddif::fail(DDIF_ERR_HIP, "ddif_linattn_core_bwd: hipFuncSetAttribute failed");
+    hipLaunchKernelGGL(ddif::linattn_bwd_kernel, dim3(B * heads), dim3(256), smem, (hipStream_t)stream, q_pre, kv_pre, dout, heads, d, H, W, 1.0f / sqrtf((float)d),
+                       dq_pre, dkv_pre);
+    return ddif::ops_done("ddif_linattn_core_bwd");
+}
+
+int ddif_linear_bwd(const float* x, const float* w, const float* dy, int B, int nin, int nout, float* dx, float* dw, float* db, void* stream) {
+    if (!w || !dy || B < 1 || nin < 1 || nout < 1 || (dw && !x)) return ddif::fail(DDIF_ERR_INVALID, "ddif_linear_bwd: bad argument");
+    const size_t total = (dx ? (size_t)B * nin : 0) + (dw ? (size_t)nout * nin : 0) + (db ? (size_t)nout : 0);
+    if (total) hipLaunchKernelGGL(ddif::linear_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, dy, B, nin, nout, dx, dw, db);
+    return ddif::ops_done("ddif_linear_bwd");
+}
+
+int ddif_swish_bwd(const float* x, const float* dy, int64_t n, float* dx, void* stream) {
+    if (!x || !dy || !dx || n < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_swish_bwd: bad argument");
+    hipLaunchKernelGGL(ddif::swish_bwd_kernel, ddif::ops_grid((size_t)n), dim3(256), 0, (hipStream_t)stream, x, dy, (size_t)n, dx);
+    return ddif::ops_done("ddif_swish_bwd");
+}
+
+int ddif_l1_loss_bwd(const float* pred, const float* target, int64_t n, float upstream, float* dpred, void* stream) {
+    if (!pred || !target || !dpred || n < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_l1_loss_bwd: bad argument");
+    hipLaunchKernelGGL(ddif::l1_bwd_kernel, ddif::ops_grid((size_t)n), dim3(256), 0, (hipStream_t)stream, pred, target, (size_t)n, upstream, dpred);
+    return ddif::ops_done("ddif_l1_loss_bwd");
+}
+
+int ddif_groupnorm_bwd(const float* x, const float* gamma, const float* dy, int B, int C, int H, int W, float* dx, float* dgamma, float* dbeta, double* workspace,
+                       void* stream) {
+    if (!x || !gamma || !dy || !workspace || B < 1 || C < 1 || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_groupnorm_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ddif::gn_bwd_sample_kernel, dim3(B), dim3(256), 2 * 256 * sizeof(double), s, x, dy, gamma, C, H * W, workspace, B);
+    if (dx) hipLaunchKernelGGL(ddif::gn_bwd_dx_kernel, ddif::ops_grid((size_t)B * C * H * W), dim3(256), 0, s, x, dy, gamma, (const double*)workspace, B, C, H * W, dx);
+    if (dgamma || dbeta) hipLaunchKernelGGL(ddif::gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, B, C, dgamma, dbeta);
+    return ddif::ops_done("ddif_groupnorm_bwd");
+}
+
+}  // extern "C"

@@ -118,6 +118,14 @@ class _Lib:
         d.ddif_blockbwd_destroy.argtypes = [vp]
         d.ddif_blockbwd_destroy.restype = None
         d.ddif_blockbwd_run.argtypes = [vp] + [vp] * 13
+        d.ddif_dwconv3x3_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+        d.ddif_film_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+        d.ddif_selfattn_core_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        d.ddif_linattn_core_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        d.ddif_linear_bwd.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+        d.ddif_groupnorm_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+        d.ddif_swish_bwd.argtypes = [vp, vp, C.c_int64, vp, vp]
+        d.ddif_l1_loss_bwd.argtypes = [vp, vp, C.c_int64, C.c_float, vp, vp]
         self.emulated = bool(d.ddif_is_emulated())
 
     def check(self, rc: int, what: str):
@@ -602,3 +610,87 @@ class BlockBackward:
                 self.h = None
         except Exception:
             pass
+
+
+# ---- stateless backward ops (include/ddif.h "stateless backward ops"): each returns the gradients autograd would produce --------
+def _ops_prepare(named):
+    lib = get_lib()
+    out = []
+    for nm, t, shp in named:
+        _check_tensor(lib, t, nm)
+        _check_shape(t, nm, shp)
+        out.append(t.contiguous())
+    return lib, out
+
+
+def dwconv3x3_backward(x, w, dy):
+    """Depthwise conv3x3 (groups = C, pad 1, no bias; reference models/sr3_dwt.py:507-520): (dx, dw)."""
+    B, Cc, H, W = x.shape
+    lib, (x, w, dy) = _ops_prepare([("x", x, (B, Cc, H, W)), ("w", w, (Cc, 1, 3, 3)), ("dy", dy, (B, Cc, H, W))])
+    dx, dw = torch.empty_like(x), torch.empty_like(w)
+    lib.check(lib.dll.ddif_dwconv3x3_bwd(_ptr(x), _ptr(w), _ptr(dy), B, Cc, H, W, _ptr(dx), _ptr(dw), _stream(lib, x.device)), "ddif_dwconv3x3_bwd")
+    return dx, dw
+
+
+def film_backward(xc, scale_shift, dout):
+    """CondInjection's xc * (1 + scale) + shift (reference :395-396): (dxc, dscale_shift)."""
+    B, Cc, H, W = xc.shape
+    lib, (xc, ss, dout) = _ops_prepare([("xc", xc, (B, Cc, H, W)), ("scale_shift", scale_shift, (B, 2 * Cc, H, W)), ("dout", dout, (B, Cc, H, W))])
+    dxc, dss = torch.empty_like(xc), torch.empty_like(ss)
+    lib.check(lib.dll.ddif_film_bwd(_ptr(xc), _ptr(ss), _ptr(dout), B, Cc, H, W, _ptr(dxc), _ptr(dss), _stream(lib, xc.device)), "ddif_film_bwd")
+    return dxc, dss
+
+
+def selfattn_core_backward(qkv, dout, heads=8):
+    """SelfAttention core (reference :345-358): gradient of qkv (B, 3C, H, W) given that of the weighted sum (B, C, H, W)."""
+    B, C3, H, W = qkv.shape
+    lib, (qkv, dout) = _ops_prepare([("qkv", qkv, (B, C3, H, W)), ("dout", dout, (B, C3 // 3, H, W))])
+    dqkv = torch.empty_like(qkv)
+    lib.check(lib.dll.ddif_selfattn_core_bwd(_ptr(qkv), _ptr(dout), B, C3 // 3, H, W, heads, _ptr(dqkv), _stream(lib, qkv.device)), "ddif_selfattn_core_bwd")
+    return dqkv
+
+
+def linattn_core_backward(q_pre, kv_pre, dout, heads=8):
+    """FastAttnCondInjection core (reference :545-566): (dq_pre, dkv_pre) given the gradient of the attention output."""
+    B, qd, H, W = q_pre.shape
+    lib, (q_pre, kv_pre, dout) = _ops_prepare([("q_pre", q_pre, (B, qd, H, W)), ("kv_pre", kv_pre, (B, 2 * qd, H, W)), ("dout", dout, (B, qd, H, W))])
+    dq, dkv = torch.empty_like(q_pre), torch.empty_like(kv_pre)
+    lib.check(lib.dll.ddif_linattn_core_bwd(_ptr(q_pre), _ptr(kv_pre), _ptr(dout), B, qd, H, W, heads, _ptr(dq), _ptr(dkv), _stream(lib, q_pre.device)),
+              "ddif_linattn_core_bwd")
+    return dq, dkv
+
+
+def linear_backward(x, w, dy):
+    """nn.Linear (reference :59-64, 241-258): (dx, dw, db)."""
+    B, nin = x.shape
+    nout = w.shape[0]
+    lib, (x, w, dy) = _ops_prepare([("x", x, (B, nin)), ("w", w, (nout, nin)), ("dy", dy, (B, nout))])
+    dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty((nout,), dtype=torch.float32, device=x.device)
+    lib.check(lib.dll.ddif_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), B, nin, nout, _ptr(dx), _ptr(dw), _ptr(db), _stream(lib, x.device)), "ddif_linear_bwd")
+    return dx, dw, db
+
+
+def swish_backward(x, dy):
+    lib, (x, dy) = _ops_prepare([("x", x, tuple(x.shape)), ("dy", dy, tuple(x.shape))])
+    dx = torch.empty_like(x)
+    lib.check(lib.dll.ddif_swish_bwd(_ptr(x), _ptr(dy), x.numel(), _ptr(dx), _stream(lib, x.device)), "ddif_swish_bwd")
+    return dx
+
+
+def l1_loss_backward(pred, target, upstream=1.0):
+    """F.l1_loss(pred, target) (mean) backward (reference diffusion/diffusion_ddpm_pan.py:742-749)."""
+    lib, (pred, target) = _ops_prepare([("pred", pred, tuple(pred.shape)), ("target", target, tuple(pred.shape))])
+    dp = torch.empty_like(pred)
+    lib.check(lib.dll.ddif_l1_loss_bwd(_ptr(pred), _ptr(target), pred.numel(), C.c_float(upstream), _ptr(dp), _stream(lib, pred.device)), "ddif_l1_loss_bwd")
+    return dp
+
+
+def groupnorm_backward(x, gamma, dy):
+    """GroupNorm(1 group, eps 1e-5) alone (reference models/sr3_dwt.py:540-573 prenorm_x): (dx, dgamma, dbeta)."""
+    B, Cc, H, W = x.shape
+    lib, (x, gamma, dy) = _ops_prepare([("x", x, (B, Cc, H, W)), ("gamma", gamma, (Cc,)), ("dy", dy, (B, Cc, H, W))])
+    dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+    ws = torch.empty((B * (2 * Cc + 4),), dtype=torch.float64, device=x.device)
+    lib.check(lib.dll.ddif_groupnorm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), B, Cc, H, W, _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream(lib, x.device)),
+              "ddif_groupnorm_bwd")
+    return dx, dg, db

@@ -231,6 +231,32 @@ DDIF_API void ddif_blockbwd_destroy(ddif_blockbwd_t h);
 DDIF_API int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, const float* beta, const float* mask, const float* w, const float* dy,
                                float* dx, float* dgamma, float* dbeta, float* dw, float* db, float* dy_plane_sums, void* stream);
 
+/* ---- stateless backward ops of the non-convolution pieces (a15) ------------------------------------------------------------
+ * NCHW fp32 device pointers on the CURRENT device; every output pointer nullable unless noted; correctness-first kernels
+ * (csrc/kernels_bwd_ops.h), fixed-order reductions.  Each mirrors what autograd does for the named reference lines. */
+/* depthwise conv3x3, groups = C, pad 1, no bias (FastAttnCondInjection.q[0] / kv[0], models/sr3_dwt.py:507-520): w (C,1,3,3) */
+DDIF_API int ddif_dwconv3x3_bwd(const float* x, const float* w, const float* dy, int B, int C, int H, int W, float* dx, float* dw, void* stream);
+/* CondInjection's out = xc * (1 + scale) + shift (:395-396): scale_shift (B,2C,H,W) = [scale | shift]; d(scale_shift) same layout */
+DDIF_API int ddif_film_bwd(const float* xc, const float* scale_shift, const float* dout, int B, int C, int H, int W, float* dxc, float* dscale_shift,
+                           void* stream);
+/* SelfAttention core (:345-358): qkv (B,3C,H,W) in the reference's per-head [q|k|v] interleave, dout = gradient of the (B,C,H,W)
+ * weighted sum in front of `out`; scale 1/sqrt(C).  H*W <= 64, head dim <= 32. */
+DDIF_API int ddif_selfattn_core_bwd(const float* qkv, const float* dout, int B, int C, int H, int W, int heads, float* dqkv, void* stream);
+/* FastAttnCondInjection core (:545-566): q_pre (B,qd,H,W) and kv_pre (B,2qd,H,W) = [k | v] BEFORE their softmaxes (over H and
+ * over W); dout = gradient of the (B,qd,H,W) attention output in front of attn_out.  Head dim <= 32, W <= 64. */
+DDIF_API int ddif_linattn_core_bwd(const float* q_pre, const float* kv_pre, const float* dout, int B, int qd, int H, int W, int heads, float* dq_pre,
+                                   float* dkv_pre, void* stream);
+/* GroupNorm(1 group, eps 1e-5, affine) alone, for a normalised tensor with several consumers (FastAttnCondInjection.prenorm_x feeds
+ * q[0] AND attn_res, :540-573; the caller adds the consumers' gradients into dy).  workspace: B * (2 C + 4) doubles (device). */
+DDIF_API int ddif_groupnorm_bwd(const float* x, const float* gamma, const float* dy, int B, int C, int H, int W, float* dx, float* dgamma, float* dbeta,
+                                double* workspace, void* stream);
+/* nn.Linear (noise_level_mlp, FeatureWiseAffine; :59-64,241-258): x (B,in), w (out,in), dy (B,out) */
+DDIF_API int ddif_linear_bwd(const float* x, const float* w, const float* dy, int B, int nin, int nout, float* dx, float* dw, float* db, void* stream);
+/* Swish x*sigmoid(x) between the two Linear layers of noise_level_mlp (:61-63) */
+DDIF_API int ddif_swish_bwd(const float* x, const float* dy, int64_t n, float* dx, void* stream);
+/* F.l1_loss(pred, target) with mean reduction (diffusion/diffusion_ddpm_pan.py:742-749): dpred = sign(pred - target) * upstream / n */
+DDIF_API int ddif_l1_loss_bwd(const float* pred, const float* target, int64_t n, float upstream, float* dpred, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 
 /* Bracket launches of the dominant kernel class (3x3 implicit-GEMM convolutions of the denoising step) with HIP

@@ -1,0 +1,192 @@
+"""Backward ops of the non-convolution pieces of the denoiser against torch autograd through the ORACLE's own
+forward formulas (oracle/ddif_oracle.py, itself pinned to the reference) on the CPU in fp32.  The reference's backward is autograd
+(`loss.backward()`, diffusion_engine.py:233), so autograd through the same forward expression is the checker.  Emulator on the
+CPU (-m "not gpu"), the real library on MI355X (-m gpu)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ddif_testlib import use_emulator, use_gpu_library
+
+BACKENDS = [pytest.param("emu", id="emulated"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+
+
+def _dev(backend):
+    if backend == "emu":
+        use_emulator()
+        return torch.device("cpu")
+    use_gpu_library()
+    return torch.device("cuda:0")
+
+
+def _close(got, want, name, rel=3e-5):
+    err = float((got.cpu() - want).abs().max())
+    assert err <= rel * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 24, 9, 13), (2, 128, 8, 8)], ids=["64@16", "24@9x13", "128@8"])
+def test_depthwise3x3_backward(backend, shape):
+    """FastAttnCondInjection.q[0] / kv[0] (models/sr3_dwt.py:507-520): conv3x3, groups = C, no bias."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cc, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cc, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cc, 1, 3, 3, generator=g) / 3).requires_grad_()
+    dy = torch.randn(B, Cc, H, W, generator=g)
+    F.conv2d(x, w, None, padding=1, groups=Cc).backward(dy)
+    dx, dw = runtime.dwconv3x3_backward(x.detach().to(dev), w.detach().to(dev), dy.to(dev))
+    _close(dx, x.grad, "dx")
+    _close(dw, w.grad, "dw")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_film_backward(backend):
+    """CondInjection: xc * (1 + scale) + shift with scale, shift = y.chunk(2, dim=1) (models/sr3_dwt.py:393-396)."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cc, H, W = 2, 32, 16, 12
+    g = torch.Generator().manual_seed(5)
+    xc = torch.randn(B, Cc, H, W, generator=g, requires_grad=True)
+    ss = torch.randn(B, 2 * Cc, H, W, generator=g, requires_grad=True)
+    dout = torch.randn(B, Cc, H, W, generator=g)
+    scale, shift = ss.chunk(2, dim=1)
+    (xc * (1 + scale) + shift).backward(dout)
+    dxc, dss = runtime.film_backward(xc.detach().to(dev), ss.detach().to(dev), dout.to(dev))
+    _close(dxc, xc.grad, "dxc", 1e-6)
+    _close(dss, ss.grad, "dss", 1e-6)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 128, 8, 8), (1, 64, 4, 8)], ids=["128@8x8", "64@4x8"])
+def test_self_attention_core_backward(backend, shape):
+    """SelfAttention between its two 1x1 convs (models/sr3_dwt.py:345-358; oracle.self_attention): per-head [q|k|v] interleave,
+    scale 1/sqrt(C)."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cc, H, W = shape
+    heads, d = 8, Cc // 8
+    g = torch.Generator().manual_seed(sum(shape))
+    qkv = torch.randn(B, 3 * Cc, H, W, generator=g, requires_grad=True)
+    dout = torch.randn(B, Cc, H, W, generator=g)
+    v4 = qkv.view(B, heads, 3 * d, H * W)
+    q, k, v = v4[:, :, :d], v4[:, :, d:2 * d], v4[:, :, 2 * d:]
+    a = torch.softmax(torch.einsum("bncp,bncq->bnpq", q, k) / math.sqrt(Cc), dim=-1)
+    torch.einsum("bnpq,bncq->bncp", a, v).reshape(B, Cc, H, W).backward(dout)
+    dqkv = runtime.selfattn_core_backward(qkv.detach().to(dev), dout.to(dev), heads=heads)
+    _close(dqkv, qkv.grad, "dqkv")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 96, 8, 12), (1, 256, 8, 8)], ids=["64@16", "96@8x12", "256@8"])
+def test_linear_attention_core_backward(backend, shape):
+    """FastAttnCondInjection between q / kv and attn_out (models/sr3_dwt.py:545-566; oracle.fast_attn_cond_injection):
+    softmax over H of q, over W of k, q * 1/sqrt(d), ctx = k v^T, out = ctx^T q."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, qd, H, W = shape
+    heads, d = 8, qd // 8
+    g = torch.Generator().manual_seed(sum(shape))
+    q_pre = (2.0 * torch.randn(B, qd, H, W, generator=g)).requires_grad_()
+    kv_pre = (2.0 * torch.randn(B, 2 * qd, H, W, generator=g)).requires_grad_()
+    dout = torch.randn(B, qd, H, W, generator=g)
+    k, v = kv_pre.chunk(2, dim=1)
+    q = q_pre.softmax(dim=-2).reshape(B, heads, d, H * W) * (1.0 / math.sqrt(d))
+    k = k.softmax(dim=-1).reshape(B, heads, d, H * W)
+    v = v.reshape(B, heads, d, H * W)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, qd, H, W).backward(dout)
+    dq, dkv = runtime.linattn_core_backward(q_pre.detach().to(dev), kv_pre.detach().to(dev), dout.to(dev), heads=heads)
+    _close(dq, q_pre.grad, "dq_pre")
+    _close(dkv, kv_pre.grad, "dkv_pre")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_time_mlp_backward_chain(backend):
+    """noise_level_mlp = Linear(32,128) -> Swish -> Linear(128,32) and one FeatureWiseAffine Linear(32, C) (models/sr3_dwt.py:59-64,
+    241-258; oracle.time_embedding), chained from the library's linear / swish backward ops."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B = 4
+    g = torch.Generator().manual_seed(3)
+    leaf = lambda *s: (torch.randn(*s, generator=g) / math.sqrt(s[-1])).requires_grad_()
+    enc = torch.randn(B, 32, generator=g)
+    w1, b1, w3, b3, wf, bf = leaf(128, 32), leaf(128), leaf(32, 128), leaf(32), leaf(64, 32), leaf(64)
+    h1 = F.linear(enc, w1, b1)
+    h2 = h1 * torch.sigmoid(h1)
+    temb = F.linear(h2, w3, b3)
+    tb = F.linear(temb, wf, bf)
+    dtb = torch.randn(B, 64, generator=g)
+    tb.backward(dtb)
+    d = lambda t: t.detach().to(dev)
+    dtemb, dwf, dbf = runtime.linear_backward(d(temb), d(wf), d(dtb))
+    dh2, dw3, db3 = runtime.linear_backward(d(h2), d(w3), dtemb)
+    dh1 = runtime.swish_backward(d(h1), dh2)
+    _, dw1, db1 = runtime.linear_backward(d(enc), d(w1), dh1)
+    for got, ref, nm in ((dwf, wf.grad, "dwf"), (dbf, bf.grad, "dbf"), (dw3, w3.grad, "dw3"), (db3, b3.grad, "db3"), (dw1, w1.grad, "dw1"), (db1, b1.grad, "db1")):
+        _close(got, ref, nm, 1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_l1_loss_backward(backend):
+    """loss = F.l1_loss(model_out, target) (diffusion/diffusion_ddpm_pan.py:742-749)."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    g = torch.Generator().manual_seed(8)
+    pred = torch.randn(2, 8, 16, 16, generator=g, requires_grad=True)
+    target = torch.randn(2, 8, 16, 16, generator=g)
+    target[0, 0, 0, :4] = pred.detach()[0, 0, 0, :4]  # exact ties: sign(0) = 0
+    F.l1_loss(pred, target).backward()
+    dp = runtime.l1_loss_backward(pred.detach().to(dev), target.to(dev))
+    assert torch.equal(dp.cpu(), pred.grad)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 24, 5, 7)], ids=["64@16", "24@5x7"])
+def test_groupnorm_alone_backward(backend, shape):
+    """FastAttnCondInjection.prenorm_x (models/sr3_dwt.py:540): its output feeds q[0] and attn_res, so the GroupNorm backward runs on
+    the sum of both consumers' gradients."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cc, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (1.5 * torch.randn(B, Cc, H, W, generator=g) + 0.4).requires_grad_()
+    gamma = (1.0 + 0.2 * torch.randn(Cc, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(Cc, generator=g)).requires_grad_()
+    dy = torch.randn(B, Cc, H, W, generator=g)
+    F.group_norm(x, 1, gamma, beta, eps=1e-5).backward(dy)
+    dx, dg, db = runtime.groupnorm_backward(x.detach().to(dev), gamma.detach().to(dev), dy.to(dev))
+    _close(dx, x.grad, "dx")
+    _close(dg, gamma.grad, "dgamma")
+    _close(db, beta.grad, "dbeta")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_cond_conv_weight_gradient_through_zero_padded_channels(backend):
+    """CondInjection.body[0] = conv3x3(cond_L: 9 channels -> 4c, no bias) (models/sr3_dwt.py:380): the conv backward needs 4 | Cin,
+    so the 9 cond channels (and the weights) are zero-padded to 12; the padded channels' weight gradient is zero, the rest is dW.
+    (dx is not needed: cond is data.)"""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, Cin, Cout, H, W = 2, 9, 128, 16, 16
+    g = torch.Generator().manual_seed(21)
+    cond = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 9).requires_grad_()
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    F.conv2d(cond, w, None, padding=1).backward(dy)
+    pad = lambda t: F.pad(t, (0, 0, 0, 0, 0, 3))  # channel axis 9 -> 12
+    op = runtime.BlockBackward(B, 12, Cout, H, W, dev, ks=3, pro="none")
+    got = op(pad(cond).to(dev), None, None, pad(w.detach()).to(dev), dy.to(dev), need_dx=False)
+    _close(got["dw"][:, :Cin], w.grad, "dw")
+    assert float(got["dw"][:, Cin:].abs().max()) == 0.0
