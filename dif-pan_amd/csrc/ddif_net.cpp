@@ -355,6 +355,8 @@ int Net::commit(hipStream_t stream) {
         add_conv(ci + ".ffn.0", false);
         add_conv(ci + ".ffn.2", false);
         add_conv(ci + ".ffn.3", true);
+        if (const HostTensor* w3 = get(ci + ".ffn.3.weight"))  // raw (cout, cin) copy for the epilogue-fused form (kernels_conv.h EPI_MIX)
+            if (w3->v.size() == 32 * 32) vec_off[ci + ".ffn.3.weight"] = b.add(w3->v.data(), w3->v.size());
     }
     add_vec("final_conv.block.0.weight");
     add_vec("final_conv.block.0.bias");
