@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--T", type=int, default=0, help="diffusion steps (0: the configuration's own)")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib", default=None, help="development aid: another build of libddif.so to benchmark (A/B of kernel variants)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget of the cpu_baseline leg (split over B=1 and B=8)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: CPUs this process may run on (sched_getaffinity)")
     args = ap.parse_args()
@@ -100,6 +101,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.lib:
+        from ddif import runtime as _rt
+
+        _rt.use_library(os.path.abspath(args.lib))
     lib = ddif.get_lib()
     assert not lib.emulated
     cf = CONFIGS[args.config]

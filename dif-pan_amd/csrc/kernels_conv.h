@@ -363,10 +363,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             }
         }
     };
-    auto finish_stage = [&](StageRegs& R, int buf) {
-        float* dst = As + buf * ABUF;
-        float* wdst = Ws + (WSB ? 0 : buf) * WBUF;
-        float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
+    // finish_stage = fs_begin; fs_item x NITEMS; [depthwise pass]; fs_witem x WITEMS; fs_end.  The pieces exist so that the bf16x3
+    // MFMA loop can carry them BETWEEN its taps: v_mfma_f32_32x32x16_bf16 runs on the matrix pipe beside the VALU / LDS work of the same
+    // and of the partner wave (tools/probes/mfma_coexec.cpp: a bf16 MFMA stream slows a v_fma / v_exp / ds_read stream on the same SIMD
+    // by < 15 % and is not slowed itself), and the six dependent MFMAs of a tap leave ~40 idle issue slots per wave.
+    float fs_ga[4] = {0.f, 0.f, 0.f, 0.f}, fs_gb[4] = {0.f, 0.f, 0.f, 0.f};
+    bool fs_colsm = false;
+    auto fs_begin = [&](StageRegs& R) {
         if (GNP) {
             if (R.pos.b != gn_b) {  // workgroup-uniform; every wavefront reduces the partials itself (no barrier)
                 gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, R.pos.b, (double)Ctot * a.Hin * a.Win, &mean, &rstd);
@@ -376,46 +379,49 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             const float4 bq = *reinterpret_cast<const float4*>(&GBs[GBN + R.cb + c4 * 4]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ga[i] = (&gq.x)[i] * rstd;
-                gb[i] = (&bq.x)[i] - mean * ga[i];
+                fs_ga[i] = (&gq.x)[i] * rstd;
+                fs_gb[i] = (&bq.x)[i] - mean * fs_ga[i];
             }
         }
-        const bool colsm = (PRO == PRO_COLSM) && R.cb < a.c0;
-        // channels past the end of a partial last chunk hold duplicates of real (finite) data: their packed weights are 0
+        fs_colsm = (PRO == PRO_COLSM) && R.cb < a.c0;
+    };
+    // channels past the end of a partial last chunk hold duplicates of real (finite) data: their packed weights are 0
+    auto fs_item = [&](StageRegs& R, int buf, int it) {
+        float* dst = As + buf * ABUF;
+        const bool ok = (R.ok >> it) & 1u;
+        float v[4];
 #pragma unroll
-        for (int it = 0; it < NITEMS; ++it) {
-            const bool ok = (R.ok >> it) & 1u;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = (&R.sv[it].x)[i];
-                if (GNP) {
-                    x = fmaf(x, ga[i], gb[i]);
-                    if (PRO == PRO_GN_SILU) x = dd_silu(x);
-                }
-                if (PRO == PRO_COLSM) {
-                    if (colsm) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
-                }
-                v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation
+        for (int i = 0; i < 4; ++i) {
+            float x = (&R.sv[it].x)[i];
+            if (GNP) {
+                x = fmaf(x, fs_ga[i], fs_gb[i]);
+                if (PRO == PRO_GN_SILU) x = dd_silu(x);
             }
-            if (DWM) {
-                *reinterpret_cast<float4*>(&Hs[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
-                // centre pixels inside the image: this IS xn = GroupNorm(cat[h, skip]) (attn_res input)
-                if (a.out_xn && ok && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
-                    *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cb + c4 * 4) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-            } else if constexpr (X3) {
-                unsigned h01, m01, l01, h23, m23, l23;
-                dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
-                dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
-                const int ps = ((a_in >> it) & 1u) ? PS : 0;  // plane stride in floats (the dummy slot takes all three)
-                *reinterpret_cast<uint2*>(&dst[a_lds[it]]) = make_uint2(h01, h23);
-                *reinterpret_cast<uint2*>(&dst[a_lds[it] + ps]) = make_uint2(m01, m23);
-                *reinterpret_cast<uint2*>(&dst[a_lds[it] + 2 * ps]) = make_uint2(l01, l23);
-            } else {
-                *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+            if (PRO == PRO_COLSM) {
+                if (fs_colsm) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
             }
+            v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation
         }
+        if (DWM) {
+            *reinterpret_cast<float4*>(&Hs[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+            // centre pixels inside the image: this IS xn = GroupNorm(cat[h, skip]) (attn_res input)
+            if (a.out_xn && ok && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
+                *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cb + c4 * 4) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (X3) {
+            unsigned h01, m01, l01, h23, m23, l23;
+            dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
+            dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
+            const int ps = ((a_in >> it) & 1u) ? PS : 0;  // plane stride in floats (the dummy slot takes all three)
+            *reinterpret_cast<uint2*>(&dst[a_lds[it]]) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(&dst[a_lds[it] + ps]) = make_uint2(m01, m23);
+            *reinterpret_cast<uint2*>(&dst[a_lds[it] + 2 * ps]) = make_uint2(l01, l23);
+        } else {
+            *reinterpret_cast<float4*>(&dst[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto fs_depthwise = [&](StageRegs& R, int buf) {
+        float* dst = As + buf * ABUF;
         if (DWM) {
             __syncthreads();  // halo tile complete in Hs
 #pragma unroll
@@ -447,14 +453,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                 }
             }
         }
-#pragma unroll
-        for (int it = 0; it < WITEMS; ++it) {
-            float* wp = w_lds[it] >= 0 ? wdst + w_lds[it] : dst + DUMMY;
-            *reinterpret_cast<float4*>(wp) = R.wv[it];
-        }
+    };
+    auto fs_witem = [&](StageRegs& R, int buf, int it) {
+        float* dst = As + buf * ABUF;
+        float* wdst = Ws + (WSB ? 0 : buf) * WBUF;
+        float* wp = w_lds[it] >= 0 ? wdst + w_lds[it] : dst + DUMMY;
+        *reinterpret_cast<float4*>(wp) = R.wv[it];
+    };
+    auto fs_end = [&](StageRegs& R, int buf) {
         bufpos[buf] = R.pos;
         bufch[buf] = R.ch;
     };
+    auto finish_stage = [&](StageRegs& R, int buf) {
+        fs_begin(R);
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it) fs_item(R, buf, it);
+        fs_depthwise(R, buf);
+#pragma unroll
+        for (int it = 0; it < WITEMS; ++it) fs_witem(R, buf, it);
+        fs_end(R, buf);
+    };
+    // interleaved form: piece p of NP = NITEMS + WITEMS follows MFMA step p * NF / NP
+#ifdef DDIF_NO_ILV
+    constexpr bool ILV = false;
+#else
+    constexpr bool ILV = X3 && !DWM && !WSB;
+#endif
+    constexpr int NP = NITEMS + WITEMS;
 
     bool pend = false;  // a statistics partial of work item pend_pos sits in red[pend_par]
     Pos pend_pos = L;
@@ -555,6 +580,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
         }
+        if constexpr (ILV && !TAIL) fs_begin(Rn);
         // (3) contraction over taps x chunk channels: both fragments from LDS, no global load in here.  Weights are
         //     the MFMA's FIRST operand: D[cout][pixel] (see the header comment).
         const float* Wc = Ws + (WSB ? 0 : cur) * WBUF + (wn * NB) * WCHUNK + h * 128 + j * 4;
@@ -598,6 +624,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                         acc[mb][nb] = c;
                     }
                 DDIF_SCHED_FENCE();
+                if constexpr (ILV && !TAIL) {  // stage +1's pieces that belong behind this step
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        if (p * NF / NP == tap) {
+                            if (p < NITEMS) fs_item(Rn, cur ^ 1, p);
+                            else fs_witem(Rn, cur ^ 1, p - NITEMS);
+                        }
+                    DDIF_SCHED_FENCE();
+                }
             }
         } else {
         //     Fragments are double-buffered in registers: the ds_reads of step f+1 are issued BEFORE the MFMAs of step f
@@ -716,7 +751,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         // (5) stage +1 (loaded one stage ago) -> the other LDS buffer
         //     (after the very last stage this writes a never-consumed copy of the last item's chunk 0: cheaper than a
         //     `has_next` branch, whose skip path would leave Rn pending at the loop-head merge)
-        if constexpr (!TAIL) finish_stage(Rn, cur ^ 1);
+        if constexpr (!TAIL) {
+            if constexpr (ILV) fs_end(Rn, cur ^ 1);
+            else finish_stage(Rn, cur ^ 1);
+        }
         stamp();
 #ifndef DDIF_EMU
         // keep the tails of stage<LAST> and stage<!LAST> distinct: the optimiser otherwise sinks their common last LDS

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_interleave(float* out, long long* cyc, 
 }
 
 // block of 512 threads = 8 waves = 2 per SIMD; waves 0-3 role A, 4-7 role B
-template <int ROLE_A, int ROLE_B>  // 0 = idle, 1 = mfma stream, 2 = valu stream, 3 = transcendental stream, 4 = lds stream
+template <int ROLE_A, int ROLE_B>  // 0 = idle, 1 = fp32 mfma stream, 2 = valu stream, 3 = transcendental stream, 4 = lds stream, 5 = bf16 mfma stream (32x32x16)
 __global__ __launch_bounds__(512) void k_pair(float* out, long long* cyc, int iters) {
     __shared__ float lds[4096];
     const int wave = threadIdx.x >> 6;
@@ -49,6 +49,13 @@ __global__ __launch_bounds__(512) void k_pair(float* out, long long* cyc, int it
         for (int it = 0; it < iters; ++it)
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    } else if (role == 5) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        const float4 fa = make_float4(a, b, a, b);
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fa), acc, 0, 0, 0);
     } else if (role == 2) {
         for (int it = 0; it < iters; ++it)
 #pragma unroll
@@ -86,7 +93,7 @@ template <int A, int B> int run_p(float* out, long long* cyc, int iters) {
     hipLaunchKernelGGL((k_pair<A, B>), dim3(256), dim3(512), 0, 0, out, cyc, iters);
     CK_(hipDeviceSynchronize());
     long long h[9]; CK_(hipMemcpy(h, cyc, 72, hipMemcpyDeviceToHost));
-    const char* nm[] = {"idle", "mfma x8/iter", "v_fma x96/iter", "v_exp x96/iter", "ds_read_b128 x24/iter"};
+    const char* nm[] = {"idle", "mfma f32 x8/iter", "v_fma x96/iter", "v_exp x96/iter", "ds_read_b128 x24/iter", "mfma bf16 x8/iter"};
     printf("pair A=%-22s B=%-22s  A: %8.1f cycles/iter   B: %8.1f cycles/iter\n", nm[A], nm[B], (double)h[1] / iters, (double)h[5] / iters);
     return 0;
 }
@@ -98,5 +105,7 @@ int main() {
     run_i<0, 2>(out, cyc, iters); run_i<8, 2>(out, cyc, iters); run_i<16, 2>(out, cyc, iters); run_i<32, 2>(out, cyc, iters);
     run_p<1, 0>(out, cyc, iters); run_p<0, 2>(out, cyc, iters); run_p<1, 2>(out, cyc, iters); run_p<1, 1>(out, cyc, iters);
     run_p<0, 3>(out, cyc, iters); run_p<1, 3>(out, cyc, iters); run_p<0, 4>(out, cyc, iters); run_p<1, 4>(out, cyc, iters); run_p<2, 2>(out, cyc, iters);
+    // round 2: the bf16 matrix instruction of the bf16x3 path beside another wave's VALU / transcendental / LDS work
+    run_p<5, 0>(out, cyc, iters); run_p<5, 2>(out, cyc, iters); run_p<5, 3>(out, cyc, iters); run_p<5, 4>(out, cyc, iters); run_p<5, 5>(out, cyc, iters);
     return 0;
 }
