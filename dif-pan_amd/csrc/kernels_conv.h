@@ -80,7 +80,7 @@ struct StageKind {
 };
 
 // ABL (microbenchmark ablations only, tools/mbench.cpp): 1 = no MFMA, 2 = no input loads, 4 = no stores, 8 = no weight loads,
-// 16 = s_memtime stamps of wave 0 (5 per stage) into a.dbg
+// 16 = s_memtime stamps of wave 0 (5 per stage) into a.dbg, 128 = no LDS fragment reads (bf16x3 loop), 256 = no staging of the tile
 // EPI (epilogue variant, compile-time so that every epilogue-operand load is unconditional straight-line code -- a load
 // under `if (a.res)` becomes a phi with undef, hipcc copies the loaded registers right after the load and the copy's
 // vmcnt wait lands in front of the prefetch):  1 = FiLM (1+scale)*y+shift,  2 = scalar output path (Cout % 4 != 0),
@@ -387,6 +387,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     };
     // channels past the end of a partial last chunk hold duplicates of real (finite) data: their packed weights are 0
     auto fs_item = [&](StageRegs& R, int buf, int it) {
+        if ((ABL & 256) && R.sv[it].x != 12345.678f) return;  // ablation: no prologue math, no LDS writes of the tile
         float* dst = As + buf * ABUF;
         const bool ok = (R.ok >> it) & 1u;
         float v[4];
@@ -595,9 +596,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) xa[slot][mb][q] = *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + q * PS]);
+                    for (int mb = 0; mb < MB; ++mb)
+                        xa[slot][mb][q] = (ABL & 128) ? make_float4(1.f, 2.f, 3.f, (float)(f + q)) : *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + q * PS]);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) wb[slot][nb][q] = *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + (f * 3 + q) * 256]);
+                    for (int nb = 0; nb < NB; ++nb)
+                        wb[slot][nb][q] = (ABL & 128) ? make_float4(4.f, 3.f, 2.f, (float)(f - q)) : *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + (f * 3 + q) * 256]);
                 }
             };
             if (FB == 2) load_frags3(0, 0);
@@ -615,6 +618,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         f32x16 c = acc[mb][nb];
+                        if (ABL & 1) {  // no matrix work: keep the fragments alive
+                            c[0] += wb[sl][nb][0].x + xa[sl][mb][0].y + wb[sl][nb][1].z + xa[sl][mb][1].w + wb[sl][nb][2].x + xa[sl][mb][2].y;
+                            acc[mb][nb] = c;
+                            continue;
+                        }
                         c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][2], xa[sl][mb][0], c);  // lo * hi
                         c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][2], c);  // hi * lo
                         c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][1], xa[sl][mb][1], c);  // mid * mid

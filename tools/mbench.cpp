@@ -84,6 +84,14 @@ int main(int argc, char** argv) {
         RUNM2(0); RUNM2(32); RUNM2(96);
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'a') {  // round 2: what a bf16x3 3x3 launch is made of (8 waves, 16x16 x 32)
+#define RUNA(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, ABLV, 0, 1>("3x3 gn_silu 32->32 @64^2 x3 8w", B, 64, 64, 32, 32, 1)
+        RUNA(0); RUNA(1); RUNA(128); RUNA(129); RUNA(256); RUNA(14); RUNA(270); RUNA(143); RUNA(399);
+        RUNA(2); RUNA(4); RUNA(8); RUNA(6); RUNA(10); RUNA(12);
+#define RUNB(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, ABLV, 0, 1>("3x3 64->32 @64^2 x3 8w (ffn.2)", B, 64, 64, 64, 32, 1)
+        RUNB(0); RUNB(1); RUNB(128); RUNB(129); RUNB(256); RUNB(14); RUNB(399);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'x') {  // bf16x3 (MATH = 1) against the exact-fp32 MFMA
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) f32", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
