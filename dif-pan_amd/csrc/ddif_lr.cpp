@@ -29,6 +29,7 @@ ConvVariant lr_for(int ks, int pro, int epi) {
         if (pro == PRO_GN_SILU && epi == EPI_RES) return lr_variant<3, MB, PRO_GN_SILU, EPI_RES>("lr3x3_gn_silu_res");
         if (pro == PRO_NONE && epi == EPI_SILU) return lr_variant<3, MB, PRO_NONE, EPI_SILU>("lr3x3_silu");
         if (pro == PRO_NONE && epi == 0) return lr_variant<3, MB, PRO_NONE, 0>("lr3x3");
+        if (pro == PRO_NONE && epi == EPI_RES) return lr_variant<3, MB, PRO_NONE, EPI_RES>("lr3x3_res");  // merged ffn[3] o ffn[2] + residual
     } else if (ks == 1) {
         if (pro == PRO_NONE && epi == EPI_FILM) return lr_variant<1, MB, PRO_NONE, EPI_FILM>("lr1x1_film");
         if (pro == PRO_NONE && epi == EPI_RES) return lr_variant<1, MB, PRO_NONE, EPI_RES>("lr1x1_res");

@@ -355,8 +355,36 @@ int Net::commit(hipStream_t stream) {
         add_conv(ci + ".ffn.0", false);
         add_conv(ci + ".ffn.2", false);
         add_conv(ci + ".ffn.3", true);
-        if (const HostTensor* w3 = get(ci + ".ffn.3.weight"))  // raw (cout, cin) copy for the epilogue-fused form (kernels_conv.h EPI_MIX)
-            if (w3->v.size() == 32 * 32) vec_off[ci + ".ffn.3.weight"] = b.add(w3->v.data(), w3->v.size());
+        // ffn[2] (conv3x3, no bias) and ffn[3] (conv1x1 + bias) have NO nonlinearity between them (models/sr3_dwt.py:530-533): in eval
+        // mode they are ONE 3x3 conv with W'[o][i][tap] = sum_k W3[o][k] W2[k][i][tap] (formed in fp64, rounded once) and bias b3.
+        // Same algebra as the reference, one fp32 rounding pattern instead of two; removes 16 launches per denoising step.
+        {
+            const HostTensor *w2 = get(ci + ".ffn.2.weight"), *w3 = get(ci + ".ffn.3.weight"), *b3 = get(ci + ".ffn.3.bias");
+            if (w2 && w3 && b3 && w2->shape.size() == 4 && w3->shape.size() == 4 && w3->shape[1] == w2->shape[0] && w3->shape[2] == 1) {
+                const int co = (int)w3->shape[0], mid = (int)w2->shape[0], cin = (int)w2->shape[1];
+                std::vector<float> wm((size_t)co * cin * 9);
+                std::vector<double> row((size_t)cin * 9);
+                for (int o = 0; o < co; ++o) {
+                    std::fill(row.begin(), row.end(), 0.0);
+                    for (int k = 0; k < mid; ++k) {
+                        const double a = (double)w3->v[(size_t)o * mid + k];
+                        const float* src = &w2->v[(size_t)k * cin * 9];
+                        for (int e = 0; e < cin * 9; ++e) row[e] += a * (double)src[e];
+                    }
+                    for (int e = 0; e < cin * 9; ++e) wm[(size_t)o * cin * 9 + e] = (float)row[e];
+                }
+                PendConv p;
+                p.name = ci + ".ffn.23";
+                p.cout = co;
+                p.cin = cin;
+                p.ks = 3;
+                p.ck = 16;
+                p.w_off = pack_conv(b, wm.data(), co, cin, 3, p.ck, &p.n_chunks);
+                p.x3_off = (long)pack_conv_x3(b, wm.data(), co, cin, 3, p.ck);
+                p.bias_off = (long)b.add(b3->v.data(), b3->v.size());
+                pend.push_back(p);
+            }
+        }
     }
     add_vec("final_conv.block.0.weight");
     add_vec("final_conv.block.0.bias");

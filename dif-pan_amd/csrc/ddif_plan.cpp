@@ -84,9 +84,6 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
         else if (ks == 3 && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv3x3_res"; }
         else if (ks == 1 && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv1x1_res"; }
         else if (ks == 1 && ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1, EPI_RES>(cfg); v.name = "conv1x1_colsoftmax_res"; }
-    } else if (epi == (EPI_RES | EPI_MIX)) {
-        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_RES | EPI_MIX>(cfg); v.name = "conv3x3_mix1x1_res"; }
-        if (v.nt != 32) v = ConvVariant();  // the mix runs on a 32-cout accumulator block
     } else if (epi == EPI_TBS) {
         if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_TBS>(cfg); v.name = "conv3x3_gn_silu_tbs"; }
     } else if (epi == EPI_SILU) {
@@ -120,10 +117,6 @@ static int num_cus();
 static int x3_enabled() {  // DDIF_X3=0: the exact-fp32 MFMA instantiation everywhere (bitwise an fmaf chain); covered by tests/test_env_switches.py
     static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();
     return x3;
-}
-static int mix_enabled() {  // DDIF_MIX=0: ffn.3 as its own launch at the 32-channel level too; covered by tests/test_env_switches.py
-    static const int mix = [] { const char* e = getenv("DDIF_MIX"); return e ? atoi(e) : 1; }();
-    return mix;
 }
 static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) as well; covered by tests/test_env_switches.py
     static const int lr = [] { const char* e = getenv("DDIF_LR"); return e ? atoi(e) : 1; }();
@@ -314,9 +307,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
     int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact);
-    const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0) |
-                    (s.mix_w ? EPI_MIX : 0);
-    if (s.mix_w && (pc.cout != 32 || s.use_bias)) return fail(DDIF_ERR_INVALID, "%s: the fused 1x1 needs a bias-free conv with 32 output channels", s.name);
+    const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0);
     if (s.cso_mx && (cfg < 20 || Hout > (cfg == 20 ? 8 : 16)))
         return fail(DDIF_ERR_INVALID, "%s: column statistics epilogue needs the low-resolution kernel and H <= 16", s.name);
     ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
@@ -359,11 +350,10 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.out_xn = s.out_xn;
     a.cso_mx = s.cso_mx;
     a.cso_sm = s.cso_sm;
-    a.mix_w = s.mix_w;
     if (s.pro == PRO_GN_DW && (!s.dw_w || c0 + c1 > 256)) return fail(DDIF_ERR_INVALID, "%s: depthwise staging needs weights and <= 256 channels", s.name);
     if (s.pro == PRO_COLSM && (!s.cs_mx || !s.cs_sm || c0 % pc.ck != 0)) return fail(DDIF_ERR_INVALID, "%s: column-softmax prologue needs statistics and c0 %% %d == 0", s.name, pc.ck);
     a.n_chunks = pc.n_chunks;
-    a.bias = s.mix_w ? s.mix_bias : ((s.use_bias && pc.bias) ? pc.bias : zeros);
+    a.bias = (s.use_bias && pc.bias) ? pc.bias : zeros;
     a.tbias = zeros;  // strides 0: a row of zeros for every sample and step
     a.st0 = s.in0.st;
     a.np0 = s.in0.np;
@@ -419,7 +409,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         snprintf(lb, sizeof lb, "%s %dx%d %d+%d->%d @%dx%d cfg%d", s.name, pc.ks, pc.ks, c0, c1, pc.cout, Hout, Wout, cfg);
         op.label = lb;
     }
-    op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks + (s.mix_w ? 2.0 * B * Hout * Wout * 32.0 * 32.0 : 0.0);
+    op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
     op.cls = (Hout * Wout <= 256) ? 2 : (pc.ks == 3 ? 0 : 1);
     op.timed = op.cls == 0;
@@ -970,19 +960,17 @@ int Plan::build_impl() {
             ConvSpec s3;
             s3.pc = PC(ci + ".ffn.3");
             if (!s3.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.3 missing", ci.c_str());
-            // 32-channel level (eval): ffn.3 (1x1, 32 -> 32) runs inside ffn.2's epilogue on the accumulators (kernels_conv.h EPI_MIX)
-            const auto w3raw = net->vec.find(ci + ".ffn.3.weight");
+            // eval: ffn[3] o ffn[2] is one 3x3 conv (no nonlinearity between them; merged weights ".ffn.23", ddif_net.cpp)
             bool fused_ffn3 = false;
-            if (!train_mode && mix_enabled() && s2.pc->cout == 32 && s3.pc->cin == 32 && s3.pc->cout == 32 && s3.pc->bias && w3raw != net->vec.end()) {
+            if (const PackedConv* pm = train_mode ? nullptr : PC(ci + ".ffn.23")) {
                 ConvSpec sf = s2;
-                sf.mix_w = w3raw->second;
-                sf.mix_bias = s3.pc->bias;
+                sf.pc = pm;
+                sf.use_bias = true;
                 sf.res = amix.p;
                 sf.stats = true;
-                sf.name = "ffn.2 + ffn.3 (fused 1x1) + res";
-                const size_t n_before = step.size();
-                if (add_conv(step, sf, &f3) == DDIF_OK) fused_ffn3 = true;
-                else step.resize(n_before);  // no mixed variant for this tiling: the two-launch form below
+                sf.name = "ffn.3(ffn.2) merged + res";
+                DDIF_TRY(add_conv(step, sf, &f3));
+                fused_ffn3 = true;
             }
             if (!fused_ffn3) DDIF_TRY(add_conv(step, s2, &f2));
             s3.in0 = f2;

@@ -67,9 +67,6 @@ struct ConvSpec {
     float* out_xn = nullptr;            // PRO_GN_DW: normalised input written out
     float* cso_mx = nullptr;            // low-resolution kernel: column-softmax statistics of the OUTPUT ([B][W][Cout]); the image
     float* cso_sm = nullptr;            //   must fit one tile vertically (caller checks with lr_colstats_ok)
-    const float* mix_w = nullptr;       // EPI_MIX: (32, 32) weights of a 1x1 conv fused into this conv's epilogue; bias / res / stats are then that conv's
-    const float* mix_bias = nullptr;
-    double mix_flop_per_px = 0.0;
     bool silu = false;
     bool stats = false;
     bool exact = false;                 // force the exact-fp32 MFMA instantiation of kernels_conv.h (gradient convs; pc->w only)

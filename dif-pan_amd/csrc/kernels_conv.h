@@ -67,7 +67,6 @@ struct ConvArgs {
     const float* cs_sm;
     const float* dw_w;       // PRO_GN_DW: depthwise 3x3 weights [9][c0 + c1] applied to the normalised input
     float* out_xn;           // PRO_GN_DW: the normalised input itself, [B,H,W,c0+c1] (consumed by attn_res) or null
-    const float* mix_w;      // EPI_MIX: (32, 32) row-major weights of a 1x1 conv applied to this conv's 32 output channels inside the epilogue
     float* cso_mx;           // kernels_lr.h EPI_COLST: column-softmax statistics of the OUTPUT (max / sum of exp over H), [B][Wout][Cout]
     float* cso_sm;
     long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
@@ -86,13 +85,8 @@ struct StageKind {
 // vmcnt wait lands in front of the prefetch):  1 = FiLM (1+scale)*y+shift,  2 = scalar output path (Cout % 4 != 0),
 // 4 = residual add,  8 = SiLU on the output (a runtime flag gets if-converted: exp + rcp computed for every conv),
 // 16 = per-SAMPLE time-bias rows (tbias_stride != 0: forward() / p_losses with one t per sample; in the samplers every
-// sample shares the step's row and bias + time bias sit in LDS for the whole launch),
-// 64 = "mix": a following 1x1 conv over the 32 output channels of this conv (FastAttnCondInjection ffn.2 -> ffn.3 at the 32-channel
-// level, models/sr3_dwt.py:530-533) runs on the accumulators before the epilogue: D2[co2][px] = sum_k W3[co2][k] D[k][px] as 16
-// exact-fp32 MFMA steps whose B operand IS the accumulator register (lane (j, h) holds D[8g+4h+i][j] in acc[4g+i], which is the B
-// fragment of the k pair (8g+i, 8g+4+i)) and whose A operand is W3[lane % 32][8g+4h+i] -- no shuffle, no LDS, no HBM round trip of
-// the intermediate tensor.  The conv itself must have no bias (ffn.2 has none); bias / residual / statistics are the 1x1 conv's.
-enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_COLST = 32, EPI_MIX = 64 };
+// sample shares the step's row and bias + time bias sit in LDS for the whole launch).
+enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_COLST = 32 };
 // VEC (input staging): 0 = scalar loads, any channel counts;  1 = float4 loads, every CK-channel chunk lies in ONE source
 // (c1 == 0 or c0 % CK == 0): the source base is wave-uniform (SGPR) and a load costs one VALU add;  2 = float4 loads with
 // a per-thread source select (the stem's cat[x, x] with 8 + 8 channels).
@@ -131,7 +125,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr bool DWM = (PRO == PRO_GN_DW);
     constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW);
     constexpr bool FILM = (EPI & EPI_FILM) != 0, SOUT = (EPI & EPI_SOUT) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0, TBS = (EPI & EPI_TBS) != 0;
-    constexpr bool MIX = (EPI & EPI_MIX) != 0 && NB == 1 && WN == 1;  // (the host only selects 32-cout tilings for a mixed conv)
     static_assert(!DWM || (KS == 1 && STRIDE == 1 && !UPS && VEC == 1), "depthwise staging is for plain 1x1 convs");
     static_assert(PRO != PRO_COLSM || VEC == 1, "column-softmax prologue needs uniform-source float4 staging");
     constexpr int LPAD = DWM ? 1 : PAD;
@@ -509,11 +502,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #endif
     };
     f32x16 acc[MB][NB];
-    [[maybe_unused]] float4 wmix[MIX ? 4 : 1];
-    if constexpr (MIX) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) wmix[g] = *reinterpret_cast<const float4*>(a.mix_w + j * 32 + 8 * g + 4 * h);
-    }
     const int nflat = (w1 - w0) * a.n_chunks;
 
     // One pipeline stage out of LDS buffer `cur`:
@@ -677,17 +665,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             // (4) epilogue of work item Cp: lane (j, h) owns pixel j of each 32-pixel block and, per accumulator quad g,
             //     the 4 consecutive couts 8g + 4h .. +3 of each 32-cout block
             float s1 = 0.f, s2 = 0.f;
-            if constexpr (MIX) {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    f32x16 m2;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m2[r] = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) m2 = DDIF_MFMA_32x32x2((&wmix[t >> 2].x)[t & 3], acc[mb][0][t], m2);
-                    acc[mb][0] = m2;
-                }
-            }
             if constexpr (!SOUT) {
                 char* obase = reinterpret_cast<char*>(a.out + tile_el);
                 auto epi = [&](auto guard) {

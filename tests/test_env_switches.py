@@ -1,4 +1,4 @@
-"""The four build-time-independent switches libddif reads from the environment, each run against the reference goldens
+"""The three build-time-independent switches libddif reads from the environment, each run against the reference goldens
 (-m gpu).  The library reads them once per process, so every case runs a slice of the parity suite in a child process:
 
   DDIF_X3=0     every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) instead of the bf16x3
@@ -6,8 +6,7 @@
   DDIF_GRAPH=0  the sampler loop as plain stream launches instead of hipGraph replay of step pairs;
   DDIF_LR=0     the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) instead of the low-resolution
                 split-K kernel (kernels_lr.h) -- the golden cases at 16x16 / 32x32 otherwise run almost entirely on the
-                latter, so this is what keeps the general kernel's small-tile instantiations covered;
-  DDIF_MIX=0    ffn.3 (1x1) as its own launch at the 32-channel level instead of inside ffn.2's epilogue (kernels_conv.h EPI_MIX).
+                latter, so this is what keeps the general kernel's small-tile instantiations covered.
 
 All other A/B switches of round 1 (wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides) were
 deleted together with their code."""
@@ -25,8 +24,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
          "or test_forward_matches_oracle_other_sizes and 8x8")
 
 
-@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_MIX": "0"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "MIX=0"])
+@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
