@@ -308,3 +308,102 @@ int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, con
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------- conv forward (training graph)
+namespace ddif {
+struct ConvFwd {
+    int device = 0, B = 0, Cin = 0, Cout = 0, H = 0, W = 0, ks = 3, stride = 1, up2 = 0;
+    Net net;
+    Plan plan;
+    PackedConv pc;
+    float *x_nhwc = nullptr, *wpack = nullptr, *bias = nullptr;
+    Tensor y;
+    std::vector<Op> prog;
+    int n_chunks = 0, nb_pad = 0;
+};
+}  // namespace ddif
+struct ddif_convfwd {
+    ddif::ConvFwd c;
+};
+
+extern "C" {
+
+int ddif_convfwd_create(ddif_convfwd_t* out, int B, int Cin, int Cout, int H, int W, int ks, int stride, int up2, int device) {
+    if (!out || B < 1 || Cin < 4 || Cout < 4 || (Cin & 3) || (Cout & 3) || H < 1 || W < 1 || (ks != 1 && ks != 3) || (stride != 1 && stride != 2) || (up2 && stride != 1))
+        return ddif::fail(DDIF_ERR_INVALID, "ddif_convfwd_create: B >= 1, 4 | Cin, 4 | Cout, ks in {1,3}, stride in {1,2}, up2 only with stride 1");
+    if (ks == 1 && (stride != 1 || up2)) return ddif::fail(DDIF_ERR_INVALID, "ddif_convfwd_create: 1x1 convs are plain in the reference");
+    *out = nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    DDIF_HIPCHK(hipSetDevice(device));
+    std::unique_ptr<ddif_convfwd> h(new ddif_convfwd());
+    ddif::ConvFwd& c = h->c;
+    c.device = device;
+    c.B = B; c.Cin = Cin; c.Cout = Cout; c.H = H; c.W = W; c.ks = ks; c.stride = stride; c.up2 = up2;
+    c.plan.net = &c.net;
+    c.plan.B = B;
+    c.plan.H = H;
+    c.plan.W = W;
+    int rc = 0;
+    auto TRY = [&](int e) { if (!rc) rc = e; };
+    TRY(c.plan.dalloc(&c.plan.zeros, (size_t)1024));
+    if (!rc && hipMemset(c.plan.zeros, 0, 1024 * sizeof(float)) != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convfwd_create: hipMemset failed");
+    TRY(c.plan.dalloc(&c.x_nhwc, (size_t)B * H * W * Cin));
+    TRY(c.plan.dalloc(&c.bias, (size_t)((Cout + 31) & ~31)));
+    c.n_chunks = (Cin + 15) / 16;
+    c.nb_pad = (((Cout + 31) / 32) + 3) & ~3;
+    TRY(c.plan.dalloc(&c.wpack, (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256));
+    c.pc.w = c.wpack;
+    c.pc.bias = c.bias;
+    c.pc.cin = Cin;
+    c.pc.cout = Cout;
+    c.pc.ks = 3;  // 1x1 weights ride in the centre tap
+    c.pc.ck = 16;
+    c.pc.n_chunks = c.n_chunks;
+    if (!rc) {
+        ddif::ConvSpec s;
+        s.pc = &c.pc;
+        s.in0.p = c.x_nhwc;
+        s.in0.C = Cin;
+        s.in0.H = H;
+        s.in0.W = W;
+        s.stride = stride;
+        s.ups = up2 ? 1 : 0;
+        s.use_bias = true;
+        s.exact = true;  // training runs on the exact-fp32 MFMA (bitwise an fmaf chain), like the gradient convs
+        s.name = "train.conv";
+        TRY(c.plan.add_conv(c.prog, s, &c.y));
+    }
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (rc) return rc;
+    *out = h.release();
+    return DDIF_OK;
+}
+
+void ddif_convfwd_destroy(ddif_convfwd_t h) { delete h; }
+
+int ddif_convfwd_run(ddif_convfwd_t h, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    if (!h || !x || !w || !y) return ddif::fail(DDIF_ERR_INVALID, "ddif_convfwd_run: NULL argument");
+    ddif::ConvFwd& c = h->c;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c.device) DDIF_HIPCHK(hipSetDevice(c.device));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * c.H * c.W * c.Cin), dim3(256), 0, s, x, c.B, c.Cin, c.H * c.W, c.x_nhwc);
+    const size_t nw = (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256;
+    hipLaunchKernelGGL(ddif::pack_fwd_weights_kernel, ddif::grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.ks, c.n_chunks, c.nb_pad, c.wpack);
+    int rc = DDIF_OK;
+    if (bias) {
+        if (hipMemcpyAsync(c.bias, bias, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convfwd_run: bias copy failed");
+    } else if (hipMemsetAsync(c.bias, 0, (size_t)c.Cout * sizeof(float), s) != hipSuccess) {
+        rc = ddif::fail(DDIF_ERR_HIP, "ddif_convfwd_run: bias clear failed");
+    }
+    ddif::StepCtx ctx;
+    for (auto& op : c.prog) op.run(s, ctx);
+    hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * c.y.H * c.y.W * c.Cout), dim3(256), 0, s, (const float*)c.y.p, c.B, c.Cout, c.y.H * c.y.W, y);
+    if (!rc && hipGetLastError() != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convfwd_run: kernel launch failed");
+    if (prev >= 0 && prev != c.device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+}  // extern "C"

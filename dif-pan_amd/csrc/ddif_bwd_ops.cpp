@@ -90,4 +90,53 @@ int ddif_groupnorm_bwd(const float* x, const float* gamma, const float* dy, int 
     return ddif::ops_done("ddif_groupnorm_bwd");
 }
 
+/* ---- forward counterparts for the training graph ---- */
+int ddif_dwconv3x3_fwd(const float* x, const float* w, int B, int C, int H, int W, float* y, void* stream) {
+    if (!x || !w || !y || B < 1 || C < 1 || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_dwconv3x3_fwd: bad argument");
+    hipLaunchKernelGGL(ddif::dwconv3x3_fwd_kernel, ddif::ops_grid((size_t)B * C * H * W), dim3(256), 0, (hipStream_t)stream, x, w, B, C, H, W, y);
+    return ddif::ops_done("ddif_dwconv3x3_fwd");
+}
+int ddif_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* mask, int B, int C, int H, int W, int silu, float* y, void* stream) {
+    if (!x || !gamma || !beta || !y || B < 1 || C < 1 || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_groupnorm_fwd: bad argument");
+    hipLaunchKernelGGL(ddif::gn_fwd_kernel, dim3(B), dim3(256), 2 * 256 * sizeof(double), (hipStream_t)stream, x, gamma, beta, mask, C, H * W, silu, y);
+    return ddif::ops_done("ddif_groupnorm_fwd");
+}
+int ddif_swish_fwd(const float* x, int64_t n, float* y, void* stream) {
+    if (!x || !y || n < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_swish_fwd: bad argument");
+    hipLaunchKernelGGL(ddif::swish_fwd_kernel, ddif::ops_grid((size_t)n), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, y);
+    return ddif::ops_done("ddif_swish_fwd");
+}
+int ddif_film_fwd(const float* xc, const float* scale_shift, int B, int C, int H, int W, float* out, void* stream) {
+    if (!xc || !scale_shift || !out || B < 1 || C < 1 || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_film_fwd: bad argument");
+    hipLaunchKernelGGL(ddif::film_fwd_kernel, ddif::ops_grid((size_t)B * C * H * W), dim3(256), 0, (hipStream_t)stream, xc, scale_shift, B, C, H * W, out);
+    return ddif::ops_done("ddif_film_fwd");
+}
+int ddif_add_scaled(const float* a, const float* f, const float* alpha, int B, int64_t per_sample, float* out, void* stream) {
+    if (!a || !f || !out || B < 1 || per_sample < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_add_scaled: bad argument");
+    hipLaunchKernelGGL(ddif::add_scaled_kernel, ddif::ops_grid((size_t)B * per_sample), dim3(256), 0, (hipStream_t)stream, a, f, alpha, (size_t)per_sample,
+                       (size_t)B * per_sample, out);
+    return ddif::ops_done("ddif_add_scaled");
+}
+int ddif_linear_fwd(const float* x, const float* w, const float* bias, int B, int nin, int nout, float* y, void* stream) {
+    if (!x || !w || !y || B < 1 || nin < 1 || nout < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_linear_fwd: bad argument");
+    hipLaunchKernelGGL(ddif::linear_fwd_kernel, dim3((B * nout + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, bias, B, nin, nout, y);
+    return ddif::ops_done("ddif_linear_fwd");
+}
+int ddif_selfattn_core_fwd(const float* qkv, int B, int C, int H, int W, int heads, float* out, void* stream) {
+    if (!qkv || !out || B < 1 || heads < 1 || C < heads || C % heads) return ddif::fail(DDIF_ERR_INVALID, "ddif_selfattn_core_fwd: bad argument");
+    const int d = C / heads, n = H * W;
+    if (n > 64 || d > 32) return ddif::fail(DDIF_ERR_INVALID, "ddif_selfattn_core_fwd: n = H*W <= 64 and head dim <= 32 only");
+    const size_t smem = ((size_t)3 * d * n + (size_t)n * n) * sizeof(float);
+    hipLaunchKernelGGL(ddif::selfattn_fwd_kernel, dim3(B * heads), dim3(256), smem, (hipStream_t)stream, qkv, heads, d, n, 1.0f / sqrtf((float)C), out);
+    return ddif::ops_done("ddif_selfattn_core_fwd");
+}
+int ddif_linattn_core_fwd(const float* q_pre, const float* kv_pre, int B, int qd, int H, int W, int heads, float* out, void* stream) {
+    if (!q_pre || !kv_pre || !out || B < 1 || heads < 1 || qd < heads || qd % heads) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_fwd: bad argument");
+    const int d = qd / heads;
+    if (d > 32 || W > 64 || H < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_fwd: head dim <= 32 and W <= 64 only");
+    const size_t smem = ((size_t)4 * d * W + (size_t)d * d + 2 * d) * sizeof(float);
+    hipLaunchKernelGGL(ddif::linattn_fwd_kernel, dim3(B * heads), dim3(256), smem, (hipStream_t)stream, q_pre, kv_pre, heads, d, H, W, 1.0f / sqrtf((float)d), out);
+    return ddif::ops_done("ddif_linattn_core_fwd");
+}
+
 }  // extern "C"

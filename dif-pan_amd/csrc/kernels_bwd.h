@@ -416,4 +416,28 @@ __global__ void sumpool2_nhwc_to_nchw_kernel(const float* dxu /* (B,2H,2W,C) */,
         dx[i] = (p[0] + p[C]) + (p[(size_t)2 * W * C] + p[(size_t)2 * W * C + C]);
     }
 }
+
+// packed fp32 fragment order of kernels_conv.h for FORWARD weights, 16-channel chunks (cf. pack_dgrad_weights_kernel):
+//   [n-block of 32 couts][chunk of 16 cins][tap][k8][half h][j][4]  with cin = chunk*16 + k8*8 + 4h + i, cout = nb*32 + j.
+// ks = 1: the (Cout, Cin) weights become the centre tap of a zero 3x3 kernel.
+__global__ void pack_fwd_weights_kernel(const float* w, int Cout, int Cin, int ks, int n_chunks, int nb_pad, float* out) {
+    const size_t total = (size_t)nb_pad * n_chunks * 9 * 2 * 256;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int i = (int)(r % 4); r /= 4;
+        const int j = (int)(r % 32); r /= 32;
+        const int h = (int)(r % 2); r /= 2;
+        const int k8 = (int)(r % 2); r /= 2;
+        const int tap = (int)(r % 9); r /= 9;
+        const int ch = (int)(r % n_chunks); r /= n_chunks;
+        const int nbi = (int)r;
+        const int ci = ch * 16 + k8 * 8 + 4 * h + i, co = nbi * 32 + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            if (ks == 3) v = w[((size_t)co * Cin + ci) * 9 + tap];
+            else if (tap == 4) v = w[(size_t)co * Cin + ci];
+        }
+        out[idx] = v;
+    }
+}
 }  // namespace ddif

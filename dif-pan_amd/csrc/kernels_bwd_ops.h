@@ -407,3 +407,190 @@ __global__ void gn_bwd_affine_kernel(const double* ws, int B, int C, float* dgam
 }
 
 }  // namespace ddif
+
+// ================================================================================================================
+// Forward counterparts used by the TRAINING graph (ddif/train.py): the inference plan fuses these into its conv prologues /
+// epilogues and never materialises what the backward pass needs, so the training forward runs them un-fused, NCHW, saving
+// every intermediate.  Same arithmetic as the reference modules (models/sr3_dwt.py); correctness first.
+namespace ddif {
+
+__global__ void dwconv3x3_fwd_kernel(const float* x, const float* w /* (C,1,3,3) */, int B, int C, int H, int W, float* y) {
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H);
+        const int c = (int)((i / ((size_t)W * H)) % C);
+        const float* plane = x + (i / ((size_t)W * H)) * H * W;
+        float s = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = yy + ky - 1, ix = xx + kx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) s = fmaf(plane[iy * W + ix], w[c * 9 + ky * 3 + kx], s);
+            }
+        y[i] = s;
+    }
+}
+// GroupNorm(1 group, eps 1e-5) [+ SiLU] [+ dropout mask], NCHW; one workgroup per sample (fp64 statistics, fixed-order tree)
+__global__ __launch_bounds__(256) void gn_fwd_kernel(const float* x, const float* gamma, const float* beta, const float* mask, int C, int HW, int silu, float* y) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [2][256]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t n = (size_t)C * HW;
+    const float* xb = x + (size_t)b * n;
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = tid; i < n; i += 256) {
+        const double v = xb[i];
+        s1 += v;
+        s2 += v * v;
+    }
+    red[tid] = s1;
+    red[256 + tid] = s2;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) {
+            red[tid] += red[tid + st];
+            red[256 + tid] += red[256 + tid + st];
+        }
+        __syncthreads();
+    }
+    const double mean = red[0] / (double)n;
+    double var = red[256] / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + DDIF_GN_EPS));
+    for (size_t i = tid; i < n; i += 256) {
+        const int c = (int)(i / HW);
+        float v = fmaf((xb[i] - meanf) * rstd, gamma[c], beta[c]);
+        if (silu) v = dd_silu(v);
+        if (mask) v *= mask[(size_t)b * n + i];
+        y[(size_t)b * n + i] = v;
+    }
+}
+// y = x * sigmoid(x) (accurate exp: the time MLP and the FFN SiLU of the training graph)
+__global__ void swish_fwd_kernel(const float* x, size_t n, float* y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] / (1.0f + dd_exp(-x[i]));
+}
+__global__ void film_fwd_kernel(const float* xc, const float* ss, int B, int C, int HW, float* out) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i % HW, c = (i / HW) % C, b = i / ((size_t)HW * C);
+        out[i] = xc[i] * (1.f + ss[(b * 2 * C + c) * HW + p]) + ss[(b * 2 * C + C + c) * HW + p];
+    }
+}
+// out = a + alpha[b] * f   (residual adds; alpha = NULL: 1; the DropPath row scale otherwise)
+__global__ void add_scaled_kernel(const float* a, const float* f, const float* alpha, size_t per_sample, size_t total, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + (alpha ? alpha[i / per_sample] : 1.f) * f[i];
+}
+__global__ void linear_fwd_kernel(const float* x, const float* w, const float* bias, int B, int nin, int nout, float* y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nout) return;
+    const int b = i / nout, o = i % nout;
+    float s = bias ? bias[o] : 0.f;
+    for (int k = 0; k < nin; ++k) s = fmaf(x[b * nin + k], w[o * nin + k], s);
+    y[i] = s;
+}
+// SelfAttention core forward (see selfattn_bwd_kernel): o[c][p] = sum_q softmax_q(q^T k sc)[p][q] v[c][q]
+__global__ __launch_bounds__(256) void selfattn_fwd_kernel(const float* qkv, int heads, int d, int n, float sc, float* out) {
+    DDIF_DYN_SMEM(smem_);
+    float* qs = reinterpret_cast<float*>(smem_);
+    float* ks = qs + d * n;
+    float* vs = ks + d * n;
+    float* as = vs + d * n;  // [n][n]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const float* base = qkv + ((size_t)b * heads + hd) * 3 * d * n;
+    for (int i = tid; i < d * n; i += 256) {
+        qs[i] = base[i];
+        ks[i] = base[d * n + i];
+        vs[i] = base[2 * d * n + i];
+    }
+    __syncthreads();
+    for (int i = tid; i < n * n; i += 256) {
+        const int p = i / n, q = i % n;
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) s = fmaf(qs[c * n + p], ks[c * n + q], s);
+        as[i] = s * sc;
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        float mx = -3.0e38f;
+        for (int q = 0; q < n; ++q) mx = fmaxf(mx, as[p * n + q]);
+        float sum = 0.f;
+        for (int q = 0; q < n; ++q) {
+            const float e = dd_exp(as[p * n + q] - mx);
+            as[p * n + q] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int q = 0; q < n; ++q) as[p * n + q] *= inv;
+    }
+    __syncthreads();
+    float* ob = out + ((size_t)b * heads + hd) * d * n;
+    for (int i = tid; i < d * n; i += 256) {
+        const int c = i / n, p = i % n;
+        float s = 0.f;
+        for (int q = 0; q < n; ++q) s = fmaf(as[p * n + q], vs[c * n + q], s);
+        ob[i] = s;
+    }
+}
+// FastAttnCondInjection core forward (see linattn_bwd_kernel)
+__global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* q_pre, const float* kv_pre, int heads, int d, int H, int W, float sc, float* out) {
+    DDIF_DYN_SMEM(smem_);
+    float* qmx = reinterpret_cast<float*>(smem_);  // [d][W]
+    float* qsm = qmx + d * W;                      // [d][W]
+    float* ctx = qsm + d * W;                      // [d][d]
+    float* rk = ctx + d * d;                       // [d][W]
+    float* rv = rk + d * W;                        // [d][W]
+    float* rmx = rv + d * W;                       // [d]
+    float* rsm = rmx + d;                          // [d]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int qd = heads * d, HW = H * W;
+    const float* qb = q_pre + ((size_t)b * qd + hd * d) * HW;
+    const float* kb = kv_pre + ((size_t)b * 2 * qd + hd * d) * HW;
+    const float* vb = kv_pre + ((size_t)b * 2 * qd + qd + hd * d) * HW;
+    float* ob = out + ((size_t)b * qd + hd * d) * HW;
+    for (int i = tid; i < d * W; i += 256) {
+        const int a = i / W, x = i % W;
+        float mx = -3.0e38f;
+        for (int y = 0; y < H; ++y) mx = fmaxf(mx, qb[(size_t)a * HW + y * W + x]);
+        float s = 0.f;
+        for (int y = 0; y < H; ++y) s += dd_exp(qb[(size_t)a * HW + y * W + x] - mx);
+        qmx[i] = mx;
+        qsm[i] = s;
+    }
+    for (int i = tid; i < d * d; i += 256) ctx[i] = 0.f;
+    __syncthreads();
+    for (int y = 0; y < H; ++y) {
+        for (int a = tid; a < d; a += 256) {
+            float mx = -3.0e38f;
+            for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)a * HW + y * W + x]);
+            float s = 0.f;
+            for (int x = 0; x < W; ++x) s += dd_exp(kb[(size_t)a * HW + y * W + x] - mx);
+            rmx[a] = mx;
+            rsm[a] = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < d * W; i += 256) {
+            const int a = i / W, x = i % W;
+            rk[i] = dd_exp(kb[(size_t)a * HW + y * W + x] - rmx[a]) / rsm[a];
+            rv[i] = vb[(size_t)a * HW + y * W + x];
+        }
+        __syncthreads();
+        for (int i = tid; i < d * d; i += 256) {
+            const int a = i / d, e = i % d;
+            float s = ctx[i];
+            for (int x = 0; x < W; ++x) s = fmaf(rk[a * W + x], rv[e * W + x], s);
+            ctx[i] = s;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < d * HW; i += 256) {  // o[e][n] = sum_a ctx[a][e] q_sm[a][n] sc
+        const int e = i / HW, nn = i % HW, x = nn % W;
+        float s = 0.f;
+        for (int a = 0; a < d; ++a) s = fmaf(ctx[a * d + e], dd_exp(qb[(size_t)a * HW + nn] - qmx[a * W + x]) / qsm[a * W + x] * sc, s);
+        ob[i] = s;
+    }
+}
+}  // namespace ddif

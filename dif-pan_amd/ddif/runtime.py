@@ -119,6 +119,18 @@ class _Lib:
         d.ddif_blockbwd_destroy.restype = None
         d.ddif_blockbwd_run.argtypes = [vp] + [vp] * 13
         d.ddif_dwconv3x3_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+        d.ddif_convfwd_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32, i32, i32]
+        d.ddif_convfwd_destroy.argtypes = [vp]
+        d.ddif_convfwd_destroy.restype = None
+        d.ddif_convfwd_run.argtypes = [vp, vp, vp, vp, vp, vp]
+        d.ddif_dwconv3x3_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        d.ddif_groupnorm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        d.ddif_swish_fwd.argtypes = [vp, C.c_int64, vp, vp]
+        d.ddif_film_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        d.ddif_add_scaled.argtypes = [vp, vp, vp, i32, C.c_int64, vp, vp]
+        d.ddif_linear_fwd.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+        d.ddif_selfattn_core_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+        d.ddif_linattn_core_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_film_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
         d.ddif_selfattn_core_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_linattn_core_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]

@@ -257,6 +257,28 @@ DDIF_API int ddif_swish_bwd(const float* x, const float* dy, int64_t n, float* d
 /* F.l1_loss(pred, target) with mean reduction (diffusion/diffusion_ddpm_pan.py:742-749): dpred = sign(pred - target) * upstream / n */
 DDIF_API int ddif_l1_loss_bwd(const float* pred, const float* target, int64_t n, float upstream, float* dpred, void* stream);
 
+/* ---- forward ops of the TRAINING graph (a15) --------------------------------------------------------------------------------
+ * The inference plan fuses GroupNorm / SiLU / FiLM / softmax into conv prologues and epilogues and never materialises what the
+ * backward pass needs; the training forward (ddif/train.py) therefore runs the reference's modules op by op on these entry
+ * points, NCHW, keeping every intermediate.  Same arithmetic as models/sr3_dwt.py; the convs run on the exact-fp32 MFMA. */
+typedef struct ddif_convfwd* ddif_convfwd_t;
+/* nn.Conv2d(Cin, Cout, ks, stride, padding = ks / 2) [+ nearest x2 upsampling in front: Upsample, models/sr3_dwt.py:266-273];
+ * x (B,Cin,H,W), w (Cout,Cin,ks,ks), bias (Cout) or NULL, y (B,Cout,Ho,Wo) */
+DDIF_API int ddif_convfwd_create(ddif_convfwd_t* out, int B, int Cin, int Cout, int H, int W, int ks, int stride, int up2, int device);
+DDIF_API void ddif_convfwd_destroy(ddif_convfwd_t h);
+DDIF_API int ddif_convfwd_run(ddif_convfwd_t h, const float* x, const float* w, const float* bias, float* y, void* stream);
+DDIF_API int ddif_dwconv3x3_fwd(const float* x, const float* w, int B, int C, int H, int W, float* y, void* stream);
+/* GroupNorm(1 group, eps 1e-5, affine) [-> x*sigmoid(x)] [-> * mask] */
+DDIF_API int ddif_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* mask, int B, int C, int H, int W, int silu, float* y,
+                                void* stream);
+DDIF_API int ddif_swish_fwd(const float* x, int64_t n, float* y, void* stream);
+DDIF_API int ddif_film_fwd(const float* xc, const float* scale_shift, int B, int C, int H, int W, float* out, void* stream);
+/* out = a + alpha[b] * f (alpha NULL: 1): residual adds and DropPath (models/sr3_dwt.py:576) */
+DDIF_API int ddif_add_scaled(const float* a, const float* f, const float* alpha, int B, int64_t per_sample, float* out, void* stream);
+DDIF_API int ddif_linear_fwd(const float* x, const float* w, const float* bias, int B, int nin, int nout, float* y, void* stream);
+DDIF_API int ddif_selfattn_core_fwd(const float* qkv, int B, int C, int H, int W, int heads, float* out, void* stream);
+DDIF_API int ddif_linattn_core_fwd(const float* q_pre, const float* kv_pre, int B, int qd, int H, int W, int heads, float* out, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 
 /* Bracket launches of the dominant kernel class (3x3 implicit-GEMM convolutions of the denoising step) with HIP

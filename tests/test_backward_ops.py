@@ -190,3 +190,69 @@ def test_cond_conv_weight_gradient_through_zero_padded_channels(backend):
     got = op(pad(cond).to(dev), None, None, pad(w.detach()).to(dev), dy.to(dev), need_dx=False)
     _close(got["dw"][:, :Cin], w.grad, "dw")
     assert float(got["dw"][:, Cin:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------- forward ops of the training graph
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [dict(cin=32, cout=64, ks=3, H=16, W=16), dict(cin=16, cout=32, ks=3, H=12, W=20), dict(cin=64, cout=64, ks=1, H=8, W=8),
+                                  dict(cin=32, cout=32, ks=3, H=16, W=16, stride=2), dict(cin=16, cout=24, ks=3, H=9, W=13, stride=2),
+                                  dict(cin=64, cout=64, ks=3, H=8, W=8, up2=True), dict(cin=9, cout=128, ks=3, H=16, W=16, bias=False),
+                                  dict(cin=32, cout=8, ks=3, H=16, W=16), dict(cin=11, cout=22, ks=1, H=8, W=8)],
+                         ids=["3x3", "stem-like", "1x1", "down", "down-odd", "up", "cond-9ch", "final-8", "kv1-11ch"])
+def test_training_graph_conv_forward(backend, case):
+    """Every conv shape of the network through ddif.functional.conv2d against F.conv2d (channel counts that are not multiples of 4
+    are zero-padded inside)."""
+    from ddif import functional as DF
+
+    dev = _dev(backend)
+    g = torch.Generator().manual_seed(case["cin"] + case["cout"])
+    B, H, W, ks = 2, case["H"], case["W"], case["ks"]
+    x = torch.randn(B, case["cin"], H, W, generator=g)
+    w = torch.randn(case["cout"], case["cin"], ks, ks, generator=g) / (ks * case["cin"] ** 0.5)
+    b = torch.randn(case["cout"], generator=g) if case.get("bias", True) else None
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if case.get("up2") else x
+    want = F.conv2d(xin, w, b, stride=case.get("stride", 1), padding=ks // 2)
+    got = DF.conv2d(x.to(dev), w.to(dev), None if b is None else b.to(dev), stride=case.get("stride", 1), up2=case.get("up2", False))
+    _close(got, want, "y", 2e-6)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_training_graph_elementwise_and_attention_forward(backend):
+    """group_norm (+SiLU, +mask), depthwise conv, FiLM, residual / DropPath add, Linear, Swish and the two attention cores against
+    the oracle's formulas (oracle/ddif_oracle.py: resnet_block, cond_injection, fast_attn_cond_injection, self_attention, time_embedding)."""
+    from ddif import functional as DF
+
+    dev = _dev(backend)
+    g = torch.Generator().manual_seed(11)
+    B, Cc, H, W = 2, 64, 8, 12
+    x = 1.3 * torch.randn(B, Cc, H, W, generator=g) + 0.2
+    gamma, beta = 1 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    mask = (torch.rand(B, Cc, H, W, generator=g) > 0.2).float() / 0.8
+    d = lambda t: t.to(dev)
+    _close(DF.group_norm(d(x), d(gamma), d(beta)), F.group_norm(x, 1, gamma, beta, eps=1e-5), "gn", 2e-6)
+    _close(DF.group_norm(d(x), d(gamma), d(beta), silu=True, mask=d(mask)), F.silu(F.group_norm(x, 1, gamma, beta, eps=1e-5)) * mask, "gn_silu_mask", 2e-6)
+    wd = torch.randn(Cc, 1, 3, 3, generator=g) / 3
+    _close(DF.dwconv3x3(d(x), d(wd)), F.conv2d(x, wd, None, padding=1, groups=Cc), "dw", 2e-6)
+    ss = torch.randn(B, 2 * Cc, H, W, generator=g)
+    sc_, sh_ = ss.chunk(2, dim=1)
+    _close(DF.film(d(x), d(ss)), x * (1 + sc_) + sh_, "film", 1e-6)
+    f = torch.randn(B, Cc, H, W, generator=g)
+    alpha = torch.tensor([0.0, 1.25])
+    _close(DF.add(d(x), d(f)), x + f, "add", 1e-7)
+    _close(DF.add(d(x), d(f), d(alpha)), x + alpha.view(B, 1, 1, 1) * f, "droppath", 1e-7)
+    xe, wl, bl = torch.randn(4, 32, generator=g), torch.randn(128, 32, generator=g) / 6, torch.randn(128, generator=g)
+    _close(DF.linear(d(xe), d(wl), d(bl)), F.linear(xe, wl, bl), "linear", 2e-6)
+    _close(DF.swish(d(xe)), xe * torch.sigmoid(xe), "swish", 1e-6)
+    qkv = torch.randn(2, 3 * 128, 8, 8, generator=g)
+    v4 = qkv.view(2, 8, 48, 64)
+    q, k, v = v4[:, :, :16], v4[:, :, 16:32], v4[:, :, 32:]
+    a = torch.softmax(torch.einsum("bncp,bncq->bnpq", q, k) / math.sqrt(128), dim=-1)
+    _close(DF.selfattn_core(d(qkv)), torch.einsum("bnpq,bncq->bncp", a, v).reshape(2, 128, 8, 8), "selfattn", 3e-6)
+    qd = 96
+    q_pre, kv_pre = 2 * torch.randn(B, qd, H, W, generator=g), 2 * torch.randn(B, 2 * qd, H, W, generator=g)
+    kk, vv = kv_pre.chunk(2, dim=1)
+    dd = qd // 8
+    qs = q_pre.softmax(dim=-2).reshape(B, 8, dd, H * W) / math.sqrt(dd)
+    ks_ = kk.softmax(dim=-1).reshape(B, 8, dd, H * W)
+    ctx = torch.einsum("bhdn,bhen->bhde", ks_, vv.reshape(B, 8, dd, H * W))
+    _close(DF.linattn_core(d(q_pre), d(kv_pre)), torch.einsum("bhde,bhdn->bhen", ctx, qs).reshape(B, qd, H, W), "linattn", 3e-6)
