@@ -114,6 +114,14 @@ TRAIN_FWD_CASES = [
     ("trainfwd_wv3_16", "wv3", 2, 16, 16, [7, 431], 61),
 ]
 
+# one training forward + backward of the reference (tools/make_golden.py traingrad): grad norms of all parameters + these full gradients
+TRAIN_GRAD_CASES = [
+    ("traingrad_wv3_16", "wv3", 2, 16, 16, [7, 431], 62),
+]
+TRAIN_GRAD_FULL = ["downs.0.", "downs.1.cond_inj.body.0.weight", "downs.1.res_block.block2.block.3.weight", "downs.1.res_block.noise_func.noise_func.0.weight",
+                   "noise_level_mlp.1.weight", "mid.0.attn.qkv.weight", "ups.0.cond_inj.q.0.weight", "ups.0.cond_inj.kv.1.weight", "ups.0.cond_inj.ffn.3.weight",
+                   "ups.0.cond_inj.prenorm_x.weight", "final_conv.block.3.weight"]
+
 LOSS_CASES = [  # (case id, dataset, B, H, W, T, t values, self-cond branch, seed)
     ("loss_wv3_16_sc0", "wv3", 2, 16, 16, 500, [3, 444], False, 41),
     ("loss_wv3_16_sc1", "wv3", 2, 16, 16, 500, [100, 7], True, 42),

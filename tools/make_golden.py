@@ -18,6 +18,7 @@ sys.dont_write_bytecode = True
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -94,7 +95,7 @@ def make_diffusion(D, net, C, T, size):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="manifest,fwd,fwdbig,trunc,dpmskip,trainfwd,sched,ddpm,ddim,dpm,loss,psnr")
+    ap.add_argument("--only", default="manifest,fwd,fwdbig,trunc,dpmskip,trainfwd,traingrad,sched,ddpm,ddim,dpm,loss,psnr")
     ap.add_argument("--skip-long", action="store_true")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -199,6 +200,49 @@ def main():
             arrs = {f"drop_{k}": np.packbits(d.numpy().reshape(-1)) for k, d in enumerate(drops)}
             arrs.update({f"drop_{k}_shape": np.array(d.shape) for k, d in enumerate(drops)})
             save(cid, y=y, n_drop=len(drops), paths=torch.stack(paths), p_drop=0.2, **arrs)
+
+    if "traingrad" in only:
+        # G7: one training forward + backward of the REAL reference under .train() (same inputs / seed / masks as trainfwd), L1 loss against
+        # a fixed target: the norm of every parameter's gradient, and a handful of full gradients
+        for cid, ds, B, H, W, tvals, seed in gc.TRAIN_GRAD_CASES:
+            C = gc.DATASETS[ds][0]
+            net = net_for(ds)
+            g = torch.Generator().manual_seed(seed)
+            x = torch.randn(B, C, H, W, generator=g)
+            sc = torch.randn(B, C, H, W, generator=g)
+            target = torch.rand(B, C, H, W, generator=g)
+            cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+            t = torch.tensor(tvals, dtype=torch.long)
+            drops, paths, hooks = [], [], []
+            for m in net.modules():
+                if isinstance(m, nn.Dropout):
+                    hooks.append(m.register_forward_hook(lambda mod, inp, out: drops.append(((out != 0) | (inp[0] == 0)).detach())))
+                elif type(m).__name__ == "DropPath":
+                    hooks.append(m.register_forward_hook(lambda mod, inp, out: paths.append(((out.detach().flatten(1).abs().sum(1) != 0).float() / (1 - mod.drop_prob)))))
+            net.train()
+            for prm in net.parameters():
+                prm.requires_grad_(True)
+                prm.grad = None
+            torch.manual_seed(seed)
+            try:
+                y = net(x, t, cond, sc)
+                loss = F.l1_loss(y, target)
+                loss.backward()
+            finally:
+                net.eval()
+                for hk in hooks:
+                    hk.remove()
+            names = [k for k, _ in net.named_parameters()]
+            norms = np.array([float(prm.grad.norm()) if prm.grad is not None else -1.0 for _, prm in net.named_parameters()], dtype=np.float64)
+            full = {}
+            for k, prm in net.named_parameters():
+                if any(k == f or k.startswith(f) for f in gc.TRAIN_GRAD_FULL):
+                    full["grad::" + k] = prm.grad.detach().clone()
+            for prm in net.parameters():
+                prm.grad = None
+            arrs = {f"drop_{k}": np.packbits(d.numpy().reshape(-1)) for k, d in enumerate(drops)}
+            arrs.update({f"drop_{k}_shape": np.array(d.shape) for k, d in enumerate(drops)})
+            save(cid, y=y.detach(), loss=float(loss), n_drop=len(drops), paths=torch.stack(paths), p_drop=0.2, names=np.array(names), grad_norms=norms, **arrs, **full)
 
     if "sched" in only:
         out = {}
