@@ -139,4 +139,15 @@ int ddif_linattn_core_fwd(const float* q_pre, const float* kv_pre, int B, int qd
     return ddif::ops_done("ddif_linattn_core_fwd");
 }
 
+int ddif_q_sample(const float* x0, const float* noise, const float* a, const float* s, int B, int64_t per_sample, float* out, void* stream) {
+    if (!x0 || !noise || !a || !s || !out || B < 1 || per_sample < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_q_sample: bad argument");
+    hipLaunchKernelGGL(ddif::q_sample_ew_kernel, ddif::ops_grid((size_t)B * per_sample), dim3(256), 0, (hipStream_t)stream, x0, noise, a, s, B, (size_t)per_sample, out);
+    return ddif::ops_done("ddif_q_sample");
+}
+int ddif_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* out, void* stream) {
+    if (!pred || !target || !out || n < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_l1_loss_fwd: bad argument");
+    hipLaunchKernelGGL(ddif::l1_fwd_kernel, dim3(1), dim3(256), 256 * sizeof(double), (hipStream_t)stream, pred, target, (size_t)n, out);
+    return ddif::ops_done("ddif_l1_loss_fwd");
+}
+
 }  // extern "C"

@@ -594,3 +594,30 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* q_pre, co
     }
 }
 }  // namespace ddif
+
+namespace ddif {
+// q_sample (diffusion/diffusion_ddpm_pan.py:668-681): x_t = a[b] * x0 + s[b] * noise (layout-agnostic: elementwise per sample)
+__global__ void q_sample_ew_kernel(const float* x0, const float* noise, const float* a, const float* s, int B, size_t per, float* out) {
+#pragma clang fp contract(off)
+    const size_t total = (size_t)B * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per;
+        out[i] = a[b] * x0[i] + s[b] * noise[i];
+    }
+}
+// mean |pred - target| (F.l1_loss): one workgroup, fp64 thread partials + fixed-order tree
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* pred, const float* target, size_t n, float* out) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (size_t i = tid; i < n; i += 256) s += (double)fabsf(pred[i] - target[i]);
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = (float)(red[0] / (double)n);
+}
+}  // namespace ddif

@@ -287,7 +287,8 @@ class GaussianDiffusion(nn.Module):
         """Reference :692-766, forward half: q_sample + (optional self-conditioning pass) + prediction + loss value.
         With the model in .train() mode both passes run the train-mode launch program (Dropout in every ResnetBlock,
         DropPath on every decoder FFN; fresh masks per pass from the library's generator seeded by torch's RNG, or the
-        masks pinned with `model.set_train_masks`).  No autograd graph is built: the backward pass is not implemented."""
+        masks pinned with `model.set_train_masks`).  With autograd enabled the main pass goes through `_train_step` (ddif.train) and the
+        returned loss supports `.backward()`; under `torch.no_grad()` it is the fused train-mode plan and a plain value."""
         b = x_start.shape[0]
         t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
         noise = default(noise, lambda: torch.randn_like(x_start))
@@ -310,11 +311,38 @@ class GaussianDiffusion(nn.Module):
         x_self_cond = None
         if self.self_condition and random.random() < 0.5:
             masks()
-            x_self_cond = plan.q_sample_forward(x_start, noise, a, s, t, None)
+            x_self_cond = plan.q_sample_forward(x_start, noise, a, s, t, None)  # no-grad pass of the reference (:703-709)
+        if training and torch.is_grad_enabled():
+            return self._train_step(x_start, noise, a, s, t, cond, x_self_cond)
         masks()
         pred = plan.q_sample_forward(x_start, noise, a, s, t, x_self_cond)
         loss = self.loss_func(x_start, pred)
         loss = (loss * extract(self.p2_loss_weight, t, loss.shape)).mean()
+        return loss, pred
+
+    def _train_step(self, x_start, noise, a, s, t, cond, x_self_cond):
+        """The differentiable pass of p_losses (:711-766): prediction through ddif.train.TrainGraph, L1 loss, and a torch autograd node
+        whose backward is the library's reverse pass -- `loss.backward()` then fills `.grad` of every parameter, as in the reference."""
+        from .. import functional as DF
+        from ..train import TrainGraph, TrainStepFn
+
+        if self.loss_type != "l1":
+            raise DdifError("training: only loss_type='l1' (the engine configuration) has a backward pass")
+        if float(getattr(self, "p2_loss_weight_gamma", 0.0)) != 0.0:
+            raise DdifError("training: p2 loss weighting is not implemented by the backward pass")
+        model = self.model
+        graph = getattr(self, "_train_graph", None)
+        if graph is None:
+            graph = self._train_graph = TrainGraph(model.cfg, dropout=float(model.cfg["dropout"]), drop_path=model.DROP_PATH_PROB)
+        named = [(n, p) for n, p in model.named_parameters()]
+        names = tuple(n for n, _ in named)
+        x_noisy = DF.q_sample(x_start, noise, a, s)
+        pinned = getattr(model, "_train_masks", None)
+        drop_masks, path_scales = (None, None)
+        if pinned is not None:
+            drop_masks, paths = pinned
+            path_scales = None if paths is None else [paths[k] for k in range(paths.shape[0])]
+        loss, pred = TrainStepFn.apply(graph, names, x_noisy, t, cond, x_self_cond, x_start, drop_masks, path_scales, *[p for _, p in named])
         return loss, pred
 
     def forward(self, x, mode="train", *args, **kwargs):

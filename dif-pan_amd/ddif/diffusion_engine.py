@@ -2,8 +2,8 @@
 (the reference runs a training and a test job at import, diffusion_engine.py:508-533).
 
     test_fn(...)        reference :352-505   inference over a test set: cond assembly -> sampler -> (sr + lms).clip(0,1)
-    engine_google(...)  reference :52-348    training loop -- needs the backward pass, which this build does not have
-                                             yet: raises DdifError instead of silently training in torch.
+    engine_google(...)  reference :52-348    training loop: cond assembly -> p_losses -> loss.backward() (ddif.train) -> [DDP all-reduce]
+                                             -> fused clip + AdamW + EMA step; periodic DDIM-25 validation with metrics
     norm / unorm / clamp_fn                  reference :33-49
 
 plus the cond assembly the reference spreads over its datasets and engine:
@@ -196,11 +196,141 @@ def test_fn(test_data_path=None, weight_path=None, schedule_type="cosine", batch
     return out
 
 
+class _Batches:
+    """Mini-batches (pan, lms, hr) of raw-count tensors out of an in-memory set {"pan", "lms", "gt"} (the three arrays PanDataset / HISRDataSets
+    read from their h5 files, dataset/pan_dataset.py:37-66, dataset/hisr.py:22-46), reshuffled every epoch like DataLoader(shuffle=True)."""
+
+    def __init__(self, data: Dict[str, torch.Tensor], batch_size: int, shuffle: bool = True):
+        self.pan, self.lms, self.gt = (torch.as_tensor(np.asarray(data[k]), dtype=torch.float32) for k in ("pan", "lms", "gt"))
+        self.n, self.bs, self.shuffle = self.gt.shape[0], batch_size, shuffle
+
+    def __iter__(self):
+        order = torch.randperm(self.n) if self.shuffle else torch.arange(self.n)
+        for k in range(0, self.n, self.bs):
+            idx = order[k:k + self.bs]
+            yield self.pan[idx], self.lms[idx], self.gt[idx]
+
+
+def _open_set(path_or_data):
+    if isinstance(path_or_data, dict):
+        return path_or_data
+    try:
+        import h5py  # not in the build image; the reference's datasets are h5 files (diffusion_engine.py:142-143)
+    except ImportError as e:
+        raise DdifError("engine_google: reading %r needs h5py; pass the arrays as a dict {'pan', 'lms', 'gt'} instead" % (path_or_data,)) from e
+    f = h5py.File(path_or_data, "r")
+    return {k: np.asarray(f[k]) for k in ("pan", "lms", "gt")}
+
+
+def lr_at(iteration: int, base: float, milestones=(100_000, 200_000, 350_000), gamma: float = 0.2) -> float:
+    """MultiStepLR of the reference (diffusion_engine.py:210-212)"""
+    return base * gamma ** sum(1 for m in milestones if iteration >= m)
+
+
 def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, image_n_channel=8, image_size=64,
                   schedule_type="cosine", n_steps=3_000, max_iterations=400_000, device="cuda:0", batch_size=128,
-                  lr_d=1e-4, show_recon=False, pretrain_weight=None, pretrain_iterations=None, *, constrain_channel=None):
-    """Reference engine_google (:52-348): training + periodic validation.  The training step needs the backward pass
-    through the denoiser, AdamW, EMA and (multi-GPU) a gradient all-reduce; only the forward half of `p_losses`
-    exists in this build.  Refusing loudly is deliberate: a silent torch fallback would not be this project's path."""
-    raise DdifError("engine_google: the training step (backward pass, config 5) is not implemented by the HIP path yet; "
-                    "sampling / validation are available through test_fn and GaussianDiffusion(mode='ddim_sample'|'ddpm_sample')")
+                  lr_d=1e-4, show_recon=False, pretrain_weight=None, pretrain_iterations=None, *, constrain_channel=None,
+                  add_n_channel=1, ema_start_iter=20_000, valid_every=5_000, save_dir=None, log=print):
+    """Reference engine_google (:52-348): the training loop.  Same keyword names and defaults; `train_dataset_path` / `valid_dataset_path`
+    may also be dicts {"pan", "lms", "gt"} of raw-count arrays (h5py is not part of this image).  Per iteration, as in the reference
+    (:218-241): cond assembly (one kernel), `diff_loss, recon = diffusion(hr - lms, cond=cond)`, `diff_loss.backward()` (the library's
+    reverse pass through ddif.train), gradient all-reduce when torch.distributed is initialised (DDP of config 5: one process per GPU,
+    RCCL), then clip 0.003 + AdamW(lr, weight_decay 1e-4) + EMA(0.995 from `ema_start_iter`) as the fused three-launch optimizer step,
+    MultiStepLR.  Every `valid_every` iterations: DDIM-25 sampling of one validation batch with the EMA weights and SAM / ERGAS / PSNR / CC
+    from `ddif_metrics`.  Plotting, tensorboard and .mat dumps of the reference are out of scope.  Returns a dict with the loss history,
+    the validation records, the model, the diffusion wrapper and the EMA weights."""
+    import torch.distributed as dist
+
+    if schedule_type != "cosine":
+        raise DdifError("engine_google: the reference trains on the cosine schedule")
+    if show_recon:
+        raise DdifError("engine_google: show_recon (matplotlib grids) is out of scope")
+    dev = torch.device(device)
+    name = dataset_name
+    if name is None:
+        if isinstance(train_dataset_path, dict):
+            raise DdifError("engine_google: dataset_name is required with in-memory data")
+        name = str(train_dataset_path).strip(".h5").split("_")[-1]
+    if name not in DIVISION:
+        raise DdifError("dataset %r not supported" % (name,))
+    hisr = name in ("cave", "harvard")
+    if hisr:
+        add_n_channel = 3
+    div = DIVISION[name]
+    order = 1 if hisr else 0
+    net = UNetSR3(in_channel=image_n_channel, out_channel=image_n_channel, lms_channel=image_n_channel, pan_channel=add_n_channel, inner_channel=32,
+                  norm_groups=1, channel_mults=(1, 2, 2, 4), attn_res=(8,), dropout=0.2, image_size=64, self_condition=True).to(dev)
+    if pretrain_weight is not None:
+        sd = torch.load(pretrain_weight[0] if isinstance(pretrain_weight, (list, tuple)) else pretrain_weight, map_location="cpu")
+        net.load_state_dict(sd.get("model", sd) if isinstance(sd, dict) else sd, strict=isinstance(pretrain_weight, (list, tuple)))
+    diffusion = GaussianDiffusion(net, image_size=image_size, channels=image_n_channel, pred_mode="x_start", loss_type="l1", device=dev, clamp_range=(0, 1))
+    diffusion.set_new_noise_schedule(betas=make_beta_schedule(schedule="cosine", n_timestep=n_steps, cosine_s=8e-3), device=dev)
+    train = _Batches(_open_set(train_dataset_path), batch_size, shuffle=True)
+    valid = _Batches(_open_set(valid_dataset_path), 16, shuffle=False) if valid_dataset_path is not None else None
+    params = [p for p in net.parameters()]
+    grads = [torch.zeros_like(p) for p in params]
+    for p, g in zip(params, grads):
+        p.grad = g  # autograd accumulates in place: the fused optimizer keeps these pointers
+    ema = [p.detach().clone() for p in params]
+    opt = _rt.FusedAdamW(params, grads, ema, lr=lr_d, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    iterations = int(pretrain_iterations) if pretrain_iterations is not None else 0
+    history, records = [], []
+
+    def validate():
+        pan, lms, gt = next(iter(valid))
+        lms, pan, gt = lms.to(dev), pan.to(dev), gt.to(dev)
+        cond = _rt.cond_assemble(lms, pan, div, wavelet_order=order)
+        keep = [p.detach().clone() for p in params]
+        was_training = net.training
+        try:
+            with torch.no_grad():
+                for p, e in zip(params, ema):
+                    p.copy_(e)
+                net.eval()
+                sr = diffusion(cond, mode="ddim_sample", section_counts="ddim25")
+                sr = (sr + cond[:, :image_n_channel]).clip(0, 1)
+        finally:
+            with torch.no_grad():
+                for p, k in zip(params, keep):
+                    p.copy_(k)
+            net.train(was_training)
+        m = _rt.metrics((gt / div).contiguous(), sr.contiguous(), ergas_ratio=4.0).mean(dim=0).cpu()
+        return {"SAM": float(m[0]), "ERGAS": float(m[1]), "PSNR": float(m[2]), "CC": float(m[3])}
+
+    net.train()
+    while iterations < max_iterations:
+        for pan, lms, hr in train:
+            pan, lms, hr = pan.to(dev), lms.to(dev), hr.to(dev)
+            cond = _rt.cond_assemble(lms, pan, div, wavelet_order=order)
+            lms_n = cond[:, :image_n_channel].contiguous()
+            for g in grads:
+                g.zero_()
+            res = (hr / div - lms_n).contiguous()
+            diff_loss, recon_x = diffusion(res, cond=cond)
+            diff_loss.backward()
+            if world > 1:  # DDP (config 5): average the gradients over the ranks, one bucket
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat /= world
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+            opt.lr = lr_at(iterations, lr_d)
+            mode = 2 if iterations >= ema_start_iter else 1  # EmaUpdater: copy before start_iter, lerp after (utils/optim_utils.py:43-58)
+            gn = opt.step(max_grad_norm=0.003, ema_mode=mode, ema_decay=0.995, return_norm=True)
+            iterations += 1
+            history.append(float(diff_loss.detach()))
+            log(f"[iter {iterations}/{max_iterations}: d_lr {opt.lr: .6f}] - denoise loss {history[-1]:.6f} (grad norm {gn:.4f})")
+            if valid is not None and valid_every and iterations % valid_every == 0:
+                rec = validate()
+                records.append((iterations, rec))
+                log(f"[iter {iterations}] validation: {rec}")
+            if save_dir and iterations % 5_000 == 0:
+                os.makedirs(save_dir, exist_ok=True)
+                torch.save({"model": net.state_dict(), "ema": [e.cpu() for e in ema], "iterations": iterations}, os.path.join(save_dir, f"diffusion_{name}_iter_{iterations}.pth"))
+            if iterations >= max_iterations:
+                break
+    net.eval()
+    return {"loss": history, "validation": records, "model": net, "diffusion": diffusion, "ema": ema, "iterations": iterations}

@@ -160,3 +160,24 @@ def linattn_core(q_pre, kv_pre, heads=8):
     out = torch.empty_like(q_pre)
     lib.check(lib.dll.ddif_linattn_core_fwd(_ptr(q_pre), _ptr(kv_pre), B, qd, H, W, heads, _ptr(out), _stream(lib, q_pre.device)), "ddif_linattn_core_fwd")
     return out
+
+
+def q_sample(x0, noise, a, s):
+    """x_t = a[b] * x0 + s[b] * noise (reference diffusion/diffusion_ddpm_pan.py:668-681); a, s: (B,) tensors"""
+    lib = get_lib()
+    x0, noise = x0.contiguous(), noise.contiguous()
+    a, s = a.to(x0.device, torch.float32).contiguous(), s.to(x0.device, torch.float32).contiguous()
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    lib.check(lib.dll.ddif_q_sample(_ptr(x0), _ptr(noise), _ptr(a), _ptr(s), B, x0.numel() // B, _ptr(out), _stream(lib, x0.device)), "ddif_q_sample")
+    return out
+
+
+def l1_loss(pred, target):
+    """F.l1_loss(pred, target) (mean): a 0-d tensor on pred's device"""
+    lib = get_lib()
+    pred, target = pred.contiguous(), target.contiguous()
+    _check_shape(target, "target", tuple(pred.shape))
+    out = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    lib.check(lib.dll.ddif_l1_loss_fwd(_ptr(pred), _ptr(target), pred.numel(), _ptr(out), _stream(lib, pred.device)), "ddif_l1_loss_fwd")
+    return out[0]

@@ -131,6 +131,8 @@ class _Lib:
         d.ddif_linear_fwd.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
         d.ddif_selfattn_core_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_linattn_core_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        d.ddif_q_sample.argtypes = [vp, vp, vp, vp, i32, C.c_int64, vp, vp]
+        d.ddif_l1_loss_fwd.argtypes = [vp, vp, C.c_int64, vp, vp]
         d.ddif_film_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
         d.ddif_selfattn_core_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_linattn_core_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]

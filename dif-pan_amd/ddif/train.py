@@ -339,3 +339,24 @@ class TrainGraph:
         # order in which their gradients were appended: first appended = last decoder cat = FIRST encoder feature ... i.e. the
         # gradient for the push met first (the deepest encoder feature) is the one appended LAST among those still pending
         return stack.pop()
+
+
+class TrainStepFn(torch.autograd.Function):
+    """Bridges the library's training step into torch autograd so that the reference's training loop runs unchanged:
+    `loss, recon = diffusion(x, cond=cond); loss.backward(); clip; optimizer.step()` (diffusion_engine.py:230-241).  The parameters are
+    the differentiable inputs; forward = TrainGraph.forward + L1 loss, backward = TrainGraph.backward -> one gradient per parameter."""
+
+    @staticmethod
+    def forward(ctx, graph, names, x_noisy, t, cond, self_cond, target, drop_masks, path_scales, *params):
+        P = {n: p.detach() for n, p in zip(names, params)}
+        y = graph.forward(P, x_noisy, t, cond, self_cond, drop_masks=drop_masks, path_scales=path_scales)
+        loss = F.l1_loss(y, target)
+        ctx.graph, ctx.names, ctx.y, ctx.target = graph, names, y, target
+        ctx.mark_non_differentiable(y)
+        return loss, y
+
+    @staticmethod
+    def backward(ctx, gloss, _grecon):
+        dy = R.l1_loss_backward(ctx.y, ctx.target, upstream=float(gloss))
+        G = ctx.graph.backward(dy)
+        return (None,) * 9 + tuple(G.get(n) for n in ctx.names)

@@ -278,6 +278,10 @@ DDIF_API int ddif_add_scaled(const float* a, const float* f, const float* alpha,
 DDIF_API int ddif_linear_fwd(const float* x, const float* w, const float* bias, int B, int nin, int nout, float* y, void* stream);
 DDIF_API int ddif_selfattn_core_fwd(const float* qkv, int B, int C, int H, int W, int heads, float* out, void* stream);
 DDIF_API int ddif_linattn_core_fwd(const float* q_pre, const float* kv_pre, int B, int qd, int H, int W, int heads, float* out, void* stream);
+/* q_sample (diffusion/diffusion_ddpm_pan.py:668-681): out = a[b] * x0 + s[b] * noise; a, s = B device floats */
+DDIF_API int ddif_q_sample(const float* x0, const float* noise, const float* a, const float* s, int B, int64_t per_sample, float* out, void* stream);
+/* F.l1_loss(pred, target), mean reduction: out = one device float */
+DDIF_API int ddif_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* out, void* stream);
 
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 

@@ -43,11 +43,13 @@ def test_assemble_cond_matches_the_fixture_generator():
     assert torch.equal(E.assemble_cond(hs["lms"], hs["pan"], None, "cave"), hs["cond"])
 
 
-def test_engine_google_refuses_loudly():
+def test_engine_google_needs_h5py_or_arrays():
+    """The reference reads h5 files (diffusion_engine.py:142-143); h5py is not in this image, so a path must fail loudly and name the
+    in-memory alternative."""
     from ddif import DdifError
 
-    with pytest.raises(DdifError, match="backward"):
-        E.engine_google("train.h5", "valid.h5", dataset_name="wv3")
+    with pytest.raises(DdifError, match="h5py"):
+        E.engine_google("train_wv3.h5", "valid_wv3.h5", dataset_name="wv3", device="cpu")
 
 
 @pytest.mark.gpu
