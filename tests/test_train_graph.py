@@ -77,7 +77,10 @@ def test_training_step_gradients_match_the_reference(backend):
     print("worst relative grad-norm error over %d parameters: %.2e" % (len(names), worst))
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
+GPU_ONLY = [pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]  # a training step takes ~40 s on the host emulator: the CPU suite keeps the parity test above
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_loss_backward_through_the_drop_in_fills_parameter_grads_and_the_optimizer_steps(backend):
     """The reference's training lines unchanged (diffusion_engine.py:230-241) on the drop-in classes: `loss, recon = diffusion(x, cond=cond);
     loss.backward()` must leave a finite `.grad` on all 702 parameters, then the fused clip + AdamW + EMA step must move the weights.
@@ -127,7 +130,7 @@ def test_loss_backward_through_the_drop_in_fills_parameter_grads_and_the_optimiz
         n_with_grad = sum(1 for _, p in net.named_parameters() if p.grad is not None)
         assert n_with_grad == 702
         assert all(torch.isfinite(p.grad).all() for p in net.parameters())
-        assert abs(float(loss) - float((recon.cpu() - x).abs().mean())) <= 1e-6
+        assert abs(float(loss.detach()) - float((recon.cpu() - x).abs().mean())) <= 1e-6
         before = {n: p.detach().clone() for n, p in list(net.named_parameters())[:8]}
         params = [p for p in net.parameters()]
         grads = [p.grad for p in params]
@@ -149,7 +152,7 @@ def _raw_set(n, C, H, seed):
     return {"gt": (t["gt"] * 2047.0).numpy(), "lms": (t["lms"] * 2047.0).numpy(), "pan": (t["pan"] * 2047.0).numpy()}
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_engine_google_trains_and_validates_on_an_in_memory_set(backend):
     """The reference's training entry point (diffusion_engine.py:52-348) end to end on a tiny in-memory WV3-shaped set: two / three iterations
     (cond assembly, p_losses, loss.backward() through the library, clip + AdamW + EMA), one DDIM-25 validation with the EMA weights.
