@@ -222,6 +222,21 @@ def _open_set(path_or_data):
     return {k: np.asarray(f[k]) for k in ("pan", "lms", "gt")}
 
 
+def average_gradients(grads, world: int):
+    """DDP of config 5 (one process per GPU, `torch.distributed`; backend "nccl" = RCCL over xGMI): the gradients of all ranks are averaged
+    in ONE flat bucket (7.1 M floats = 28 MB for the engine network: a single ring all-reduce, bandwidth-bound on the xGMI links rather
+    than latency-bound on 702 small ones).  In place: the fused optimizer keeps the gradient pointers."""
+    import torch.distributed as dist
+
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
 def lr_at(iteration: int, base: float, milestones=(100_000, 200_000, 350_000), gamma: float = 0.2) -> float:
     """MultiStepLR of the reference (diffusion_engine.py:210-212)"""
     return base * gamma ** sum(1 for m in milestones if iteration >= m)
@@ -309,14 +324,8 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
             res = (hr / div - lms_n).contiguous()
             diff_loss, recon_x = diffusion(res, cond=cond)
             diff_loss.backward()
-            if world > 1:  # DDP (config 5): average the gradients over the ranks, one bucket
-                flat = torch.cat([g.reshape(-1) for g in grads])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat /= world
-                off = 0
-                for g in grads:
-                    g.copy_(flat[off:off + g.numel()].view_as(g))
-                    off += g.numel()
+            if world > 1:
+                average_gradients(grads, world)
             opt.lr = lr_at(iterations, lr_d)
             mode = 2 if iterations >= ema_start_iter else 1  # EmaUpdater: copy before start_iter, lerp after (utils/optim_utils.py:43-58)
             gn = opt.step(max_grad_norm=0.003, ema_mode=mode, ema_decay=0.995, return_norm=True)

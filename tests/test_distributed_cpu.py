@@ -65,3 +65,53 @@ def test_cut_and_stitch_roundtrip():
     assert shard_range(64, 3, 8) == (24, 32)
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------- training: DDP gradient averaging
+def _run_train(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HIPEMU_THREADS="4")
+    torch.set_num_threads(2)
+    use_emulator()
+    import random
+
+    import ddif.diffusion_engine as E
+    from ddif.synth import synth_tiles
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    # unit: the flat-bucket average
+    g = [torch.full((3, 2), float(rank + 1)), torch.full((5,), 10.0 * (rank + 1))]
+    if world > 1:
+        E.average_gradients(g, world)
+        assert torch.equal(g[0], torch.full((3, 2), 1.5)) and torch.equal(g[1], torch.full((5,), 15.0))
+    # one training iteration of engine_google: same initial weights and masks (same torch seed) on both ranks, DIFFERENT data per rank
+    t = synth_tiles(1, 4, 1, 8, 8, seed=50 + rank)
+    data = {"gt": (t["gt"] * 1023.0).numpy(), "lms": (t["lms"] * 1023.0).numpy(), "pan": (t["pan"] * 1023.0).numpy()}
+    torch.manual_seed(9)
+    random.seed(9)
+    out = E.engine_google(data, None, dataset_name="gf2", image_n_channel=4, image_size=8, n_steps=20, max_iterations=1, device="cpu", batch_size=1,
+                          lr_d=1e-2, valid_every=0, log=lambda *_: None)
+    names = ["downs.0.weight", "mid.0.attn.qkv.weight", "ups.0.cond_inj.ffn.3.weight", "final_conv.block.3.bias"]
+    sd = dict(out["model"].named_parameters())
+    q.put((rank, out["loss"][0], {n: sd[n].detach().clone().numpy() for n in names}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_averages_gradients_and_keeps_the_replicas_identical():
+    """Config 5 (DDP): two ranks start from the same weights, see different samples, all-reduce their gradients (gloo here, RCCL on the
+    GPUs) and take the same optimizer step: their weights must stay bit-identical, while their losses differ (different data)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run_train, args=(r, 2, 29621, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=900) for _ in range(2)], key=lambda e: e[0])
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0
+    (_, loss0, w0), (_, loss1, w1) = got
+    assert loss0 != loss1
+    for n in w0:
+        assert (w0[n] == w1[n]).all(), n
