@@ -1,5 +1,7 @@
 // Host side of the 3x3 convolution backward op (kernels_bwd.h): the first building block of the training step
 // (SURVEY.md 8(a) a15).  extern "C" entry points are declared in include/ddif.h.
+#include <algorithm>
+
 #include "ddif_plan.h"
 #include "kernels_bwd.h"
 
@@ -101,7 +103,7 @@ int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device)
         if (want > 256) want = 256;
         c.nsplit = want;
         TRY(c.plan.dalloc(&c.partial, (size_t)c.nsplit * c.n_co * c.n_ci * 9 * 1024));
-        c.nbchunk = 64;
+        c.nbchunk = (int)std::min<size_t>(512, std::max<size_t>(1, (size_t)B * H * W / 16));  // >= 16 pixels per chunk
         TRY(c.plan.dalloc(&c.bpart, (size_t)c.nbchunk * Cout));
         if (!rc && c.wg_smem > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.wg_smem) != hipSuccess)
@@ -133,8 +135,8 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
                            c.Cout, c.Cin, dw);
     }
     if (db) {
-        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 0, s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
-        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((c.Cout + 255) / 256), dim3(256), 0, s, (const float*)c.bpart, c.nbchunk, c.Cout, db);
+        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 256 * sizeof(float), s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
+        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(c.Cout), dim3(64), 64 * sizeof(float), s, (const float*)c.bpart, c.nbchunk, c.Cout, db);
     }
 }
 }  // namespace ddif

@@ -10,6 +10,30 @@ static inline dim3 ops_grid(size_t n) {
     if (g < 1) g = 1;
     return dim3((unsigned)g);
 }
+// per-device scratch for the two-pass reductions (partials between the passes).  One host thread and one stream per device at a time,
+// like every handle of this library; grown on demand, never shrunk, freed at process exit by the driver.
+static double* ops_scratch(size_t doubles) {
+    static double* buf[64] = {nullptr};
+    static size_t cap[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (cap[dev] < doubles) {
+        if (buf[dev]) {
+            (void)hipDeviceSynchronize();  // nothing in flight may still read the old block
+            (void)hipFree(buf[dev]);
+            buf[dev] = nullptr;
+            cap[dev] = 0;
+        }
+        const size_t want = doubles < (1u << 16) ? (1u << 16) : doubles;
+        if (hipMalloc(reinterpret_cast<void**>(&buf[dev]), want * sizeof(double)) != hipSuccess) return nullptr;
+        cap[dev] = want;
+    }
+    return buf[dev];
+}
+static inline int gn_chunks(size_t per_sample) {
+    size_t n = per_sample / 4096;
+    return (int)(n < 1 ? 1 : (n > 32 ? 32 : n));
+}
 static int ops_done(const char* what) {
     if (hipGetLastError() != hipSuccess) return fail(DDIF_ERR_HIP, "%s: kernel launch failed", what);
     return DDIF_OK;
@@ -22,7 +46,12 @@ int ddif_dwconv3x3_bwd(const float* x, const float* w, const float* dy, int B, i
     if (!w || !dy || B < 1 || C < 1 || H < 1 || W < 1 || (dw && !x)) return ddif::fail(DDIF_ERR_INVALID, "ddif_dwconv3x3_bwd: bad argument");
     [[maybe_unused]] hipStream_t s = (hipStream_t)stream;
     if (dx) hipLaunchKernelGGL(ddif::dwconv3x3_bwd_dx_kernel, ddif::ops_grid((size_t)B * C * H * W), dim3(256), 0, s, dy, w, B, C, H, W, dx);
-    if (dw) hipLaunchKernelGGL(ddif::dwconv3x3_bwd_dw_kernel, dim3(C), dim3(256), 9 * 256 * sizeof(double), s, x, dy, B, C, H, W, dw);
+    if (dw) {
+        double* part = ddif::ops_scratch((size_t)B * C * 9);
+        if (!part) return ddif::fail(DDIF_ERR_HIP, "ddif_dwconv3x3_bwd: scratch allocation failed");
+        hipLaunchKernelGGL(ddif::dwconv3x3_bwd_dw_partial_kernel, dim3(C, B), dim3(256), 9 * 256 * sizeof(double), s, x, dy, C, H, W, part);
+        hipLaunchKernelGGL(ddif::dwconv3x3_bwd_dw_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, (const double*)part, B, C, dw);
+    }
     return ddif::ops_done("ddif_dwconv3x3_bwd");
 }
 
@@ -84,7 +113,13 @@ int ddif_groupnorm_bwd(const float* x, const float* gamma, const float* dy, int 
                        void* stream) {
     if (!x || !gamma || !dy || !workspace || B < 1 || C < 1 || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_groupnorm_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ddif::gn_bwd_sample_kernel, dim3(B), dim3(256), 2 * 256 * sizeof(double), s, x, dy, gamma, C, H * W, workspace, B);
+    const size_t per = (size_t)C * H * W;
+    const int nchunk = ddif::gn_chunks(per);
+    double* part = ddif::ops_scratch((size_t)B * nchunk * 2);
+    if (!part) return ddif::fail(DDIF_ERR_HIP, "ddif_groupnorm_bwd: scratch allocation failed");
+    hipLaunchKernelGGL(ddif::gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, x, per, nchunk, part);
+    hipLaunchKernelGGL(ddif::gn_bwd_plane_kernel, dim3(C, B), dim3(256), 2 * 256 * sizeof(double), s, x, dy, (const double*)part, nchunk, C, H * W, workspace);
+    hipLaunchKernelGGL(ddif::gn_bwd_sample_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)part, nchunk, gamma, B, C, H * W, workspace);
     if (dx) hipLaunchKernelGGL(ddif::gn_bwd_dx_kernel, ddif::ops_grid((size_t)B * C * H * W), dim3(256), 0, s, x, dy, gamma, (const double*)workspace, B, C, H * W, dx);
     if (dgamma || dbeta) hipLaunchKernelGGL(ddif::gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, B, C, dgamma, dbeta);
     return ddif::ops_done("ddif_groupnorm_bwd");
@@ -98,7 +133,15 @@ int ddif_dwconv3x3_fwd(const float* x, const float* w, int B, int C, int H, int 
 }
 int ddif_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* mask, int B, int C, int H, int W, int silu, float* y, void* stream) {
     if (!x || !gamma || !beta || !y || B < 1 || C < 1 || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_groupnorm_fwd: bad argument");
-    hipLaunchKernelGGL(ddif::gn_fwd_kernel, dim3(B), dim3(256), 2 * 256 * sizeof(double), (hipStream_t)stream, x, gamma, beta, mask, C, H * W, silu, y);
+    const size_t per = (size_t)C * H * W;
+    const int nchunk = ddif::gn_chunks(per);
+    double* part = ddif::ops_scratch((size_t)B * nchunk * 2);
+    if (!part) return ddif::fail(DDIF_ERR_HIP, "ddif_groupnorm_fwd: scratch allocation failed");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ddif::gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, x, per, nchunk, part);
+    const size_t blocks = (per + 255) / 256;
+    hipLaunchKernelGGL(ddif::gn_apply_nchw_kernel, dim3((unsigned)(blocks > 64 ? 64 : blocks), B), dim3(256), 0, s, x, (const double*)part, nchunk, gamma, beta, mask, C,
+                       H * W, silu, y);
     return ddif::ops_done("ddif_groupnorm_fwd");
 }
 int ddif_swish_fwd(const float* x, int64_t n, float* y, void* stream) {

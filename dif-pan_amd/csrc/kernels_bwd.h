@@ -135,22 +135,43 @@ __global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, 
     }
 }
 
-// db[co] = sum over pixels of dY[., co]  (NHWC): grid.x = chunks of pixels -> partial [chunk][Cout]; then fixed-order sum
+// db[co] = sum over pixels of dY[., co]  (NHWC): grid.x = chunks of pixels -> partial [chunk][Cout]; then fixed-order sum.
+// thread = (pixel row r, channel c): rows = 256 / Cout threads walk the chunk's pixels side by side, combined through LDS in row order
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* dy, size_t npix, int Cout, int nchunk, float* partial) {
+    DDIF_DYN_SMEM(smem_);
+    float* red = reinterpret_cast<float*>(smem_);  // [256]
+    const int tid = threadIdx.x;
     const size_t per = (npix + nchunk - 1) / nchunk;
     const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
-    for (int c = threadIdx.x; c < Cout; c += 256) {
+    for (int c0 = 0; c0 < Cout; c0 += 256) {
+        const int cw = Cout - c0 < 256 ? Cout - c0 : 256, rows = 256 / cw;
+        const int c = tid % cw, r = tid / cw;
         float s = 0.f;
-        for (size_t p = p0; p < p1; ++p) s += dy[p * Cout + c];
-        partial[(size_t)blockIdx.x * Cout + c] = s;
+        if (r < rows)
+            for (size_t p = p0 + r; p < p1; p += rows) s += dy[p * Cout + c0 + c];
+        red[tid] = s;
+        __syncthreads();
+        if (r == 0) {
+            for (int rr = 1; rr < rows; ++rr) s += red[rr * cw + c];
+            partial[(size_t)blockIdx.x * Cout + c0 + c] = s;
+        }
+        __syncthreads();
     }
 }
-__global__ void bias_grad_reduce_kernel(const float* partial, int nchunk, int Cout, float* db) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cout) return;
+// one 64-thread workgroup per channel: thread-strided partial sums, then a fixed-order tree
+__global__ __launch_bounds__(64) void bias_grad_reduce_kernel(const float* partial, int nchunk, int Cout, float* db) {
+    DDIF_DYN_SMEM(smem_);
+    float* red = reinterpret_cast<float*>(smem_);  // [64]
+    const int c = blockIdx.x, tid = threadIdx.x;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += partial[(size_t)k * Cout + c];
-    db[c] = s;
+    for (int k = tid; k < nchunk; k += 64) s += partial[(size_t)k * Cout + c];
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 32; st >= 1; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) db[c] = red[0];
 }
 
 }  // namespace ddif

@@ -621,3 +621,153 @@ __global__ __launch_bounds__(256) void l1_fwd_kernel(const float* pred, const fl
     if (tid == 0) out[0] = (float)(red[0] / (double)n);
 }
 }  // namespace ddif
+
+namespace ddif {
+// ---- wider-grid forms of the per-sample kernels above (a 32-workgroup launch leaves 7/8 of the GPU idle) -------------------------------
+// GroupNorm statistics: grid (nchunk, B) -> part[b][chunk][2] (fp64 sums of x and x^2 over a flat slice of the sample)
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* x, size_t per_sample, int nchunk, double* part) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [2][256]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const size_t per = (per_sample + nchunk - 1) / nchunk;
+    const size_t i0 = (size_t)blockIdx.x * per, i1 = i0 + per < per_sample ? i0 + per : per_sample;
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = i0 + tid; i < i1; i += 256) {
+        const double v = x[(size_t)b * per_sample + i];
+        s1 += v;
+        s2 += v * v;
+    }
+    red[tid] = s1;
+    red[256 + tid] = s2;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) {
+            red[tid] += red[tid + st];
+            red[256 + tid] += red[256 + tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[((size_t)b * nchunk + blockIdx.x) * 2 + 0] = red[0];
+        part[((size_t)b * nchunk + blockIdx.x) * 2 + 1] = red[256];
+    }
+}
+__device__ __forceinline__ void gn_stats_from_partials(const double* part, int b, int nchunk, double n, float* mean, float* rstd) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += part[((size_t)b * nchunk + k) * 2 + 0];
+        s2 += part[((size_t)b * nchunk + k) * 2 + 1];
+    }
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    *mean = (float)m;
+    *rstd = (float)(1.0 / sqrt(var + DDIF_GN_EPS));
+}
+// apply: grid (chunks, B), NCHW
+__global__ __launch_bounds__(256) void gn_apply_nchw_kernel(const float* x, const double* part, int nchunk, const float* gamma, const float* beta, const float* mask,
+                                                            int C, int HW, int silu, float* y) {
+    const int b = blockIdx.y;
+    const size_t n = (size_t)C * HW;
+    float mean, rstd;
+    gn_stats_from_partials(part, b, nchunk, (double)n, &mean, &rstd);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i / HW);
+        float v = fmaf((x[(size_t)b * n + i] - mean) * rstd, gamma[c], beta[c]);
+        if (silu) v = dd_silu(v);
+        if (mask) v *= mask[(size_t)b * n + i];
+        y[(size_t)b * n + i] = v;
+    }
+}
+// GroupNorm-alone backward, plane sums: grid (C, B): P[b][c] = {sum dy, sum dy x_hat} over the plane (fp64, fixed-order tree)
+__global__ __launch_bounds__(256) void gn_bwd_plane_kernel(const float* x, const float* dy, const double* part, int nchunk, int C, int HW, double* P) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [2][256]
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    float mean, rstd;
+    gn_stats_from_partials(part, b, nchunk, (double)C * HW, &mean, &rstd);
+    const size_t base = ((size_t)b * C + c) * HW;
+    double p0 = 0.0, p1 = 0.0;
+    for (int i = tid; i < HW; i += 256) {
+        const float g = dy[base + i], xh = (x[base + i] - mean) * rstd;
+        p0 += (double)g;
+        p1 += (double)g * (double)xh;
+    }
+    red[tid] = p0;
+    red[256 + tid] = p1;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) {
+            red[tid] += red[tid + st];
+            red[256 + tid] += red[256 + tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        P[((size_t)b * C + c) * 2 + 0] = red[0];
+        P[((size_t)b * C + c) * 2 + 1] = red[256];
+    }
+}
+// per sample: M[b] = {mean, rstd, sum_c gamma_c P0 / N, sum_c gamma_c P1 / N} (the layout gn_bwd_dx_kernel / gn_bwd_affine_kernel read)
+__global__ void gn_bwd_sample_finalize_kernel(const double* part, int nchunk, const float* gamma, int B, int C, int HW, double* ws) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double n = (double)C * HW;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += part[((size_t)b * nchunk + k) * 2 + 0];
+        s2 += part[((size_t)b * nchunk + k) * 2 + 1];
+    }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = 0; c < C; ++c) {
+        a1 += (double)gamma[c] * ws[((size_t)b * C + c) * 2 + 0];
+        a2 += (double)gamma[c] * ws[((size_t)b * C + c) * 2 + 1];
+    }
+    double* M = ws + (size_t)B * C * 2 + (size_t)b * 4;
+    M[0] = mean;
+    M[1] = 1.0 / sqrt(var + DDIF_GN_EPS);
+    M[2] = a1 / n;
+    M[3] = a2 / n;
+}
+// depthwise dW: grid (C, B) -> partial[b][c][9] (fp64 tree), then a fixed-order sum over samples
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_dw_partial_kernel(const float* x, const float* dy, int C, int H, int W, double* partial) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [9][256]
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int HW = H * W;
+    const float* gp = dy + ((size_t)b * C + c) * HW;
+    const float* plane = x + ((size_t)b * C + c) * HW;
+    for (int p = tid; p < HW; p += 256) {
+        const int y = p / W, xx = p % W;
+        const float g = gp[p];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = xx + kx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[ky * 3 + kx] += (double)g * (double)plane[iy * W + ix];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[k * 256 + tid] = acc[k];
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) red[k * 256 + tid] += red[k * 256 + tid + st];
+        __syncthreads();
+    }
+    if (tid < 9) partial[((size_t)b * C + c) * 9 + tid] = red[tid * 256];
+}
+__global__ void dwconv3x3_bwd_dw_reduce_kernel(const double* partial, int B, int C, float* dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 9) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += partial[(size_t)b * C * 9 + i];
+    dw[i] = (float)s;
+}
+}  // namespace ddif

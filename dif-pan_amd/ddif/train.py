@@ -241,7 +241,14 @@ class TrainGraph:
         temb, temb_bwd = self._time_embedding(P, t)
         c_enc = cond[:, : Cc + Pp].contiguous()
         c_dec = cond[:, -(Cc + 3 * Pp):].contiguous()
-        resize = lambda c, hw: c if tuple(c.shape[-2:]) == tuple(hw) else TF.interpolate(c, size=hw, mode="bilinear").contiguous()
+        sized = {}
+
+        def resize(c, hw):  # the cond image at a level's resolution, formed once per forward pass (28 uses, 4 sizes x 2 halves)
+            key = (id(c), tuple(hw))
+            if key not in sized:
+                sized[key] = c if tuple(c.shape[-2:]) == tuple(hw) else TF.interpolate(c, size=tuple(hw), mode="bilinear").contiguous()
+            return sized[key]
+
         feats = []
         for i, L in enumerate(self.plan["downs"]):
             p = f"downs.{i}"
