@@ -49,6 +49,9 @@ CONFIGS = {
     # configs[3]: CAVE 31-band HSI + 3-band MSI, 128x128 patches, T=2000 DDPM
     "cave128_t2000": dict(ds="cave", C=31, P=3, batch=8, tile=128, T=2000, sampler="ddpm",
                           metric="fused megapixels/sec at T=%d, CAVE 128x128x31 patches"),
+    # configs[4]: one training iteration of sr3_dwt on WV3 tiles, batch 32 per GPU, AdamW, DDP over the ranks (engine_google's loop body)
+    "wv3_train_b32": dict(ds="wv3", C=8, P=1, batch=32, tile=64, T=3000, sampler="train",
+                          metric="training tiles/sec, sr3_dwt on WV3 64x64x8 tiles, batch 32 per GPU (T=%d schedule)"),
 }
 
 
@@ -108,6 +111,8 @@ def main():
     lib = ddif.get_lib()
     assert not lib.emulated
     cf = CONFIGS[args.config]
+    if cf["sampler"] == "train":
+        return bench_training(args, cf, rank, world, dev)
     C, P = cf["C"], cf["P"]
     B, H, T = args.batch or cf["batch"], args.tile or cf["tile"], args.T or cf["T"]
     order = "hisr" if cf["ds"] == "cave" else "pan"
@@ -267,6 +272,84 @@ def main():
         result["vs_cpu_baseline_b1"] = value / cb["by_batch"]["1"]["value"]
     if rank == 0:
         print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_training(args, cf, rank, world, dev):
+    """BASELINE configs[4]: one "step" = one training iteration as engine_google runs it (reference diffusion_engine.py:218-241): q_sample +
+    self-conditioning draw + forward + loss.backward() through the library's reverse pass + gradient all-reduce over the ranks + fused
+    clip / AdamW / EMA.  Weak scaling: every rank trains its own batch; value = tiles per second over all ranks."""
+    import random
+
+    import torch
+    import torch.distributed as dist
+
+    from ddif import runtime
+    from ddif.diffusion.diffusion_ddpm_pan import GaussianDiffusion, make_beta_schedule
+    from ddif.diffusion_engine import average_gradients
+    from ddif.layout import engine_cfg
+    from ddif.models.sr3_dwt import UNetSR3
+    from ddif.synth import synth_state_dict, synth_tiles
+
+    C, P, B, H, T = cf["C"], cf["P"], args.batch or cf["batch"], args.tile or cf["tile"], args.T or cf["T"]
+    cfg = engine_cfg(C, P)
+    keys = ("in_channel", "out_channel", "inner_channel", "lms_channel", "pan_channel", "norm_groups", "channel_mults", "attn_res", "res_blocks", "dropout",
+            "image_size", "self_condition")
+    net = UNetSR3(**{k: cfg[k] for k in keys})
+    net.load_state_dict(synth_state_dict(cfg, 1234))
+    net = net.to(dev).train()
+    d = GaussianDiffusion(net, image_size=H, channels=C, pred_mode="x_start", loss_type="l1", device=dev, clamp_range=(0, 1))
+    d.set_new_noise_schedule(betas=make_beta_schedule("cosine", T, cosine_s=8e-3), device=dev)
+    tiles = synth_tiles(B, C, P, H, H, seed=100 + rank)
+    cond = tiles["cond"].to(dev)
+    res = (tiles["gt"].to(dev) - cond[:, :C]).contiguous()
+    params = [p for p in net.parameters()]
+    grads = [torch.zeros_like(p) for p in params]
+    for p, g in zip(params, grads):
+        p.grad = g
+    ema = [p.detach().clone() for p in params]
+    opt = runtime.FusedAdamW(params, grads, ema, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    torch.manual_seed(7 + rank)
+    random.seed(7 + rank)
+
+    def one_step():
+        for g in grads:
+            g.zero_()
+        loss, _ = d(res, cond=cond)
+        loss.backward()
+        if world > 1:
+            average_gradients(grads, world)
+        opt.step(max_grad_norm=0.003, ema_mode=1, ema_decay=0.995)
+        return loss
+
+    for w in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    loss = None
+    for k in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(loss.detach()).all())
+    if rank == 0:
+        line = {"metric": cf["metric"] % T, "value": world * B * args.steps / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "sr3_dwt training iteration (q_sample, 50 %% self-conditioning pass, forward, backward, DDP all-reduce, clip + AdamW + EMA), "
+                                       "WV3 %dx%dx%d tiles, batch %d per GPU, fp32" % (H, H, C, B), "name": args.config, "tiles_per_gpu": B, "tile": [H, H, C],
+                           "T": T, "parallelism": "ddp x%d" % world},
+                "roofline": None, "cpu_baseline": None, "build_id": build_id(),
+                "note": "correctness-first training graph (ddif/train.py): per-kernel split in profiles/r02_z_train_kernel_stats_after.csv"}
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -36,8 +36,14 @@ python3 bench.py > gpurun_out/${tag}_bench_T1000_B64.json 2> gpurun_out/${tag}_b
 cat gpurun_out/${tag}_bench_T1000_B64.json
 python3 bench.py --config gf2_dpm50 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_gf2_dpm50.json 2> gpurun_out/${tag}_bench_gf2_dpm50.log
 python3 bench.py --config cave128_t2000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${tag}_bench_cave128_t2000.json 2> gpurun_out/${tag}_bench_cave128_t2000.log
+python3 bench.py --config wv3_train_b32 --steps 10 --warmup 3 > gpurun_out/${tag}_bench_wv3_train_b32.json 2> gpurun_out/${tag}_bench_wv3_train_b32.log
 python3 - <<PY
 import json
+try:
+    r = json.load(open("gpurun_out/${tag}_bench_wv3_train_b32.json"))
+    print("wv3_train_b32", r["value"], r["unit"], "ms/iteration", r["ms_per_step"])
+except Exception as e:
+    print("wv3_train_b32 failed", e)
 for n in ("gf2_dpm50", "cave128_t2000"):
     try:
         r = json.load(open("gpurun_out/${tag}_bench_%s.json" % n))
