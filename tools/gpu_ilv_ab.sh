@@ -1,6 +1,9 @@
 #!/bin/bash
 # usage: tools/gpu_ilv_ab.sh <tag>  -- parity tests on the default build, then job time / op timing of the default build (staging
-# pieces interleaved into the bf16x3 MFMA loop) against lib/libddif_noilv.so (same sources with -DDDIF_NO_ILV)
+# pieces interleaved into the bf16x3 MFMA loop) against lib/libddif_noilv.so (same sources with -DDDIF_NO_ILV).  Build that one first:
+#   cd dif-pan_amd && hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DDDIF_NO_ILV -c csrc/ddif_plan.cpp -o /tmp/plan_noilv.o
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libddif_noilv.so build/ddif_net.o /tmp/plan_noilv.o build/ddif_lr.o build/ddif_aux.o build/ddif_bwd.o \
+#         build/ddif_bwd_ops.o build/ddif_capi.o -Wl,--exclude-libs,ALL
 tag=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
