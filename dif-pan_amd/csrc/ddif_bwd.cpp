@@ -23,6 +23,7 @@ struct ConvBwd {
     std::vector<Op> prog;
     int n_chunks = 0, nb_pad = 0, n_co = 0, n_ci = 0, nsplit = 0, rb = 4, nbchunk = 0;
     size_t wg_smem = 0;
+    bool centre_only = false;  // a 1x1 conv riding the 3x3 kernels: dW is (Cout, Cin) from the centre tap
 };
 int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device);
 void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float* dw, float* db);
@@ -130,9 +131,14 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
         a.rb = c.rb;
         a.bands_y = (c.H + c.rb - 1) / c.rb;
         a.partial = c.partial;
+        a.centre_only = c.centre_only ? 1 : 0;
         hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)c.Cout * c.Cin * 9), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
-                           c.Cout, c.Cin, dw);
+        if (c.centre_only)
+            hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)c.Cout * c.Cin), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
+                               c.Cout, c.Cin, dw);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)c.Cout * c.Cin * 9), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
+                               c.Cout, c.Cin, dw);
     }
     if (db) {
         hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 256 * sizeof(float), s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
@@ -172,7 +178,7 @@ struct BlockBwd {
     ConvBwd conv;      // owns the NHWC staging buffers: conv.x_nhwc = a (the conv's input), conv.dy_nhwc = dY, conv.dx = dA
     float *x_nhwc = nullptr, *mask_nhwc = nullptr, *dx_nhwc = nullptr, *ms = nullptr, *S = nullptr;
     double *spart = nullptr, *cpart = nullptr, *planes = nullptr;
-    float *w3 = nullptr, *dw3 = nullptr;  // ks == 1: the 1x1 weights / weight gradient embedded in 3x3 tensors
+    float* w3 = nullptr;  // ks == 1: the 1x1 weights embedded in a 3x3 tensor for the dgrad conv
     int nchunk = 32, ks = 3, pro = DDIF_BWD_PRO_GN_SILU, resample = DDIF_BWD_PLAIN;
     int H = 0, W = 0;  // of the op's INPUT x (the conv runs at 2H x 2W under DDIF_BWD_UP2)
 };
@@ -213,7 +219,7 @@ int ddif_blockbwd_create_ex(ddif_blockbwd_t* out, int B, int Cin, int Cout, int 
     ddif::Plan& pl = k.conv.plan;
     if (ks == 1) {
         TRY(pl.dalloc(&k.w3, (size_t)Cout * Cin * 9));
-        TRY(pl.dalloc(&k.dw3, (size_t)Cout * Cin * 9));
+        k.conv.centre_only = true;
     }
     TRY(pl.dalloc(&k.x_nhwc, n));
     TRY(pl.dalloc(&k.mask_nhwc, n));
@@ -275,8 +281,7 @@ int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, con
     const size_t nw1 = (size_t)c.Cout * Ci;
     if (k.ks == 1) {
         hipLaunchKernelGGL(ddif::embed_1x1_kernel, ddif::grid_for(nw1 * 9), dim3(256), 0, s, w, nw1, k.w3);
-        ddif::convbwd_core(c, s, k.w3, want_da, dw ? k.dw3 : nullptr, db);
-        if (dw) hipLaunchKernelGGL(ddif::extract_centre_kernel, ddif::grid_for(nw1), dim3(256), 0, s, (const float*)k.dw3, nw1, dw);
+        ddif::convbwd_core(c, s, k.w3, want_da, dw, db);  // dW comes out as (Cout, Cin): only the centre tap is contracted
     } else {
         ddif::convbwd_core(c, s, w, want_da, dw, db);
     }

@@ -45,6 +45,7 @@ struct WgradArgs {
     int rb;            // rows per band (4, 2 or 1: the largest whose tiles fit LDS)
     int bands_y;       // ceil(H / rb)
     float* partial;    // [gridDim.y][n_co * n_ci][9][32 co][32 ci]
+    int centre_only;   // 1x1 convs riding this kernel: only tap 4 (the centre) is contracted and written
 };
 
 // grid = (n_co * n_ci, NSPLIT); block 256.  LDS: dY band [rb*W][32] + X band [(rb+2)*(W+2)][32] + reduction scratch [4][1024].
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             const int p = pv ? pr : npix - 1;
             const int py = p / W, px = p % W;
             const float av = pv ? Ys[p * 32 + j] : 0.f;  // A[i = co j][k = h]
+            if (a.centre_only) {
+                acc[4] = DDIF_MFMA_32x32x2(av, Xs[((py + 1) * IW + px + 1) * 32 + j], acc[4]);
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float bv = Xs[((py + t / 3) * IW + px + t % 3) * 32 + j];  // B[k = h][j = ci]: X at (y + ky - 1, x + kx - 1)
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     // combine the four waves tap by tap in fixed order, write this workgroup's partial block
     float* outp = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 1024;
     for (int t = 0; t < 9; ++t) {
+        if (a.centre_only && t != 4) continue;  // workgroup-uniform
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) Rs[(wave * 16 + r) * 64 + lane] = acc[t][r];
@@ -120,6 +126,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// 1x1 form: dW (Cout, Cin) from the centre-tap blocks only
+__global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw) {
+    const size_t total = (size_t)Cout * Cin;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin), co = (int)(i / Cin);
+        const int blk = (co / 32) * n_ci + ci / 32;
+        const size_t off = ((size_t)blk * 9 + 4) * 1024 + (size_t)(co % 32) * 32 + ci % 32;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * nblk * 9 * 1024 + off];
+        dw[i] = s;
+    }
+}
 // dW (OIHW) = fixed-order sum of the partial blocks; one thread per weight element
 __global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw) {
     const size_t total = (size_t)Cout * Cin * 9;
@@ -387,12 +405,9 @@ __global__ __launch_bounds__(256) void plane_sum_nchw_kernel(const float* in, in
     if (tid == 0) out[blockIdx.x] = (float)red[0];
 }
 // 1x1 convolutions ride the 3x3 backward kernels for now (correctness first): the (Cout, Cin) weights become the centre tap of a
-// zero 3x3 kernel -- its dgrad IS the 1x1 dgrad, and the centre tap of its wgrad IS the 1x1 wgrad (the other taps are never read)
+// zero 3x3 kernel -- its dgrad IS the 1x1 dgrad; the wgrad kernel contracts the centre tap only (WgradArgs::centre_only)
 __global__ void embed_1x1_kernel(const float* w1, size_t n /* Cout * Cin */, float* w3) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 9; i += (size_t)gridDim.x * blockDim.x) w3[i] = (i % 9 == 4) ? w1[i / 9] : 0.f;
-}
-__global__ void extract_centre_kernel(const float* dw3, size_t n, float* dw1) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dw1[i] = dw3[i * 9 + 4];
 }
 // ---- SiLU alone in front of a conv (FastAttnCondInjection.ffn: conv3x3 -> SiLU -> conv3x3, models/sr3_dwt.py:528-533)
 __global__ void silu_fwd_kernel(const float* x, size_t n, float* a) {

@@ -222,8 +222,8 @@ DDIF_API int ddif_blockbwd_create(ddif_blockbwd_t* out, int B, int Cin, int Cout
  * conv's dgrad), GN (SelfAttention.norm -> qkv, the attention prenorms), GN_SILU (Block; CondInjection.body's tail), SILU (ffn.2
  * behind ffn.0's SiLU).  resample: PLAIN; DOWN2 = Downsample, conv3x3 stride 2 pad 1 (models/sr3_dwt.py:276-282): x is (B,Cin,H,W),
  * dy (B,Cout,(H-1)/2+1,(W-1)/2+1); UP2 = Upsample, nearest x2 then conv3x3 (:266-273): x (B,Cin,H,W), dy (B,Cout,2H,2W).
- * Correctness first: 1x1 convs run on the 3x3 kernels with the weights in the centre tap (9x the matrix work), DOWN2 on the
- * stride-1 kernels with zeros inserted into dy (4x). */
+ * Correctness first: the dgrad of a 1x1 conv runs on the 3x3 kernel with the weights in the centre tap (9x the matrix work; its
+ * wgrad contracts the centre tap only), DOWN2 on the stride-1 kernels with zeros inserted into dy (4x). */
 enum { DDIF_BWD_PRO_NONE = 0, DDIF_BWD_PRO_GN = 1, DDIF_BWD_PRO_GN_SILU = 2, DDIF_BWD_PRO_SILU = 3 };
 enum { DDIF_BWD_PLAIN = 0, DDIF_BWD_DOWN2 = 1, DDIF_BWD_UP2 = 2 };
 DDIF_API int ddif_blockbwd_create_ex(ddif_blockbwd_t* out, int B, int Cin, int Cout, int H, int W, int ks, int pro, int resample, int device);
