@@ -364,15 +364,16 @@ def committed_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
     if not files:
         return None, {"traffic_from_committed_profile": False}
-    try:
-        with open(files[-1]) as f:
-            j = json.load(f)
-        name = "profiles/" + os.path.basename(files[-1])
-        if j.get("build_id") == build_id():
-            return float(j["class_hbm_bytes_per_launch"]), {"traffic_from_committed_profile": True, "traffic_source": name}
-        return None, {"traffic_from_committed_profile": False, "traffic_stale_profile": name}
-    except (OSError, ValueError, KeyError):
-        return None, {"traffic_from_committed_profile": False}
+    bid = build_id()
+    for path in reversed(files):  # the set taken from THIS build, whatever its tag sorts like
+        try:
+            with open(path) as f:
+                j = json.load(f)
+            if j.get("build_id") == bid:
+                return float(j["class_hbm_bytes_per_launch"]), {"traffic_from_committed_profile": True, "traffic_source": "profiles/" + os.path.basename(path)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, {"traffic_from_committed_profile": False, "traffic_stale_profile": "profiles/" + os.path.basename(files[-1])}
 
 
 def usable_cpus():
