@@ -160,10 +160,10 @@ int ddif_convbwd_run(ddif_convbwd_t h, const float* x, const float* w, const flo
     if (prev != c.device) DDIF_HIPCHK(hipSetDevice(c.device));
     hipStream_t s = (hipStream_t)stream;
     const int HW = c.H * c.W;
-    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cout), dim3(256), 0, s, dy, c.B, c.Cout, HW, c.dy_nhwc);
-    if (dw) hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, x, c.B, c.Cin, HW, c.x_nhwc);
+    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cout), dim3(256), ddif::TR_SMEM, s, dy, c.B, c.Cout, HW, c.dy_nhwc);
+    if (dw) hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), ddif::TR_SMEM, s, x, c.B, c.Cin, HW, c.x_nhwc);
     ddif::convbwd_core(c, s, w, dx != nullptr, dw, db);
-    if (dx) hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), 0, s, (const float*)c.dx.p, c.B, c.Cin, HW, dx);
+    if (dx) hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * HW * c.Cin), dim3(256), ddif::TR_SMEM, s, (const float*)c.dx.p, c.B, c.Cin, HW, dx);
     int rc = DDIF_OK;
     if (hipGetLastError() != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_run: kernel launch failed");
     if (prev >= 0 && prev != c.device) (void)hipSetDevice(prev);
@@ -262,12 +262,12 @@ int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, con
     if (k.resample == DDIF_BWD_UP2)
         hipLaunchKernelGGL(ddif::upsample2_nchw_to_nhwc_kernel, ddif::grid_for(n * 4), dim3(256), 0, s, x, B, Ci, k.H, k.W, c.x_nhwc);
     else
-        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), 0, s, x, B, Ci, HW, pre ? k.x_nhwc : c.x_nhwc);
-    if (mask) hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), 0, s, mask, B, Ci, HW, k.mask_nhwc);
+        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), ddif::TR_SMEM, s, x, B, Ci, HW, pre ? k.x_nhwc : c.x_nhwc);
+    if (mask) hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for(n), dim3(256), ddif::TR_SMEM, s, mask, B, Ci, HW, k.mask_nhwc);
     if (k.resample == DDIF_BWD_DOWN2)
         hipLaunchKernelGGL(ddif::zero_stuff_nchw_to_nhwc_kernel, ddif::grid_for((size_t)B * c.H * c.W * c.Cout), dim3(256), 0, s, dy, B, c.Cout, Ho, Wo, c.H, c.W, c.dy_nhwc);
     else
-        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)B * c.H * c.W * c.Cout), dim3(256), 0, s, dy, B, c.Cout, c.H * c.W, c.dy_nhwc);
+        hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)B * c.H * c.W * c.Cout), dim3(256), ddif::TR_SMEM, s, dy, B, c.Cout, c.H * c.W, c.dy_nhwc);
     if (gn) {
         // forward recompute: GroupNorm statistics of x, then a = Dropout(SiLU(GroupNorm(x))) -- the conv's input, needed by wgrad
         hipLaunchKernelGGL(ddif::gnb_stats_kernel, dim3(k.nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, (const float*)k.x_nhwc, (size_t)HW * Ci, k.nchunk, k.spart);
@@ -296,16 +296,16 @@ int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, con
         if (dx) {
             hipLaunchKernelGGL(ddif::gnb_bwd_dx_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, da, m, (const float*)k.ms, gamma, beta, (const float*)k.S, HW, Ci,
                                silu, k.dx_nhwc);
-            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
+            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), ddif::TR_SMEM, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
         }
     } else if (dx) {
         if (act) {
             hipLaunchKernelGGL(ddif::silu_bwd_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.x_nhwc, da, n, k.dx_nhwc);
-            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
+            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), ddif::TR_SMEM, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
         } else if (k.resample == DDIF_BWD_UP2) {
             hipLaunchKernelGGL(ddif::sumpool2_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, da, B, Ci, k.H, k.W, dx);
         } else {
-            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), 0, s, da, B, Ci, HW, dx);
+            hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), ddif::TR_SMEM, s, da, B, Ci, HW, dx);
         }
     }
     int rc = DDIF_OK;
@@ -396,7 +396,7 @@ int ddif_convfwd_run(ddif_convfwd_t h, const float* x, const float* w, const flo
     (void)hipGetDevice(&prev);
     if (prev != c.device) DDIF_HIPCHK(hipSetDevice(c.device));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * c.H * c.W * c.Cin), dim3(256), 0, s, x, c.B, c.Cin, c.H * c.W, c.x_nhwc);
+    hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * c.H * c.W * c.Cin), dim3(256), ddif::TR_SMEM, s, x, c.B, c.Cin, c.H * c.W, c.x_nhwc);
     const size_t nw = (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256;
     hipLaunchKernelGGL(ddif::pack_fwd_weights_kernel, ddif::grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.ks, c.n_chunks, c.nb_pad, c.wpack);
     int rc = DDIF_OK;
@@ -407,7 +407,7 @@ int ddif_convfwd_run(ddif_convfwd_t h, const float* x, const float* w, const flo
     }
     ddif::StepCtx ctx;
     for (auto& op : c.prog) op.run(s, ctx);
-    hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * c.y.H * c.y.W * c.Cout), dim3(256), 0, s, (const float*)c.y.p, c.B, c.Cout, c.y.H * c.y.W, y);
+    hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for((size_t)c.B * c.y.H * c.y.W * c.Cout), dim3(256), ddif::TR_SMEM, s, (const float*)c.y.p, c.B, c.Cout, c.y.H * c.y.W, y);
     if (!rc && hipGetLastError() != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convfwd_run: kernel launch failed");
     if (prev >= 0 && prev != c.device) (void)hipSetDevice(prev);
     return rc;

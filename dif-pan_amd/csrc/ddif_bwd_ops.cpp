@@ -81,7 +81,8 @@ int ddif_linattn_core_bwd(const float* q_pre, const float* kv_pre, const float* 
         return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_bwd: bad argument");
     const int d = qd / heads;
     if (d > 32 || W > 64 || H < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_bwd: head dim <= 32 and W <= 64 only");
-    const size_t smem = ((size_t)8 * d * W + (size_t)2 * d * d + d) * sizeof(float);
+    if (H > 64) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_bwd: H <= 64 only");
+    const size_t smem = ((size_t)8 * d * W + (size_t)2 * d * d + d + (size_t)2 * d * H) * sizeof(float);
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::linattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return ddif::fail(DDIF_ERR_HIP, "ddif_linattn_core_bwd: hipFuncSetAttribute failed");
@@ -177,7 +178,11 @@ int ddif_linattn_core_fwd(const float* q_pre, const float* kv_pre, int B, int qd
     if (!q_pre || !kv_pre || !out || B < 1 || heads < 1 || qd < heads || qd % heads) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_fwd: bad argument");
     const int d = qd / heads;
     if (d > 32 || W > 64 || H < 1) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_fwd: head dim <= 32 and W <= 64 only");
-    const size_t smem = ((size_t)4 * d * W + (size_t)d * d + 2 * d) * sizeof(float);
+    if (H > 64) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_core_fwd: H <= 64 only");
+    const size_t smem = ((size_t)4 * d * W + (size_t)d * d + (size_t)2 * d * H) * sizeof(float);
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::linattn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return ddif::fail(DDIF_ERR_HIP, "ddif_linattn_core_fwd: hipFuncSetAttribute failed");
     hipLaunchKernelGGL(ddif::linattn_fwd_kernel, dim3(B * heads), dim3(256), smem, (hipStream_t)stream, q_pre, kv_pre, heads, d, H, W, 1.0f / sqrtf((float)d), out);
     return ddif::ops_done("ddif_linattn_core_fwd");
 }

@@ -195,24 +195,36 @@ __global__ __launch_bounds__(64) void bias_grad_reduce_kernel(const float* parti
 }  // namespace ddif
 
 namespace ddif {
-// layout conversion at this op's NCHW boundary (the reference's layout)
-__global__ void bwd_nchw_to_nhwc_kernel(const float* in, int B, int C, int HW, float* out) {
-    const size_t total = (size_t)B * HW * C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
-        out[i] = in[(b * C + c) * HW + p];
+// layout conversion at this op's NCHW boundary (the reference's layout): a batched matrix transpose out[b][s][r] = in[b][r][s] through a
+// 32 x 33 LDS tile, so that both the reads (along s) and the writes (along r) are coalesced.  256 threads = 32 x 8; dynamic LDS = TR_SMEM.
+constexpr size_t TR_SMEM = 32 * 33 * sizeof(float);
+__device__ __forceinline__ void transpose_batched(const float* in, int B, int R, int S, float* out) {
+    DDIF_DYN_SMEM(smem_);
+    float* tile = reinterpret_cast<float*>(smem_);  // [32][33]
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tr = (R + 31) / 32, ts = (S + 31) / 32;
+    const long long ntiles = (long long)B * tr * ts;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = (int)(t / (tr * ts)), rem = (int)(t % (tr * ts));
+        const int r0 = (rem / ts) * 32, s0 = (rem % ts) * 32;
+        const float* ib = in + (size_t)b * R * S;
+        float* ob = out + (size_t)b * R * S;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, sidx = s0 + tx;
+            if (r < R && sidx < S) tile[(ty + 8 * k) * 33 + tx] = ib[(size_t)r * S + sidx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int sidx = s0 + ty + 8 * k, r = r0 + tx;
+            if (r < R && sidx < S) ob[(size_t)sidx * R + r] = tile[tx * 33 + ty + 8 * k];
+        }
+        __syncthreads();
     }
 }
-__global__ void bwd_nhwc_to_nchw_kernel(const float* in, int B, int C, int HW, float* out) {
-    const size_t total = (size_t)B * HW * C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t p = i % HW;
-        const int c = (int)((i / HW) % C);
-        const size_t b = i / ((size_t)C * HW);
-        out[i] = in[(b * HW + p) * C + c];
-    }
-}
+__global__ __launch_bounds__(256) void bwd_nchw_to_nhwc_kernel(const float* in, int B, int C, int HW, float* out) { transpose_batched(in, B, C, HW, out); }
+__global__ __launch_bounds__(256) void bwd_nhwc_to_nchw_kernel(const float* in, int B, int C, int HW, float* out) { transpose_batched(in, B, HW, C, out); }
 }  // namespace ddif
 
 namespace ddif {

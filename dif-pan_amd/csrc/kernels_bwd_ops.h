@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const float* q_pre, co
     float* rg = rq + d * W;                        // [d][W] do of the current row
     float* rdk = rg + d * W;                       // [d][W] dk of the current row
     float* rdot = rdk + d * W;                     // [d] row dots of the k softmax backward
+    float* kmx = rdot + d;                         // [d][H] row max of k_pre (softmax over W)
+    float* ksm = kmx + d * H;                      // [d][H] row sum of exp
     const int tid = threadIdx.x;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int qd = heads * d, HW = H * W;
@@ -201,21 +203,21 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const float* q_pre, co
         ctx[i] = 0.f;
         dctx[i] = 0.f;
     }
+    for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre for every (channel, row): one thread per pair
+        const int a = i / H, y = i % H;
+        float mx = -3.0e38f;
+        for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)a * HW + y * W + x]);
+        float sm = 0.f;
+        for (int x = 0; x < W; ++x) sm += dd_exp(kb[(size_t)a * HW + y * W + x] - mx);
+        kmx[i] = mx;
+        ksm[i] = sm;
+    }
     __syncthreads();
     auto load_row = [&](int y) {  // k softmax (over this row), v, q softmax * sc, do  -> LDS
-        for (int a = tid; a < d; a += 256) {  // row statistics of k_pre: one thread per channel
-            float mx = -3.0e38f;
-            for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)a * HW + y * W + x]);
-            float s = 0.f;
-            for (int x = 0; x < W; ++x) s += dd_exp(kb[(size_t)a * HW + y * W + x] - mx);
-            rdot[a] = mx;
-            rdk[a] = s;  // parked: rdk[0..d) = row sums, consumed right below
-        }
-        __syncthreads();
         for (int i = tid; i < d * W; i += 256) {
             const int a = i / W, x = i % W;
             const size_t e = (size_t)a * HW + y * W + x;
-            rk[i] = dd_exp(kb[e] - rdot[a]) / rdk[a];
+            rk[i] = dd_exp(kb[e] - kmx[a * H + y]) / ksm[a * H + y];
             rv[i] = vb[e];
             rq[i] = dd_exp(qb[e] - qmx[i]) / qsm[i] * sc;
             rg[i] = gb[e];
@@ -542,8 +544,8 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* q_pre, co
     float* ctx = qsm + d * W;                      // [d][d]
     float* rk = ctx + d * d;                       // [d][W]
     float* rv = rk + d * W;                        // [d][W]
-    float* rmx = rv + d * W;                       // [d]
-    float* rsm = rmx + d;                          // [d]
+    float* rmx = rv + d * W;                       // [d][H] row max of k_pre
+    float* rsm = rmx + d * H;                      // [d][H] row sum of exp
     const int tid = threadIdx.x;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int qd = heads * d, HW = H * W;
@@ -561,20 +563,20 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* q_pre, co
         qsm[i] = s;
     }
     for (int i = tid; i < d * d; i += 256) ctx[i] = 0.f;
+    for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre for every (channel, row)
+        const int a = i / H, y = i % H;
+        float mx = -3.0e38f;
+        for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)a * HW + y * W + x]);
+        float s = 0.f;
+        for (int x = 0; x < W; ++x) s += dd_exp(kb[(size_t)a * HW + y * W + x] - mx);
+        rmx[i] = mx;
+        rsm[i] = s;
+    }
     __syncthreads();
     for (int y = 0; y < H; ++y) {
-        for (int a = tid; a < d; a += 256) {
-            float mx = -3.0e38f;
-            for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)a * HW + y * W + x]);
-            float s = 0.f;
-            for (int x = 0; x < W; ++x) s += dd_exp(kb[(size_t)a * HW + y * W + x] - mx);
-            rmx[a] = mx;
-            rsm[a] = s;
-        }
-        __syncthreads();
         for (int i = tid; i < d * W; i += 256) {
             const int a = i / W, x = i % W;
-            rk[i] = dd_exp(kb[(size_t)a * HW + y * W + x] - rmx[a]) / rsm[a];
+            rk[i] = dd_exp(kb[(size_t)a * HW + y * W + x] - rmx[a * H + y]) / rsm[a * H + y];
             rv[i] = vb[(size_t)a * HW + y * W + x];
         }
         __syncthreads();
