@@ -229,8 +229,11 @@ def average_gradients(grads, world: int):
     import torch.distributed as dist
 
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= world
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective
+    else:  # gloo (the CPU tests) has no AVG
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
     off = 0
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))

@@ -13,6 +13,15 @@ _CONV_FWD = {}
 _CONV_BWD = {}
 
 
+def clear_caches():
+    """Destroy the per-shape conv handles (each owns its NHWC staging buffers on the device)."""
+    lib = get_lib()
+    for h in _CONV_FWD.values():
+        lib.dll.ddif_convfwd_destroy(h)
+    _CONV_FWD.clear()
+    _CONV_BWD.clear()  # BlockBackward objects free themselves
+
+
 def _dev_index(t):
     return t.device.index if t.device.type == "cuda" and t.device.index is not None else 0
 
