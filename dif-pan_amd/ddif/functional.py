@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import runtime as R
-from .runtime import _check_shape, _check_tensor, _ptr, _stream, get_lib
+from .runtime import _check_current_device, _check_shape, _check_tensor, _ptr, _stream, get_lib
 
 _CONV_FWD = {}
 _CONV_BWD = {}
@@ -93,6 +93,7 @@ def _launch(name, fn, *args):
 
 def dwconv3x3(x, w):
     lib = get_lib()
+    _check_current_device(x, "x")
     B, Cc, H, W = x.shape
     x, w = x.contiguous(), w.contiguous()
     y = torch.empty_like(x)
@@ -102,6 +103,7 @@ def dwconv3x3(x, w):
 
 def group_norm(x, gamma, beta, silu=False, mask=None):
     lib = get_lib()
+    _check_current_device(x, "x")
     B, Cc, H, W = x.shape
     x = x.contiguous()
     mask = None if mask is None else mask.contiguous()
@@ -113,6 +115,7 @@ def group_norm(x, gamma, beta, silu=False, mask=None):
 
 def swish(x):
     lib = get_lib()
+    _check_current_device(x, "x")
     x = x.contiguous()
     y = torch.empty_like(x)
     lib.check(lib.dll.ddif_swish_fwd(_ptr(x), x.numel(), _ptr(y), _stream(lib, x.device)), "ddif_swish_fwd")
@@ -121,6 +124,7 @@ def swish(x):
 
 def film(xc, scale_shift):
     lib = get_lib()
+    _check_current_device(xc, "xc")
     B, Cc, H, W = xc.shape
     xc, ss = xc.contiguous(), scale_shift.contiguous()
     _check_shape(ss, "scale_shift", (B, 2 * Cc, H, W))
@@ -132,6 +136,7 @@ def film(xc, scale_shift):
 def add(a, f, alpha=None):
     """a + alpha[b] * f (alpha None: plain residual add)"""
     lib = get_lib()
+    _check_current_device(a, "a")
     a, f = a.contiguous(), f.contiguous()
     _check_shape(f, "f", tuple(a.shape))
     out = torch.empty_like(a)
@@ -143,6 +148,7 @@ def add(a, f, alpha=None):
 
 def linear(x, w, b=None):
     lib = get_lib()
+    _check_current_device(x, "x")
     B, nin = x.shape
     nout = w.shape[0]
     x, w = x.contiguous(), w.contiguous()
@@ -154,6 +160,7 @@ def linear(x, w, b=None):
 
 def selfattn_core(qkv, heads=8):
     lib = get_lib()
+    _check_current_device(qkv, "qkv")
     B, C3, H, W = qkv.shape
     qkv = qkv.contiguous()
     out = torch.empty((B, C3 // 3, H, W), dtype=torch.float32, device=qkv.device)
@@ -163,6 +170,7 @@ def selfattn_core(qkv, heads=8):
 
 def linattn_core(q_pre, kv_pre, heads=8):
     lib = get_lib()
+    _check_current_device(q_pre, "q_pre")
     B, qd, H, W = q_pre.shape
     q_pre, kv_pre = q_pre.contiguous(), kv_pre.contiguous()
     _check_shape(kv_pre, "kv_pre", (B, 2 * qd, H, W))
@@ -174,6 +182,7 @@ def linattn_core(q_pre, kv_pre, heads=8):
 def q_sample(x0, noise, a, s):
     """x_t = a[b] * x0 + s[b] * noise (reference diffusion/diffusion_ddpm_pan.py:668-681); a, s: (B,) tensors"""
     lib = get_lib()
+    _check_current_device(x0, "x0")
     x0, noise = x0.contiguous(), noise.contiguous()
     a, s = a.to(x0.device, torch.float32).contiguous(), s.to(x0.device, torch.float32).contiguous()
     out = torch.empty_like(x0)
@@ -185,6 +194,7 @@ def q_sample(x0, noise, a, s):
 def l1_loss(pred, target):
     """F.l1_loss(pred, target) (mean): a 0-d tensor on pred's device"""
     lib = get_lib()
+    _check_current_device(pred, "pred")
     pred, target = pred.contiguous(), target.contiguous()
     _check_shape(target, "target", tuple(pred.shape))
     out = torch.empty((1,), dtype=torch.float32, device=pred.device)

@@ -184,6 +184,14 @@ def _check_tensor(lib: _Lib, t: torch.Tensor, name: str):
                         f"(move the tensors to cuda)")
 
 
+def _check_current_device(t: torch.Tensor, name: str):
+    """The stateless ops (include/ddif.h) launch on the CURRENT device: a tensor living on another GPU would be read through the wrong
+    context.  One process per GPU makes this always true (torch.cuda.set_device(local_rank)); refuse anything else loudly."""
+    if t.device.type == "cuda" and t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise DdifError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                        f"make it current (torch.cuda.set_device / one process per GPU) before calling this op")
+
+
 def _check_shape(t: torch.Tensor, name: str, expected: tuple):
     """The kernels index with the plan's shapes: a mismatched tensor would read out of bounds on the GPU (the process
     dies with a bare 'Aborted').  The reference raises a shape error from torch in the same situation."""
@@ -633,6 +641,7 @@ def _ops_prepare(named):
     for nm, t, shp in named:
         _check_tensor(lib, t, nm)
         _check_shape(t, nm, shp)
+        _check_current_device(t, nm)
         out.append(t.contiguous())
     return lib, out
 
