@@ -182,3 +182,35 @@ def test_engine_google_trains_and_validates_on_an_in_memory_set(backend):
     if backend == "gpu":
         again = run()
         assert again["loss"] == out["loss"]
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_reference_optimizer_lines_run_unchanged_on_the_drop_in(backend):
+    """diffusion_engine.py:205-241 verbatim in spirit: torch.optim.AdamW over `denoise_fn.parameters()`, `opt.zero_grad()`,
+    `diff_loss.backward()`, `clip_grad_norm_(…, 0.003)`, `opt.step()` -- two iterations; the loss must be finite, the clipped gradient norm
+    must respect the bound and the weights must move.  (The fused optimizer of `engine_google` is optional: plain torch optimizers see
+    ordinary `.grad` tensors.)"""
+    from ddif_testlib import make_diffusion, make_net
+
+    dev = _dev(backend)
+    _, ds, x, sc, target, cond, t, masks, paths = _case_inputs(gc.TRAIN_GRAD_CASES[0])
+    net = make_net(ds, dev)
+    d = make_diffusion(net, 8, 500, 16, dev)
+    d.loss_type = "l1"
+    net.train()
+    try:
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4)
+        first = next(net.parameters()).detach().clone()
+        torch.manual_seed(3)
+        for _ in range(2):
+            opt.zero_grad()
+            loss, recon = d(x.to(dev) * 0.1, cond=cond.to(dev))
+            loss.backward()
+            total = torch.nn.utils.clip_grad_norm_(net.parameters(), 0.003)
+            assert torch.isfinite(loss.detach()) and torch.isfinite(total)
+            after = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters()))
+            assert float(after) <= 0.003 * (1 + 1e-4)
+            opt.step()
+        assert float((next(net.parameters()).detach() - first).abs().max()) > 0
+    finally:
+        net.eval()
