@@ -114,14 +114,17 @@ def time_embedding(sd: Dict[str, Tensor], t: Tensor, inner: int) -> Tensor:
     return F.linear(h, sd["noise_level_mlp.3.weight"], sd["noise_level_mlp.3.bias"])
 
 
-def resnet_block(sd, p: str, x: Tensor, temb: Tensor, groups: int) -> Tensor:
-    """ResnetBlock in eval mode (models/sr3_dwt.py:303-327,288-300,241-258); res_conv is Identity here."""
+def resnet_block(sd, p: str, x: Tensor, temb: Tensor, groups: int, drop_mask: Optional[Tensor] = None) -> Tensor:
+    """ResnetBlock (models/sr3_dwt.py:303-327,288-300,241-258); res_conv is Identity here.  drop_mask: block2's nn.Dropout made
+    explicit (0 or 1/(1-p), train mode :295,318-319); None = eval."""
     h = F.conv2d(_swish(_gn(x, sd, p + ".block1.block.0", groups)),
                  sd[p + ".block1.block.3.weight"], sd[p + ".block1.block.3.bias"], padding=1)
     tb = F.linear(temb, sd[p + ".noise_func.noise_func.0.weight"], sd[p + ".noise_func.noise_func.0.bias"])
     h = h + tb.view(x.shape[0], -1, 1, 1)
-    h = F.conv2d(_swish(_gn(h, sd, p + ".block2.block.0", groups)),
-                 sd[p + ".block2.block.3.weight"], sd[p + ".block2.block.3.bias"], padding=1)
+    a2 = _swish(_gn(h, sd, p + ".block2.block.0", groups))
+    if drop_mask is not None:
+        a2 = a2 * drop_mask
+    h = F.conv2d(a2, sd[p + ".block2.block.3.weight"], sd[p + ".block2.block.3.bias"], padding=1)
     if (p + ".res_conv.weight") in sd:
         x = F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
     return h + x
@@ -149,8 +152,9 @@ def cond_injection(sd, p: str, x: Tensor, cL: Tensor, groups: int) -> Tensor:
     return xc * (1 + scale) + shift
 
 
-def fast_attn_cond_injection(sd, p: str, x: Tensor, cL: Tensor, groups: int, heads: int = 8) -> Tensor:
-    """Decoder FastAttnCondInjection in eval mode (models/sr3_dwt.py:493-577)."""
+def fast_attn_cond_injection(sd, p: str, x: Tensor, cL: Tensor, groups: int, heads: int = 8, path_scale: Optional[Tensor] = None) -> Tensor:
+    """Decoder FastAttnCondInjection (models/sr3_dwt.py:493-577).  path_scale: the DropPath row scale (B,) of the FFN branch (0 or
+    1/(1-p), train mode :534,576); None = eval."""
     B, Cf, H, W = x.shape
     xn = _gn(x, sd, p + ".prenorm_x", groups)
     q = F.conv2d(F.conv2d(xn, sd[p + ".q.0.weight"], None, padding=1, groups=Cf),
@@ -176,6 +180,8 @@ def fast_attn_cond_injection(sd, p: str, x: Tensor, cL: Tensor, groups: int, hea
     f = F.conv2d(a, sd[p + ".ffn.0.weight"], None, padding=1)
     f = F.conv2d(F.silu(f), sd[p + ".ffn.2.weight"], None, padding=1)
     f = F.conv2d(f, sd[p + ".ffn.3.weight"], sd[p + ".ffn.3.bias"])
+    if path_scale is not None:
+        f = f * path_scale.view(-1, 1, 1, 1)
     return f + a
 
 
@@ -187,8 +193,14 @@ def _resize(c: Tensor, hw: Tuple[int, int]) -> Tensor:
 
 
 def unet_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, time: Tensor, cond: Tensor,
-                 self_cond: Optional[Tensor] = None) -> Tensor:
-    """UNetSR3.forward in eval mode (models/sr3_dwt.py:169-219, 658-673)."""
+                 self_cond: Optional[Tensor] = None, drop_masks: Optional[Sequence[Tensor]] = None,
+                 path_scales: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """UNetSR3.forward (models/sr3_dwt.py:169-219, 658-673): eval mode, or train mode with the Dropout masks (one per ResnetBlock, execution
+    order) and DropPath row scales (one per decoder block) given explicitly."""
+    masks = iter(drop_masks) if drop_masks is not None else None
+    paths = iter(path_scales) if path_scales is not None else None
+    nm = (lambda: next(masks)) if masks is not None else (lambda: None)
+    npth = (lambda: next(paths)) if paths is not None else (lambda: None)
     g = cfg["norm_groups"]
     C, P = cfg["lms_channel"], cfg["pan_channel"]
     plan = layer_plan(cfg)
@@ -207,13 +219,13 @@ def unet_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, time: Tensor, cond
             x = F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=2, padding=1)
         else:
             x = cond_injection(sd, p + ".cond_inj", x, _resize(c_enc, x.shape[-2:]), g)
-            x = resnet_block(sd, p + ".res_block", x, temb, g)
+            x = resnet_block(sd, p + ".res_block", x, temb, g, nm())
             if L["attn"]:
                 x = self_attention(sd, p + ".attn", x, g)
         feats.append(x)
     for i, L in enumerate(plan["mid"]):
         p = f"mid.{i}"
-        x = resnet_block(sd, p + ".res_block", x, temb, g)
+        x = resnet_block(sd, p + ".res_block", x, temb, g, nm())
         if L["attn"]:
             x = self_attention(sd, p + ".attn", x, g)
     for i, L in enumerate(plan["ups"]):
@@ -223,8 +235,8 @@ def unet_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, time: Tensor, cond
             x = F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
         else:
             x = torch.cat([x, feats.pop()], dim=1)
-            x = fast_attn_cond_injection(sd, p + ".cond_inj", x, _resize(c_dec, x.shape[-2:]), g)
-            x = resnet_block(sd, p + ".res_block", x, temb, g)
+            x = fast_attn_cond_injection(sd, p + ".cond_inj", x, _resize(c_dec, x.shape[-2:]), g, path_scale=npth())
+            x = resnet_block(sd, p + ".res_block", x, temb, g, nm())
             if L["attn"]:
                 x = self_attention(sd, p + ".attn", x, g)
     x = _swish(_gn(x, sd, "final_conv.block.0", g))

@@ -209,3 +209,36 @@ def test_psnr_sign_quirk():
     b = (a + 0.05 * torch.randn(8, 33, 35, generator=gen)).clamp(0, 1)
     assert abs(O.psnr_reference_sign(a, b) - float(g["ref_psnr"])) < 1e-4
     assert O.psnr(a, b) > 0 > O.psnr_reference_sign(a, b)
+
+
+def test_oracle_train_mode_forward_and_autograd_match_the_reference_gradients():
+    """Golden G7 (tools/make_golden.py traingrad: the REAL reference under .train(), its own Dropout / DropPath masks, F.l1_loss, loss.backward()):
+    the oracle with those masks made explicit must reproduce the output, the loss and -- through torch autograd -- the gradient norm of all 702
+    parameters.  This pins the oracle's train-mode restatement; the product's hand-written backward is checked against the same file
+    (tests/test_train_graph.py)."""
+    import os
+
+    cid, ds, B, H, W, tvals, seed = gc.TRAIN_GRAD_CASES[0]
+    g = np.load(os.path.join(gc.GOLDEN_DIR, cid + ".npz"))
+    C = gc.DATASETS[ds][0]
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=gen)
+    sc = torch.randn(B, C, H, W, generator=gen)
+    target = torch.rand(B, C, H, W, generator=gen)
+    cond = gc.tiles_for(ds, B, H, W, seed=seed)["cond"]
+    t = torch.tensor(tvals, dtype=torch.long)
+    masks = []
+    for k in range(int(g["n_drop"])):
+        shp = tuple(int(v) for v in g[f"drop_{k}_shape"])
+        bits = np.unpackbits(g[f"drop_{k}"])[: int(np.prod(shp))].reshape(shp)
+        masks.append(torch.from_numpy(bits.astype(np.float32)) / (1.0 - float(g["p_drop"])))
+    paths = [p for p in torch.from_numpy(g["paths"])]
+    sd = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in gc.weights_for(ds).items()}
+    y = O.unet_forward(sd, gc.cfg_for(ds), x, t, cond, sc, drop_masks=masks, path_scales=paths)
+    assert float((y.detach() - torch.from_numpy(g["y"])).abs().max()) <= 2e-6
+    loss = (y - target).abs().mean()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6
+    loss.backward()
+    for n, ref in zip([str(n) for n in g["names"]], g["grad_norms"]):
+        got = float(sd[n].grad.double().norm()) if sd[n].grad is not None else 0.0
+        assert abs(got - float(ref)) <= 1e-4 * max(float(ref), 1e-4), (n, got, float(ref))
