@@ -6,6 +6,12 @@
 #include "kernels_bwd.h"
 
 namespace ddif {
+// DDIF_TRAIN_X3=0: the training convs (forward and dgrad) on the exact-fp32 MFMA instead of the bf16x3 split products the inference path uses
+// (same fp32-class accuracy, ~2.5x the matrix rate; kernels_conv.h MATH = 1).  The weight gradient always runs on the exact instruction.
+static bool train_x3() {
+    static const bool v = [] { const char* e = getenv("DDIF_TRAIN_X3"); return !e || atoi(e) != 0; }();
+    return v;
+}
 static inline dim3 grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     if (g > 8192) g = 8192;
@@ -18,7 +24,7 @@ struct ConvBwd {
     Net net;          // only its cfg is read (add_conv's launch closure); no weights
     Plan plan;        // owns every device buffer of this op
     PackedConv pc;    // the dgrad conv: Cout "input" channels -> Cin "output" channels, weights = wpack
-    float *x_nhwc = nullptr, *dy_nhwc = nullptr, *wpack = nullptr, *partial = nullptr, *bpart = nullptr;
+    float *x_nhwc = nullptr, *dy_nhwc = nullptr, *wpack = nullptr, *wpack_x3 = nullptr, *partial = nullptr, *bpart = nullptr;
     Tensor dx;        // NHWC output of the dgrad conv
     std::vector<Op> prog;
     int n_chunks = 0, nb_pad = 0, n_co = 0, n_ci = 0, nsplit = 0, rb = 4, nbchunk = 0;
@@ -70,7 +76,9 @@ int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device)
     c.n_chunks = (Cout + 15) / 16;
     c.nb_pad = (((Cin + 31) / 32) + 3) & ~3;
     TRY(c.plan.dalloc(&c.wpack, (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256));
+    TRY(c.plan.dalloc(&c.wpack_x3, (size_t)c.nb_pad * c.n_chunks * 9 * 3 * 256));
     c.pc.w = c.wpack;
+    c.pc.w_x3 = c.wpack_x3;
     c.pc.cin = Cout;
     c.pc.cout = Cin;
     c.pc.ks = 3;
@@ -84,7 +92,7 @@ int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device)
         s.in0.H = H;
         s.in0.W = W;
         s.use_bias = false;
-        s.exact = true;  // gradients on the exact-fp32 MFMA (bitwise an fmaf chain)
+        s.exact = !train_x3();  // exact-fp32 MFMA (bitwise an fmaf chain) on request; bf16x3 split products by default
         s.name = "conv3x3.dgrad";
         TRY(c.plan.add_conv(c.prog, s, &c.dx));
     }
@@ -119,6 +127,7 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
     if (want_dx) {
         const size_t nw = (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256;
         hipLaunchKernelGGL(pack_dgrad_weights_kernel, grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.n_chunks, c.nb_pad, c.wpack);
+        hipLaunchKernelGGL(pack_weights_x3_kernel, grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, 3, 1, c.n_chunks, c.nb_pad, c.wpack_x3);
         StepCtx ctx;
         for (auto& op : c.prog) op.run(s, ctx);
     }
@@ -323,7 +332,7 @@ struct ConvFwd {
     Net net;
     Plan plan;
     PackedConv pc;
-    float *x_nhwc = nullptr, *wpack = nullptr, *bias = nullptr;
+    float *x_nhwc = nullptr, *wpack = nullptr, *wpack_x3 = nullptr, *bias = nullptr;
     Tensor y;
     std::vector<Op> prog;
     int n_chunks = 0, nb_pad = 0;
@@ -360,7 +369,9 @@ int ddif_convfwd_create(ddif_convfwd_t* out, int B, int Cin, int Cout, int H, in
     c.n_chunks = (Cin + 15) / 16;
     c.nb_pad = (((Cout + 31) / 32) + 3) & ~3;
     TRY(c.plan.dalloc(&c.wpack, (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256));
+    TRY(c.plan.dalloc(&c.wpack_x3, (size_t)c.nb_pad * c.n_chunks * 9 * 3 * 256));
     c.pc.w = c.wpack;
+    c.pc.w_x3 = c.wpack_x3;
     c.pc.bias = c.bias;
     c.pc.cin = Cin;
     c.pc.cout = Cout;
@@ -377,7 +388,7 @@ int ddif_convfwd_create(ddif_convfwd_t* out, int B, int Cin, int Cout, int H, in
         s.stride = stride;
         s.ups = up2 ? 1 : 0;
         s.use_bias = true;
-        s.exact = true;  // training runs on the exact-fp32 MFMA (bitwise an fmaf chain), like the gradient convs
+        s.exact = !ddif::train_x3();  // bf16x3 split products like the inference path; DDIF_TRAIN_X3=0: exact-fp32 MFMA
         s.name = "train.conv";
         TRY(c.plan.add_conv(c.prog, s, &c.y));
     }
@@ -399,6 +410,7 @@ int ddif_convfwd_run(ddif_convfwd_t h, const float* x, const float* w, const flo
     hipLaunchKernelGGL(ddif::bwd_nchw_to_nhwc_kernel, ddif::grid_for((size_t)c.B * c.H * c.W * c.Cin), dim3(256), ddif::TR_SMEM, s, x, c.B, c.Cin, c.H * c.W, c.x_nhwc);
     const size_t nw = (size_t)c.nb_pad * c.n_chunks * 9 * 2 * 256;
     hipLaunchKernelGGL(ddif::pack_fwd_weights_kernel, ddif::grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.ks, c.n_chunks, c.nb_pad, c.wpack);
+    hipLaunchKernelGGL(ddif::pack_weights_x3_kernel, ddif::grid_for(nw), dim3(256), 0, s, w, c.Cout, c.Cin, c.ks, 0, c.n_chunks, c.nb_pad, c.wpack_x3);
     int rc = DDIF_OK;
     if (bias) {
         if (hipMemcpyAsync(c.bias, bias, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = ddif::fail(DDIF_ERR_HIP, "ddif_convfwd_run: bias copy failed");

@@ -489,3 +489,38 @@ __global__ void pack_fwd_weights_kernel(const float* w, int Cout, int Cin, int k
     }
 }
 }  // namespace ddif
+
+namespace ddif {
+// The same weights as three bf16 planes for the bf16x3 conv kernels (host counterpart: pack_conv_x3 in ddif_net.cpp), 16-channel chunks:
+//   [n-block of 32][chunk of 16][tap][plane hi|mid|lo][lane = h*32 + j][8 bf16: cin = chunk*16 + 8h + t];  `flip` = dgrad form (taps mirrored,
+//   in / out channels swapped: value = w[co = cin'][ci = cout'][8 - tap]), ks = 1 = centre tap of a zero 3x3 kernel.
+__global__ void pack_weights_x3_kernel(const float* w, int Cout, int Cin, int ks, int flip, int n_chunks, int nb_pad, float* out) {
+    // forward: rows (n-blocks) = conv couts, contraction = conv cins;  dgrad: rows = conv cins, contraction = conv couts
+    const int Crow = flip ? Cin : Cout, Ccon = flip ? Cout : Cin;
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    const size_t total = (size_t)nb_pad * n_chunks * 9 * 2 * 32 * 8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int t = (int)(r % 8); r /= 8;
+        const int j = (int)(r % 32); r /= 32;
+        const int h = (int)(r % 2); r /= 2;
+        const int tap = (int)(r % 9); r /= 9;
+        const int ch = (int)(r % n_chunks); r /= n_chunks;
+        const int nbi = (int)r;
+        const int kc = ch * 16 + 8 * h + t, row = nbi * 32 + j;
+        float val = 0.f;
+        if (row < Crow && kc < Ccon) {
+            const int co = flip ? kc : row, ci = flip ? row : kc;
+            const int tp = flip ? 8 - tap : tap;
+            if (ks == 3) val = w[((size_t)co * Cin + ci) * 9 + tp];
+            else if (tap == 4) val = w[(size_t)co * Cin + ci];
+        }
+        unsigned hi, mid, lo;
+        dd_split3(val, &hi, &mid, &lo);
+        const size_t fl = ((((size_t)nbi * n_chunks + ch) * 9 + tap) * 3) * 256 + (size_t)(h * 32 + j) * 4;  // float index of the lane's 16 bytes, plane 0
+        o[fl * 2 + t] = (unsigned short)hi;
+        o[(fl + 256) * 2 + t] = (unsigned short)mid;
+        o[(fl + 512) * 2 + t] = (unsigned short)lo;
+    }
+}
+}  // namespace ddif

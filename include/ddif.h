@@ -200,8 +200,9 @@ DDIF_API int ddif_plan_train_random_masks(ddif_plan_t plan, uint64_t seed, uint6
  *   dx = conv_transpose(dy, w), dw[co,ci,ky,kx] = sum dy[b,co,y,x] * x[b,ci,y+ky-1,x+kx-1], db[co] = sum dy[b,co,y,x].
  * All pointers are DEVICE pointers in the reference's layouts: x (B,Cin,H,W), w (Cout,Cin,3,3), dy (B,Cout,H,W),
  * dx (B,Cin,H,W), dw (Cout,Cin,3,3), db (Cout); dx / dw / db may be NULL (skipped).  4 | Cin, 4 | Cout.
- * dgrad = the forward implicit-GEMM kernel on flipped / transposed weights (exact fp32 MFMA); wgrad = split-K MFMA kernel
- * with a fixed-order two-level reduction; bitwise reproducible. */
+ * dgrad = the forward implicit-GEMM kernel on flipped / transposed weights packed on the device (bf16x3 split products like the
+ * inference path; DDIF_TRAIN_X3=0: exact fp32 MFMA); wgrad = split-K exact-fp32 MFMA kernel with a fixed-order two-level
+ * reduction; bitwise reproducible. */
 typedef struct ddif_convbwd* ddif_convbwd_t;
 DDIF_API int ddif_convbwd_create(ddif_convbwd_t* out, int B, int Cin, int Cout, int H, int W, int device);
 DDIF_API void ddif_convbwd_destroy(ddif_convbwd_t h);
@@ -260,7 +261,8 @@ DDIF_API int ddif_l1_loss_bwd(const float* pred, const float* target, int64_t n,
 /* ---- forward ops of the TRAINING graph (a15) --------------------------------------------------------------------------------
  * The inference plan fuses GroupNorm / SiLU / FiLM / softmax into conv prologues and epilogues and never materialises what the
  * backward pass needs; the training forward (ddif/train.py) therefore runs the reference's modules op by op on these entry
- * points, NCHW, keeping every intermediate.  Same arithmetic as models/sr3_dwt.py; the convs run on the exact-fp32 MFMA. */
+ * points, NCHW, keeping every intermediate.  Same arithmetic as models/sr3_dwt.py; the convs run on the bf16x3 split products of
+ * the inference path (fp32-class; DDIF_TRAIN_X3=0: the exact-fp32 MFMA). */
 typedef struct ddif_convfwd* ddif_convfwd_t;
 /* nn.Conv2d(Cin, Cout, ks, stride, padding = ks / 2) [+ nearest x2 upsampling in front: Upsample, models/sr3_dwt.py:266-273];
  * x (B,Cin,H,W), w (Cout,Cin,ks,ks), bias (Cout) or NULL, y (B,Cout,Ho,Wo) */

@@ -1,4 +1,4 @@
-"""The three build-time-independent switches libddif reads from the environment, each run against the reference goldens
+"""The build-time-independent switches libddif reads from the environment, each run against the reference goldens
 (-m gpu).  The library reads them once per process, so every case runs a slice of the parity suite in a child process:
 
   DDIF_X3=0     every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) instead of the bf16x3
@@ -46,3 +46,16 @@ def test_multi_item_path_under_switch(env):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout, tail
+
+
+def test_training_gradients_on_the_exact_fp32_convs():
+    """DDIF_TRAIN_X3=0: the training convs (forward and dgrad) on the exact-fp32 MFMA instead of the bf16x3 split products; the gradient
+    parity test against the reference must hold on that path too."""
+    e = dict(os.environ)
+    e["DDIF_TRAIN_X3"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_train_graph.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "gradients_match_the_reference", "-p", "no:cacheprovider"], env=e, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout, tail
+
