@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- fused megapixels/sec of the DDIF sampler on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the driver launches the ranks (`python -m torch.distributed.run ... bench.py --gpus N`:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or, when WORLD_SIZE is not set, this script launches them
+ITSELF: the parent process -- which never imports torch and never touches a GPU -- starts `torch.distributed.run` as a child
+process, relays rank 0's JSON line and exits with the child's status.
 
 One "step" = one complete sampler call over one batch of synthetic WV3-shaped tiles already resident in HBM:
 set_cond (cond-only precompute) + T=1000 DDPM p_sample steps + (img + lms).clip(0,1) (+ the RCCL all-gather that
@@ -9,9 +14,14 @@ stitches the tiles of all ranks when N > 1).  Workload at N=1 = BASELINE.json co
 T=1000 (computed in fp32 -- the parity configuration; bf16 is not used).  Tiles shard across ranks (weak scaling:
 every rank samples its own 64 tiles, noise keyed by global tile index).
 
+`--config gf2_dpm50` is BASELINE.json configs[2] as stated: ONE 512x512 GF2 scene = 64 tiles split over the N ranks (STRONG
+scaling: 64 / N tiles per GPU), DPM-Solver++ 2M 50 NFE, all-gather + stitch of the scene inside the timed region.
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     : dominant kernel class (3x3 implicit-GEMM convolutions on v_mfma_f32_32x32x2_f32) timed with HIP events
-                 on the launch stream inside the timed region, algorithmic flops / duration vs the dense fp32 MFMA peak
+  roofline     : dominant kernel class (3x3 implicit-GEMM convolutions, bf16x3 split products on v_mfma_f32_32x32x16_bf16) timed
+                 with HIP events on the launch stream inside the timed region; `achieved` = algorithmic fp32 flops / duration,
+                 `peak` = the dense bf16 MFMA peak / 6 (six bf16 products are issued per fp32 product), so `frac` is the issued
+                 fraction of the matrix pipe the kernel actually runs on
   cpu_baseline : the CPU oracle (a port of the reference sampler, oracle/ddif_oracle.py) timed on this box's host cores
                  on a bounded sample of the same workload (N=1, rank 0 only).
 """
@@ -37,20 +47,23 @@ def log(msg):
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix (= vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2516.8  # dense bf16 MFMA (16 x the fp32 rate); the bf16x3 path issues 6 bf16 products per fp32 product
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0  # fp32-equivalent ceiling of the bf16x3 path: algorithmic TF / this = issued TF / bf16 peak
 PEAK_HBM_GBS = 8000.0
+PROF_STEPS_TARGET = 40  # denoising steps bracketed with events over the whole timed region (every launch of such a step has its own pair)
 
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on (default; what the driver runs)
-    "wv3": dict(ds="wv3", C=8, P=1, batch=64, tile=64, T=1000, sampler="ddpm",
+    "wv3": dict(ds="wv3", C=8, P=1, batch=64, tile=64, T=1000, sampler="ddpm", scaling="weak",
                 metric="fused megapixels/sec at T=%d, WV3 64x64x8 tiles"),
-    # configs[2]: GF2 512x512 scene = 64 tiles of 64x64, DPM-Solver++ 2M, 50 model evaluations (per GPU: 64 tiles at N=1)
-    "gf2_dpm50": dict(ds="gf2", C=4, P=1, batch=64, tile=64, T=1000, sampler="dpmpp2m", nfe=50,
-                      metric="fused megapixels/sec, GF2 64x64x4 tiles, DPM-Solver++ 2M %d NFE"),
+    # configs[2]: ONE GF2 512x512 scene = 64 tiles of 64x64 split over the ranks (strong scaling), DPM-Solver++ 2M, 50 model evaluations,
+    # all-gather + stitch inside the timed region
+    "gf2_dpm50": dict(ds="gf2", C=4, P=1, batch=64, tile=64, T=1000, sampler="dpmpp2m", nfe=50, scaling="strong",
+                      metric="fused megapixels/sec, GF2 512x512 scene as 64x64x4 tiles, DPM-Solver++ 2M %d NFE"),
     # configs[3]: CAVE 31-band HSI + 3-band MSI, 128x128 patches, T=2000 DDPM
-    "cave128_t2000": dict(ds="cave", C=31, P=3, batch=8, tile=128, T=2000, sampler="ddpm",
+    "cave128_t2000": dict(ds="cave", C=31, P=3, batch=8, tile=128, T=2000, sampler="ddpm", scaling="weak",
                           metric="fused megapixels/sec at T=%d, CAVE 128x128x31 patches"),
     # configs[4]: one training iteration of sr3_dwt on WV3 tiles, batch 32 per GPU, AdamW, DDP over the ranks (engine_google's loop body)
-    "wv3_train_b32": dict(ds="wv3", C=8, P=1, batch=32, tile=64, T=3000, sampler="train",
+    "wv3_train_b32": dict(ds="wv3", C=8, P=1, batch=32, tile=64, T=3000, sampler="train", scaling="weak",
                           metric="training tiles/sec, sr3_dwt on WV3 64x64x8 tiles, batch 32 per GPU (T=%d schedule)"),
 }
 
@@ -66,20 +79,57 @@ def build_id():
     return h.hexdigest()[:16]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="wv3", choices=sorted(CONFIGS), help="wv3 = BASELINE.json's metric configuration (default)")
-    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (0: the configuration's own)")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (gf2_dpm50: tiles of the whole scene, split over the GPUs); 0: the configuration's own")
     ap.add_argument("--T", type=int, default=0, help="diffusion steps (0: the configuration's own)")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lib", default=None, help="development aid: another build of libddif.so to benchmark (A/B of kernel variants)")
-    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget of the cpu_baseline leg (split over B=1 and B=8)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: CPUs this process may run on (sched_getaffinity)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (torch.distributed.run, one rank per GPU) from
+    this parent, which has not imported torch and never initialises a GPU (no exec of a GPU-initialised process anywhere), relay rank 0's
+    JSON line on stdout and exit non-zero when any rank failed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log("no WORLD_SIZE in the environment: launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        log("multi-GPU launch failed (exit status %d, %s result line)" % (rc, "with a" if line else "no"))
+        raise SystemExit(rc if rc != 0 else 1)
+    print(line, flush=True)
+    raise SystemExit(0)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -88,14 +138,14 @@ def main():
     from ddif.diffusion.diffusion_ddpm_pan import GaussianDiffusion, make_beta_schedule
     from ddif.layout import engine_cfg
     from ddif.models.sr3_dwt import UNetSR3
+    from ddif.sharding import shard_range, stitch_tiles
     from ddif.synth import synth_state_dict, synth_tiles
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ddif hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -113,6 +163,7 @@ def main():
     cf = CONFIGS[args.config]
     if cf["sampler"] == "train":
         return bench_training(args, cf, rank, world, dev)
+    strong = cf["scaling"] == "strong"
     C, P = cf["C"], cf["P"]
     B, H, T = args.batch or cf["batch"], args.tile or cf["tile"], args.T or cf["T"]
     order = "hisr" if cf["ds"] == "cave" else "pan"
@@ -127,16 +178,31 @@ def main():
                                   clamp_range=(0, 1))
     diffusion.set_new_noise_schedule(betas=make_beta_schedule("cosine", T, cosine_s=8e-3), device=dev)
 
-    log("network built (%d params), generating %d synthetic tiles" % (sum(p.numel() for p in net.parameters()), B))
-    tiles = synth_tiles(B, C, P, H, H, seed=100 + rank, order=order)
+    if strong:
+        # one scene of `total` tiles (the same on every rank), this rank's contiguous block of it; noise keyed by the tile's index in the scene
+        total = B
+        ny = int(round(total ** 0.5))
+        if ny * ny != total or total % world:
+            raise SystemExit("gf2_dpm50: %d scene tiles must be a square number divisible by %d GPUs" % (total, world))
+        lo, hi = shard_range(total, rank, world)
+        tiles = synth_tiles(total, C, P, H, H, seed=100, order=order)
+        tiles = {k: v[lo:hi].contiguous() for k, v in tiles.items()}
+        B, tile0 = hi - lo, lo
+    else:
+        total, ny = world * B, 0
+        tiles = synth_tiles(B, C, P, H, H, seed=100 + rank, order=order)
+        tile0 = rank * B
+    log("network built (%d params), %d synthetic tiles on this rank" % (sum(p.numel() for p in net.parameters()), B))
     cond = tiles["cond"].to(dev)
     lms = cond[:, :C].contiguous()
-    gathered = torch.empty((world * B, C, H, H), device=dev) if world > 1 else None
+    gathered = torch.empty((total, C, H, H), device=dev) if (world > 1 or strong) else None
     plan = diffusion._plan(cond)  # builds workspaces + runs set_cond once (not timed)
     cost = plan.cost()
     mem = plan.memory()
+    n_launch = plan.num_launches()
     torch.cuda.synchronize()
-    log("plan ready: %.3f GFLOP and %.1f MB (algorithmic) per denoising step of the batch" % (cost["step_flop"] / 1e9, cost["step_bytes"] / 1e6))
+    log("plan ready: %.3f GFLOP and %.1f MB (algorithmic) per denoising step of the batch, %d launches per step"
+        % (cost["step_flop"] / 1e9, cost["step_bytes"] / 1e6, n_launch["step"]))
 
     solver = None
     n_evals = T
@@ -152,14 +218,19 @@ def main():
     def one_step(seed):
         plan.set_cond(cond, force=True)  # once-per-tile precompute is part of the job
         if solver is not None:
-            xT = torch.randn((B, C, H, H), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+            if strong:  # x_T of the whole scene from one seeded stream, this rank's block of it: independent of the GPU count
+                xT = torch.randn((total, C, H, H), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))[tile0:tile0 + B].contiguous()
+            else:
+                xT = torch.randn((B, C, H, H), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
             res = solver.sample(xT, steps=n_evals, order=2, skip_type="time_uniform", method="multistep")
         else:
-            res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=rank * B, device_rng=True)
+            res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=tile0, device_rng=True)
         sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
         if world > 1:
-            dist.all_gather_into_tensor(gathered, sr)  # stitch: every rank ends with the whole scene
-            return gathered
+            dist.all_gather_into_tensor(gathered, sr)  # the only exchange: every rank ends with all tiles
+            sr = gathered
+        if strong:
+            return stitch_tiles(sr, ny, ny)  # (C, 512, 512): the fused scene
         return sr
 
     for w in range(args.warmup):
@@ -170,8 +241,13 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    prof_every = max(10, n_evals // 20)  # a profiled step has an event pair around every launch: keep it to <= 1 step in 10
-    plan.prof_begin(prof_every, 16384)
+    # profiled denoising steps: about PROF_STEPS_TARGET over the whole timed region, at most one step in 10 (a profiled step is launched
+    # kernel by kernel with an event pair around each); the event buffer is sized for exactly those steps, and the library reports how
+    # many whole steps it recorded (ddif_prof_collect.steps_recorded) -- per-step figures divide by THAT
+    per_job = max(1, min(n_evals // 10 if n_evals >= 10 else 1, PROF_STEPS_TARGET // max(1, args.steps)))
+    prof_every = -(-n_evals // per_job)
+    n_prof_planned = len(range(0, n_evals, prof_every)) * args.steps
+    plan.prof_begin(prof_every, n_prof_planned * n_launch["step"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = None
@@ -182,35 +258,42 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = plan.prof_collect()
-    log("timed region: %.3f s for %d step(s)" % (dt, args.steps))
+    log("timed region: %.3f s for %d step(s); %d of %d planned denoising steps profiled" % (dt, args.steps, prof["steps_recorded"], n_prof_planned))
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert out is not None and bool(torch.isfinite(out).all())
 
-    mp_per_step = world * B * H * H / 1e6
+    mp_per_step = total * H * H / 1e6
     value = mp_per_step * args.steps / dt
     ach_tflops = prof["total_flop"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] > 0 else 0.0
     step_flop_total = cost["step_flop"] * n_evals + cost["cond_flop"]
     # the committed PMC passes are of the default (wv3, B = 64) command: other configurations report no traffic
     traffic, traffic_info = committed_traffic() if (args.config == "wv3" and B == 64) else (None, {"traffic_from_committed_profile": False})
     x3 = "bf16x3" in prof["kernel"]
+    peak = PEAK_X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    ms_step = dt / args.steps * 1e3 / n_evals
     # per-class breakdown of the profiled denoising steps (every launch of those steps sits between two HIP events)
-    n_prof_steps = max(1, sum(1 for k in range(n_evals) if k % prof_every == 0) * args.steps)
+    n_rec = prof["steps_recorded"]
     classes, cls_ms_total = [], 0.0
     for c in prof["classes"]:
-        if not c["launches"]:
+        if not c["launches"] or not n_rec:
             continue
-        ms = c["total_ms"] / n_prof_steps
-        floor_ms = max(c["total_flop"] / (PEAK_F32_MFMA_TFLOPS * 1e12), c["total_bytes"] / (PEAK_HBM_GBS * 1e9)) * 1e3 / n_prof_steps
+        ms = c["total_ms"] / n_rec
+        floor_ms = max(c["total_flop"] / (peak * 1e12), c["total_bytes"] / (PEAK_HBM_GBS * 1e9)) * 1e3 / n_rec
         cls_ms_total += ms
-        classes.append({"class": c["name"], "launches_per_step": c["launches"] / n_prof_steps, "ms_per_step": ms,
+        classes.append({"class": c["name"], "launches_per_step": c["launches"] / n_rec, "ms_per_step": ms,
                         "tflops": c["total_flop"] / (c["total_ms"] * 1e-3) / 1e12, "algorithmic_gbytes_per_s": c["total_bytes"] / (c["total_ms"] * 1e-3) / 1e9,
                         "floor_ms_per_step": floor_ms, "frac_of_floor": floor_ms / ms if ms > 0 else None})
+    # the table is only printed when it adds up: sum of the classes within 15 % of the measured denoising step, no class above its floor
+    classes_ok = bool(classes) and abs(cls_ms_total - ms_step) / ms_step < 0.15 and all(c["frac_of_floor"] is None or c["frac_of_floor"] <= 1.0 for c in classes)
+    if not classes_ok:
+        log("per-class table INCONSISTENT with the step (sum %.3f ms vs %.3f ms per denoising step): not reported" % (cls_ms_total, ms_step))
     if cf["sampler"] == "dpmpp2m":
         metric = cf["metric"] % n_evals
-        workload = "GF2 pansharpening, batch %d of %dx%dx%d tiles per GPU, DPM-Solver++ 2M %d NFE (T=%d schedule), fp32" % (B, H, H, C, n_evals, T)
+        workload = "GF2 pansharpening, one %dx%d scene = %d tiles of %dx%dx%d split over %d GPU(s) (%d per GPU), DPM-Solver++ 2M %d NFE (T=%d schedule), all-gather + stitch, fp32" % (
+            ny * H, ny * H, total, H, H, C, world, B, n_evals, T)
     else:
         metric = cf["metric"] % T
         workload = "%s, batch %d of %dx%dx%d tiles per GPU, T=%d DDPM p_sample, fp32" % ("WV3 pansharpening" if cf["ds"] == "wv3" else "CAVE MHIF", B, H, H, C, T)
@@ -223,12 +306,12 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": cf["scaling"],
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": workload, "name": args.config, "tiles_per_gpu": B, "tile": [H, H, C], "T": T, "model_evaluations": n_evals,
-                   "sampler": cf["sampler"], "parallelism": "tile-shard x%d" % world,
+        "config": {"workload": workload, "name": args.config, "tiles_per_gpu": B, "tiles_total": total, "tile": [H, H, C], "T": T, "model_evaluations": n_evals,
+                   "sampler": cf["sampler"], "parallelism": "tile-shard x%d" % world, "launches_per_denoising_step": n_launch["step"],
                    "plan_memory_mb": {"total": mem["total_bytes"] / 1e6, "step_activation_arena": mem["arena_bytes"] / 1e6,
                                       "same_activations_unaliased": mem["unaliased_bytes"] / 1e6},
                    "conv_math": ("fp32 operands split into 3 bf16 planes, 6 exact products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (3x3 convs, "
@@ -236,13 +319,15 @@ def main():
         "roofline": {
             "bound": "mfma",
             "achieved": ach_tflops,
-            "peak": PEAK_F32_MFMA_TFLOPS,
+            "peak": peak,
             "unit": "TFLOP/s",
-            "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS,
-            "peak_note": "dense fp32 matrix peak (guide); `achieved` counts ALGORITHMIC fp32 flops (2*M*N*K, unpadded) of the dominant class",
+            "frac": ach_tflops / peak,
+            "peak_note": ("`achieved` counts ALGORITHMIC fp32 flops (2*M*N*K, unpadded) of the dominant class; every fp32 product is issued as 6 bf16 MFMA products "
+                          "(3-way split of both operands), so the ceiling of this kernel is the dense bf16 MFMA peak %.1f / 6 = %.1f TF and `frac` = issued "
+                          "bf16 TFLOP/s / %.1f" % (PEAK_BF16_MFMA_TFLOPS, PEAK_X3_TFLOPS, PEAK_BF16_MFMA_TFLOPS)) if x3 else "dense fp32 matrix peak (guide); exact fp32 MFMA",
             "mfma_issued_tflops": (6.0 * ach_tflops) if x3 else ach_tflops,
-            "mfma_issued_note": ("every fp32 product is issued as 6 bf16 MFMA products: issued rate vs the dense bf16 peak %.1f TF" % PEAK_BF16_MFMA_TFLOPS) if x3 else "exact fp32 MFMA",
-            "frac_of_bf16_mfma_peak_issued": (6.0 * ach_tflops / PEAK_BF16_MFMA_TFLOPS) if x3 else None,
+            "frac_of_f32_mfma_peak_algorithmic": ach_tflops / PEAK_F32_MFMA_TFLOPS,
+            "frac_of_f32_note": "secondary: algorithmic TFLOP/s over the 157.3 TF fp32-matrix peak -- NOT a bound of the bf16x3 path (it may exceed 1)",
             "traffic": traffic,
             "traffic_unit": "bytes of HBM traffic per launch of the dominant class (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this command)",
             **traffic_info,
@@ -252,13 +337,16 @@ def main():
             "avg_launch_us": (prof["total_ms"] * 1e3 / prof["launches"]) if prof["launches"] else None,
             "algorithmic_gflop_per_launch": (prof["total_flop"] / prof["launches"] / 1e9) if prof["launches"] else None,
             "whole_step": {
-                "ms_per_denoising_step": dt / args.steps * 1e3 / n_evals,
+                "ms_per_denoising_step": ms_step,
                 "tflops": step_flop_total * args.steps / dt / 1e12,
-                "frac_of_f32_mfma_peak": step_flop_total * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "frac_of_x3_peak": step_flop_total * args.steps / dt / 1e12 / peak,
+                "frac_of_f32_mfma_peak_algorithmic": step_flop_total * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "hbm_frac": (cost["step_bytes"] * n_evals + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
-                "classes_note": "HIP events around every launch of one denoising step in %d; floor = max(flops / 157.3 TF, algorithmic bytes / 8 TB/s)" % prof_every,
-                "classes_ms_per_step_sum": cls_ms_total,
-                "classes": classes,
+                "profiled_steps": n_rec,
+                "classes_note": "HIP events around every launch of %d whole denoising steps (one in %d); floor = max(flops / %.1f TF, algorithmic bytes / 8 TB/s)" % (n_rec, prof_every, peak),
+                "classes_ms_per_step_sum": cls_ms_total if classes_ok else None,
+                "classes": classes if classes_ok else None,
+                **({} if classes_ok else {"classes_error": "class sum %.3f ms vs %.3f ms per step: table withheld" % (cls_ms_total, ms_step)}),
             },
         },
         "build_id": build_id(),
@@ -271,7 +359,7 @@ def main():
         result["vs_cpu_baseline"] = value / cb["value"]
         result["vs_cpu_baseline_b1"] = value / cb["by_batch"]["1"]["value"]
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -287,7 +375,7 @@ def bench_training(args, cf, rank, world, dev):
 
     from ddif import runtime
     from ddif.diffusion.diffusion_ddpm_pan import GaussianDiffusion, make_beta_schedule
-    from ddif.diffusion_engine import average_gradients
+    from ddif.diffusion_engine import average_gradients, broadcast_parameters
     from ddif.layout import engine_cfg
     from ddif.models.sr3_dwt import UNetSR3
     from ddif.synth import synth_state_dict, synth_tiles
@@ -296,8 +384,9 @@ def bench_training(args, cf, rank, world, dev):
     cfg = engine_cfg(C, P)
     keys = ("in_channel", "out_channel", "inner_channel", "lms_channel", "pan_channel", "norm_groups", "channel_mults", "attn_res", "res_blocks", "dropout",
             "image_size", "self_condition")
+    sd = synth_state_dict(cfg, 1234)
     net = UNetSR3(**{k: cfg[k] for k in keys})
-    net.load_state_dict(synth_state_dict(cfg, 1234))
+    net.load_state_dict(sd)
     net = net.to(dev).train()
     d = GaussianDiffusion(net, image_size=H, channels=C, pred_mode="x_start", loss_type="l1", device=dev, clamp_range=(0, 1))
     d.set_new_noise_schedule(betas=make_beta_schedule("cosine", T, cosine_s=8e-3), device=dev)
@@ -309,18 +398,38 @@ def bench_training(args, cf, rank, world, dev):
     for p, g in zip(params, grads):
         p.grad = g
     ema = [p.detach().clone() for p in params]
+    if world > 1:
+        broadcast_parameters(params + ema)
     opt = runtime.FusedAdamW(params, grads, ema, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
     torch.manual_seed(7 + rank)
     random.seed(7 + rank)
+    n_param = sum(p.numel() for p in params)
+    comm_ms = [0.0]
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if world > 1 else None
+    sc_passes = [0]
+    qsf = runtime.PlanHandle.q_sample_forward
 
-    def one_step():
+    def counted(self, *a, **k):  # the no-grad self-conditioning forward of half of the iterations (reference :703-709)
+        sc_passes[0] += 1
+        return qsf(self, *a, **k)
+
+    runtime.PlanHandle.q_sample_forward = counted
+
+    def one_step(timed=False):
         for g in grads:
             g.zero_()
         loss, _ = d(res, cond=cond)
         loss.backward()
         if world > 1:
+            if timed:
+                ev[0].record()
             average_gradients(grads, world)
+            if timed:
+                ev[1].record()
+                ev[1].synchronize()
+                comm_ms[0] += ev[0].elapsed_time(ev[1])
         opt.step(max_grad_norm=0.003, ema_mode=1, ema_decay=0.995)
+        net.mark_weights_dirty()
         return loss
 
     for w in range(args.warmup):
@@ -328,10 +437,11 @@ def bench_training(args, cf, rank, world, dev):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    sc_passes[0] = 0
     t0 = time.perf_counter()
     loss = None
     for k in range(args.steps):
-        loss = one_step()
+        loss = one_step(timed=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -341,17 +451,78 @@ def bench_training(args, cf, rank, world, dev):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert bool(torch.isfinite(loss.detach()).all())
+    # algorithmic flops of one iteration: forward + backward = 3 x the un-hoisted forward (dgrad + wgrad = 2 x forward), plus one
+    # forward per self-conditioning pass actually run
+    cost = d._plan(cond, train=True).cost()
+    fwd_flop = cost["step_flop"] + cost["cond_flop"]
+    step_flop = fwd_flop * (3.0 + sc_passes[0] / max(1, args.steps))
+    tf = step_flop * args.steps / dt / 1e12
     if rank == 0:
         line = {"metric": cf["metric"] % T, "value": world * B * args.steps / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "sr3_dwt training iteration (q_sample, 50 %% self-conditioning pass, forward, backward, DDP all-reduce, clip + AdamW + EMA), "
                                        "WV3 %dx%dx%d tiles, batch %d per GPU, fp32" % (H, H, C, B), "name": args.config, "tiles_per_gpu": B, "tile": [H, H, C],
-                           "T": T, "parallelism": "ddp x%d" % world},
-                "roofline": None, "cpu_baseline": None, "build_id": build_id(),
-                "note": "correctness-first training graph (ddif/train.py): per-kernel split in profiles/r02_z_train_kernel_stats_after.csv"}
+                           "T": T, "parallelism": "ddp x%d" % world, "self_conditioning_passes_in_timed_region": sc_passes[0]},
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                             "algorithmic_gflop_per_iteration": step_flop / 1e9,
+                             "peak_note": "whole training iteration: algorithmic flops (3 x un-hoisted forward + self-conditioning forwards) / wall time vs the dense fp32 "
+                                          "matrix peak; the weight-gradient kernels run the exact fp32 MFMA, forward / dgrad convs the bf16x3 path"},
+                "build_id": build_id()}
+        if world > 1:
+            line["allreduce"] = {"bytes": 4 * n_param, "ms_per_iteration": comm_ms[0] / args.steps,
+                                 "algorithmic_gbytes_per_s": 4 * n_param / (comm_ms[0] / args.steps * 1e-3) / 1e9 if comm_ms[0] > 0 else None,
+                                 "bus_gbytes_per_s": 2.0 * (world - 1) / world * 4 * n_param / (comm_ms[0] / args.steps * 1e-3) / 1e9 if comm_ms[0] > 0 else None,
+                                 "note": "one flat fp32 bucket, RCCL ring all-reduce (AVG); timed with HIP events around the collective, rank 0"}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_training(sd, cfg, tiles, T, args.cpu_seconds, args.cpu_threads)
+            line["vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline_training(sd, cfg, tiles, T, budget_s, threads=0):
+    """The oracle's forward (oracle/ddif_oracle.unet_forward, pinned to the reference's training golden) + torch autograd + torch.optim.AdamW on
+    the host cores: whole training iterations (q_sample, forward, L1, backward, clip, AdamW) on a batch of 4 tiles, as many as fit the budget."""
+    import torch
+
+    from oracle import ddif_oracle as O
+
+    if threads <= 0:
+        threads = usable_cpus()
+    torch.set_num_threads(threads)
+    bsz = 4
+    cond = tiles["cond"][:bsz].contiguous()
+    x0 = (tiles["gt"][:bsz] - cond[:, : cfg["lms_channel"]]).contiguous()
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    g = torch.Generator().manual_seed(3)
+
+    def it():
+        t = torch.randint(0, T, (bsz,), generator=g)
+        noise = torch.randn(x0.shape, generator=g)
+        xt = O.q_sample(tabs, x0, t, noise)
+        opt.zero_grad(set_to_none=True)
+        pred = O.unet_forward(P, cfg, xt, t, cond, None)
+        loss = (x0 - pred).abs().mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(P.values()), 0.003)
+        opt.step()
+
+    t0 = time.perf_counter()
+    it()  # warm-up (oneDNN primitive creation)
+    probe = time.perf_counter() - t0
+    n = int(max(1, min(50, (budget_s - probe) / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        it()
+    dt = time.perf_counter() - t0
+    log("cpu baseline (training): %.3f s per iteration of %d tiles over %d iterations, %d threads" % (dt / n, bsz, n, threads))
+    return {"value": bsz * n / dt, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d training iterations (q_sample, oracle forward, L1, autograd backward, clip 0.003, AdamW) on a batch of %d WV3 64x64 tiles, %.1f s; no "
+                      "self-conditioning pass, Dropout / DropPath off (both add work on the reference's side)" % (n, bsz, dt),
+            "host_cpus": os.cpu_count()}
 
 
 def committed_traffic():

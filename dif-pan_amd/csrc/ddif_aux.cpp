@@ -84,8 +84,29 @@ int ddif_metrics(const float* gt, const float* pred, int B, int C, int H, int W,
     return DDIF_OK;
 }
 
+int ddif_ssim(const float* gt, const float* pred, int B, int C, int H, int W, float data_range, float* out, void* stream) {
+    if (!gt || !pred || !out) return ddif::fail(DDIF_ERR_INVALID, "ddif_ssim: NULL argument");
+    if (B < 1 || C < 1 || H < 7 || W < 7 || !(data_range > 0.f)) return ddif::fail(DDIF_ERR_INVALID, "ddif_ssim: images must be at least 7x7 (the window) and data_range > 0");
+    const int n = (H - 6) * (W - 6);
+    int nchunk = (n + 255) / 256;
+    if (nchunk > 64) nchunk = 64;
+    double* part = nullptr;
+    if (int e = ddif::scratch((size_t)B * C * nchunk, &part)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ddif::ssim_window_kernel, dim3(nchunk, C, B), dim3(256), 64, s, gt, pred, C, H, W, nchunk, data_range, part);
+    hipLaunchKernelGGL(ddif::ssim_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)part, B, C, H, W, nchunk, out);
+    DDIF_HIPCHK(hipGetLastError());
+    return DDIF_OK;
+}
+
 int ddif_optim_create(ddif_optim_t* out, int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
                       float* const* ema, int device) {
+    return ddif_optim_create_ex(out, n_tensors, sizes, params, grads, ema, nullptr, nullptr, device);
+}
+
+int ddif_optim_create_ex(ddif_optim_t* out, int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
+                         float* const* ema, float* const* exp_avg, float* const* exp_avg_sq, int device) {
+    if ((exp_avg == nullptr) != (exp_avg_sq == nullptr)) return ddif::fail(DDIF_ERR_INVALID, "ddif_optim_create_ex: give both moment arrays or neither");
     if (!out || n_tensors < 1 || !sizes || !params || !grads) return ddif::fail(DDIF_ERR_INVALID, "ddif_optim_create: bad arguments");
     *out = nullptr;
     int prev = -1;
@@ -105,15 +126,24 @@ int ddif_optim_create(ddif_optim_t* out, int n_tensors, const int64_t* sizes, fl
         }
         if (n == 0) continue;
         float *m = nullptr, *v = nullptr;
-        if (hipMalloc((void**)&m, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&v, (size_t)n * 4) != hipSuccess) {
-            rc = ddif::fail(DDIF_ERR_HIP, "ddif_optim_create: hipMalloc of the moment buffers failed");
-            if (m) (void)hipFree(m);
-            break;
+        if (exp_avg) {  // caller-owned moments (checkpointable optimizer state): borrowed like params / grads, NOT zeroed here
+            m = exp_avg[t];
+            v = exp_avg_sq[t];
+            if (!m || !v) {
+                rc = ddif::fail(DDIF_ERR_INVALID, "ddif_optim_create_ex: tensor %d has a NULL moment pointer", t);
+                break;
+            }
+        } else {
+            if (hipMalloc((void**)&m, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&v, (size_t)n * 4) != hipSuccess) {
+                rc = ddif::fail(DDIF_ERR_HIP, "ddif_optim_create: hipMalloc of the moment buffers failed");
+                if (m) (void)hipFree(m);
+                break;
+            }
+            o.allocs.push_back(m);
+            o.allocs.push_back(v);
+            (void)hipMemset(m, 0, (size_t)n * 4);
+            (void)hipMemset(v, 0, (size_t)n * 4);
         }
-        o.allocs.push_back(m);
-        o.allocs.push_back(v);
-        (void)hipMemset(m, 0, (size_t)n * 4);
-        (void)hipMemset(v, 0, (size_t)n * 4);
         for (int64_t off = 0; off < n; off += CH) {
             ddif::OptimChunk c{};
             c.p = params[t] + off;

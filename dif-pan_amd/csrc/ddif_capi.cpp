@@ -223,6 +223,7 @@ int ddif_prof_begin(ddif_plan_t plan, int every_n_steps, int max_events) {
     p.ev_bytes.assign(p.ev0.size(), 0.0);
     p.ev_cls.assign(p.ev0.size(), 5);
     p.ev_used = 0;
+    p.prof_steps = 0;
     p.prof_all = true;
     p.prof_every = every_n_steps;
     p.prof_max = max_events;
@@ -255,8 +256,11 @@ int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
         std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions; bf16x3 split products on %d of %d)", p.n_conv3_x3, p.n_conv3);
     else
         std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions; exact fp32 MFMA)");
+    out->steps_recorded = p.prof_steps;
+    out->launches_per_step = (int64_t)p.step.size();
     p.prof_every = 0;
     p.ev_used = 0;
+    p.prof_steps = 0;
     return DDIF_OK;
     DDIF_GUARD_END
 }
@@ -269,6 +273,13 @@ int ddif_prof_classes(ddif_plan_t plan, ddif_prof_class* out6) {
         out6[k] = plan->p.cls_res[k];
         std::snprintf(out6[k].name, sizeof(out6[k].name), "%s", names[k]);
     }
+    return DDIF_OK;
+}
+
+int ddif_plan_num_launches(ddif_plan_t plan, int* step_launches, int* cond_launches) {
+    if (!plan) return ddif::fail(DDIF_ERR_INVALID, "NULL plan");
+    if (step_launches) *step_launches = (int)plan->p.step.size();
+    if (cond_launches) *cond_launches = (int)plan->p.pre.size();
     return DDIF_OK;
 }
 

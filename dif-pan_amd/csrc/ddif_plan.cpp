@@ -1081,6 +1081,9 @@ void Plan::run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bo
             }
         }
     }
+    // a step is profiled completely or not at all: per-step figures divide by prof_steps
+    if (prof && ev_used + (int)prog.size() > (int)ev0.size()) prof = false;
+    if (prof) ++prof_steps;
     for (auto& op : prog) {
         const bool t = prof && (op.timed || prof_all) && ev_used < (int)ev0.size();
         if (t) (void)hipEventRecord(ev0[ev_used], s);

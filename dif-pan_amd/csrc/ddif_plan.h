@@ -117,6 +117,7 @@ struct Plan {
     std::vector<double> ev_flop, ev_bytes;
     std::vector<int> ev_cls;
     int ev_used = 0;
+    long long prof_steps = 0;  // whole steps recorded since ddif_prof_begin (a step that does not fit the remaining events is not profiled)
     std::string prof_name;
     ddif_prof_class cls_res[6] = {};  // per-class sums of the last ddif_prof_collect
 

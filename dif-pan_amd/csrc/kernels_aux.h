@@ -158,6 +158,59 @@ __global__ void metric_finalize_kernel(const double* sums, const double* part, i
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// SSIM of the validation pass (reference utils/metric.py:153-166: skimage.metrics.structural_similarity(gt, pred, channel_axis=0) with
+// library defaults -- 7x7 uniform window, K1 = 0.01, K2 = 0.03, sample covariance (NP / (NP - 1)), mean over the image cropped by
+// (win - 1) / 2 = 3 pixels per side and over the channels; for float images without data_range the library takes dmax - dmin of the dtype
+// range (-1, 1), i.e. 2.0 -- the caller passes it).  The crop removes exactly the pixels whose window touches the border, so the filter's
+// boundary rule never enters.  skimage is NOT in the build image: this restatement is parity-unpinned against the library itself.
+//   ssim_window_kernel   grid (row chunks, C, B): one thread per interior pixel, 49-tap window sums in fp64, fp64 partial per workgroup
+//   ssim_finalize_kernel per image: fixed-order sum of the partials / (C * (H-6) * (W-6))
+__global__ __launch_bounds__(256) void ssim_window_kernel(const float* gt, const float* pred, int C, int H, int W, int nchunk, float data_range, double* part) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);
+    const int b = blockIdx.z, c = blockIdx.y, hc = H - 6, wc = W - 6, n = hc * wc;
+    const size_t plane = (size_t)H * W;
+    const float* a = gt + ((size_t)b * C + c) * plane;
+    const float* p = pred + ((size_t)b * C + c) * plane;
+    const double c1 = (0.01 * (double)data_range) * (0.01 * (double)data_range), c2 = (0.03 * (double)data_range) * (0.03 * (double)data_range);
+    const double np_ = 49.0, cov_norm = np_ / (np_ - 1.0);
+    double acc = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += nchunk * 256) {
+        const int y = i / wc, x = i - y * wc;  // top-left corner of the window = centre (y + 3, x + 3)
+        double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int dy = 0; dy < 7; ++dy) {
+            const float* ar = a + (size_t)(y + dy) * W + x;
+            const float* pr = p + (size_t)(y + dy) * W + x;
+            for (int dx = 0; dx < 7; ++dx) {
+                const double av = ar[dx], pv = pr[dx];
+                sx += av;
+                sy += pv;
+                sxx += av * av;
+                syy += pv * pv;
+                sxy += av * pv;
+            }
+        }
+        const double ux = sx / np_, uy = sy / np_;
+        const double vx = cov_norm * (sxx / np_ - ux * ux), vy = cov_norm * (syy / np_ - uy * uy), vxy = cov_norm * (sxy / np_ - ux * uy);
+        acc += ((2.0 * ux * uy + c1) * (2.0 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2));
+    }
+    const double t = block_sum_256(acc, red);
+    if (threadIdx.x == 0) part[((size_t)b * C + c) * nchunk + blockIdx.x] = t;
+}
+
+__global__ void ssim_finalize_kernel(const double* part, int B, int C, int H, int W, int nchunk, float* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) {
+        double sc = 0.0;
+        for (int k = 0; k < nchunk; ++k) sc += part[((size_t)b * C + c) * nchunk + k];
+        s += sc / ((double)(H - 6) * (W - 6));
+    }
+    out[b] = (float)(s / C);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Fused optimizer step of the training loop (reference diffusion_engine.py:237-241): clip_grad_norm_(0.003)
 // (utils/misc.py:25-36 -> torch.nn.utils.clip_grad_norm_), torch.optim.AdamW.step, EmaUpdater.update
 // (utils/optim_utils.py:43-58).  Multi-tensor: a device table of chunks (tensor pointers + offset + length, <= 4096

@@ -198,15 +198,25 @@ def test_fn(test_data_path=None, weight_path=None, schedule_type="cosine", batch
 
 class _Batches:
     """Mini-batches (pan, lms, hr) of raw-count tensors out of an in-memory set {"pan", "lms", "gt"} (the three arrays PanDataset / HISRDataSets
-    read from their h5 files, dataset/pan_dataset.py:37-66, dataset/hisr.py:22-46), reshuffled every epoch like DataLoader(shuffle=True)."""
+    read from their h5 files, dataset/pan_dataset.py:37-66, dataset/hisr.py:22-46), reshuffled every epoch like DataLoader(shuffle=True).
+    With `world > 1` every epoch's permutation comes from a generator seeded by (seed, epoch) -- the SAME on every rank -- and rank r takes
+    order[r::world] (what DistributedSampler does): the ranks see disjoint samples whatever their own torch RNG state is."""
 
-    def __init__(self, data: Dict[str, torch.Tensor], batch_size: int, shuffle: bool = True):
+    def __init__(self, data: Dict[str, torch.Tensor], batch_size: int, shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0):
         self.pan, self.lms, self.gt = (torch.as_tensor(np.asarray(data[k]), dtype=torch.float32) for k in ("pan", "lms", "gt"))
         self.n, self.bs, self.shuffle = self.gt.shape[0], batch_size, shuffle
+        self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
 
     def __iter__(self):
-        order = torch.randperm(self.n) if self.shuffle else torch.arange(self.n)
-        for k in range(0, self.n, self.bs):
+        if self.world > 1:
+            g = torch.Generator().manual_seed(self.seed * 1_000_003 + self.epoch)
+            order = torch.randperm(self.n, generator=g) if self.shuffle else torch.arange(self.n)
+            n_even = (self.n // self.world) * self.world  # every rank the same number of samples (the tail is dropped, as drop_last does)
+            order = order[:n_even][self.rank::self.world] if n_even else order[self.rank::self.world]
+        else:
+            order = torch.randperm(self.n) if self.shuffle else torch.arange(self.n)
+        self.epoch += 1
+        for k in range(0, len(order), self.bs):
             idx = order[k:k + self.bs]
             yield self.pan[idx], self.lms[idx], self.gt[idx]
 
@@ -240,6 +250,20 @@ def average_gradients(grads, world: int):
         off += g.numel()
 
 
+def broadcast_parameters(tensors, src: int = 0):
+    """What DistributedDataParallel does at construction: every rank starts from rank `src`'s parameters (and EMA copies), whatever its own
+    RNG drew at initialisation.  One flat bucket, in place."""
+    import torch.distributed as dist
+
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
 def lr_at(iteration: int, base: float, milestones=(100_000, 200_000, 350_000), gamma: float = 0.2) -> float:
     """MultiStepLR of the reference (diffusion_engine.py:210-212)"""
     return base * gamma ** sum(1 for m in milestones if iteration >= m)
@@ -248,15 +272,23 @@ def lr_at(iteration: int, base: float, milestones=(100_000, 200_000, 350_000), g
 def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, image_n_channel=8, image_size=64,
                   schedule_type="cosine", n_steps=3_000, max_iterations=400_000, device="cuda:0", batch_size=128,
                   lr_d=1e-4, show_recon=False, pretrain_weight=None, pretrain_iterations=None, *, constrain_channel=None,
-                  add_n_channel=1, ema_start_iter=20_000, valid_every=5_000, save_dir=None, log=print):
+                  add_n_channel=1, ema_start_iter=20_000, valid_every=5_000, save_dir=None, save_every=5_000, resume_state=None,
+                  data_seed=0, log=print):
     """Reference engine_google (:52-348): the training loop.  Same keyword names and defaults; `train_dataset_path` / `valid_dataset_path`
     may also be dicts {"pan", "lms", "gt"} of raw-count arrays (h5py is not part of this image).  Per iteration, as in the reference
     (:218-241): cond assembly (one kernel), `diff_loss, recon = diffusion(hr - lms, cond=cond)`, `diff_loss.backward()` (the library's
-    reverse pass through ddif.train), gradient all-reduce when torch.distributed is initialised (DDP of config 5: one process per GPU,
-    RCCL), then clip 0.003 + AdamW(lr, weight_decay 1e-4) + EMA(0.995 from `ema_start_iter`) as the fused three-launch optimizer step,
-    MultiStepLR.  Every `valid_every` iterations: DDIM-25 sampling of one validation batch with the EMA weights and SAM / ERGAS / PSNR / CC
-    from `ddif_metrics`.  Plotting, tensorboard and .mat dumps of the reference are out of scope.  Returns a dict with the loss history,
-    the validation records, the model, the diffusion wrapper and the EMA weights."""
+    reverse pass), gradient all-reduce when torch.distributed is initialised (DDP of config 5: one process per GPU, RCCL; parameters
+    broadcast from rank 0 at start, every epoch's permutation sharded by rank), then clip 0.003 + AdamW(lr, weight_decay 1e-4) +
+    EMA(0.995 after `ema_start_iter`) as the fused three-launch optimizer step, MultiStepLR.  Every `valid_every` iterations: DDIM-25
+    sampling of one validation batch on a SEPARATE diffusion object holding the EMA weights (the reference validates on
+    `ema_updater.ema_model`, a deep copy, :277-329 -- the training schedule is never respaced) with SAM / ERGAS / PSNR / CC / SSIM from
+    `ddif_metrics`.  Every `save_every` iterations (rank 0): `diffusion_{name}_iter_{N}.pth` and `ema_diffusion_{name}_iter_{N}.pth` as bare
+    state_dicts like the reference (:333-340; `test_fn(weight_path=...)` loads either) plus `train_state_{name}_iter_{N}.pth` with the
+    optimizer moments, step, iteration and RNG states; `resume_state=<that file>` continues such a run bit-identically.
+    Plotting, tensorboard and .mat dumps of the reference are out of scope.  Returns a dict with the loss history, the validation records,
+    the model, the diffusion wrapper and the EMA weights."""
+    import random as _random
+
     import torch.distributed as dist
 
     if schedule_type != "cosine":
@@ -264,6 +296,8 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
     if show_recon:
         raise DdifError("engine_google: show_recon (matplotlib grids) is out of scope")
     dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)  # reference :78; the stateless ops launch on the current device
     name = dataset_name
     if name is None:
         if isinstance(train_dataset_path, dict):
@@ -276,45 +310,81 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
         add_n_channel = 3
     div = DIVISION[name]
     order = 1 if hisr else 0
-    net = UNetSR3(in_channel=image_n_channel, out_channel=image_n_channel, lms_channel=image_n_channel, pan_channel=add_n_channel, inner_channel=32,
-                  norm_groups=1, channel_mults=(1, 2, 2, 4), attn_res=(8,), dropout=0.2, image_size=64, self_condition=True).to(dev)
+    net_kw = dict(in_channel=image_n_channel, out_channel=image_n_channel, lms_channel=image_n_channel, pan_channel=add_n_channel, inner_channel=32,
+                  norm_groups=1, channel_mults=(1, 2, 2, 4), attn_res=(8,), dropout=0.2, image_size=64, self_condition=True)
+    net = UNetSR3(**net_kw).to(dev)
     if pretrain_weight is not None:
         sd = torch.load(pretrain_weight[0] if isinstance(pretrain_weight, (list, tuple)) else pretrain_weight, map_location="cpu")
-        net.load_state_dict(sd.get("model", sd) if isinstance(sd, dict) else sd, strict=isinstance(pretrain_weight, (list, tuple)))
+        net.load_state_dict(sd.get("model", sd) if isinstance(sd, dict) and "model" in sd else sd, strict=isinstance(pretrain_weight, (list, tuple)))
     diffusion = GaussianDiffusion(net, image_size=image_size, channels=image_n_channel, pred_mode="x_start", loss_type="l1", device=dev, clamp_range=(0, 1))
     diffusion.set_new_noise_schedule(betas=make_beta_schedule(schedule="cosine", n_timestep=n_steps, cosine_s=8e-3), device=dev)
-    train = _Batches(_open_set(train_dataset_path), batch_size, shuffle=True)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    train = _Batches(_open_set(train_dataset_path), batch_size, shuffle=True, rank=rank, world=world, seed=data_seed)
     valid = _Batches(_open_set(valid_dataset_path), 16, shuffle=False) if valid_dataset_path is not None else None
     params = [p for p in net.parameters()]
     grads = [torch.zeros_like(p) for p in params]
     for p, g in zip(params, grads):
         p.grad = g  # autograd accumulates in place: the fused optimizer keeps these pointers
+    if world > 1:
+        broadcast_parameters(params)  # DDP: every replica starts from rank 0's initialisation
+        net.mark_weights_dirty()
     ema = [p.detach().clone() for p in params]
     opt = _rt.FusedAdamW(params, grads, ema, lr=lr_d, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     iterations = int(pretrain_iterations) if pretrain_iterations is not None else 0
     history, records = [], []
+    names = [n for n, _ in net.named_parameters()]
+    if resume_state is not None:
+        st = torch.load(resume_state, map_location="cpu", weights_only=False) if isinstance(resume_state, (str, os.PathLike)) else resume_state
+        with torch.no_grad():
+            for n, p, e in zip(names, params, ema):
+                p.copy_(st["model"][n])
+                e.copy_(st["ema"][n])
+        net.mark_weights_dirty()
+        opt.load_state_dict(st["optimizer"])
+        iterations = int(st["iterations"])
+        train.epoch = int(st.get("epoch", 0))
+        torch.set_rng_state(st["rng"]["torch"])
+        _random.setstate(st["rng"]["python"])
+        if dev.type == "cuda" and st["rng"].get("cuda") is not None:
+            torch.cuda.set_rng_state(st["rng"]["cuda"], dev)
+
+    # validation runs on its own network + diffusion (the reference's `ema_model` deep copy): ddim_sample_loop respaces ITS schedule
+    # (3000 -> 25, in place, once); the training diffusion's schedule is never touched
+    val = {}
 
     def validate():
+        if not val:
+            vnet = UNetSR3(**net_kw).to(dev).eval()
+            vdiff = GaussianDiffusion(vnet, image_size=image_size, channels=image_n_channel, pred_mode="x_start", loss_type="l1", device=dev, clamp_range=(0, 1))
+            vdiff.set_new_noise_schedule(betas=make_beta_schedule(schedule="cosine", n_timestep=n_steps, cosine_s=8e-3), device=dev)
+            val["net"], val["diffusion"] = vnet, vdiff
+        vnet, vdiff = val["net"], val["diffusion"]
+        with torch.no_grad():
+            for p, e in zip(vnet.parameters(), ema):
+                p.copy_(e)
+        vnet.mark_weights_dirty()
         pan, lms, gt = next(iter(valid))
         lms, pan, gt = lms.to(dev), pan.to(dev), gt.to(dev)
         cond = _rt.cond_assemble(lms, pan, div, wavelet_order=order)
-        keep = [p.detach().clone() for p in params]
-        was_training = net.training
-        try:
-            with torch.no_grad():
-                for p, e in zip(params, ema):
-                    p.copy_(e)
-                net.eval()
-                sr = diffusion(cond, mode="ddim_sample", section_counts="ddim25")
-                sr = (sr + cond[:, :image_n_channel]).clip(0, 1)
-        finally:
-            with torch.no_grad():
-                for p, k in zip(params, keep):
-                    p.copy_(k)
-            net.train(was_training)
-        m = _rt.metrics((gt / div).contiguous(), sr.contiguous(), ergas_ratio=4.0).mean(dim=0).cpu()
-        return {"SAM": float(m[0]), "ERGAS": float(m[1]), "PSNR": float(m[2]), "CC": float(m[3])}
+        with torch.no_grad():
+            sr = vdiff(cond, mode="ddim_sample", section_counts="ddim25")
+            sr = (sr + cond[:, :image_n_channel]).clip(0, 1)
+        gtn = (gt / div).contiguous()
+        m = _rt.metrics(gtn, sr.contiguous(), ergas_ratio=4.0).mean(dim=0).cpu()
+        ssim = float(_rt.ssim(gtn, sr.contiguous()).mean().cpu())
+        return {"SAM": float(m[0]), "ERGAS": float(m[1]), "PSNR": float(m[2]), "CC": float(m[3]), "SSIM": ssim}
+
+    def save(it):
+        os.makedirs(save_dir, exist_ok=True)
+        model_sd = {n: p.detach().cpu().clone() for n, p in zip(names, params)}
+        ema_sd = {n: e.detach().cpu().clone() for n, e in zip(names, ema)}
+        torch.save(model_sd, os.path.join(save_dir, f"diffusion_{name}_iter_{it}.pth"))      # bare state_dicts, reference :333-340
+        torch.save(ema_sd, os.path.join(save_dir, f"ema_diffusion_{name}_iter_{it}.pth"))
+        torch.save({"model": model_sd, "ema": ema_sd, "optimizer": opt.state_dict(), "iterations": it, "epoch": train.epoch,
+                    "rng": {"torch": torch.get_rng_state(), "python": _random.getstate(),
+                            "cuda": torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None}},
+                   os.path.join(save_dir, f"train_state_{name}_iter_{it}.pth"))
 
     net.train()
     while iterations < max_iterations:
@@ -330,19 +400,21 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
             if world > 1:
                 average_gradients(grads, world)
             opt.lr = lr_at(iterations, lr_d)
-            mode = 2 if iterations >= ema_start_iter else 1  # EmaUpdater: copy before start_iter, lerp after (utils/optim_utils.py:43-58)
+            # EmaUpdater.update(iterations) runs BEFORE `iterations += 1` (reference :239-242): copy while that 0-based count <= start_iter, lerp after
+            mode = 2 if iterations > ema_start_iter else 1
             gn = opt.step(max_grad_norm=0.003, ema_mode=mode, ema_decay=0.995, return_norm=True)
             iterations += 1
+            net.mark_weights_dirty()  # the fused step wrote the parameters through raw pointers
             history.append(float(diff_loss.detach()))
             log(f"[iter {iterations}/{max_iterations}: d_lr {opt.lr: .6f}] - denoise loss {history[-1]:.6f} (grad norm {gn:.4f})")
             if valid is not None and valid_every and iterations % valid_every == 0:
                 rec = validate()
                 records.append((iterations, rec))
                 log(f"[iter {iterations}] validation: {rec}")
-            if save_dir and iterations % 5_000 == 0:
-                os.makedirs(save_dir, exist_ok=True)
-                torch.save({"model": net.state_dict(), "ema": [e.cpu() for e in ema], "iterations": iterations}, os.path.join(save_dir, f"diffusion_{name}_iter_{iterations}.pth"))
+            if save_dir and save_every and iterations % save_every == 0 and rank == 0:
+                save(iterations)
             if iterations >= max_iterations:
                 break
     net.eval()
-    return {"loss": history, "validation": records, "model": net, "diffusion": diffusion, "ema": ema, "iterations": iterations}
+    return {"loss": history, "validation": records, "model": net, "diffusion": diffusion, "ema": ema, "iterations": iterations,
+            "optimizer": opt}

@@ -99,6 +99,12 @@ class UNetSR3(nn.Module):
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def mark_weights_dirty(self):
+        """The parameters were written behind torch's back (raw-pointer kernels such as the fused optimizer step): the packed copy the
+        library holds is stale and is rebuilt at the next forward / sampler call.  (`FusedAdamW.step` also bumps the version counters the
+        signature is made of; this is the explicit form for any other writer.)"""
+        self._weights_sig = None
+
     def pe_freqs(self) -> torch.Tensor:
         """exp(-ln(1e4) * j / count) evaluated with torch on the CPU exactly as PositionalEncoding does
         (models/sr3_dwt.py:229-236), so the kernels use bit-identical frequencies."""

@@ -53,7 +53,8 @@ class DpmTables(C.Structure):
 
 class ProfResult(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flop", C.c_double),
-                ("total_bytes", C.c_double), ("kernel_name", C.c_char * 128)]
+                ("total_bytes", C.c_double), ("kernel_name", C.c_char * 128), ("steps_recorded", C.c_int64),
+                ("launches_per_step", C.c_int64)]
 
 
 class ProfClass(C.Structure):
@@ -101,11 +102,14 @@ class _Lib:
         d.ddif_prof_collect.argtypes = [vp, C.POINTER(ProfResult)]
         d.ddif_prof_classes.argtypes = [vp, C.POINTER(ProfClass)]
         d.ddif_plan_cost.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
+        d.ddif_plan_num_launches.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
         d.ddif_debug_set_grid_cap.argtypes = [i32]
         d.ddif_plan_memory.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         d.ddif_cond_assemble.argtypes = [vp, vp, f32, i32, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_metrics.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
+        d.ddif_ssim.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
         d.ddif_optim_create.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32]
+        d.ddif_optim_create_ex.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32]
         d.ddif_optim_destroy.argtypes = [vp]
         d.ddif_optim_destroy.restype = None
         d.ddif_optim_step.argtypes = [vp, f32, f32, f32, f32, f32, C.c_int64, f32, i32, f32, C.POINTER(C.c_float), vp]
@@ -459,7 +463,13 @@ class PlanHandle:
         classes = [dict(name=c.name.decode(), launches=c.launches, total_ms=c.total_ms, total_flop=c.total_flop, total_bytes=c.total_bytes)
                    for c in cls]
         return dict(launches=r.launches, total_ms=r.total_ms, total_flop=r.total_flop, total_bytes=r.total_bytes,
-                    kernel=r.kernel_name.decode(), classes=classes)
+                    kernel=r.kernel_name.decode(), classes=classes, steps_recorded=int(r.steps_recorded),
+                    launches_per_step=int(r.launches_per_step))
+
+    def num_launches(self) -> dict:
+        a, b = C.c_int(), C.c_int()
+        self.lib.check(self.lib.dll.ddif_plan_num_launches(self.h, C.byref(a), C.byref(b)), "ddif_plan_num_launches")
+        return dict(step=a.value, cond=b.value)
 
     def memory(self) -> dict:
         v = [C.c_int64() for _ in range(3)]
@@ -502,9 +512,27 @@ def metrics(gt: torch.Tensor, pred: torch.Tensor, ergas_ratio: float = 4.0) -> t
     return out
 
 
+def ssim(gt: torch.Tensor, pred: torch.Tensor, data_range: float = 2.0) -> torch.Tensor:
+    """(B,) SSIM per image = skimage.metrics.structural_similarity(gt[b], pred[b], channel_axis=0) with library defaults (reference
+    utils/metric.py:153-166).  data_range 2.0 is what skimage derives for float images when none is given (dtype range (-1, 1)), which is
+    how the reference calls it.  skimage is not in the build image: parity-unpinned restatement."""
+    lib = get_lib()
+    _check_tensor(lib, gt, "gt")
+    _check_tensor(lib, pred, "pred")
+    _check_shape(pred, "pred", tuple(gt.shape))
+    B, Cc, H, W = gt.shape
+    gt, pred = gt.contiguous(), pred.contiguous()
+    out = torch.empty((B,), dtype=torch.float32, device=gt.device)
+    lib.check(lib.dll.ddif_ssim(_ptr(gt), _ptr(pred), B, Cc, H, W, float(data_range), _ptr(out), _stream(lib, gt.device)), "ddif_ssim")
+    return out
+
+
 class FusedAdamW:
     """clip_grad_norm_ + torch.optim.AdamW.step + EmaUpdater.update as three launches (reference diffusion_engine.py:237-241).
-    `params`, `grads` (and `ema`, optional) are lists of contiguous fp32 tensors that stay alive and in place."""
+    `params`, `grads` (and `ema`, optional) are lists of contiguous fp32 tensors that stay alive and in place.  The moments (exp_avg,
+    exp_avg_sq) are torch tensors owned by this object, so `state_dict()` / `load_state_dict()` make the optimizer checkpointable.
+    The kernels write the parameters through raw pointers: `step()` bumps the tensors' version counters so that anything keyed on
+    `Tensor._version` (UNetSR3's packed-weight cache) sees the update."""
 
     def __init__(self, params, grads, ema=None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.lib = get_lib()
@@ -515,16 +543,20 @@ class FusedAdamW:
             if not (p.is_contiguous() and g.is_contiguous()) or p.numel() != g.numel():
                 raise DdifError(f"param[{i}] / grad[{i}] must be contiguous and of equal size")
         n = len(self.params)
+        self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         sizes = (C.c_int64 * n)(*[p.numel() for p in self.params])
         pp = (C.c_void_p * n)(*[p.data_ptr() for p in self.params])
         gp = (C.c_void_p * n)(*[g.data_ptr() for g in self.grads])
+        mp = (C.c_void_p * n)(*[m.data_ptr() for m in self.exp_avg])
+        vp = (C.c_void_p * n)(*[v.data_ptr() for v in self.exp_avg_sq])
         ep = None
         if self.ema is not None:
             ep = (C.c_void_p * n)(*[e.data_ptr() for e in self.ema])
         dev = self.params[0].device
         idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
         h = C.c_void_p()
-        self.lib.check(self.lib.dll.ddif_optim_create(C.byref(h), n, sizes, pp, gp, ep, idx), "ddif_optim_create")
+        self.lib.check(self.lib.dll.ddif_optim_create_ex(C.byref(h), n, sizes, pp, gp, ep, mp, vp, idx), "ddif_optim_create_ex")
         self.h, self.device = h, dev
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.t = 0
@@ -535,7 +567,26 @@ class FusedAdamW:
         self.lib.check(self.lib.dll.ddif_optim_step(self.h, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
                                                     float(max_grad_norm), int(ema_mode), float(ema_decay),
                                                     C.byref(gn) if return_norm else None, _stream(self.lib, self.device)), "ddif_optim_step")
+        _bump_versions(self.params)
+        if self.ema is not None and ema_mode:
+            _bump_versions(self.ema)
         return gn.value if return_norm else None
+
+    def state_dict(self) -> dict:
+        """torch.optim.AdamW-shaped state: per-parameter exp_avg / exp_avg_sq (in `params` order) + the step count and hyper-parameters."""
+        return {"step": self.t, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                "exp_avg": [m.detach().cpu().clone() for m in self.exp_avg], "exp_avg_sq": [v.detach().cpu().clone() for v in self.exp_avg_sq]}
+
+    def load_state_dict(self, sd: dict):
+        if len(sd["exp_avg"]) != len(self.exp_avg) or len(sd["exp_avg_sq"]) != len(self.exp_avg_sq):
+            raise DdifError("FusedAdamW.load_state_dict: the state holds a different number of tensors")
+        with torch.no_grad():
+            for dst, src in zip(self.exp_avg + self.exp_avg_sq, list(sd["exp_avg"]) + list(sd["exp_avg_sq"])):
+                if tuple(dst.shape) != tuple(src.shape):
+                    raise DdifError("FusedAdamW.load_state_dict: moment shape mismatch")
+                dst.copy_(src)  # in place: the handle keeps these pointers
+        self.t = int(sd["step"])
+        self.lr, self.betas, self.eps, self.weight_decay = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
 
     def __del__(self):
         try:
@@ -544,6 +595,18 @@ class FusedAdamW:
                 self.h = None
         except Exception:
             pass
+
+
+def _bump_versions(tensors):
+    """The library wrote these tensors through raw pointers: tell torch (version counters) so caches keyed on `_version` invalidate."""
+    inc = getattr(torch._C, "_increment_version", None)
+    if inc is None:  # pragma: no cover
+        raise DdifError("torch._C._increment_version is missing: cannot signal in-place parameter updates")
+    try:
+        inc(list(tensors))  # torch >= 2.3: an iterable of tensors (a bare tensor would be iterated row by row)
+    except TypeError:
+        for t in tensors:
+            inc(t)
 
 
 class Conv3x3Backward:

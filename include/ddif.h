@@ -165,6 +165,11 @@ DDIF_API int ddif_cond_assemble(const float* lms_raw, const float* pan_raw, floa
  * out: device, B*4 floats.  The reference's quirks are kept: last row / column dropped, pi = 3.14159256, SAM rounded to
  * 6 digits, PSNR = -20 log10(1/rmse). */
 DDIF_API int ddif_metrics(const float* gt, const float* pred, int B, int C, int H, int W, float ergas_ratio, float* out, void* stream);
+/* SSIM per image (out: B floats) as `skimage.metrics.structural_similarity(gt, pred, channel_axis=0)` computes it with library defaults
+ * (reference utils/metric.py:153-166): 7x7 uniform window, K1 0.01, K2 0.03, sample covariance, mean over the image cropped by 3 pixels
+ * per side and over the channels.  data_range: the reference passes none, for which skimage takes the float dtype range (-1, 1) -> 2.0.
+ * PARITY UNPINNED: skimage is absent from the build image; the oracle restates the published algorithm. */
+DDIF_API int ddif_ssim(const float* gt, const float* pred, int B, int C, int H, int W, float data_range, float* out, void* stream);
 
 /* Fused optimizer step of the training loop (diffusion_engine.py:237-241): global-norm gradient clipping
  * (utils/misc.py:25-36 -> clip_grad_norm_), torch.optim.AdamW.step and EmaUpdater.update (utils/optim_utils.py:43-58) as
@@ -174,6 +179,11 @@ DDIF_API int ddif_metrics(const float* gt, const float* pred, int B, int C, int 
 typedef struct ddif_optim* ddif_optim_t;
 DDIF_API int ddif_optim_create(ddif_optim_t* out, int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
                                float* const* ema, int device);
+/* Same with CALLER-OWNED moment buffers (exp_avg / exp_avg_sq of torch.optim.AdamW, one device array per tensor, borrowed for the handle's
+ * lifetime and not zeroed): the optimizer state then lives where a checkpoint can save and restore it (reference diffusion_engine.py:333-340
+ * saves weights only; full-state resume is SURVEY 8f-4). */
+DDIF_API int ddif_optim_create_ex(ddif_optim_t* out, int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
+                                  float* const* ema, float* const* exp_avg, float* const* exp_avg_sq, int device);
 DDIF_API void ddif_optim_destroy(ddif_optim_t h);
 /* step: 1-based AdamW step count; max_grad_norm <= 0 disables clipping; ema_mode 0 = leave ema alone, 1 = ema <- p
  * (iteration <= start_iter), 2 = ema <- ema*decay + p*(1-decay); grad_norm_host (nullable) receives the pre-clip global
@@ -287,9 +297,9 @@ DDIF_API int ddif_l1_loss_fwd(const float* pred, const float* target, int64_t n,
 
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 
-/* Bracket launches of the dominant kernel class (3x3 implicit-GEMM convolutions of the denoising step) with HIP
- * events on the launch stream: every launch inside one denoising step out of `every_n_steps`.  Collect after the
- * stream has been synchronised. */
+/* Bracket EVERY launch of one denoising step out of `every_n_steps` with HIP events on the launch stream.  A step is either
+ * profiled completely or not at all: when fewer than one step's worth of the `max_events` event pairs are left, profiling
+ * stops, and `steps_recorded` says how many whole steps the sums cover.  Collect after the stream has been synchronised. */
 DDIF_API int ddif_prof_begin(ddif_plan_t plan, int every_n_steps, int max_events);
 typedef struct ddif_prof_result {
     int64_t launches;        /* timed launches */
@@ -297,6 +307,8 @@ typedef struct ddif_prof_result {
     double total_flop;       /* algorithmic flops of the timed launches (2*M*N*K, unpadded) */
     double total_bytes;      /* algorithmic activation bytes read + written by them */
     char kernel_name[128];
+    int64_t steps_recorded;  /* whole denoising steps the sums (and ddif_prof_classes) cover */
+    int64_t launches_per_step; /* launches of the step program (event pairs one profiled step consumes) */
 } ddif_prof_result;
 DDIF_API int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out);
 /* Per-class breakdown of the same profiled steps (EVERY launch of a profiled step is bracketed): six entries -- 3x3 convs and
@@ -308,6 +320,8 @@ typedef struct ddif_prof_class {
     char name[64];
 } ddif_prof_class;
 DDIF_API int ddif_prof_classes(ddif_plan_t plan, ddif_prof_class* out6);
+/* launches of the step program (one denoising step = this many event pairs when profiled) and of the set_cond program */
+DDIF_API int ddif_plan_num_launches(ddif_plan_t plan, int* step_launches, int* cond_launches);
 
 /* flops / bytes of one denoising step and of set_cond for this plan (algorithmic, SURVEY.md 8d accounting) */
 DDIF_API int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_bytes, double* cond_flop, double* cond_bytes);

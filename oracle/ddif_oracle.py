@@ -587,6 +587,31 @@ def analysis_accu(img_base: Tensor, img_out: Tensor, ratio: float = 4.0) -> Dict
     return dict(SAM=float(sam), ERGAS=float(ergas), PSNR=float(psnr_), CC=float(cc))
 
 
+def ssim_skimage(gt: Tensor, pred: Tensor, data_range: float = 2.0, win_size: int = 7, k1: float = 0.01, k2: float = 0.03) -> float:
+    """`skimage.metrics.structural_similarity(gt, pred, channel_axis=0)` (utils/metric.py:153-157) restated from the published algorithm
+    (Wang et al. 2004 as implemented by scikit-image `_structural_similarity.py`): per channel, uniform `win_size` filter of x, y, x*x, y*y,
+    x*y (scipy.ndimage.uniform_filter, mode "reflect", as the library does), sample covariance (NP / (NP - 1)), S map, mean over the map
+    cropped by (win_size - 1) // 2 per side; mean over channels.  data_range: the reference passes none; for float images scikit-image
+    <= 0.21 then uses the dtype range (-1, 1) -> 2.0.  PARITY UNPINNED: skimage is not installed in the build image."""
+    from scipy.ndimage import uniform_filter
+
+    x = gt.detach().cpu().numpy().astype(np.float64)
+    y = pred.detach().cpu().numpy().astype(np.float64)
+    npix = win_size ** 2
+    cov_norm = npix / (npix - 1.0)
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    pad = (win_size - 1) // 2
+    vals = []
+    for ch in range(x.shape[0]):
+        a, b = x[ch], y[ch]
+        ux, uy = uniform_filter(a, size=win_size), uniform_filter(b, size=win_size)
+        uxx, uyy, uxy = uniform_filter(a * a, size=win_size), uniform_filter(b * b, size=win_size), uniform_filter(a * b, size=win_size)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        smap = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+        vals.append(smap[pad:-pad, pad:-pad].mean())
+    return float(np.mean(vals))
+
+
 def optimizer_steps(params: List[Tensor], grads_per_step: List[List[Tensor]], lr=1e-4, weight_decay=1e-4, max_norm=0.003,
                     ema_decay=0.995, ema_start_iter=1):
     """The reference's update sequence (diffusion_engine.py:237-241): clip_grad_norm_ (utils/misc.py:33-34),

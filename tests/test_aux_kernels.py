@@ -266,3 +266,85 @@ def test_conv_op_backward_variants_match_autograd(backend, ks, pro, resample, sh
     for nm, ref in want.items():
         err = float((got[nm].cpu() - ref).abs().max())
         assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (nm, err, float(ref.abs().max()))
+
+
+def test_ssim_oracle_properties():
+    """The SSIM restatement (oracle.ssim_skimage; skimage itself is absent -> parity unpinned) against what the published
+    definition fixes: identical images give exactly 1; two constant images give the luminance term alone (both variances are 0);
+    symmetry; and the crop of 3 pixels per side means the border never enters."""
+    gen = torch.Generator().manual_seed(11)
+    a = torch.rand(3, 20, 22, generator=gen)
+    b = (a + 0.1 * torch.randn(3, 20, 22, generator=gen)).clamp(0, 1)
+    assert abs(O.ssim_skimage(a, a) - 1.0) <= 1e-12
+    assert abs(O.ssim_skimage(a, b) - O.ssim_skimage(b, a)) <= 1e-12
+    ca, cb = torch.full((2, 9, 9), 0.25), torch.full((2, 9, 9), 0.75)
+    c1 = (0.01 * 2.0) ** 2
+    want = (2 * 0.25 * 0.75 + c1) / (0.25 ** 2 + 0.75 ** 2 + c1)
+    assert abs(O.ssim_skimage(ca, cb) - want) <= 1e-9
+    b2 = b.clone()
+    b2[:, :3], b2[:, -3:], b2[:, :, :3], b2[:, :, -3:] = 0.0, 0.0, 0.0, 0.0  # (only windows centred in the interior count, and they reach 3 px out)
+    inner_a, inner_b = a[:, 3:-3, 3:-3], b[:, 3:-3, 3:-3]
+    assert O.ssim_skimage(a, b2) != O.ssim_skimage(a, b)  # the outer ring IS inside the 7x7 windows of the first interior pixels
+    assert 0.0 < O.ssim_skimage(inner_a, inner_b) < 1.0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_ssim_kernel_matches_oracle(backend):
+    from ddif import runtime
+
+    dev = _dev(backend)
+    gen = torch.Generator().manual_seed(12)
+    gt = torch.rand(3, 8, 33, 35, generator=gen)
+    pred = (gt + 0.05 * torch.randn(3, 8, 33, 35, generator=gen)).clamp(0, 1)
+    pred[2] = gt[2]
+    got = runtime.ssim(gt.to(dev), pred.to(dev)).cpu()
+    for b in range(3):
+        assert abs(float(got[b]) - O.ssim_skimage(gt[b], pred[b])) <= 2e-6, b
+    assert float(got[2]) == 1.0
+    got1 = runtime.ssim(gt.to(dev), pred.to(dev), data_range=1.0).cpu()
+    assert abs(float(got1[0]) - O.ssim_skimage(gt[0], pred[0], data_range=1.0)) <= 2e-6
+    with pytest.raises(runtime.DdifError):
+        runtime.ssim(gt[:, :, :6].contiguous().to(dev), pred[:, :, :6].contiguous().to(dev))  # smaller than the 7x7 window
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fused_adamw_state_is_checkpointable_and_signals_updates(backend):
+    """The optimizer's moments are torch tensors (ddif_optim_create_ex borrows them): state_dict() / load_state_dict() continue a run bit for
+    bit; and step() bumps the parameters' version counters -- the signature UNetSR3 keys its packed weights on (the fused step
+    writes through raw pointers)."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    gen = torch.Generator().manual_seed(13)
+    shapes = [(5, 3), (7,), (2, 3, 3, 3)]
+
+    def fresh():
+        g2 = torch.Generator().manual_seed(14)
+        ps = [torch.randn(s, generator=g2).to(dev) for s in shapes]
+        gs = [torch.zeros_like(p) for p in ps]
+        es = [p.clone() for p in ps]
+        return ps, gs, es, runtime.FusedAdamW(ps, gs, es, lr=1e-2, weight_decay=1e-2)
+
+    grads = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(4)]
+    ps, gs, es, opt = fresh()
+    v0 = [p._version for p in ps]
+    for k in range(4):
+        for g, src in zip(gs, grads[k]):
+            g.copy_(src.to(dev))
+        opt.step(max_grad_norm=1.0, ema_mode=2, ema_decay=0.9)
+        if k == 1:
+            saved = opt.state_dict()
+            saved_p, saved_e = [p.clone() for p in ps], [e.clone() for e in es]
+    assert all(p._version > v for p, v in zip(ps, v0))
+    assert saved["step"] == 2 and float(saved["exp_avg"][0].abs().max()) > 0
+    ps2, gs2, es2, opt2 = fresh()
+    for p, e, sp, se in zip(ps2, es2, saved_p, saved_e):
+        p.copy_(sp)
+        e.copy_(se)
+    opt2.load_state_dict(saved)
+    for k in (2, 3):
+        for g, src in zip(gs2, grads[k]):
+            g.copy_(src.to(dev))
+        opt2.step(max_grad_norm=1.0, ema_mode=2, ema_decay=0.9)
+    for a, b in zip(ps + es, ps2 + es2):
+        assert torch.equal(a, b)

@@ -84,11 +84,13 @@ def _run_train(rank, world, port, q):
     if world > 1:
         E.average_gradients(g, world)
         assert torch.equal(g[0], torch.full((3, 2), 1.5)) and torch.equal(g[1], torch.full((5,), 15.0))
-    # one training iteration of engine_google: same initial weights and masks (same torch seed) on both ranks, DIFFERENT data per rank
-    t = synth_tiles(1, 4, 1, 8, 8, seed=50 + rank)
+    # one training iteration of engine_google as DDP runs it: the SAME two-sample set on both ranks (the per-epoch permutation is sharded by
+    # rank: one sample each) and DIFFERENT torch seeds per rank (different default initialisation, different masks): the rank-0 broadcast
+    # must make the replicas identical before the step, the gradient average must keep them identical after it
+    t = synth_tiles(2, 4, 1, 8, 8, seed=50)
     data = {"gt": (t["gt"] * 1023.0).numpy(), "lms": (t["lms"] * 1023.0).numpy(), "pan": (t["pan"] * 1023.0).numpy()}
-    torch.manual_seed(9)
-    random.seed(9)
+    torch.manual_seed(9 + 100 * rank)
+    random.seed(9 + 100 * rank)
     out = E.engine_google(data, None, dataset_name="gf2", image_n_channel=4, image_size=8, n_steps=20, max_iterations=1, device="cpu", batch_size=1,
                           lr_d=1e-2, valid_every=0, log=lambda *_: None)
     names = ["downs.0.weight", "mid.0.attn.qkv.weight", "ups.0.cond_inj.ffn.3.weight", "final_conv.block.3.bias"]
@@ -100,8 +102,9 @@ def _run_train(rank, world, port, q):
 
 
 def test_two_rank_training_step_averages_gradients_and_keeps_the_replicas_identical():
-    """Config 5 (DDP): two ranks start from the same weights, see different samples, all-reduce their gradients (gloo here, RCCL on the
-    GPUs) and take the same optimizer step: their weights must stay bit-identical, while their losses differ (different data)."""
+    """Config 5 (DDP): two ranks initialise with different seeds, receive rank 0's parameters (broadcast), see disjoint shards of the same
+    set, all-reduce their gradients (gloo here, RCCL on the GPUs) and take the same optimizer step: their weights must be bit-identical
+    after it, while their losses differ (different samples)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_run_train, args=(r, 2, 29621, q)) for r in range(2)]
@@ -115,3 +118,24 @@ def test_two_rank_training_step_averages_gradients_and_keeps_the_replicas_identi
     assert loss0 != loss1
     for n in w0:
         assert (w0[n] == w1[n]).all(), n
+
+
+def test_epoch_permutation_is_sharded_by_rank():
+    """_Batches with world > 1: every rank derives the SAME permutation from (seed, epoch) and takes order[rank::world] -- disjoint, together
+    the whole (even part of the) set, different from epoch to epoch, independent of the ranks' own torch RNG state."""
+    import numpy as np
+
+    import ddif.diffusion_engine as E
+
+    n = 10
+    data = {"gt": np.arange(n, dtype=np.float32).reshape(n, 1, 1, 1), "lms": np.zeros((n, 1, 1, 1), np.float32), "pan": np.zeros((n, 1, 1, 1), np.float32)}
+    seen = []
+    for rank in range(3):
+        torch.manual_seed(1000 * rank)  # must not matter
+        b = E._Batches(data, 2, shuffle=True, rank=rank, world=3, seed=4)
+        e0 = [int(v) for _, _, gt in b for v in gt.reshape(-1)]
+        e1 = [int(v) for _, _, gt in b for v in gt.reshape(-1)]
+        assert len(e0) == 3 and e0 != e1
+        seen.append(e0)
+    flat = sum(seen, [])
+    assert len(set(flat)) == 9  # 10 // 3 * 3 samples, each exactly once

@@ -188,3 +188,74 @@ def test_ddpm_T1000_batch64_every_tile_matches_the_reference_golden(net):
     sr_hip, sr_ref = (out[:1].cpu() + lms).clip(0, 1), (ref + lms).clip(0, 1)
     assert abs(O.psnr(sr_hip, tiles["gt"]) - O.psnr(sr_ref, tiles["gt"])) <= 1e-3  # north-star PSNR tolerance (dB)
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------- the benchmark's own random stream / solver at B = 64
+def test_ddpm_device_rng_batch64_equals_per_tile_runs(net):
+    """`bench.py` samples with the on-device counter-based generator (x_T and the per-step noise from Philox keyed by the GLOBAL tile
+    index, randn_nhwc_kernel / ddpm_step_kernel): a tile of the batch-64 job must be bit-equal to the same tile sampled alone with
+    `tile0 = b` -- what a tile-sharded multi-GPU run relies on."""
+    B, H, T = 64, 64, 6
+    cond = gc.tiles_for("wv3", B, H, H, seed=41)["cond"].to(DEV)
+    d = make_diffusion(net, 8, T, H, DEV)
+    full = d(cond, mode="ddpm_sample", seed=77, tile0=0, device_rng=True)
+    assert torch.isfinite(full).all() and float(full.std()) > 0
+    for b in SPOT:
+        one = d(cond[b:b + 1].contiguous(), mode="ddpm_sample", seed=77, tile0=b, device_rng=True)
+        assert torch.equal(one[0], full[b]), f"tile {b}"
+    other = d(cond, mode="ddpm_sample", seed=78, tile0=0, device_rng=True)
+    assert not torch.equal(other, full)  # the seed matters
+
+
+def test_device_randn_moments():
+    """Moments of the generator behind the throughput runs (Philox4x32-10 + Box-Muller, csrc/kernels_misc.h randn_nhwc_kernel) over the
+    64 x 8 x 64^2 draws of one x_T of the benchmark: mean, variance, skewness, excess kurtosis within 5 sigma of N(0, 1), and no two
+    tiles alike.  The draw is reached through the public sampler: T = 1 with coefficients (0, 1, 0) returns x_T itself."""
+    B, H = 64, 64
+    net = make_net("wv3", DEV)
+    plan = net.plan_for(B, H, H, torch.device(DEV))
+    plan.set_cond(gc.tiles_for("wv3", B, H, H, seed=43)["cond"].to(DEV))
+    x = plan.sample_ddpm([0.0], [0.0], [1.0], [0.0], None, None, 12345, 0, None, torch.device(DEV)).double().cpu()
+    n = x.numel()
+    m, v = float(x.mean()), float(x.var())
+    z = (x - m) / v ** 0.5
+    skew, kurt = float((z ** 3).mean()), float((z ** 4).mean()) - 3.0
+    assert abs(m) <= 5 / n ** 0.5 and abs(v - 1) <= 5 * (2 / n) ** 0.5, (m, v)
+    assert abs(skew) <= 5 * (6 / n) ** 0.5 and abs(kurt) <= 5 * (24 / n) ** 0.5, (skew, kurt)
+    assert float(x.abs().max()) < 7.0
+    flat = x.reshape(B, -1)
+    assert len({tuple(row[:8].tolist()) for row in flat}) == B  # every tile its own stream
+    c = torch.corrcoef(flat[:16])  # neighbouring tiles uncorrelated
+    assert float((c - torch.eye(16, dtype=c.dtype)).abs().max()) <= 6 / (flat.shape[1]) ** 0.5
+
+
+def test_dpm_solver_gf2_batch64_equals_single_tile_runs_and_oracle():
+    """BASELINE configs[2]'s per-GPU work: DPM-Solver++ 2M, 50 model evaluations, 64 GF2 tiles of 64x64 in one fused call.  Spot tiles
+    must be bit-equal to B = 1 runs (the reference itself only runs B = 1 here, SURVEY D-8) and two tiles within 1e-4 of the oracle."""
+    from ddif.solver.dpm_solver import DPM_Solver, ImageSpaceClamp, NoiseScheduleVP, model_wrapper
+
+    ds, B, H, T, steps = "gf2", 64, 64, 1000, 50
+    C = gc.DATASETS[ds][0]
+    gnet = make_net(ds, DEV)
+    d = make_diffusion(gnet, C, T, H, DEV)
+    tiles = gc.tiles_for(ds, B, H, H, seed=45)
+    cond = tiles["cond"].to(DEV)
+    xT = torch.randn(B, C, H, H, generator=torch.Generator().manual_seed(46))
+
+    def solve(cnd, x):
+        ns = NoiseScheduleVP("discrete", betas=d.betas)
+        fn = model_wrapper(gnet, ns, model_type="x_start", guidance_type="classifier-free", guidance_scale=1.0, condition=cnd)
+        slv = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(cnd[:, :C].contiguous(), 0.0, 1.0))
+        assert slv._fused_target() is not None
+        return slv.sample(x, steps=steps, order=2, skip_type="time_uniform", method="multistep")
+
+    full = solve(cond, xT.to(DEV))
+    assert torch.isfinite(full).all()
+    for b in SPOT:
+        one = solve(cond[b:b + 1].contiguous(), xT[b:b + 1].to(DEV))
+        assert torch.equal(one[0], full[b]), f"tile {b}"
+    sd, cfg = gc.weights_for(ds), gc.cfg_for(ds)
+    for b in (0, 63):
+        with torch.no_grad():
+            ref = O.dpmpp_multistep_sample(sd, cfg, tiles["cond"][b:b + 1], d.betas.cpu(), xT[b:b + 1], steps=steps, order=2)
+        assert float((full[b:b + 1].cpu() - ref).abs().max()) <= 1e-4, f"tile {b}"

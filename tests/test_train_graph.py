@@ -185,6 +185,74 @@ def test_engine_google_trains_and_validates_on_an_in_memory_set(backend):
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
+def test_engine_google_trains_on_after_validation_checkpoints_and_resumes(backend, tmp_path):
+    """ADVICE r2 + SURVEY 8f-4.  (1) Validation (DDIM-25 respaces ITS schedule in place) runs on a separate diffusion object holding the EMA
+    weights, as the reference validates on `ema_model`: training continues afterwards on the untouched n_steps schedule.  (2) The no-grad
+    self-conditioning pass sees the weights the fused optimizer just wrote (packed-weight cache invalidated).  (3) Checkpoints are the
+    reference's two bare state_dicts (+ a full-state file): `test_fn(weight_path=<ema file>)` loads one.  (4) Resuming from the full-state
+    file reproduces the uninterrupted run bit for bit (weights, EMA, losses)."""
+    import random
+
+    import ddif.diffusion_engine as E2
+
+    dev = _dev(backend)
+    train, valid = _raw_set(4, 8, 16, 1), _raw_set(2, 8, 16, 2)
+    kw = dict(dataset_name="wv3", image_n_channel=8, image_size=16, n_steps=50, device=str(dev), batch_size=2, lr_d=1e-3, valid_every=2,
+              ema_start_iter=1, log=lambda *_: None)
+
+    def seeded():
+        torch.manual_seed(5)
+        random.seed(5)
+        torch.cuda.manual_seed(5)
+
+    seeded()
+    a_dir = str(tmp_path / "a")
+    A = E2.engine_google(train, valid, max_iterations=4, save_dir=a_dir, save_every=2, **kw)
+    assert A["diffusion"].num_timesteps == 50 and A["diffusion"].betas.numel() == 50  # (1)
+    assert [it for it, _ in A["validation"]] == [2, 4]
+    assert all(np.isfinite(v) for _, rec in A["validation"] for v in rec.values()) and "SSIM" in A["validation"][0][1]
+    assert all(np.isfinite(A["loss"]))
+    # (2) the train-mode no-grad forward follows the optimizer: same inputs and masks, before and after one more fused step
+    net, d = A["model"], A["diffusion"]
+    net.train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 16, 16, generator=g).to(dev)
+    cond = gc.tiles_for("wv3", 2, 16, 16, seed=3)["cond"].to(dev)
+    t = torch.tensor([3, 30])
+
+    def nograd_forward():
+        torch.manual_seed(77)  # same masks both times
+        with torch.no_grad():
+            return net(x, t, cond, None).clone()
+
+    y0 = nograd_forward()
+    for p in net.parameters():
+        p.grad.normal_(generator=None)
+    A["optimizer"].step(max_grad_norm=0.0, ema_mode=0)
+    y1 = nograd_forward()
+    assert float((y1 - y0).abs().max()) > 0
+    net.eval()
+    # (3) reference checkpoint format
+    for it in (2, 4):
+        for stem in ("diffusion", "ema_diffusion", "train_state"):
+            assert os.path.exists(os.path.join(a_dir, f"{stem}_wv3_iter_{it}.pth")), (stem, it)
+    ema_sd = torch.load(os.path.join(a_dir, "ema_diffusion_wv3_iter_4.pth"), map_location="cpu")
+    assert set(ema_sd) == set(n for n, _ in net.named_parameters())
+    out = E2.test_fn(data=valid, weight_path=os.path.join(a_dir, "ema_diffusion_wv3_iter_4.pth"), n_steps=50, dataset_name="wv3", division=2047.0,
+                     device=str(dev), batch_size=2, seed=1)
+    assert out["sr"].shape == (2, 8, 16, 16) and np.isfinite(out["sr"]).all()
+    # (4) resume from iteration 2 == the uninterrupted run
+    st = torch.load(os.path.join(a_dir, "train_state_wv3_iter_2.pth"), map_location="cpu", weights_only=False)
+    final = torch.load(os.path.join(a_dir, "train_state_wv3_iter_4.pth"), map_location="cpu", weights_only=False)
+    torch.manual_seed(999)  # whatever the process state is now: the checkpoint carries the RNG
+    B = E2.engine_google(train, valid, max_iterations=4, resume_state=st, **kw)
+    assert B["iterations"] == 4 and B["loss"] == A["loss"][2:]
+    for (n, p), e in zip(B["model"].named_parameters(), B["ema"]):
+        assert torch.equal(p.detach().cpu(), final["model"][n]), n
+        assert torch.equal(e.cpu(), final["ema"][n]), n
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_reference_optimizer_lines_run_unchanged_on_the_drop_in(backend):
     """diffusion_engine.py:205-241 verbatim in spirit: torch.optim.AdamW over `denoise_fn.parameters()`, `opt.zero_grad()`,
     `diff_loss.backward()`, `clip_grad_norm_(…, 0.003)`, `opt.step()` -- two iterations; the loss must be finite, the clipped gradient norm
