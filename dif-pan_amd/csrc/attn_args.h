@@ -16,6 +16,7 @@ struct AttnBlockArgs {
     float* out;           // [B, 64, 128]
     double* st_out;       // [B][1][2] or null
     int B;
+    int b0;               // batch window [b0, b0 + B)
 };
 
 }  // namespace ddif

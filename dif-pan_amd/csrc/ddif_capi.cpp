@@ -33,7 +33,10 @@ struct DeviceScope {
     if (!dscope__.ok) return ddif::fail(DDIF_ERR_HIP, what ": hipSetDevice(%d) failed", (plan)->p.net->device);      \
     if ((plan)->p.generation != (plan)->p.net->generation)                                                            \
         return ddif::fail(DDIF_ERR_STATE, what ": the network's weights were re-committed after this plan was built " \
-                                               "(its launch program points into the old weight blob); create a new plan")
+                                               "(its launch program points into the old weight blob); create a new plan"); \
+    if ((plan)->p.net->merged_stale && !(plan)->p.train_mode)                                                         \
+        return ddif::fail(DDIF_ERR_STATE, what ": the weights were refreshed on the device for training (ddif_net_refresh), which leaves the "   \
+                                               "inference-only merged FFN weights stale; load + commit the weights again before inference")
 
 #define DDIF_GUARD_BEGIN try {
 #define DDIF_GUARD_END                                                                    \
@@ -77,6 +80,15 @@ int ddif_net_commit(ddif_net_t net, void* stream) {
     DeviceScope ds(net->n.device);
     if (!ds.ok) return ddif::fail(DDIF_ERR_HIP, "ddif_net_commit: hipSetDevice(%d) failed", net->n.device);
     return net->n.commit((hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_net_refresh(ddif_net_t net, int n, const char* const* keys, const float* const* params_dev, void* stream) {
+    DDIF_GUARD_BEGIN
+    if (!net) return ddif::fail(DDIF_ERR_INVALID, "ddif_net_refresh: NULL net");
+    DeviceScope ds(net->n.device);
+    if (!ds.ok) return ddif::fail(DDIF_ERR_HIP, "ddif_net_refresh: hipSetDevice(%d) failed", net->n.device);
+    return net->n.refresh_device(n, keys, params_dev, (hipStream_t)stream);
     DDIF_GUARD_END
 }
 

@@ -2,6 +2,8 @@
 // Layer list = UNetSR3.__init__ (reference models/sr3_dwt.py:69-163); checkpoint keys = SURVEY.md appendix C.
 #include "ddif_net.h"
 #include <cstdint>
+#include <tuple>
+#include "kernels_refresh.h"
 
 namespace ddif {
 
@@ -226,6 +228,33 @@ int Net::commit(hipStream_t stream) {
     std::vector<PendConv> pend;
     std::map<std::string, size_t> vec_off;
     std::string missing;
+    recipes.clear();
+    auto rec_pack = [&](int kind, const std::string& s0, const std::string& s1, size_t off, int cout, int cin0, int cin1, int ks, int ck, int n_chunks) {
+        Recipe r;
+        r.kind = kind;
+        r.src0 = s0;
+        r.src1 = s1;
+        r.dst_off = off;
+        r.cout = cout;
+        r.cin0 = cin0;
+        r.cin1 = cin1;
+        r.ks = ks;
+        r.ck = ck;
+        r.n_chunks = n_chunks;
+        const size_t nb_pad = (size_t)(((cout + 31) / 32 + 3) & ~3);
+        r.n_out = kind == RF_PACK_F32 ? nb_pad * n_chunks * ks * ks * (ck / 8) * 256 : nb_pad * n_chunks * ks * ks * (ck / 16) * 3 * 256;
+        recipes.push_back(r);
+    };
+    auto rec_copy = [&](int kind, const std::string& s0, const std::string& s1, size_t off, size_t n, int C = 0) {
+        Recipe r;
+        r.kind = kind;
+        r.src0 = s0;
+        r.src1 = s1;
+        r.dst_off = off;
+        r.n_out = n;
+        r.cout = C;
+        recipes.push_back(r);
+    };
 
     auto need = [&](const std::string& key) -> const HostTensor* {
         const HostTensor* t = get(key);
@@ -244,13 +273,21 @@ int Net::commit(hipStream_t stream) {
         p.ks = (int)w->shape[2];
         p.ck = (p.ks == 3 || p.cin <= 16) ? 16 : 32;  // 3x3: 16-channel chunks (A + W double-buffered = 65 KB of LDS)
         p.w_off = pack_conv(b, w->v.data(), p.cout, p.cin, p.ks, p.ck, &p.n_chunks);
-        if (p.ck % 16 == 0 && (p.ks == 3 || p.ck == 32)) p.x3_off = (long)pack_conv_x3(b, w->v.data(), p.cout, p.cin, p.ks, p.ck);
+        rec_pack(RF_PACK_F32, name + ".weight", "", p.w_off, p.cout, p.cin, 0, p.ks, p.ck, p.n_chunks);
+        if (p.ck % 16 == 0 && (p.ks == 3 || p.ck == 32)) {
+            p.x3_off = (long)pack_conv_x3(b, w->v.data(), p.cout, p.cin, p.ks, p.ck);
+            rec_pack(RF_PACK_X3, name + ".weight", "", (size_t)p.x3_off, p.cout, p.cin, 0, p.ks, p.ck, p.n_chunks);
+        }
         p.bias_off = bs ? (long)b.add(bs->v.data(), bs->v.size()) : -1;
+        if (bs) rec_copy(RF_COPY, name + ".bias", "", (size_t)p.bias_off, bs->v.size());
         pend.push_back(p);
     };
     auto add_vec = [&](const std::string& key) {
         const HostTensor* t = need(key);
-        if (t) vec_off[key] = b.add(t->v.data(), t->v.size());
+        if (t) {
+            vec_off[key] = b.add(t->v.data(), t->v.size());
+            rec_copy(RF_COPY, key, "", vec_off[key], t->v.size());
+        }
     };
     auto add_dw = [&](const std::string& key) {  // (C,1,3,3) -> [9][C]
         const HostTensor* t = need(key);
@@ -260,6 +297,7 @@ int Net::commit(hipStream_t stream) {
         for (int c = 0; c < C; ++c)
             for (int k = 0; k < 9; ++k) r[(size_t)k * C + c] = t->v[(size_t)c * 9 + k];
         vec_off[key] = b.add(r.data(), r.size());
+        rec_copy(RF_DW, key, "", vec_off[key], r.size(), C);
     };
     auto add_resblock = [&](const std::string& p) {
         add_vec(p + ".block1.block.0.weight");
@@ -278,6 +316,7 @@ int Net::commit(hipStream_t stream) {
 
     // time embedding: concatenated FeatureWiseAffine matrices
     std::vector<float> wall_h, ball_h;
+    std::vector<std::tuple<std::string, size_t, size_t, size_t, size_t>> slot_keys;  // res_block prefix, offset in wall, offset in ball, sizes
     slot_off.clear();
     nslots = 0;
     auto add_slot = [&](const std::string& rb) {
@@ -285,6 +324,7 @@ int Net::commit(hipStream_t stream) {
         const HostTensor* bs = need(rb + ".noise_func.noise_func.0.bias");
         if (!w || !bs) return;
         slot_off[rb] = nslots;
+        slot_keys.emplace_back(rb, wall_h.size(), (size_t)nslots, w->v.size(), bs->v.size());
         wall_h.insert(wall_h.end(), w->v.begin(), w->v.end());
         ball_h.insert(ball_h.end(), bs->v.begin(), bs->v.end());
         nslots += (int)bs->v.size();
@@ -325,8 +365,14 @@ int Net::commit(hipStream_t stream) {
         const HostTensor *wo = need(ci + ".attn_out.weight"), *bo = need(ci + ".attn_out.bias");
         const HostTensor* wr = get(ci + ".attn_res.weight");
         const HostTensor* br = get(ci + ".attn_res.bias");
-        if (wo) vec_off[ci + ".attn_out.weight"] = b.add(wo->v.data(), wo->v.size());
-        if (wr) vec_off[ci + ".attn_res.weight"] = b.add(wr->v.data(), wr->v.size());
+        if (wo) {
+            vec_off[ci + ".attn_out.weight"] = b.add(wo->v.data(), wo->v.size());
+            rec_copy(RF_COPY, ci + ".attn_out.weight", "", vec_off[ci + ".attn_out.weight"], wo->v.size());
+        }
+        if (wr) {
+            vec_off[ci + ".attn_res.weight"] = b.add(wr->v.data(), wr->v.size());
+            rec_copy(RF_COPY, ci + ".attn_res.weight", "", vec_off[ci + ".attn_res.weight"], wr->v.size());
+        }
         if (wo && bo) {
             const int co = (int)wo->shape[0], fea = (int)wo->shape[1];
             PendConv p;
@@ -344,12 +390,16 @@ int Net::commit(hipStream_t stream) {
                 p.cin = 2 * fea;
                 p.ck = 32;
                 p.w_off = pack_conv(b, cat.data(), co, p.cin, 1, p.ck, &p.n_chunks);
+                rec_pack(RF_PACK_F32, ci + ".attn_out.weight", ci + ".attn_res.weight", p.w_off, co, fea, fea, 1, p.ck, p.n_chunks);
             } else {  // attn_res is Identity (fea == dim_out): xn is added as a residual
                 p.cin = fea;
                 p.ck = fea <= 16 ? 16 : 32;
                 p.w_off = pack_conv(b, wo->v.data(), co, fea, 1, p.ck, &p.n_chunks);
+                rec_pack(RF_PACK_F32, ci + ".attn_out.weight", "", p.w_off, co, fea, 0, 1, p.ck, p.n_chunks);
             }
             p.bias_off = (long)b.add(bsum.data(), bsum.size());
+            if (wr && br) rec_copy(RF_SUM, ci + ".attn_out.bias", ci + ".attn_res.bias", (size_t)p.bias_off, bsum.size());
+            else rec_copy(RF_COPY, ci + ".attn_out.bias", "", (size_t)p.bias_off, bsum.size());
             pend.push_back(p);
         }
         add_conv(ci + ".ffn.0", false);
@@ -407,6 +457,16 @@ int Net::commit(hipStream_t stream) {
     const size_t o_w1 = b.add(hw1->v.data(), hw1->v.size()), o_b1 = b.add(hb1->v.data(), hb1->v.size());
     const size_t o_w3 = b.add(hw3->v.data(), hw3->v.size()), o_b3 = b.add(hb3->v.data(), hb3->v.size());
     const size_t o_wall = b.add(wall_h.data(), wall_h.size()), o_ball = b.add(ball_h.data(), ball_h.size());
+    rec_copy(RF_COPY, "noise_level_mlp.1.weight", "", o_w1, hw1->v.size());
+    rec_copy(RF_COPY, "noise_level_mlp.1.bias", "", o_b1, hb1->v.size());
+    rec_copy(RF_COPY, "noise_level_mlp.3.weight", "", o_w3, hw3->v.size());
+    rec_copy(RF_COPY, "noise_level_mlp.3.bias", "", o_b3, hb3->v.size());
+    for (auto& sk : slot_keys) {
+        rec_copy(RF_COPY, std::get<0>(sk) + ".noise_func.noise_func.0.weight", "", o_wall + std::get<1>(sk), std::get<3>(sk));
+        rec_copy(RF_COPY, std::get<0>(sk) + ".noise_func.noise_func.0.bias", "", o_ball + std::get<2>(sk), std::get<4>(sk));
+    }
+    merged_stale = false;
+    last_ptrs.clear();
 
     if (blob) {
         DDIF_HIPCHK(hipFree(blob));
@@ -441,6 +501,67 @@ int Net::commit(hipStream_t stream) {
     ball = blob + o_ball;
     committed = true;
     ++generation;
+    return 0;
+}
+
+// Rewrites every packed tensor of the blob in place from DEVICE parameter tensors (reference layouts), one launch.  Plans built
+// on this net stay valid (no pointer moves, same generation).  The eval-only merged ffn weights are left stale (merged_stale).
+int Net::refresh_device(int n, const char* const* keys, const float* const* ptrs, hipStream_t stream) {
+    if (!committed) return fail(DDIF_ERR_STATE, "ddif_net_refresh: ddif_net_commit has not been called");
+    if (n < 1 || !keys || !ptrs) return fail(DDIF_ERR_INVALID, "ddif_net_refresh: bad arguments");
+    std::map<std::string, const float*> by_key;
+    for (int i = 0; i < n; ++i) {
+        if (!keys[i] || !ptrs[i]) return fail(DDIF_ERR_INVALID, "ddif_net_refresh: NULL key / pointer at %d", i);
+        by_key[keys[i]] = ptrs[i];
+    }
+    std::vector<const float*> flat;
+    flat.reserve(recipes.size() * 2);
+    for (auto& r : recipes) {
+        auto i0 = by_key.find(r.src0);
+        if (i0 == by_key.end()) return fail(DDIF_ERR_MISSING, "ddif_net_refresh: parameter '%s' was not given", r.src0.c_str());
+        const float* p1 = nullptr;
+        if (!r.src1.empty()) {
+            auto i1 = by_key.find(r.src1);
+            if (i1 == by_key.end()) return fail(DDIF_ERR_MISSING, "ddif_net_refresh: parameter '%s' was not given", r.src1.c_str());
+            p1 = i1->second;
+        }
+        flat.push_back(i0->second);
+        flat.push_back(p1);
+    }
+    if (flat != last_ptrs || !d_recs) {  // (re)build the device table: only when the parameter tensors moved
+        std::vector<RefreshRec> recs(recipes.size());
+        long long blk = 0;
+        for (size_t k = 0; k < recipes.size(); ++k) {
+            const Recipe& r = recipes[k];
+            RefreshRec& d = recs[k];
+            d.kind = r.kind;
+            d.src0 = flat[2 * k];
+            d.src1 = flat[2 * k + 1];
+            d.dst = blob + r.dst_off;
+            d.cout = r.cout;
+            d.cin0 = r.cin0;
+            d.cin1 = r.cin1;
+            d.ks = r.ks;
+            d.ck = r.ck;
+            d.n_chunks = r.n_chunks;
+            d.n_out = (long long)r.n_out;
+            d.blk0 = blk;
+            blk += (long long)((r.n_out + 255) / 256);
+        }
+        if (d_recs) {
+            DDIF_HIPCHK(hipStreamSynchronize(stream));  // an earlier refresh may still read the old table
+            DDIF_HIPCHK(hipFree(d_recs));
+            d_recs = nullptr;
+        }
+        DDIF_HIPCHK(hipMalloc(&d_recs, recs.size() * sizeof(RefreshRec)));
+        DDIF_HIPCHK(hipMemcpy(d_recs, recs.data(), recs.size() * sizeof(RefreshRec), hipMemcpyHostToDevice));
+        n_recs = (int)recs.size();
+        refresh_blocks = blk;
+        last_ptrs = flat;
+    }
+    hipLaunchKernelGGL(refresh_blob_kernel, dim3((unsigned)refresh_blocks), dim3(256), 0, stream, (const RefreshRec*)d_recs, n_recs);
+    DDIF_HIPCHK(hipGetLastError());
+    merged_stale = true;
     return 0;
 }
 

@@ -71,8 +71,25 @@ struct Net {
     int nslots = 0;                               // total FeatureWiseAffine output channels
     std::map<std::string, int> slot_off;          // res_block prefix -> offset into a time-bias row
 
+    // device-side refresh (training): how every packed tensor of the blob derives from the parameter tensors, recorded by commit()
+    struct Recipe {
+        int kind = 0;                 // RF_* (kernels_refresh.h)
+        std::string src0, src1;       // state-dict keys
+        size_t dst_off = 0;           // floats into the blob
+        int cout = 0, cin0 = 0, cin1 = 0, ks = 1, ck = 32, n_chunks = 0;
+        size_t n_out = 0;
+    };
+    std::vector<Recipe> recipes;
+    bool merged_stale = false;        // the eval-only merged ffn[3] o ffn[2] weights were NOT refreshed (train-mode plans do not use them)
+    void* d_recs = nullptr;           // device RefreshRec table of the last refresh
+    std::vector<const float*> last_ptrs;
+    int n_recs = 0;
+    long long refresh_blocks = 0;
+    int refresh_device(int n, const char* const* keys, const float* const* ptrs, hipStream_t stream);
+
     ~Net() {
         if (blob) (void)hipFree(blob);
+        if (d_recs) (void)hipFree(d_recs);
     }
     int build_layers();
     int load(const char* key, const float* data, const int64_t* shape, int ndim);

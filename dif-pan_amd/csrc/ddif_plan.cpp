@@ -186,6 +186,11 @@ Plan::~Plan() {
 #ifndef DDIF_EMU
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
 #endif
+#ifndef DDIF_EMU
+    for (auto st : side) (void)hipStreamDestroy(st);
+    for (auto e : fork_ev) (void)hipEventDestroy(e);
+    for (auto e : join_ev) (void)hipEventDestroy(e);
+#endif
     for (void* p : allocs) (void)hipFree(p);
     for (auto e : ev0) (void)hipEventDestroy(e);
     for (auto e : ev1) (void)hipEventDestroy(e);
@@ -246,6 +251,15 @@ int Plan::build() {
         auto it = fake2id.find(net_out.p);
         if (it != fake2id.end()) lives[it->second].last = 1 << 30;
     }
+    // inside a forked region the sub-batches run out of program order relative to each other (one may be several launches ahead):
+    // a tensor that is live anywhere inside a region must not share memory with another one that is -- extend both to the whole region
+    compute_regions();
+    for (auto& rg : regions)
+        for (auto& l : lives)
+            if (l.last >= rg.first && l.first < rg.second) {
+                if (l.first > rg.first) l.first = rg.first;
+                if (l.last < rg.second) l.last = rg.second;
+            }
     // first-fit interval colouring in order of first use
     std::vector<int> order(lives.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
@@ -292,7 +306,96 @@ int Plan::build() {
     }
     if (int e = build_impl()) return e;
     if (arena_next != (int)lives.size()) return fail(DDIF_ERR_STATE, "plan arena: the two build passes disagree");
+    compute_regions();
     return 0;
+}
+
+// forked regions (DDIF_SPLIT=k; default 1 = OFF): maximal runs of window-capable ops of the low-resolution levels and the bottleneck
+// attention (classes 2, 3); DDIF_SPLIT_ALL=1 makes the whole step one region.  MEASURED NEGATIVE on MI355X / ROCm 7.2 (profiles/
+// r03_b_split_ab.txt, B = 64, same box): 5.44 ms per denoising step unsplit, 5.51 / 5.78 / 6.93 / 9.37 ms with 2 / 4 / 8 / 16 sub-batches
+// of the low-resolution region, 5.63 / 5.66 ms with the whole step in 2 / 4 -- parallel branches of a captured graph do not overlap
+// enough to pay for their fork / join dependencies.  Kept as a tested switch (tests/test_env_switches.py), not a default.
+void Plan::compute_regions() {
+    static const int split_env = [] { const char* e = getenv("DDIF_SPLIT"); return e ? atoi(e) : 1; }();
+    static const bool split_all = [] { const char* e = getenv("DDIF_SPLIT_ALL"); return e && atoi(e) != 0; }();
+    split_k = 1;
+    regions.clear();
+    int k = split_env;
+    while (k > 1 && B % k != 0) --k;
+    if (k <= 1 || train_mode) return;
+    int i = 0;
+    const int n = (int)step.size();
+    auto in_region = [&](const Op& op) { return op.win && (split_all || op.cls == 2 || op.cls == 3); };
+    while (i < n) {
+        if (!in_region(step[i])) {
+            ++i;
+            continue;
+        }
+        int j = i;
+        while (j < n && in_region(step[j])) ++j;
+        if (j - i >= 4) regions.emplace_back(i, j);
+        i = j;
+    }
+    if (!regions.empty()) split_k = k;
+}
+
+int Plan::ensure_fork_resources() {
+#ifndef DDIF_EMU
+    while ((int)side.size() < split_k - 1) {
+        hipStream_t st = nullptr;
+        DDIF_HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        side.push_back(st);
+    }
+    while ((int)fork_ev.size() < (int)regions.size()) {
+        hipEvent_t e;
+        DDIF_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        fork_ev.push_back(e);
+    }
+    while ((int)join_ev.size() < (int)regions.size() * (split_k - 1)) {
+        hipEvent_t e;
+        DDIF_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        join_ev.push_back(e);
+    }
+#endif
+    return 0;
+}
+
+// The step program with its forked regions: outside a region ops run on `s` over the whole batch; a region runs as split_k batch
+// windows, window 0 on `s` and the others on side streams forked from / joined to `s` with events (under stream capture these become
+// parallel branches of the graph).  Profiled steps (an event pair around every launch) and the emulator run everything on `s`.
+void Plan::run_step_prog(hipStream_t s, const StepCtx& ctx, bool prof) {
+#ifdef DDIF_EMU
+    run_prog(step, s, ctx, prof);
+#else
+    static const char* op_timing = getenv("DDIF_OP_TIMING");
+    if (prof || split_k <= 1 || regions.empty() || (int)side.size() < split_k - 1 || (op_timing && !op_timing_done)) {
+        run_prog(step, s, ctx, prof);
+        return;
+    }
+    const int per = B / split_k;
+    int pos = 0;
+    for (size_t r = 0; r < regions.size(); ++r) {
+        const int r0 = regions[r].first, r1 = regions[r].second;
+        for (int i = pos; i < r0; ++i) step[i].run(s, ctx);
+        (void)hipEventRecord(fork_ev[r], s);
+        for (int w = 1; w < split_k; ++w) (void)hipStreamWaitEvent(side[w - 1], fork_ev[r], 0);
+        // launch order: op by op across the windows, so that the branches advance together
+        for (int i = r0; i < r1; ++i)
+            for (int w = 0; w < split_k; ++w) {
+                StepCtx c = ctx;
+                c.b0 = w * per;
+                c.bn = per;
+                step[i].run(w == 0 ? s : side[w - 1], c);
+            }
+        for (int w = 1; w < split_k; ++w) {
+            hipEvent_t e = join_ev[r * (split_k - 1) + (w - 1)];
+            (void)hipEventRecord(e, side[w - 1]);
+            (void)hipStreamWaitEvent(s, e, 0);
+        }
+        pos = r1;
+    }
+    for (int i = pos; i < (int)step.size(); ++i) step[i].run(s, ctx);
+#endif
 }
 
 int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
@@ -374,7 +477,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     }
     a.n_ct = gy;
     // persistent launch: a few workgroups per CU, each walking a contiguous range of (cout tile, pixel tile) items
-    const long nwork = (long)B * a.tiles_x * a.tiles_y * gy;
+    const long items_per_sample = (long)a.tiles_x * a.tiles_y * gy;
+    const long nwork = (long)B * items_per_sample;
     const int gy0 = (pc.cout + var.nt - 1) / var.nt;
     const size_t smem = var.lr ? var.smem : var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
     long cap = (long)num_cus() * wg_per_cu(smem, var.wg_cap);
@@ -417,8 +521,16 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         ++n_conv3;
         if (var.x3) ++n_conv3_x3;
     }
-    op.run = [a, var, fn_tbs, grid, block, smem, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
+    op.win = true;
+    op.run = [a, var, fn_tbs, grid, block, smem, dyn, self_c, tb_off, items_per_sample, cap](hipStream_t st, const StepCtx& ctx) {
         ConvArgs aa = a;
+        dim3 g = grid;
+        if (ctx.bn) {  // batch window of a forked region
+            aa.b0 = ctx.b0;
+            aa.B = ctx.bn;
+            const long nw = (long)ctx.bn * items_per_sample;
+            g = dim3((unsigned)(nw < cap ? nw : cap), 1u);
+        }
         if (dyn) {
             if (self_c) {
                 aa.in0 = ctx.sc;
@@ -433,7 +545,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
             aa.step_ptr = ctx.step_ptr;
             aa.tb_rowstride = ctx.tb_rowstride;
         }
-        hipLaunchKernelGGL((tb_off >= 0 && ctx.tb_stride != 0) ? fn_tbs : var.fn, grid, block, smem, st, aa);
+        hipLaunchKernelGGL((tb_off >= 0 && ctx.tb_stride != 0) ? fn_tbs : var.fn, g, block, smem, st, aa);
     };
     prog.push_back(std::move(op));
     return 0;
@@ -611,8 +723,16 @@ int Plan::build_impl() {
             op.cls = 3;
             op.flop = 2.0 * B * 64 * 128.0 * (384 + 128) + 4.0 * B * 8 * 64.0 * 64 * 16;
             op.bytes = 8.0 * B * 64 * 128;
-            const int grid = B < num_cus() ? B : num_cus();
-            op.run = [a, grid](hipStream_t s, const StepCtx&) { attn_block_launch(a, grid, s); };
+            const int ncu = num_cus();
+            op.win = true;
+            op.run = [a, ncu](hipStream_t s, const StepCtx& ctx) {
+                AttnBlockArgs aa = a;
+                if (ctx.bn) {
+                    aa.b0 = ctx.b0;
+                    aa.B = ctx.bn;
+                }
+                attn_block_launch(aa, aa.B < ncu ? aa.B : ncu, s);
+            };
             step.push_back(std::move(op));
             return 0;
         }
@@ -636,8 +756,11 @@ int Plan::build_impl() {
             const float scale = 1.0f / std::sqrt((float)Cc);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)
             op.flop = 4.0 * B * 8 * (double)n * n * 16;
             op.bytes = 4.0 * B * n * 4.0 * Cc;
-            op.run = [qkv, o, n, Cc, BB, scale](hipStream_t s, const StepCtx&) {
-                hipLaunchKernelGGL(self_attn_mfma_kernel, dim3((n + 63) / 64, 8, BB), dim3(64), 0, s, (const float*)qkv.p, n, Cc, scale, o.p);
+            op.win = true;
+            op.run = [qkv, o, n, Cc, BB, scale](hipStream_t s, const StepCtx& ctx) {
+                const int b0 = ctx.bn ? ctx.b0 : 0, bn = ctx.bn ? ctx.bn : BB;
+                hipLaunchKernelGGL(self_attn_mfma_kernel, dim3((n + 63) / 64, 8, bn), dim3(64), 0, s, (const float*)qkv.p + (size_t)b0 * n * 3 * Cc, n, Cc, scale,
+                                   o.p + (size_t)b0 * n * Cc);
             };
             step.push_back(std::move(op));
         }
@@ -857,8 +980,11 @@ int Plan::build_impl() {
             op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
             const size_t sm = (size_t)(Hl + 2) * (Wl + 2) * 36 * sizeof(float);
             if (sm > 64 * 1024) DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_dw3x3_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-            op.run = [a, BB, fea, sm](hipStream_t s, const StepCtx&) {
-                hipLaunchKernelGGL(gn_dw3x3_small_kernel, dim3((fea + 31) / 32, BB), dim3(256), sm, s, a);
+            op.win = true;
+            op.run = [a, BB, fea, sm](hipStream_t s, const StepCtx& ctx) {
+                DwArgs aa = a;
+                aa.b0 = ctx.bn ? ctx.b0 : 0;
+                hipLaunchKernelGGL(gn_dw3x3_small_kernel, dim3((fea + 31) / 32, ctx.bn ? ctx.bn : BB), dim3(256), sm, s, aa);
             };
             step.push_back(std::move(op));
             ConvSpec s;
@@ -895,8 +1021,11 @@ int Plan::build_impl() {
             op.name = "q.softmax_stats";
             op.cls = 4;
             op.bytes = 8.0 * B * Hl * Wl * fea;
-            op.run = [q, qmx, qsm, fea, BB, Hl, Wl](hipStream_t s, const StepCtx&) {
-                hipLaunchKernelGGL(softmax_stats_kernel, ew_grid((size_t)BB * Wl * fea), dim3(256), 0, s, (const float*)q.p, fea, 0, fea, BB, Hl, Wl, 0, qmx, qsm);
+            op.win = true;
+            op.run = [q, qmx, qsm, fea, BB, Hl, Wl](hipStream_t s, const StepCtx& ctx) {
+                const int b0 = ctx.bn ? ctx.b0 : 0, bn = ctx.bn ? ctx.bn : BB;
+                hipLaunchKernelGGL(softmax_stats_kernel, ew_grid((size_t)bn * Wl * fea), dim3(256), 0, s, (const float*)q.p + (size_t)b0 * Hl * Wl * fea, fea, 0, fea, bn, Hl, Wl,
+                                   0, qmx + (size_t)b0 * Wl * fea, qsm + (size_t)b0 * Wl * fea);
             };
             step.push_back(std::move(op));
         }
@@ -1172,6 +1301,7 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
     // the host copies above must have been consumed before `run` (stack) goes away: pageable H2D copies are staged
     // synchronously by the runtime, so returning after the enqueue is safe.
 
+    if (int e = ensure_fork_resources()) return e;
     auto one_step = [&](int parity, hipStream_t st, bool prof) {
         StepCtx ctx;
         ctx.x = ctx.sc = img[parity];  // self-conditioning == current image (diffusion_ddpm_pan.py:491,502; sr3_dwt.py:173)
@@ -1179,7 +1309,7 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
         ctx.tb_stride = 0;
         ctx.step_ptr = d_step;
         ctx.tb_rowstride = net->nslots;
-        run_prog(step, st, ctx, prof);
+        run_step_prog(st, ctx, prof);
         StepArgs a{};
         a.x0 = net_out.p;
         a.img = img[parity];
@@ -1303,6 +1433,7 @@ int Plan::sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, floa
     const size_t n = (size_t)B * HW * C;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
     if (int e = time_rows(t->t_model, t->n_evals, s)) return e;
+    if (int e = ensure_fork_resources()) return e;
     int cur = 0;
     float* hist[3] = {nullptr, nullptr, nullptr};  // newest first
     int nhist = 0, slot = 0;
@@ -1311,7 +1442,7 @@ int Plan::sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, floa
         ctx.x = ctx.sc = img[cur];  // model_wrapper never passes self_cond (dpm_solver.py:295) -> x
         ctx.tb = tb + (size_t)k * net->nslots;
         const bool prof = prof_every > 0 && (k % prof_every) == 0;
-        run_prog(step, s, ctx, prof);
+        run_step_prog(s, ctx, prof);
         float* mnew = mbuf[slot];
         slot = (slot + 1) % 3;
         hipLaunchKernelGGL(dpm_x0_kernel, ew_grid(n), dim3(256), 0, s, (const float*)net_out.p, (const float*)img[cur], (const float*)lms.p,

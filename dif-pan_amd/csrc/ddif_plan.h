@@ -21,12 +21,14 @@ struct StepCtx {
     int tb_stride = 0;          // floats between the rows of consecutive samples (0: one row for the batch)
     const int* step_ptr = nullptr;  // samplers: device step counter selecting the time-bias row (row stride tb_rowstride)
     int tb_rowstride = 0;
+    int b0 = 0, bn = 0;         // batch window [b0, b0 + bn) of a forked region (bn = 0: the whole batch)
 };
 
 struct Op {
     std::function<void(hipStream_t, const StepCtx&)> run;
     double flop = 0, bytes = 0;
     bool timed = false;  // member of the dominant kernel class (3x3 implicit-GEMM convs at the high-resolution levels)
+    bool win = false;    // the launch honours StepCtx's batch window (every op of the eval-mode step program does)
     int cls = 5;         // profiling class: 0 conv3x3 (> 256 px / sample), 1 conv1x1 (> 256 px), 2 low-resolution levels, 3 attention, 4 softmax statistics, 5 other
     const char* name = "";
     std::string label;   // layer + shape, for the DDIF_OP_TIMING dump
@@ -109,6 +111,16 @@ struct Plan {
     hipStream_t cap_stream = nullptr;
     void* graph_exec[2] = {nullptr, nullptr};  // [0] DDPM pair, [1] DDIM pair
     bool use_graph = true;
+    // forked regions: runs of launch-latency-bound ops (the 8x8 / 16x16 levels) are executed as `split_k` independent sub-batches on
+    // concurrent streams (branches of the captured graph): tiles never mix, so any op runs on any batch window; while one sub-batch
+    // waits out a launch's latency chain the others compute
+    int split_k = 1;
+    std::vector<std::pair<int, int>> regions;  // [first, last) op index ranges of the step program that fork
+    std::vector<hipStream_t> side;              // split_k - 1 side streams
+    std::vector<hipEvent_t> fork_ev, join_ev;
+    void compute_regions();
+    int ensure_fork_resources();
+    void run_step_prog(hipStream_t s, const StepCtx& ctx, bool prof);  // the step program, forking where `regions` say so (unless profiled)
 
     // profiling
     int prof_every = 0, prof_max = 0;

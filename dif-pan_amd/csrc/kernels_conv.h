@@ -70,6 +70,7 @@ struct ConvArgs {
     float* cso_mx;           // kernels_lr.h EPI_COLST: column-softmax statistics of the OUTPUT (max / sum of exp over H), [B][Wout][Cout]
     float* cso_sm;
     long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
+    int b0;                  // batch window: the launch covers samples [b0, b0 + B) of the tensors (sub-batches of a forked region run concurrently)
 };
 
 template <int F>
@@ -216,8 +217,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         p.work = work;
         const int pt = work / a.n_ct;  // cout tile FASTEST: consecutive items re-read the same input tile out of L2
         p.ct = work - pt * a.n_ct;
-        p.b = pt / tiles;
-        const int t = pt - p.b * tiles;
+        const int bl = pt / tiles;
+        p.b = a.b0 + bl;
+        const int t = pt - bl * tiles;
         const int ty = t / a.tiles_x;
         p.oy0 = ty * TH;
         p.ox0 = (t - ty * a.tiles_x) * TW;

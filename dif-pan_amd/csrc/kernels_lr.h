@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
 
     for (int work = w0; work < w1; ++work) {
         const int pt = work / a.n_ct, ct = work - pt * a.n_ct;  // cout tile fastest: neighbours re-read the same input from L2
-        const int b = pt / tiles, t = pt - b * tiles;
+        const int bl = pt / tiles, t = pt - bl * tiles;
+        const int b = a.b0 + bl;
         const int oy0 = (t / a.tiles_x) * TH, ox0 = (t % a.tiles_x) * TW;
 
         // ================= (1) every load of the work item that does not depend on another one, in one burst ==========

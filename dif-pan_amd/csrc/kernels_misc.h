@@ -26,6 +26,7 @@ struct DwArgs {
     float* out_xn;       // [B,H,W,C] or null
     int tiles_x, tiles_y;
     int use_gn;
+    int b0;              // gn_dw3x3_small_kernel: batch window (blockIdx.y counts from b0)
 };
 
 __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void gn_dw3x3_small_kernel(DwArgs a) {
     DDIF_DYN_SMEM(smem);
     float* Hs = reinterpret_cast<float*>(smem);  // [(H+2)*(W+2)][HP]
     const int tid = threadIdx.x;
-    const int b = blockIdx.y, cb = blockIdx.x * CK;
+    const int b = a.b0 + blockIdx.y, cb = blockIdx.x * CK;
     const int C = a.c0 + a.c1, IW = a.W + 2, n = a.H * a.W, nh = (a.H + 2) * IW;
     const int c4 = tid & 7, c = cb + c4 * 4;
     const bool cok = c < C;

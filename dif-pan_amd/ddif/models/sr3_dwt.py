@@ -112,21 +112,31 @@ class UNetSR3(nn.Module):
         step = torch.arange(count, dtype=torch.float32) / count
         return torch.exp(-math.log(1e4) * step.unsqueeze(0)).reshape(-1)
 
-    def _ensure_net(self, device: torch.device) -> NetHandle:
+    def _ensure_net(self, device: torch.device, train: bool = False) -> NetHandle:
+        """The library-side copy of the weights, brought up to date.  Inference: host repack + upload (ddif_net_commit) whenever the
+        parameters changed.  `train=True` (train-mode plans only): once committed, changed parameters are re-packed ON THE DEVICE in one
+        launch (ddif_net_refresh) -- the training loop changes them every iteration."""
         device = torch.device(device)
         if self._net is None or self._net.device != device:
             self._net = NetHandle(self.cfg, device)
             self._weights_sig = None
         sig = self._signature()
-        if sig != self._weights_sig:
-            self._net.load_state_dict(self.state_dict(), self.pe_freqs())
+        net = self._net
+        committed = getattr(net, "device_refreshed", None) is not None
+        if train and committed and all(p.device == device for p in self.parameters()):
+            if sig != self._weights_sig:
+                net.refresh_from_device(self.named_parameters())
+                self._weights_sig = sig
+            return net
+        if sig != self._weights_sig or getattr(net, "device_refreshed", False):
+            net.load_state_dict(self.state_dict(), self.pe_freqs())
             self._weights_sig = sig
-        return self._net
+        return net
 
     DROP_PATH_PROB = 0.2  # FastAttnCondInjection's default drop_path_prob, never overridden by UNetSR3 (models/sr3_dwt.py:502,534)
 
     def plan_for(self, B: int, H: int, W: int, device, train: bool = False) -> PlanHandle:
-        return self._ensure_net(device).plan(B, H, W, train=train)
+        return self._ensure_net(device, train=train).plan(B, H, W, train=train)
 
     def set_train_masks(self, dropout_masks, droppath_scales):
         """Pin the masks of the NEXT train-mode forward passes (parity tests against a reference run whose masks were captured);

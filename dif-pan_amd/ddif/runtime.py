@@ -81,6 +81,7 @@ class _Lib:
         d.ddif_net_destroy.restype = None
         d.ddif_net_load.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]
         d.ddif_net_commit.argtypes = [vp, vp]
+        d.ddif_net_refresh.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(vp), vp]
         d.ddif_net_num_params.argtypes = [vp]
         d.ddif_net_num_params.restype = C.c_int64
         d.ddif_plan_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
@@ -273,7 +274,27 @@ class NetHandle:
         self.lib.check(dll.ddif_net_load(self.h, b"noise_level_mlp.0.freqs", C.c_void_p(f.data_ptr()), shape, 1),
                        "ddif_net_load(freqs)")
         self.lib.check(dll.ddif_net_commit(self.h, _stream(self.lib, self.device)), "ddif_net_commit")
+        self.device_refreshed = False
         self.plans.clear()  # plans hold pointers into the old weight blob
+
+    def refresh_from_device(self, named_params):
+        """Training: rewrite the packed weights in place from the DEVICE parameter tensors (one launch, no host copy): `named_params` =
+        [(state-dict key, tensor)].  Existing plans stay valid; only train-mode plans may run afterwards (the inference-only merged FFN
+        weights are left stale) until the next load_state_dict."""
+        named_params = list(named_params)
+        n = len(named_params)
+        keys = (C.c_char_p * n)(*[k.encode() for k, _ in named_params])
+        ts = []
+        for k, t in named_params:
+            t = t.detach()
+            _check_tensor(self.lib, t, k)
+            if not t.is_contiguous():
+                raise DdifError(f"{k}: parameters must be contiguous")
+            ts.append(t)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self.lib.check(self.lib.dll.ddif_net_refresh(self.h, n, keys, ptrs, _stream(self.lib, self.device)), "ddif_net_refresh")
+        self.device_refreshed = True
+        self.epoch = getattr(self, "epoch", 0) + 1  # the plans' cond-only caches (FiLM bodies, kv contexts, folded attn_out weights) are stale
 
     def plan(self, B: int, H: int, W: int, train: bool = False) -> "PlanHandle":
         key = (int(B), int(H), int(W)) + (("train",) if train else ())
@@ -353,8 +374,9 @@ class PlanHandle:
         _check_tensor(self.lib, cond, "cond")
         _check_shape(cond, "cond", (self.B, self.net.cond_channel, self.H, self.W))
         cond_c = cond.contiguous()
+        epoch = getattr(self.net, "epoch", 0)
         same = (not force and self._cond_ref is not None and self._cond_ref() is cond
-                and self._cond_ver == cond._version and cond_c is cond)
+                and self._cond_ver == cond._version and cond_c is cond and getattr(self, "_cond_epoch", epoch) == epoch)
         if same:
             return
         self.lib.check(self.lib.dll.ddif_plan_set_cond(self.h, _ptr(cond_c), _stream(self.lib, cond.device)),
@@ -362,6 +384,7 @@ class PlanHandle:
         self._keep = cond_c  # borrowed by the enqueued work
         self._cond_ref = weakref.ref(cond)
         self._cond_ver = cond._version
+        self._cond_epoch = epoch
 
     # -- network ------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, time: torch.Tensor, self_cond: Optional[torch.Tensor]) -> torch.Tensor:

@@ -66,6 +66,12 @@ DDIF_API void ddif_net_destroy(ddif_net_t net);
 DDIF_API int ddif_net_load(ddif_net_t net, const char* key, const float* data, const int64_t* shape, int ndim);
 /* Repack everything loaded so far for the kernels and upload.  Must follow the last ddif_net_load. */
 DDIF_API int ddif_net_commit(ddif_net_t net, void* stream);
+/* Training: rewrite the packed weights IN PLACE from DEVICE parameter tensors (reference layouts, fp32; n (key, pointer) pairs covering
+ * every learnable tensor of the state dict) -- one launch on `stream`, no host copy.  Plans of this net stay valid.  The eval-only
+ * merged decoder-FFN weights are NOT refreshed: after a refresh only train-mode plans (ddif_plan_create_train) may run until the next
+ * ddif_net_load + ddif_net_commit (inference plans are refused).  Replaces nothing in the reference: there `optimizer.step()` writes
+ * the tensors the next forward reads (diffusion_engine.py:238); here the kernels read a packed copy. */
+DDIF_API int ddif_net_refresh(ddif_net_t net, int n, const char* const* keys, const float* const* params_dev, void* stream);
 DDIF_API int64_t ddif_net_num_params(ddif_net_t net);
 
 /* ---- plan ----------------------------------------------------------------------------------------------------- */

@@ -8,6 +8,10 @@
                 split-K kernel (kernels_lr.h) -- the golden cases at 16x16 / 32x32 otherwise run almost entirely on the
                 latter, so this is what keeps the general kernel's small-tile instantiations covered.
 
+  DDIF_SPLIT=4  the low-resolution region of every denoising step as 4 concurrent sub-batches (batch windows of every launch, forked
+                branches of the captured graph; csrc/ddif_plan.cpp run_step_prog) -- measured slower on MI355X and OFF by default, but it
+                must stay correct: device-RNG DDPM at B = 64 bit-equal to per-tile runs, and the T = 20 batch-64 job against the oracle.
+
 All other A/B switches of round 1 (wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides) were
 deleted together with their code."""
 import os
@@ -59,3 +63,16 @@ def test_training_gradients_on_the_exact_fp32_convs():
     assert r.returncode == 0, tail
     assert " passed" in r.stdout, tail
 
+
+
+def test_forked_low_resolution_region_is_bit_exact():
+    """DDIF_SPLIT=4: batch windows + forked graph branches.  Tiles never mix, so the B = 64 results must still be bit-equal to single-tile
+    runs (which never fork) and match the oracle."""
+    e = dict(os.environ)
+    e["DDIF_SPLIT"] = "4"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_batch64.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "device_rng_batch64 or reference_noise_vs_single_tiles or forward_batch64", "-p", "no:cacheprovider"], env=e, cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail

@@ -184,6 +184,46 @@ def test_engine_google_trains_and_validates_on_an_in_memory_set(backend):
         assert again["loss"] == out["loss"]
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_device_side_weight_refresh_equals_a_host_commit(backend):
+    """Training changes the parameters every iteration, on the device.  `ddif_net_refresh` re-packs them there (one launch); the result must
+    be what `ddif_net_load` + `ddif_net_commit` (host repack + upload) produce from the same values: the train-mode forward of a refreshed
+    network is BIT-equal to that of a freshly committed one, and an inference plan is refused until the weights are committed again."""
+    from ddif import runtime
+    from ddif_testlib import make_net
+
+    dev = _dev(backend)
+    _, ds, x, sc, target, cond, t, masks, paths = _case_inputs(gc.TRAIN_GRAD_CASES[0])
+    B, _, H, W = x.shape
+    net = make_net(ds, dev).train()
+    net.set_train_masks([m.to(dev) for m in masks], paths)
+    try:
+        y0 = net(x.to(dev), t, cond.to(dev), sc.to(dev)).clone()
+        g = torch.Generator().manual_seed(99)
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_((0.05 * torch.randn(p.shape, generator=g)).to(dev))
+        runtime._bump_versions(list(net.parameters()))
+        y_ref = net(x.to(dev), t, cond.to(dev), sc.to(dev)).clone()     # train=True and committed -> device refresh
+        assert net._net.device_refreshed and float((y_ref - y0).abs().max()) > 0
+        fresh = make_net(ds, dev).train()
+        fresh.load_state_dict(net.state_dict())
+        fresh.set_train_masks([m.to(dev) for m in masks], paths)
+        y_host = fresh(x.to(dev), t, cond.to(dev), sc.to(dev))          # first use: host commit
+        assert not fresh._net.device_refreshed
+        assert torch.equal(y_ref, y_host)
+        # an inference plan built BEFORE the refresh is refused afterwards; the drop-in re-commits for eval mode by itself
+        stale = net._net.plan(B, H, W)
+        with pytest.raises(runtime.DdifError, match="refreshed on the device"):
+            stale.set_cond(cond.to(dev), force=True)
+        net.eval()
+        fresh.eval()
+        assert torch.equal(net(x.to(dev), t, cond.to(dev), sc.to(dev)), fresh(x.to(dev), t, cond.to(dev), sc.to(dev)))
+    finally:
+        net.set_train_masks(None, None)
+        net.eval()
+
+
 @pytest.mark.parametrize("backend", GPU_ONLY)
 def test_engine_google_trains_on_after_validation_checkpoints_and_resumes(backend, tmp_path):
     """ADVICE r2 + SURVEY 8f-4.  (1) Validation (DDIM-25 respaces ITS schedule in place) runs on a separate diffusion object holding the EMA
