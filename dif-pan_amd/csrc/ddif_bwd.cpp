@@ -426,3 +426,72 @@ int ddif_convfwd_run(ddif_convfwd_t h, const float* x, const float* w, const flo
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------- launchers for the native training step (ddif_train.cpp)
+namespace ddif {
+namespace tk {
+void silu_fwd(hipStream_t s, const float* x, size_t n, float* y) { hipLaunchKernelGGL(silu_fwd_kernel, grid_for(n), dim3(256), 0, s, x, n, y); }
+void silu_bwd(hipStream_t s, const float* x, const float* da, size_t n, float* dx) { hipLaunchKernelGGL(silu_bwd_kernel, grid_for(n), dim3(256), 0, s, x, da, n, dx); }
+WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_init
+    WgradGeom g;
+    g.n_co = (Cout + 31) / 32;
+    g.n_ci = (Cin + 31) / 32;
+    for (g.rb = 4; g.rb >= 1; g.rb >>= 1) {
+        g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
+        if (g.smem <= 150 * 1024) break;
+    }
+    if (g.rb < 1) g.rb = 0;  // W too wide (caller checks)
+    const int bands = B * ((H + (g.rb ? g.rb : 1) - 1) / (g.rb ? g.rb : 1));
+    int want = (2 * 256) / (g.n_co * g.n_ci);
+    if (want < 1) want = 1;
+    if (want > bands) want = bands;
+    if (want > 256) want = 256;
+    g.nsplit = want;
+    g.partial_floats = (size_t)g.nsplit * g.n_co * g.n_ci * 9 * 1024;
+    g.nbchunk = (int)std::min<size_t>(512, std::max<size_t>(1, (size_t)B * H * W / 16));
+    return g;
+}
+int wgrad_prepare() {
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    return 0;
+}
+void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw) {
+    WgradArgs a{};
+    a.x = x;
+    a.dy = dy;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.n_ci = g.n_ci;
+    a.rb = g.rb;
+    a.bands_y = (H + g.rb - 1) / g.rb;
+    a.partial = partial;
+    a.centre_only = centre ? 1 : 0;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
+    if (centre)
+        hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)Cout * Cin * 9), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
+}
+void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db) {
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nbchunk), dim3(256), 256 * sizeof(float), s, dy, npix, Cout, nbchunk, bpart);
+    hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(Cout), dim3(64), 64 * sizeof(float), s, (const float*)bpart, nbchunk, Cout, db);
+}
+void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart, float* ms) {
+    hipLaunchKernelGGL(gnb_stats_kernel, dim3(nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, x, per_sample, nchunk, spart);
+    hipLaunchKernelGGL(gnb_finalize_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)spart, nchunk, (double)per_sample, B, ms);
+}
+static inline dim3 ew_grid2(int B, int HW, int C) {
+    const size_t nq = ((size_t)HW * C / 4 + 255) / 256;
+    return dim3((unsigned)(nq > 64 ? 64 : (nq < 1 ? 1 : nq)), (unsigned)B);
+}
+void gn_act(hipStream_t s, const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out) {
+    hipLaunchKernelGGL(gnb_act_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, ms, gamma, beta, mask, HW, C, silu, out);
+}
+void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta, int B, int HW, int C, int nchunk,
+            int silu, double* cpart, double* planes, float* S, float* dgamma, float* dbeta, float* dx) {
+    hipLaunchKernelGGL(gnb_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, x, da, mask, ms, gamma, beta, HW, C, nchunk, silu, cpart);
+    hipLaunchKernelGGL(gnb_bwd_planes_kernel, grid_for((size_t)B * C), dim3(256), 0, s, (const double*)cpart, B, nchunk, C, planes);
+    hipLaunchKernelGGL(gnb_bwd_finalize_kernel, dim3((C + B + 255) / 256), dim3(256), 0, s, (const double*)planes, gamma, B, C, dgamma, dbeta, S);
+    if (dx) hipLaunchKernelGGL(gnb_bwd_dx_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, da, mask, ms, gamma, beta, (const float*)S, HW, C, silu, dx);
+}
+}  // namespace tk
+}  // namespace ddif

@@ -199,3 +199,19 @@ int ddif_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* o
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------- launchers for the native training step (ddif_train.cpp)
+namespace ddif {
+namespace tk {
+void linear_bwd(hipStream_t s, const float* x, const float* w, const float* dy, int B, int nin, int nout, float* dx, float* dw, float* db) {
+    const int total = (dx ? B * nin : 0) + (dw ? nout * nin : 0) + (db ? nout : 0);
+    hipLaunchKernelGGL(linear_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, w, dy, B, nin, nout, dx, dw, db);
+}
+void l1_fwd(hipStream_t s, const float* pred, const float* target, size_t n, float* out) {
+    hipLaunchKernelGGL(l1_fwd_kernel, dim3(1), dim3(256), 256 * sizeof(double), s, pred, target, n, out);
+}
+void l1_bwd(hipStream_t s, const float* pred, const float* target, size_t n, float upstream, float* dpred) {
+    hipLaunchKernelGGL(l1_bwd_kernel, ops_grid(n), dim3(256), 0, s, pred, target, n, upstream, dpred);
+}
+}  // namespace tk
+}  // namespace ddif

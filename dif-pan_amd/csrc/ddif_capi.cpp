@@ -134,6 +134,35 @@ int ddif_plan_create_train(ddif_plan_t* out, ddif_net_t net, int B, int H, int W
     DDIF_GUARD_END
 }
 
+int ddif_plan_train_bind(ddif_plan_t plan, int n, const char* const* keys, float* const* grads_dev) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_bind");
+    return plan->p.train_bind(n, keys, grads_dev);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_train_num_grads(ddif_plan_t plan, int* n) {
+    if (!plan || !plan->p.train_mode || !n) return ddif::fail(DDIF_ERR_STATE, "ddif_plan_train_num_grads: not a train-mode plan");
+    *n = (int)plan->p.grad_slots.size();
+    return DDIF_OK;
+}
+
+int ddif_plan_train_step(ddif_plan_t plan, const float* x0, const float* noise, const float* sqrt_ac_host, const float* sqrt_1mac_host, const float* time_host,
+                         const float* self_cond, float* loss_dev, float* pred, void* stream) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_step");
+    return plan->p.train_step(x0, noise, sqrt_ac_host, sqrt_1mac_host, time_host, self_cond, loss_dev, pred, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_train_forward_backward(ddif_plan_t plan, const float* x, const float* time_host, const float* self_cond, const float* target, float* loss_dev,
+                                     float* pred, void* stream) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_forward_backward");
+    return plan->p.train_forward_backward(x, time_host, self_cond, target, loss_dev, pred, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
 int ddif_plan_train_info(ddif_plan_t plan, int* n_dropout_sites, int* n_droppath_sites) {
     if (!plan || !plan->p.train_mode) return ddif::fail(DDIF_ERR_STATE, "ddif_plan_train_info: not a train-mode plan");
     if (n_dropout_sites) *n_dropout_sites = (int)plan->p.drop_sites.size();

@@ -391,11 +391,18 @@ int Net::commit(hipStream_t stream) {
                 p.ck = 32;
                 p.w_off = pack_conv(b, cat.data(), co, p.cin, 1, p.ck, &p.n_chunks);
                 rec_pack(RF_PACK_F32, ci + ".attn_out.weight", ci + ".attn_res.weight", p.w_off, co, fea, fea, 1, p.ck, p.n_chunks);
+                // (train-mode plans run this conv with the SHARED weights -- the per-sample folded copies belong to inference -- on the bf16x3 path)
+                p.x3_off = (long)pack_conv_x3(b, cat.data(), co, p.cin, 1, p.ck);
+                rec_pack(RF_PACK_X3, ci + ".attn_out.weight", ci + ".attn_res.weight", (size_t)p.x3_off, co, fea, fea, 1, p.ck, p.n_chunks);
             } else {  // attn_res is Identity (fea == dim_out): xn is added as a residual
                 p.cin = fea;
                 p.ck = fea <= 16 ? 16 : 32;
                 p.w_off = pack_conv(b, wo->v.data(), co, fea, 1, p.ck, &p.n_chunks);
                 rec_pack(RF_PACK_F32, ci + ".attn_out.weight", "", p.w_off, co, fea, 0, 1, p.ck, p.n_chunks);
+                if (p.ck == 32) {
+                    p.x3_off = (long)pack_conv_x3(b, wo->v.data(), co, fea, 1, p.ck);
+                    rec_pack(RF_PACK_X3, ci + ".attn_out.weight", "", (size_t)p.x3_off, co, fea, 0, 1, p.ck, p.n_chunks);
+                }
             }
             p.bias_off = (long)b.add(bsum.data(), bsum.size());
             if (wr && br) rec_copy(RF_SUM, ci + ".attn_out.bias", ci + ".attn_res.bias", (size_t)p.bias_off, bsum.size());
@@ -467,6 +474,11 @@ int Net::commit(hipStream_t stream) {
     }
     merged_stale = false;
     last_ptrs.clear();
+    dconv.clear();  // re-derived on demand (build_dgrad_packs) from the recipes of THIS commit
+    if (dgrad_blob) {
+        DDIF_HIPCHK(hipFree(dgrad_blob));
+        dgrad_blob = nullptr;
+    }
 
     if (blob) {
         DDIF_HIPCHK(hipFree(blob));
@@ -537,7 +549,10 @@ int Net::refresh_device(int n, const char* const* keys, const float* const* ptrs
             d.kind = r.kind;
             d.src0 = flat[2 * k];
             d.src1 = flat[2 * k + 1];
-            d.dst = blob + r.dst_off;
+            d.dst = (r.dblob ? dgrad_blob : blob) + r.dst_off;
+            d.tr = r.tr;
+            d.fc0 = r.fc0;
+            d.fc1 = r.fc1;
             d.cout = r.cout;
             d.cin0 = r.cin0;
             d.cin1 = r.cin1;
@@ -562,6 +577,86 @@ int Net::refresh_device(int n, const char* const* keys, const float* const* ptrs
     hipLaunchKernelGGL(refresh_blob_kernel, dim3((unsigned)refresh_blocks), dim3(256), 0, stream, (const RefreshRec*)d_recs, n_recs);
     DDIF_HIPCHK(hipGetLastError());
     merged_stale = true;
+    return 0;
+}
+
+// Training: allocate + describe the dgrad packs of every conv the reverse pass differentiates through (called once by the first
+// train-mode plan after a commit).  The packs are FILLED by refresh_device() -- a train-mode plan therefore needs one refresh before
+// its first backward pass.
+int Net::build_dgrad_packs() {
+    if (!committed) return fail(DDIF_ERR_STATE, "build_dgrad_packs: ddif_net_commit has not been called");
+    if (dgrad_blob) return 0;
+    size_t off = 0;
+    std::vector<Recipe> extra;
+    auto add = [&](const std::string& name, const std::string& s0, const std::string& s1, int cout_f, int fc0, int fc1, int ks) {
+        // dgrad conv: contraction over the forward couts, output = the forward cins (padded to a multiple of 4 for float4 stores)
+        PackedConv pc;
+        pc.cin = cout_f;
+        pc.cout = (fc0 + fc1 + 3) & ~3;
+        pc.ks = ks;
+        pc.ck = (ks == 3 || pc.cin <= 16) ? 16 : 32;
+        pc.n_chunks = (pc.cin + pc.ck - 1) / pc.ck;
+        const size_t nb_pad = (size_t)(((pc.cout + 31) / 32 + 3) & ~3);
+        const bool x3 = pc.ck % 16 == 0 && (ks == 3 || pc.ck == 32);
+        Recipe r;
+        r.kind = RF_PACK_F32;
+        r.src0 = s0;
+        r.src1 = s1;
+        r.cout = pc.cout;
+        r.cin0 = cout_f;
+        r.ks = ks;
+        r.ck = pc.ck;
+        r.n_chunks = pc.n_chunks;
+        r.tr = 1;
+        r.fc0 = fc0;
+        r.fc1 = fc1;
+        r.dblob = true;
+        r.dst_off = off;
+        r.n_out = nb_pad * pc.n_chunks * ks * ks * (pc.ck / 8) * 256;
+        const size_t w_off = off;
+        off += (r.n_out + 63) & ~(size_t)63;
+        extra.push_back(r);
+        size_t x3_off = 0;
+        if (x3) {
+            Recipe q = r;
+            q.kind = RF_PACK_X3;
+            q.dst_off = off;
+            q.n_out = nb_pad * pc.n_chunks * ks * ks * (pc.ck / 16) * 3 * 256;
+            x3_off = off;
+            off += (q.n_out + 63) & ~(size_t)63;
+            extra.push_back(q);
+        }
+        // pointers are fixed up below, once the blob exists
+        pc.w = reinterpret_cast<const float*>(w_off + 1);
+        pc.w_x3 = x3 ? reinterpret_cast<const float*>(x3_off + 1) : nullptr;
+        pc.bias = nullptr;
+        dconv[name] = pc;
+    };
+    for (auto& kv : conv) {
+        const std::string& name = kv.first;
+        const PackedConv& f = kv.second;
+        const size_t n = name.size();
+        auto ends = [&](const char* suf) { const size_t m = strlen(suf); return n >= m && name.compare(n - m, m, suf) == 0; };
+        if (ends(".ffn.23") || ends(".body.0") || name == "downs.0") continue;  // eval-only merge; convs whose input needs no gradient
+        if (ends(".attn_mix")) {
+            const std::string ci = name.substr(0, n - strlen(".attn_mix"));
+            const bool has_res = get(ci + ".attn_res.weight") != nullptr;
+            const int fea = has_res ? f.cin / 2 : f.cin;
+            add(name, ci + ".attn_out.weight", has_res ? ci + ".attn_res.weight" : "", f.cout, fea, has_res ? fea : 0, 1);
+            continue;
+        }
+        add(name, name + ".weight", "", f.cout, f.cin, 0, f.ks);
+    }
+    dgrad_floats = off + 64;
+    DDIF_HIPCHK(hipMalloc((void**)&dgrad_blob, dgrad_floats * sizeof(float)));
+    DDIF_HIPCHK(hipMemset(dgrad_blob, 0, dgrad_floats * sizeof(float)));
+    for (auto& kv : dconv) {
+        PackedConv& pc = kv.second;
+        pc.w = dgrad_blob + (reinterpret_cast<size_t>(pc.w) - 1);
+        if (pc.w_x3) pc.w_x3 = dgrad_blob + (reinterpret_cast<size_t>(pc.w_x3) - 1);
+    }
+    recipes.insert(recipes.end(), extra.begin(), extra.end());
+    last_ptrs.clear();  // the device table must be rebuilt
     return 0;
 }
 

@@ -77,9 +77,17 @@ struct Net {
         std::string src0, src1;       // state-dict keys
         size_t dst_off = 0;           // floats into the blob
         int cout = 0, cin0 = 0, cin1 = 0, ks = 1, ck = 32, n_chunks = 0;
+        int tr = 0, fc0 = 0, fc1 = 0; // dgrad packs (kernels_refresh.h)
+        bool dblob = false;           // destination lives in the dgrad blob
         size_t n_out = 0;
     };
     std::vector<Recipe> recipes;
+    // training only: the weights of every conv's DGRAD conv (transposed, taps flipped), packed by the same refresh launch.  Built on
+    // demand by the first train-mode plan (build_dgrad_packs); key = forward conv key (".attn_mix": dgrad over cat[o, xn])
+    std::map<std::string, PackedConv> dconv;
+    float* dgrad_blob = nullptr;
+    size_t dgrad_floats = 0;
+    int build_dgrad_packs();
     bool merged_stale = false;        // the eval-only merged ffn[3] o ffn[2] weights were NOT refreshed (train-mode plans do not use them)
     void* d_recs = nullptr;           // device RefreshRec table of the last refresh
     std::vector<const float*> last_ptrs;
@@ -90,6 +98,7 @@ struct Net {
     ~Net() {
         if (blob) (void)hipFree(blob);
         if (d_recs) (void)hipFree(d_recs);
+        if (dgrad_blob) (void)hipFree(dgrad_blob);
     }
     int build_layers();
     int load(const char* key, const float* data, const int64_t* shape, int ndim);

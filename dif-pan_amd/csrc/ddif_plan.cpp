@@ -218,7 +218,7 @@ int Plan::alloc_tensor(Tensor* t, int C_, int H_, int W_, bool step_act) {
     t->W = W_;
     t->st = nullptr;
     t->np = 0;
-    if (!step_act) return dalloc(&t->p, (size_t)B * H_ * W_ * C_);
+    if (!step_act || train_mode) return dalloc(&t->p, (size_t)B * H_ * W_ * C_);  // train: every activation lives until the reverse pass
     // activation of the step program: lives in the arena between its first and its last launch
     const size_t bytes = ((size_t)B * H_ * W_ * C_ * sizeof(float) + 255) & ~(size_t)255;
     if (dry) {
@@ -244,6 +244,14 @@ void Plan::use(const void* p) {
 
 // Two passes over the same builder: the dry pass only records shapes and liveness, the real pass allocates.
 int Plan::build() {
+    if (train_mode) {  // no activation arena: the reverse pass reads the forward's tensors
+        dry = false;
+        tmods.clear();
+        if (int e = net->build_dgrad_packs()) return e;
+        if (int e = build_impl()) return e;
+        compute_regions();
+        return build_backward();
+    }
     dry = true;
     if (int e = build_impl()) return e;
     // the network output is read by the sampler update / layout conversion AFTER the last launch of the program
@@ -669,7 +677,18 @@ int Plan::build_impl() {
             s2.res = in.p;
             s2.stats = true;
             s2.name = "res.conv2 (train)";
-            return add_conv(step, s2, out);
+            DDIF_TRY(add_conv(step, s2, out));
+            TrainMod m;
+            m.kind = TrainMod::RES;
+            m.key = rb;
+            m.in = in;
+            m.out = *out;
+            m.t[0] = h1;
+            m.t[1] = y2;
+            m.mask = drop_sites.back().mask;
+            m.slot = net->slot_off.at(rb);
+            tmods.push_back(m);
+            return 0;
         }
         ConvSpec s1;
         s1.pc = c1;
@@ -695,7 +714,7 @@ int Plan::build_impl() {
     auto attention = [&](const std::string& ap, Tensor in, Tensor* out) -> int {
         const PackedConv *cq = PC(ap + ".qkv"), *co = PC(ap + ".out");
         if (!cq || !co) return fail(DDIF_ERR_MISSING, "%s: conv weights missing", ap.c_str());
-        if (in.H * in.W == 64 && in.C == 128 && x3_enabled() && lr_enabled() && cq->w_x3 && co->w_x3 && cq->ck == 32 && co->ck == 32 && in.st) {
+        if (!train_mode && in.H * in.W == 64 && in.C == 128 && x3_enabled() && lr_enabled() && cq->w_x3 && co->w_x3 && cq->ck == 32 && co->ck == 32 && in.st) {
             // 64-token tiles: GroupNorm -> qkv -> softmax(q k^T / sqrt(C)) v -> out + bias + x in ONE kernel, one workgroup per
             // sample (kernels_attn.h); other sizes take the three-launch path below
             use(in.p);
@@ -770,12 +789,24 @@ int Plan::build_impl() {
         s2.res = in.p;
         s2.stats = true;
         s2.name = "attn.out";
-        return add_conv(step, s2, out);
+        DDIF_TRY(add_conv(step, s2, out));
+        if (train_mode) {
+            TrainMod m;
+            m.kind = TrainMod::ATTN;
+            m.key = ap;
+            m.in = in;
+            m.out = *out;
+            m.t[0] = qkv;
+            m.t[1] = o;
+            tmods.push_back(m);
+        }
+        return 0;
     };
 
     // ---- step program
     Tensor cur;
     std::vector<Tensor> feats;
+    std::vector<int> feat_mod;  // train: index in tmods of the module that produced each feature
     int lev = 0;
     for (auto& L : net->downs) {
         if (L.kind == L_STEM) {
@@ -793,6 +824,13 @@ int Plan::build_impl() {
             s.stats = true;
             s.name = "stem";
             DDIF_TRY(add_conv(step, s, &cur));
+            if (train_mode) {
+                TrainMod m;
+                m.kind = TrainMod::STEM;
+                m.key = L.p;
+                m.out = cur;
+                tmods.push_back(m);
+            }
         } else if (L.kind == L_DOWN) {
             ConvSpec s;
             s.pc = PC(L.p + ".conv");
@@ -801,8 +839,17 @@ int Plan::build_impl() {
             s.stride = 2;
             s.stats = true;
             s.name = "down";
+            const Tensor din = cur;
             DDIF_TRY(add_conv(step, s, &cur));
             ++lev;
+            if (train_mode) {
+                TrainMod m;
+                m.kind = TrainMod::DOWN;
+                m.key = L.p + ".conv";
+                m.in = din;
+                m.out = cur;
+                tmods.push_back(m);
+            }
         } else {
             const std::string ci = L.p + ".cond_inj";
             // cond-only: body(cond) -> FiLM scale|shift   (sr3_dwt.py:379-391)
@@ -831,10 +878,49 @@ int Plan::build_impl() {
             s.pc = PC(ci + ".x_conv");
             if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.x_conv missing", ci.c_str());
             s.in0 = cur;
+            if (train_mode) {
+                // train: xc = x_conv(x) is kept (FiLM's backward needs it), the modulation is a launch of its own
+                Tensor xc;
+                s.name = "film.x_conv (train)";
+                DDIF_TRY(add_conv(step, s, &xc));
+                DDIF_TRY(alloc_tensor(&y, xc.C, xc.H, xc.W, true));
+                const int HWl = xc.H * xc.W, Cc = xc.C, BB = B;
+                const int chunks = tk::film_chunks(HWl, Cc);
+                y.np = chunks;
+                DDIF_TRY(dalloc(&y.st, (size_t)B * chunks * 2));
+                Tensor yy = y;
+                Op op;
+                op.name = "film_apply";
+                op.cls = (HWl <= 256) ? 2 : 5;
+                op.bytes = 16.0 * B * HWl * Cc;
+                op.run = [xc, film, yy, HWl, Cc, BB, chunks](hipStream_t st, const StepCtx&) {
+                    tk::film_apply(st, xc.p, film.p, BB, HWl, Cc, yy.p, yy.st, chunks);
+                };
+                step.push_back(std::move(op));
+                // the cond image zero-padded to 4 | channels: input of body.0's weight gradient (cond-only, part of set_cond)
+                if ((int)cenc_pad.size() < nlev) cenc_pad.resize(nlev);
+                if (!cenc_pad[lev].p) {
+                    const int Cp = (cenc[lev].C + 3) & ~3;
+                    DDIF_TRY(alloc_tensor(&cenc_pad[lev], Cp, cenc[lev].H, cenc[lev].W));
+                }
+                TrainMod m;
+                m.kind = TrainMod::FILM;
+                m.key = ci;
+                m.in = cur;
+                m.out = y;
+                m.t[0] = xc;
+                m.t[1] = film;
+                m.t[2] = hid;
+                m.t[3] = cenc[lev];
+                m.t[4] = cenc_pad[lev];
+                m.lev = lev;
+                tmods.push_back(m);
+            } else {
             s.film = film.p;
             s.stats = true;
             s.name = "film.x_conv";
             DDIF_TRY(add_conv(step, s, &y));
+            }
             DDIF_TRY(resblock(L.p + ".res_block", y, &cur));
             if (L.attn) {
                 Tensor t2;
@@ -843,6 +929,10 @@ int Plan::build_impl() {
             }
         }
         feats.push_back(cur);
+        if (train_mode) {
+            tmods.back().pushes_feat = true;
+            feat_mod.push_back((int)tmods.size() - 1);
+        }
     }
     for (auto& L : net->mid) {
         Tensor t1;
@@ -863,21 +953,35 @@ int Plan::build_impl() {
             s.ups = 1;
             s.stats = true;
             s.name = "up";
+            const Tensor uin = cur;
             DDIF_TRY(add_conv(step, s, &cur));
             --lev;
+            if (train_mode) {
+                TrainMod m;
+                m.kind = TrainMod::UP;
+                m.key = L.p + ".conv";
+                m.in = uin;
+                m.out = cur;
+                tmods.push_back(m);
+            }
             continue;
         }
         const std::string ci = L.p + ".cond_inj";
         Tensor skip = feats.back();
         feats.pop_back();
+        int skip_from = -1;
+        if (train_mode) {
+            skip_from = feat_mod.back();
+            feat_mod.pop_back();
+        }
         if (skip.C != L.cskip || cur.C != L.cx || skip.H != cur.H || skip.W != cur.W)
             return fail(DDIF_ERR_INVALID, "%s: skip/feature shape mismatch", L.p.c_str());
         const int fea = L.cin, d = fea / 8, Hl = cur.H, Wl = cur.W, BB = B;
         const int cd = Cl + 3 * P;
         // ---- cond-only: kv -> softmax_W(k) -> context   (sr3_dwt.py:514-517,541,546,563)
         float* ctx = nullptr;
+        Tensor kdw, kv;
         {
-            Tensor kdw, kv;
             DDIF_TRY(alloc_tensor(&kdw, cd, Hl, Wl));
             {
                 DwArgs a{};
@@ -906,7 +1010,8 @@ int Plan::build_impl() {
             s.in0 = kdw;
             s.name = "kv.1x1";
             DDIF_TRY(add_conv(pre, s, &kv));
-            float *kmx, *ksm;
+            float *kmx = nullptr, *ksm = nullptr;
+            if (!train_mode) {
             DDIF_TRY(dalloc(&kmx, (size_t)B * Hl * fea));
             DDIF_TRY(dalloc(&ksm, (size_t)B * Hl * fea));
             DDIF_TRY(dalloc(&ctx, (size_t)B * 8 * d * d));
@@ -929,6 +1034,167 @@ int Plan::build_impl() {
                 };
                 pre.push_back(std::move(op));
             }
+            }  // !train_mode (the train-mode forward runs the attention core itself)
+        }
+        if (train_mode) {
+            // ---- train mode: the block op by op (models/sr3_dwt.py:536-577), every intermediate the reverse pass needs kept in memory:
+            //   xn = GN(cat[h, skip]), dwq = dw3x3(xn)        one launch (dw3x3_kernel, two sources, GroupNorm from the producers' partials)
+            //   q = q.1(dwq);  o = linear attention(q, kv)     (kv comes from set_cond);  a = attn_out(o) + attn_res(xn)  as one 1x1 conv over cat[o, xn]
+            //   f0 = ffn.0(a); f1 = silu(f0); f2 = ffn.2(f1); f3c = ffn.3(f2) + b;  out = a + DropPath(f3c)
+            const PackedConv* pq1t = PC(ci + ".q.1");
+            const PackedConv* pmixt = PC(ci + ".attn_mix");
+            if (!pq1t || !pmixt) return fail(DDIF_ERR_MISSING, "%s: q.1 / attn_out missing", ci.c_str());
+            if (!cur.st || !skip.st) return fail(DDIF_ERR_STATE, "%s: prenorm without producer statistics", ci.c_str());
+            const float *pn_g = V(ci + ".prenorm_x.weight"), *pn_b = V(ci + ".prenorm_x.bias"), *q0w = V(ci + ".q.0.weight");
+            if (!pn_g || !pn_b || !q0w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
+            Tensor xn, dwq, q, o, a, f0, f1, f2, f3c, f3, kdw_pad;
+            DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl, true));
+            DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl, true));
+            {
+                DwArgs da{};
+                da.in0 = cur.p;
+                da.c0 = cur.C;
+                da.in1 = skip.p;
+                da.c1 = skip.C;
+                da.B = B;
+                da.H = Hl;
+                da.W = Wl;
+                da.st0 = cur.st;
+                da.np0 = cur.np;
+                da.st1 = skip.st;
+                da.np1 = skip.np;
+                da.gamma = pn_g;
+                da.beta = pn_b;
+                da.w = q0w;
+                da.out_dw = dwq.p;
+                da.out_xn = xn.p;
+                da.use_gn = 1;
+                da.tiles_x = (Wl + 15) / 16;
+                da.tiles_y = (Hl + 7) / 8;
+                Op op;
+                op.name = "q.gn_dw3x3 (train)";
+                op.cls = (Hl * Wl <= 256) ? 2 : 5;
+                op.flop = 2.0 * 9 * B * Hl * Wl * fea;
+                op.bytes = 12.0 * B * Hl * Wl * fea;
+                op.run = [da, BB](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * da.tiles_x * da.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, da);
+                };
+                step.push_back(std::move(op));
+            }
+            {
+                ConvSpec s;
+                s.pc = pq1t;
+                s.in0 = dwq;
+                s.name = "q.1x1 (train)";
+                DDIF_TRY(add_conv(step, s, &q));
+            }
+            DDIF_TRY(alloc_tensor(&o, fea, Hl, Wl, true));
+            {
+                Op op;
+                op.name = "linattn_fwd";
+                op.cls = (Hl * Wl <= 256) ? 2 : 5;
+                op.flop = 4.0 * B * 8 * d * d * (double)Hl * Wl;
+                op.bytes = 16.0 * B * Hl * Wl * fea;
+                Tensor qq = q, kk = kv, oo = o;
+                op.run = [qq, kk, oo, BB, d, Hl, Wl, fea](hipStream_t s, const StepCtx&) { tk::linattn_fwd(s, qq.p, kk.p, BB, 8, d, Hl, Wl, oo.p, fea); };
+                step.push_back(std::move(op));
+            }
+            const bool has_res = pmixt->cin == 2 * fea;
+            {
+                ConvSpec s;
+                s.pc = pmixt;
+                s.in0 = o;
+                if (has_res) s.in1 = xn;
+                else s.res = xn.p;  // attn_res is Identity
+                s.name = "attn_out+res (train)";
+                DDIF_TRY(add_conv(step, s, &a));
+            }
+            {
+                ConvSpec s;
+                s.pc = PC(ci + ".ffn.0");
+                if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.0 missing", ci.c_str());
+                s.in0 = a;
+                s.use_bias = false;
+                s.name = "ffn.0 (train)";
+                DDIF_TRY(add_conv(step, s, &f0));
+                DDIF_TRY(alloc_tensor(&f1, f0.C, f0.H, f0.W, true));
+                Op op;
+                op.name = "silu";
+                op.cls = (Hl * Wl <= 256) ? 2 : 5;
+                op.bytes = 8.0 * B * Hl * Wl * f0.C;
+                Tensor ff0 = f0, ff1 = f1;
+                const size_t n = (size_t)B * Hl * Wl * f0.C;
+                op.run = [ff0, ff1, n](hipStream_t st, const StepCtx&) { tk::silu_fwd(st, ff0.p, n, ff1.p); };
+                step.push_back(std::move(op));
+                ConvSpec s2;
+                s2.pc = PC(ci + ".ffn.2");
+                if (!s2.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.2 missing", ci.c_str());
+                s2.in0 = f1;
+                s2.use_bias = false;
+                s2.name = "ffn.2 (train)";
+                DDIF_TRY(add_conv(step, s2, &f2));
+                ConvSpec s3;
+                s3.pc = PC(ci + ".ffn.3");
+                if (!s3.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.3 missing", ci.c_str());
+                s3.in0 = f2;
+                s3.name = "ffn.3 (train)";
+                DDIF_TRY(add_conv(step, s3, &f3c));
+            }
+            float* scale = nullptr;
+            {
+                DDIF_TRY(alloc_tensor(&f3, f3c.C, f3c.H, f3c.W, true));
+                DDIF_TRY(dalloc(&scale, (size_t)B));
+                path_sites.push_back(scale);
+                const int HW = f3c.H * f3c.W, Cc = f3c.C;
+                int chunks = (HW * Cc / 4 + 256 * 8 - 1) / (256 * 8);
+                if (chunks < 1) chunks = 1;
+                f3.np = chunks;
+                DDIF_TRY(dalloc(&f3.st, (size_t)B * chunks * 2));
+                Tensor fo = f3, fc = f3c, aa = a;
+                Op op;
+                op.name = "droppath_add";
+                op.cls = (HW <= 256) ? 2 : 5;
+                op.bytes = 12.0 * B * HW * Cc;
+                op.run = [fc, scale, aa, fo, HW, Cc, BB, chunks](hipStream_t s, const StepCtx&) {
+                    hipLaunchKernelGGL(droppath_add_kernel, dim3(chunks, BB), dim3(256), 64, s, (const float*)fc.p, (const float*)scale, (const float*)aa.p, HW, Cc, fo.p, fo.st);
+                };
+                step.push_back(std::move(op));
+            }
+            // kv.0's output zero-padded to 4 | channels: input of kv.1's weight gradient (cond-only)
+            {
+                const int Cp = (cd + 3) & ~3;
+                DDIF_TRY(alloc_tensor(&kdw_pad, Cp, Hl, Wl));
+            }
+            TrainMod m;
+            m.kind = TrainMod::DEC;
+            m.key = ci;
+            m.in = cur;
+            m.out = f3;
+            m.t[0] = skip;
+            m.t[1] = xn;
+            m.t[2] = dwq;
+            m.t[3] = q;
+            m.t[4] = kv;
+            m.t[5] = kdw;
+            m.t[6] = kdw_pad;
+            m.t[7] = o;
+            m.t[8] = a;
+            m.t[9] = f0;
+            m.t[10] = f1;
+            m.t[11] = f2;
+            m.scale = scale;
+            m.has_res = has_res;
+            m.skip_from = skip_from;
+            m.lev = lev;
+            tmods.push_back(m);
+            // f3c is only needed by the reverse pass through DropPath's scale: d(f3c) = scale * d(out); not stored in the record
+            DDIF_TRY(resblock(L.p + ".res_block", f3, &cur));
+            if (L.attn) {
+                Tensor t2;
+                DDIF_TRY(attention(L.p + ".attn", cur, &t2));
+                cur = t2;
+            }
+            continue;
         }
         // ---- per step
         Tensor xn, q, amix, f1, f2, f3;
@@ -1153,6 +1419,14 @@ int Plan::build_impl() {
         s.beta = V("final_conv.block.0.bias");
         s.name = "final";
         DDIF_TRY(add_conv(step, s, &net_out));
+        if (train_mode) {
+            TrainMod m;
+            m.kind = TrainMod::FINAL;
+            m.key = "final_conv";
+            m.in = cur;
+            m.out = net_out;
+            tmods.push_back(m);
+        }
     }
     DDIF_TRY(ensure_tb(B));
     return 0;
@@ -1182,7 +1456,88 @@ int Plan::time_rows(const float* t_host, int rows, hipStream_t s) {
     DDIF_HIPCHK(hipMemcpyAsync(tvals, t_host, (size_t)rows * sizeof(float), hipMemcpyHostToDevice, s));
     const int inner = net->cfg.inner_channel;
     hipLaunchKernelGGL(time_embed_kernel, dim3(rows), dim3(128), (size_t)6 * inner * sizeof(float), s, (const float*)tvals,
-                       net->freqs, net->w1, net->b1, net->w3, net->b3, net->wall, net->ball, inner, net->nslots, tb);
+                       net->freqs, net->w1, net->b1, net->w3, net->b3, net->wall, net->ball, inner, net->nslots, tb, (float*)nullptr);
+    return 0;
+}
+
+static int check_sampler_net(const Net* n);
+
+int Plan::time_rows_aux(const float* t_host, int rows, float* aux, hipStream_t s) {
+    if (int e = ensure_tb(rows)) return e;
+    DDIF_HIPCHK(hipMemcpyAsync(tvals, t_host, (size_t)rows * sizeof(float), hipMemcpyHostToDevice, s));
+    const int inner = net->cfg.inner_channel;
+    hipLaunchKernelGGL(time_embed_kernel, dim3(rows), dim3(128), (size_t)6 * inner * sizeof(float), s, (const float*)tvals,
+                       net->freqs, net->w1, net->b1, net->w3, net->b3, net->wall, net->ball, inner, net->nslots, tb, aux);
+    return 0;
+}
+
+namespace tk {
+void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, const float* w9c, float* out) {
+    DwArgs a{};
+    a.in0 = in;
+    a.c0 = C;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.w = w9c;
+    a.out_dw = out;
+    a.tiles_x = (W + 15) / 16;
+    a.tiles_y = (H + 7) / 8;
+    hipLaunchKernelGGL(dw3x3_kernel, dim3(B * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+}
+}  // namespace tk
+
+// One training iteration's device work (reference diffusion_ddpm_pan.py:692-766 main pass + diffusion_engine.py:233 loss.backward()):
+// x_t = a x0 + s noise, train-mode forward (masks as set), L1 loss against x0, reverse program -> gradients in the bound tensors.
+int Plan::train_step(const float* x0, const float* noise, const float* a_h, const float* s_h, const float* t_h, const float* sc, float* loss_dev, float* pred,
+                     hipStream_t s) {
+    if (!train_mode || bwd.empty()) return fail(DDIF_ERR_STATE, "ddif_plan_train_step: not a train-mode plan");
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_train_step before ddif_plan_set_cond");
+    if (!x0 || !noise || !a_h || !s_h || !t_h) return fail(DDIF_ERR_INVALID, "ddif_plan_train_step: NULL argument");
+    for (auto& kv : grad_slots)
+        if (!kv.second) return fail(DDIF_ERR_STATE, "ddif_plan_train_step: gradient tensors are not bound (ddif_plan_train_bind); first missing: %s", kv.first.c_str());
+    if (int e = check_sampler_net(net)) return e;
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW * C;
+    DDIF_HIPCHK(hipMemcpyAsync(small, a_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    DDIF_HIPCHK(hipMemcpyAsync(small + B, s_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, x0, B, C, HW, 0, C, img[0]);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, noise, B, C, HW, 0, C, img[1]);
+    hipLaunchKernelGGL(q_sample_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[0], (const float*)img[1], (const float*)small, (const float*)(small + B), B, (size_t)HW * C, x_in.p);
+    if (sc) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, sc, B, C, HW, 0, C, sc_in.p);
+    return train_core(t_h, sc != nullptr, img[0], loss_dev, pred, s);
+}
+
+// forward + loss + reverse pass on a GIVEN network input (parity tests feed the reference's own x / target): x, target (B,C,H,W)
+int Plan::train_forward_backward(const float* x, const float* t_h, const float* sc, const float* target, float* loss_dev, float* pred, hipStream_t s) {
+    if (!train_mode || bwd.empty()) return fail(DDIF_ERR_STATE, "ddif_plan_train_forward_backward: not a train-mode plan");
+    if (!cond_set) return fail(DDIF_ERR_STATE, "ddif_plan_train_forward_backward before ddif_plan_set_cond");
+    if (!x || !t_h || !target) return fail(DDIF_ERR_INVALID, "ddif_plan_train_forward_backward: NULL argument");
+    for (auto& kv : grad_slots)
+        if (!kv.second) return fail(DDIF_ERR_STATE, "ddif_plan_train_forward_backward: gradient tensors are not bound; first missing: %s", kv.first.c_str());
+    if (int e = check_sampler_net(net)) return e;
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW * C;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, x, B, C, HW, 0, C, x_in.p);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, target, B, C, HW, 0, C, img[0]);
+    if (sc) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, sc, B, C, HW, 0, C, sc_in.p);
+    return train_core(t_h, sc != nullptr, img[0], loss_dev, pred, s);
+}
+
+int Plan::train_core(const float* t_h, bool has_sc, const float* target_nhwc, float* loss_dev, float* pred, hipStream_t s) {
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW * C;
+    if (int e = time_rows_aux(t_h, B, taux, s)) return e;
+    StepCtx ctx;
+    ctx.x = x_in.p;
+    ctx.sc = has_sc ? sc_in.p : x_in.p;
+    ctx.tb = tb;
+    ctx.tb_stride = net->nslots;
+    train_set_stem_source(ctx.sc);
+    run_prog(step, s, ctx, false);
+    if (int e = train_backward(target_nhwc, 1.0f, loss_dev, s)) return e;
+    if (pred) hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid(n), dim3(256), 0, s, (const float*)net_out.p, B, C, HW, pred);
+    DDIF_HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -1,6 +1,7 @@
 // Plan: per-(B,H,W) workspaces, the cond-only caches and the launch program of one denoising step.
 #pragma once
 #include <string>
+#include <memory>
 #include "ddif_net.h"
 
 namespace ddif {
@@ -46,6 +47,31 @@ struct ConvVariant {
 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi);
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi);  // ddif_lr.cpp
+// launchers of kernels that live in other translation units (every non-template kernel header is compiled into exactly one object)
+namespace tk {
+// kernels_train.h  (ddif_train.cpp)
+void film_apply(hipStream_t s, const float* xc, const float* film, int B, int HW, int C, float* out, double* st_out, int chunks);
+int film_chunks(int HW, int C);
+void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o);
+// kernels_bwd.h  (ddif_bwd.cpp)
+void silu_fwd(hipStream_t s, const float* x, size_t n, float* y);
+void silu_bwd(hipStream_t s, const float* x, const float* da, size_t n, float* dx);
+struct WgradGeom { int n_co = 0, n_ci = 0, nsplit = 0, rb = 0, nbchunk = 0; size_t smem = 0, partial_floats = 0; };
+WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W);
+int wgrad_prepare();
+void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw);
+void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db);
+void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart, float* ms);
+void gn_act(hipStream_t s, const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out);
+void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta, int B, int HW, int C, int nchunk,
+            int silu, double* cpart, double* planes, float* S, float* dgamma, float* dbeta, float* dx);
+// kernels_bwd_ops.h  (ddif_bwd_ops.cpp)
+void linear_bwd(hipStream_t s, const float* x, const float* w, const float* dy, int B, int nin, int nout, float* dx, float* dw, float* db);
+void l1_fwd(hipStream_t s, const float* pred, const float* target, size_t n, float* out);
+void l1_bwd(hipStream_t s, const float* pred, const float* target, size_t n, float upstream, float* dpred);
+// kernels_misc.h  (ddif_plan.cpp)
+void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, const float* w9c, float* out);  // depthwise conv, weights [9][C]
+}  // namespace tk
 struct AttnBlockArgs;
 int attn_block_prepare();                                                        // ddif_lr.cpp (kernels_attn.h)
 void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s);
@@ -157,6 +183,41 @@ struct Plan {
     void run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof);
     int n_conv3 = 0, n_conv3_x3 = 0;  // 3x3 conv ops of the step program / of them on the bf16x3 path (reported by prof_collect)
     bool op_timing_done = false;  // DDIF_OP_TIMING=<csv path>: one profiled step is timed op by op (development aid)
+
+    // ---- native training step (ddif_train.cpp): the forward builder (ddif_plan.cpp, train_mode) records one TrainMod per module of
+    //      UNetSR3.forward with every tensor the reverse pass needs; build_backward() turns the list into the reverse launch program
+    struct TrainMod {
+        enum Kind { STEM, FILM, RES, ATTN, DOWN, UP, DEC, FINAL } kind = STEM;
+        std::string key;             // state-dict prefix of the module (e.g. "downs.3.cond_inj", "ups.2.res_block", "mid.0.attn")
+        Tensor in, out;              // chain input / output
+        Tensor t[12];                // module-specific saved tensors (see ddif_train.cpp)
+        float* mask = nullptr;       // RES: dropout mask of block2 (NHWC)
+        float* scale = nullptr;      // DEC: per-sample DropPath scales
+        int slot = -1;               // RES: offset of the block's FeatureWiseAffine row in a time-bias row
+        int lev = 0;
+        bool has_res = false;        // DEC: attn_res is a conv (fea != dim_out)
+        bool pushes_feat = false;    // the output is also a skip connection (encoder feature)
+        int skip_from = -1;          // DEC: index (in tmods) of the module whose output is this block's skip input
+    };
+    std::vector<TrainMod> tmods;
+    std::vector<Tensor> cenc_pad, kdw_pad_unused;  // train: cond images zero-padded to 4 | channels (weight gradients)
+    std::map<std::string, float*> grad_slots;      // state-dict key -> bound gradient tensor (reference layout), ddif_plan_train_bind
+    std::vector<std::function<void(hipStream_t)>> bwd;  // reverse program, in FORWARD order (run back to front)
+    struct TrainScratch;
+    std::shared_ptr<TrainScratch> ts;
+    float* d_loss = nullptr;          // device scalar
+    float* dtb = nullptr;             // [B][nslots] gradient of the time-bias rows
+    float* taux = nullptr;            // [B][32 + 128 + 128 + 32] pe | pre-activation | hidden | temb of the time MLP (train forward)
+    float* d_net_out = nullptr;       // d(loss)/d(net_out), NHWC
+    int build_backward();
+    int train_step(const float* x0, const float* noise, const float* a_h, const float* s_h, const float* t_h, const float* sc, float* loss_dev, float* pred,
+                   hipStream_t s);
+    int train_bind(int n, const char* const* keys, float* const* grads);
+    int train_forward_backward(const float* x, const float* t_h, const float* sc, const float* target, float* loss_dev, float* pred, hipStream_t s);
+    int train_core(const float* t_h, bool has_sc, const float* target_nhwc, float* loss_dev, float* pred, hipStream_t s);
+    int train_backward(const float* target_nhwc, float upstream, float* loss_dev, hipStream_t s);
+    void train_set_stem_source(const float* sc_nhwc);
+    int time_rows_aux(const float* t_host, int rows, float* aux, hipStream_t s);
 
     int train_set_dropout(int site, const float* mask_nchw, hipStream_t s);
     int train_set_droppath(const float* scales_host, hipStream_t s);

@@ -1,0 +1,617 @@
+// Native training step (BASELINE configs[4]): the reverse launch program of UNetSR3 under .train().
+//
+// Reference: `diff_loss, recon = diffusion(res, cond=cond); diff_loss.backward()` (diffusion_engine.py:230-233) -- autograd through
+// models/sr3_dwt.py:169-219 (+ F.l1_loss, diffusion/diffusion_ddpm_pan.py:742-749).  Here the forward is the train-mode launch program of
+// ddif_plan.cpp (every activation NHWC, kept until the reverse pass; Plan::tmods records one entry per module with the tensors it saved)
+// and this file builds the reverse program from that list: per module a closure that enqueues its backward kernels --
+//   * conv dgrad   = the forward implicit-GEMM kernels (bf16x3 split products / low-resolution split-K kernel, kernels_conv.h / kernels_lr.h)
+//                    on transposed + tap-flipped weights packed on the device by the same launch that refreshes the forward packs
+//                    (Net::build_dgrad_packs, kernels_refresh.h);  real 1x1 kernels for 1x1 convs;
+//   * conv wgrad   = conv3x3_wgrad_kernel (exact-fp32 MFMA, fixed-order split-K reduction), centre tap only for 1x1 convs;
+//   * GroupNorm (+ SiLU, + Dropout mask) backward, FiLM, SiLU, DropPath, linear attention, self-attention, depthwise convs: kernels_bwd.h /
+//     kernels_train.h, all NHWC -- no layout conversion anywhere between the boundary tensors.
+// Gradients are written (not accumulated) into caller-bound tensors in the reference's parameter layouts (ddif_plan_train_bind).
+// Everything is deterministic: fixed-order reductions, no atomics.
+#include <algorithm>
+
+#include "ddif_plan.h"
+#include "kernels_train.h"
+
+namespace ddif {
+
+static bool train_x3_() {  // DDIF_TRAIN_X3=0: exact-fp32 MFMA for the dgrad convs (as ddif_bwd.cpp)
+    static const bool v = [] { const char* e = getenv("DDIF_TRAIN_X3"); return !e || atoi(e) != 0; }();
+    return v;
+}
+static inline dim3 tgrid(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g);
+}
+
+namespace tk {
+int film_chunks(int HW, int C) {
+    int chunks = (HW * C / 4 + 256 * 8 - 1) / (256 * 8);
+    return chunks < 1 ? 1 : chunks;
+}
+void film_apply(hipStream_t s, const float* xc, const float* film, int B, int HW, int C, float* out, double* st_out, int chunks) {
+    hipLaunchKernelGGL(film_apply_kernel, dim3(chunks, B), dim3(256), 64, s, xc, film, HW, C, out, st_out);
+}
+void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o) {
+    const size_t sm = (size_t)(4 * d * W + d * d + 2 * d * H) * sizeof(float);
+    hipLaunchKernelGGL(linattn_fwd_nhwc_kernel, dim3(B * heads), dim3(256), sm, s, q, kv, heads, d, H, W, 1.0f / std::sqrt((float)d), out, ld_o);
+}
+}  // namespace tk
+
+struct Plan::TrainScratch {
+    float *a = nullptr, *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *bpart = nullptr, *ms = nullptr, *S = nullptr, *wpad = nullptr, *dwflip = nullptr;
+    double *spart = nullptr, *cpart = nullptr, *planes = nullptr, *dwpart = nullptr;
+    size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_planes = 0, n_wpad = 0, n_dwpart = 0, n_dwflip = 0;
+    const float* stem_sc = nullptr;  // set by train_step: the self-conditioning source of THIS iteration (sc_in or x_in)
+    // time MLP backward
+    float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr;
+};
+
+int Plan::train_bind(int n, const char* const* keys, float* const* grads) {
+    if (!train_mode) return fail(DDIF_ERR_STATE, "ddif_plan_train_bind: not a train-mode plan");
+    if (n < 1 || !keys || !grads) return fail(DDIF_ERR_INVALID, "ddif_plan_train_bind: bad arguments");
+    std::map<std::string, float*> given;
+    for (int i = 0; i < n; ++i) {
+        if (!keys[i] || !grads[i]) return fail(DDIF_ERR_INVALID, "ddif_plan_train_bind: NULL key / pointer at %d", i);
+        given[keys[i]] = grads[i];
+    }
+    for (auto& kv : grad_slots) {
+        auto it = given.find(kv.first);
+        if (it == given.end()) return fail(DDIF_ERR_MISSING, "ddif_plan_train_bind: no gradient tensor for '%s'", kv.first.c_str());
+        kv.second = it->second;
+    }
+    return 0;
+}
+
+int Plan::build_backward() {
+#define DDIF_TRY(x) do { if (int e__ = (x)) return e__; } while (0)
+    ts = std::make_shared<TrainScratch>();
+    TrainScratch* T = ts.get();
+    bwd.clear();
+    grad_slots.clear();
+    const int BB = B;
+    auto V = [&](const std::string& k) -> const float* {
+        auto it = net->vec.find(k);
+        return it == net->vec.end() ? nullptr : it->second;
+    };
+    auto G = [&](const std::string& k) -> float** { return &grad_slots[k]; };  // std::map nodes are stable
+    auto need = [](size_t& cur, size_t n) { if (n > cur) cur = n; };
+    auto numel = [&](const Tensor& t) { return (size_t)BB * t.H * t.W * t.C; };
+    auto fbuf = [&](float** p, size_t n) -> int { return dalloc(p, n); };
+    DDIF_TRY(tk::wgrad_prepare());
+
+    // ---- building blocks (each appends launches to a closure list `L` executed in order)
+    using Launch = std::function<void(hipStream_t)>;
+    struct Seq { std::vector<Launch> v; };
+
+    // dgrad conv of forward conv `key`: dy [B,H,W,Cout_f] -> dx [B,H,W,(Cin_f padded to 4)]
+    auto add_dgrad = [&](Seq& L, const std::string& key, Tensor dy, Tensor* dx) -> int {
+        auto it = net->dconv.find(key);
+        if (it == net->dconv.end()) return fail(DDIF_ERR_MISSING, "training: no dgrad weights for %s", key.c_str());
+        auto prog = std::make_shared<std::vector<Op>>();
+        ConvSpec s;
+        s.pc = &it->second;
+        s.in0 = dy;
+        s.in0.st = nullptr;
+        s.use_bias = false;
+        s.exact = !train_x3_();
+        s.name = "dgrad";
+        if (int e = add_conv(*prog, s, dx)) return e;
+        L.v.push_back([prog](hipStream_t st) {
+            StepCtx ctx;
+            for (auto& op : *prog) op.run(st, ctx);
+        });
+        return 0;
+    };
+    // weight (+ bias) gradient of a conv with input x [B,H,W,Cin] (Cin % 4 == 0) and output gradient dy [B,H,W,Cout]
+    auto add_wgrad = [&](Seq& L, const float* x, int Cin, const float* dy, int Cout, int H_, int W_, int ks, float** dw, float** db) -> int {
+        if (Cin % 4 || Cout % 4) return fail(DDIF_ERR_INVALID, "training: weight gradient needs 4 | channels (got %d -> %d)", Cin, Cout);
+        const tk::WgradGeom g = tk::wgrad_geom(BB, Cin, Cout, H_, W_);
+        if (g.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", W_);
+        need(T->n_partial, g.partial_floats);
+        need(T->n_bpart, (size_t)g.nbchunk * Cout);
+        const size_t npix = (size_t)BB * H_ * W_;
+        L.v.push_back([=](hipStream_t st) {
+            tk::wgrad(st, x, dy, BB, H_, W_, Cin, Cout, g, ks == 1, T->partial, *dw);
+            if (db) tk::bias_grad(st, dy, npix, Cout, g.nbchunk, T->bpart, *db);
+        });
+        return 0;
+    };
+    // backward of  [GroupNorm (+SiLU) (+mask)] -> conv  (one `Block` of the reference, :288-300, and the other normalised convs)
+    //   pro: 0 none, 1 GroupNorm, 2 GroupNorm + SiLU.  a_mat: the conv's input if the forward materialised it (block2's dropped activation).
+    auto add_block_bwd = [&](Seq& L, Tensor x, int pro, const std::string& nkey, const float* mask, const float* a_mat, const std::string& ckey, int ks, bool has_bias,
+                             Tensor dy, bool need_dx, float** dx_out) -> int {
+        const int HW = x.H * x.W, C = x.C;
+        const size_t n = numel(x);
+        const int nchunk = HW < 32 ? HW : 32;
+        const float *gamma = nullptr, *beta = nullptr;
+        if (pro) {
+            gamma = V(nkey + ".weight");
+            beta = V(nkey + ".bias");
+            if (!gamma || !beta) return fail(DDIF_ERR_MISSING, "training: %s weights missing", nkey.c_str());
+            need(T->n_cpart, (size_t)BB * nchunk * C * 2);
+            need(T->n_planes, (size_t)BB * C * 2);
+            if (!a_mat) need(T->n_a, n);
+            L.v.push_back([=](hipStream_t st) { tk::gn_stats(st, x.p, BB, (size_t)HW * C, nchunk, T->spart, T->ms); });
+            if (!a_mat) L.v.push_back([=](hipStream_t st) { tk::gn_act(st, x.p, T->ms, gamma, beta, mask, BB, HW, C, pro == 2, T->a); });
+        }
+        float** dw = G(ckey + ".weight");
+        float** db = has_bias ? G(ckey + ".bias") : nullptr;
+        // (the scratch pointer T->a is read when the launch runs, not now)
+        if (pro && !a_mat) {
+            const tk::WgradGeom g = tk::wgrad_geom(BB, C, dy.C, x.H, x.W);
+            if (g.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", x.W);
+            need(T->n_partial, g.partial_floats);
+            need(T->n_bpart, (size_t)g.nbchunk * dy.C);
+            const size_t npix = (size_t)BB * HW;
+            const int Co = dy.C, H_ = x.H, W_ = x.W;
+            L.v.push_back([=](hipStream_t st) {
+                tk::wgrad(st, T->a, dy.p, BB, H_, W_, C, Co, g, ks == 1, T->partial, *dw);
+                if (db) tk::bias_grad(st, dy.p, npix, Co, g.nbchunk, T->bpart, *db);
+            });
+        } else {
+            DDIF_TRY(add_wgrad(L, a_mat ? a_mat : x.p, C, dy.p, dy.C, x.H, x.W, ks, dw, db));
+        }
+        if (!need_dx && !pro) return 0;
+        Tensor da;
+        DDIF_TRY(add_dgrad(L, ckey, dy, &da));
+        if (da.C != C) return fail(DDIF_ERR_STATE, "training: dgrad of %s yields %d channels, expected %d", ckey.c_str(), da.C, C);
+        if (!pro) {
+            *dx_out = da.p;
+            return 0;
+        }
+        float* dx = nullptr;
+        if (need_dx) DDIF_TRY(fbuf(&dx, n));
+        float** dg = G(nkey + ".weight");
+        float** dbt = G(nkey + ".bias");
+        L.v.push_back([=](hipStream_t st) {
+            tk::gn_bwd(st, x.p, da.p, mask, T->ms, gamma, beta, BB, HW, C, nchunk, pro == 2, T->cpart, T->planes, T->S, *dg, *dbt, dx);
+        });
+        *dx_out = dx;
+        return 0;
+    };
+    auto add_add2 = [&](Seq& L, const float* a, const float* b, size_t n, float* out) {
+        L.v.push_back([=](hipStream_t st) { hipLaunchKernelGGL(add2_kernel, tgrid(n), dim3(256), 0, st, a, b, n, out); });
+    };
+
+    // ---- cond-only padding ops of the weight gradients over 9 / 11-channel cond images (part of set_cond)
+    {
+        std::vector<const float*> done;
+        for (auto& m : tmods) {
+            Tensor src, dst;
+            if (m.kind == TrainMod::FILM) {
+                src = m.t[3];
+                dst = m.t[4];
+            } else if (m.kind == TrainMod::DEC) {
+                src = m.t[5];
+                dst = m.t[6];
+            } else {
+                continue;
+            }
+            if (std::find(done.begin(), done.end(), (const float*)dst.p) != done.end()) continue;
+            done.push_back(dst.p);
+            const size_t npix = (size_t)BB * src.H * src.W;
+            Op op;
+            op.name = "pad_channels";
+            op.run = [src, dst, npix](hipStream_t st, const StepCtx&) {
+                hipLaunchKernelGGL(pad_channels_kernel, tgrid(npix * dst.C), dim3(256), 0, st, (const float*)src.p, src.C, dst.C, npix, dst.p);
+            };
+            pre.push_back(std::move(op));
+        }
+    }
+
+    // ---- loss gradient buffer, time-bias gradient rows
+    DDIF_TRY(fbuf(&d_net_out, numel(net_out)));
+    DDIF_TRY(fbuf(&d_loss, 64));
+    DDIF_TRY(fbuf(&dtb, (size_t)BB * net->nslots));
+    const int inner = net->cfg.inner_channel;
+    DDIF_TRY(fbuf(&taux, (size_t)BB * 10 * inner));
+
+    // ---- walk the modules back to front
+    float* g = d_net_out;
+    std::map<int, float*> skipg;
+    std::vector<Seq> seqs;  // in EXECUTION order (reverse of the forward)
+    for (int i = (int)tmods.size() - 1; i >= 0; --i) {
+        const TrainMod& m = tmods[i];
+        Seq L;
+        float* dy = g;
+        if (m.pushes_feat) {
+            auto it = skipg.find(i);
+            if (it == skipg.end()) return fail(DDIF_ERR_STATE, "training: encoder feature %d has no decoder consumer", i);
+            float* sum = nullptr;
+            DDIF_TRY(fbuf(&sum, numel(m.out)));
+            add_add2(L, g, it->second, numel(m.out), sum);
+            dy = sum;
+        }
+        Tensor dyT = m.out;
+        dyT.p = dy;
+        dyT.st = nullptr;
+        float* dx = nullptr;
+        switch (m.kind) {
+            case TrainMod::FINAL: {
+                DDIF_TRY(add_block_bwd(L, m.in, 2, "final_conv.block.0", nullptr, nullptr, "final_conv.block.3", 3, true, dyT, true, &dx));
+                break;
+            }
+            case TrainMod::RES: {
+                const Tensor h1 = m.t[0], y2 = m.t[1];
+                const std::string rb = m.key;
+                // block2: GroupNorm + SiLU + Dropout -> conv (the dropped activation y2 was materialised by the forward)
+                float* dh1 = nullptr;
+                DDIF_TRY(add_block_bwd(L, h1, 2, rb + ".block2.block.0", m.mask, y2.p, rb + ".block2.block.3", 3, true, dyT, true, &dh1));
+                // FeatureWiseAffine: h1 = conv1(...) + row[b][c]  ->  d(row) = plane sums of dh1
+                {
+                    const int HW = h1.H * h1.W, C = h1.C, ld = net->nslots, slot = m.slot;
+                    float* dst = dtb + slot;
+                    L.v.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plane_sum_nhwc_kernel, dim3(BB), dim3(256), 256 * sizeof(float), st, (const float*)dh1, HW, C, ld, dst); });
+                }
+                Tensor dh1T = h1;
+                dh1T.p = dh1;
+                dh1T.st = nullptr;
+                float* dx1 = nullptr;
+                DDIF_TRY(add_block_bwd(L, m.in, 2, rb + ".block1.block.0", nullptr, nullptr, rb + ".block1.block.3", 3, true, dh1T, true, &dx1));
+                DDIF_TRY(fbuf(&dx, numel(m.in)));
+                add_add2(L, dx1, dy, numel(m.in), dx);  // + the residual path
+                break;
+            }
+            case TrainMod::ATTN: {
+                const Tensor qkv = m.t[0], o = m.t[1];
+                const int n = m.in.H * m.in.W, C = m.in.C, d = C / 8;
+                if (n > 64 || d > 32) return fail(DDIF_ERR_INVALID, "training: self-attention over %d tokens (head dim %d): the reverse pass handles <= 64 tokens", n, d);
+                float* do_ = nullptr;
+                DDIF_TRY(add_block_bwd(L, o, 0, "", nullptr, nullptr, m.key + ".out", 1, true, dyT, true, &do_));
+                float* dqkv = nullptr;
+                DDIF_TRY(fbuf(&dqkv, numel(qkv)));
+                {
+                    const size_t sm = (size_t)(4 * d * n + 2 * n * n + n) * sizeof(float);
+                    const float sc = 1.0f / std::sqrt((float)C);
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(selfattn_bwd_nhwc_kernel, dim3(BB * 8), dim3(256), sm, st, (const float*)qkv.p, (const float*)do_, 8, d, n, sc, dqkv);
+                    });
+                }
+                Tensor dq = qkv;
+                dq.p = dqkv;
+                dq.st = nullptr;
+                float* dx1 = nullptr;
+                DDIF_TRY(add_block_bwd(L, m.in, 1, m.key + ".norm", nullptr, nullptr, m.key + ".qkv", 1, false, dq, true, &dx1));
+                DDIF_TRY(fbuf(&dx, numel(m.in)));
+                add_add2(L, dx1, dy, numel(m.in), dx);
+                break;
+            }
+            case TrainMod::FILM: {
+                const Tensor xc = m.t[0], film = m.t[1], hid = m.t[2], cpad = m.t[4];
+                const std::string ci = m.key;
+                float *dxc = nullptr, *dfilm = nullptr;
+                DDIF_TRY(fbuf(&dxc, numel(xc)));
+                DDIF_TRY(fbuf(&dfilm, numel(film)));
+                {
+                    const size_t npix = (size_t)BB * xc.H * xc.W;
+                    const int C = xc.C;
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(film_bwd_nhwc_kernel, tgrid(npix * C), dim3(256), 0, st, (const float*)xc.p, (const float*)film.p, (const float*)dy, npix, C, dxc, dfilm);
+                    });
+                }
+                Tensor dxcT = xc;
+                dxcT.p = dxc;
+                DDIF_TRY(add_block_bwd(L, m.in, 0, "", nullptr, nullptr, ci + ".x_conv", 1, true, dxcT, true, &dx));
+                Tensor dfT = film;
+                dfT.p = dfilm;
+                float* dhid = nullptr;
+                DDIF_TRY(add_block_bwd(L, hid, 2, ci + ".body.1", nullptr, nullptr, ci + ".body.3", 1, true, dfT, true, &dhid));
+                // body.0: conv3x3 over the (zero-padded) cond image, no bias, no input gradient
+                {
+                    const int Cp = cpad.C, Cr = m.t[3].C, Co = hid.C;
+                    need(T->n_wpad, (size_t)Co * Cp * 9);
+                    float** dwp = &T->wpad;
+                    DDIF_TRY(add_wgrad(L, cpad.p, Cp, dhid, Co, hid.H, hid.W, 3, dwp, nullptr));
+                    float** dw = G(ci + ".body.0.weight");
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)Co * Cr * 9), dim3(256), 0, st, (const float*)T->wpad, Co, Cp, Cr, 9, *dw);
+                    });
+                }
+                break;
+            }
+            case TrainMod::DOWN: {
+                const int H_ = m.in.H, W_ = m.in.W, C = m.in.C, Ho = m.out.H, Wo = m.out.W, Co = m.out.C;
+                float* dyz = nullptr;
+                DDIF_TRY(fbuf(&dyz, (size_t)BB * H_ * W_ * Co));
+                L.v.push_back([=](hipStream_t st) {
+                    hipLaunchKernelGGL(zero_stuff_nhwc_kernel, tgrid((size_t)BB * H_ * W_ * Co), dim3(256), 0, st, (const float*)dy, BB, Co, Ho, Wo, H_, W_, dyz);
+                });
+                Tensor dz;
+                dz.p = dyz;
+                dz.C = Co;
+                dz.H = H_;
+                dz.W = W_;
+                DDIF_TRY(add_wgrad(L, m.in.p, C, dyz, Co, H_, W_, 3, G(m.key + ".weight"), nullptr));
+                {
+                    const tk::WgradGeom gg = tk::wgrad_geom(BB, C, Co, Ho, Wo);
+                    need(T->n_bpart, (size_t)gg.nbchunk * Co);
+                    float** db = G(m.key + ".bias");
+                    const size_t npix = (size_t)BB * Ho * Wo;
+                    L.v.push_back([=](hipStream_t st) { tk::bias_grad(st, dy, npix, Co, gg.nbchunk, T->bpart, *db); });
+                }
+                Tensor dxT;
+                DDIF_TRY(add_dgrad(L, m.key, dz, &dxT));
+                dx = dxT.p;
+                break;
+            }
+            case TrainMod::UP: {
+                const int H_ = m.in.H, W_ = m.in.W, C = m.in.C, Co = m.out.C;
+                need(T->n_tmp, (size_t)BB * 4 * H_ * W_ * C);
+                L.v.push_back([=](hipStream_t st) {
+                    hipLaunchKernelGGL(upsample2_nhwc_kernel, tgrid((size_t)BB * 4 * H_ * W_ * C), dim3(256), 0, st, (const float*)m.in.p, BB, C, H_, W_, T->tmp);
+                });
+                // (T->tmp is read when the launch runs)
+                {
+                    const tk::WgradGeom gg = tk::wgrad_geom(BB, C, Co, 2 * H_, 2 * W_);
+                    if (gg.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", 2 * W_);
+                    need(T->n_partial, gg.partial_floats);
+                    need(T->n_bpart, (size_t)gg.nbchunk * Co);
+                    float** dw = G(m.key + ".weight");
+                    float** db = G(m.key + ".bias");
+                    const size_t npix = (size_t)BB * 4 * H_ * W_;
+                    L.v.push_back([=](hipStream_t st) {
+                        tk::wgrad(st, T->tmp, dy, BB, 2 * H_, 2 * W_, C, Co, gg, false, T->partial, *dw);
+                        tk::bias_grad(st, dy, npix, Co, gg.nbchunk, T->bpart, *db);
+                    });
+                }
+                Tensor dxu;
+                DDIF_TRY(add_dgrad(L, m.key, dyT, &dxu));
+                DDIF_TRY(fbuf(&dx, numel(m.in)));
+                L.v.push_back([=](hipStream_t st) {
+                    hipLaunchKernelGGL(sumpool2_nhwc_kernel, tgrid((size_t)BB * H_ * W_ * C), dim3(256), 0, st, (const float*)dxu.p, BB, C, H_, W_, dx);
+                });
+                break;
+            }
+            case TrainMod::STEM: {
+                // input = cat[self_cond, x] (:174); padded to 4 | channels for the weight-gradient kernel.  No input gradient.
+                const int Cx = x_in.C, Cs = net->cfg.self_condition ? sc_in.C : 0;
+                const int Cin = Cs + Cx, Cp = (Cin + 3) & ~3, Co = m.out.C, H_ = m.out.H, W_ = m.out.W;
+                const size_t npix = (size_t)BB * H_ * W_;
+                need(T->n_tmp, npix * Cin);
+                need(T->n_a, npix * Cp);
+                const float* xin = x_in.p;
+                L.v.push_back([=](hipStream_t st) {
+                    if (Cs) hipLaunchKernelGGL(concat2_kernel, tgrid(npix * Cin), dim3(256), 0, st, T->stem_sc, Cs, xin, Cx, npix, T->tmp);
+                    hipLaunchKernelGGL(pad_channels_kernel, tgrid(npix * Cp), dim3(256), 0, st, Cs ? (const float*)T->tmp : xin, Cin, Cp, npix, T->a);
+                });
+                {
+                    const tk::WgradGeom gg = tk::wgrad_geom(BB, Cp, Co, H_, W_);
+                    if (gg.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", W_);
+                    need(T->n_partial, gg.partial_floats);
+                    need(T->n_bpart, (size_t)gg.nbchunk * Co);
+                    need(T->n_wpad, (size_t)Co * Cp * 9);
+                    float** dw = G(m.key + ".weight");
+                    float** db = G(m.key + ".bias");
+                    L.v.push_back([=](hipStream_t st) {
+                        tk::wgrad(st, T->a, dy, BB, H_, W_, Cp, Co, gg, false, T->partial, T->wpad);
+                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)Co * Cin * 9), dim3(256), 0, st, (const float*)T->wpad, Co, Cp, Cin, 9, *dw);
+                        tk::bias_grad(st, dy, npix, Co, gg.nbchunk, T->bpart, *db);
+                    });
+                }
+                dx = nullptr;
+                break;
+            }
+            case TrainMod::DEC: {
+                const Tensor skip = m.t[0], xn = m.t[1], dwq = m.t[2], q = m.t[3], kv = m.t[4], kdw = m.t[5], kdwp = m.t[6], o = m.t[7], a = m.t[8], f0 = m.t[9], f1 = m.t[10],
+                             f2 = m.t[11];
+                const std::string ci = m.key;
+                const int Hl = xn.H, Wl = xn.W, fea = xn.C, d = fea / 8, Co = a.C;
+                const size_t npix = (size_t)BB * Hl * Wl;
+                if (Hl > 64 || Wl > 64 || d > 32) return fail(DDIF_ERR_INVALID, "training: linear attention at %dx%d (head dim %d): the reverse pass handles <= 64x64, d <= 32", Hl, Wl, d);
+                // DropPath: out = a + scale[b] * f3c
+                float* df3c = nullptr;
+                DDIF_TRY(fbuf(&df3c, numel(a)));
+                {
+                    const size_t per = (size_t)Hl * Wl * Co, tot = npix * Co;
+                    const float* sc = m.scale;
+                    L.v.push_back([=](hipStream_t st) { hipLaunchKernelGGL(scale_rows_kernel, tgrid(tot), dim3(256), 0, st, (const float*)dy, sc, per, tot, df3c); });
+                }
+                Tensor d3 = a;
+                d3.p = df3c;
+                d3.st = nullptr;
+                float* df2 = nullptr;
+                DDIF_TRY(add_block_bwd(L, f2, 0, "", nullptr, nullptr, ci + ".ffn.3", 1, true, d3, true, &df2));
+                Tensor d2 = f2;
+                d2.p = df2;
+                d2.st = nullptr;
+                float* df1 = nullptr;
+                DDIF_TRY(add_block_bwd(L, f1, 0, "", nullptr, nullptr, ci + ".ffn.2", 3, false, d2, true, &df1));
+                float* df0 = nullptr;
+                DDIF_TRY(fbuf(&df0, numel(f0)));
+                {
+                    const size_t n = numel(f0);
+                    L.v.push_back([=](hipStream_t st) { tk::silu_bwd(st, f0.p, df1, n, df0); });
+                }
+                Tensor d0 = f0;
+                d0.p = df0;
+                d0.st = nullptr;
+                float* da_f = nullptr;
+                DDIF_TRY(add_block_bwd(L, a, 0, "", nullptr, nullptr, ci + ".ffn.0", 3, false, d0, true, &da_f));
+                float* da = nullptr;
+                DDIF_TRY(fbuf(&da, numel(a)));
+                add_add2(L, dy, da_f, numel(a), da);
+                // a = attn_out(o) + b_o + [attn_res(xn) + b_r | xn]
+                DDIF_TRY(add_wgrad(L, o.p, fea, da, Co, Hl, Wl, 1, G(ci + ".attn_out.weight"), G(ci + ".attn_out.bias")));
+                if (m.has_res) {
+                    DDIF_TRY(add_wgrad(L, xn.p, fea, da, Co, Hl, Wl, 1, G(ci + ".attn_res.weight"), G(ci + ".attn_res.bias")));
+                }
+                Tensor daT = a;
+                daT.p = da;
+                daT.st = nullptr;
+                Tensor dcat;  // [do | dxn_a] (2 fea channels) or do (fea channels)
+                DDIF_TRY(add_dgrad(L, ci + ".attn_mix", daT, &dcat));
+                const int ldc = dcat.C;
+                if (ldc != (m.has_res ? 2 * fea : fea)) return fail(DDIF_ERR_STATE, "training: %s.attn_mix dgrad yields %d channels", ci.c_str(), ldc);
+                // linear attention core
+                float *dq = nullptr, *dkv = nullptr;
+                DDIF_TRY(fbuf(&dq, numel(q)));
+                DDIF_TRY(fbuf(&dkv, numel(kv)));
+                {
+                    const size_t sm = (size_t)(8 * d * Wl + 2 * d * d + d + 2 * d * Hl) * sizeof(float);
+                    const float sc = 1.0f / std::sqrt((float)d);
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(linattn_bwd_nhwc_kernel, dim3(BB * 8), dim3(256), sm, st, (const float*)q.p, (const float*)kv.p, (const float*)dcat.p, ldc, 8, d, Hl, Wl, sc,
+                                           dq, dkv);
+                    });
+                }
+                // q = q.1(dwq) + b;  dwq = depthwise3x3(xn; q.0)
+                Tensor dqT = q;
+                dqT.p = dq;
+                dqT.st = nullptr;
+                float* ddwq = nullptr;
+                DDIF_TRY(add_block_bwd(L, dwq, 0, "", nullptr, nullptr, ci + ".q.1", 1, true, dqT, true, &ddwq));
+                float* dxn = nullptr;  // total gradient of xn
+                DDIF_TRY(fbuf(&dxn, numel(xn)));
+                {
+                    const float* w9 = V(ci + ".q.0.weight");  // [9][C], refreshed with the weights
+                    need(T->n_dwflip, (size_t)9 * fea);
+                    need(T->n_tmp, numel(xn));
+                    const int nsplit = std::min(64, BB * Hl);
+                    need(T->n_dwpart, (size_t)nsplit * fea * 9);
+                    float** dw0 = G(ci + ".q.0.weight");
+                    const float* other = m.has_res ? dcat.p + fea : da;  // gradient of xn through attn_res (or the identity)
+                    const int ld_other = m.has_res ? ldc : Co;
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(flip_dw_taps_kernel, dim3((9 * fea + 255) / 256), dim3(256), 0, st, w9, fea, T->dwflip);
+                        tk::dw3x3_plain(st, ddwq, fea, BB, Hl, Wl, T->dwflip, T->tmp);  // d(xn) through the depthwise conv
+                        hipLaunchKernelGGL(add2_ld_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)T->tmp, fea, other, ld_other, fea, npix, dxn);
+                        hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((fea + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), st, (const float*)xn.p, fea,
+                                           (const float*)ddwq, fea, BB, fea, Hl, Wl, nsplit, T->dwpart);
+                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((fea * 9 + 255) / 256), dim3(256), 0, st, (const double*)T->dwpart, nsplit, fea, *dw0);
+                    });
+                }
+                // kv = kv.1(kdw) + b;  kdw = depthwise3x3(cond; kv.0): weight gradients only (cond needs no gradient)
+                {
+                    const int cd = kdw.C, Cp = kdwp.C;
+                    need(T->n_wpad, (size_t)2 * fea * Cp);
+                    float** dwp = &T->wpad;
+                    DDIF_TRY(add_wgrad(L, kdwp.p, Cp, dkv, 2 * fea, Hl, Wl, 1, dwp, G(ci + ".kv.1.bias")));
+                    float** dw1 = G(ci + ".kv.1.weight");
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)2 * fea * cd), dim3(256), 0, st, (const float*)T->wpad, 2 * fea, Cp, cd, 1, *dw1);
+                    });
+                    Tensor dkvT = kv;
+                    dkvT.p = dkv;
+                    dkvT.st = nullptr;
+                    Tensor dkdw;  // padded to Cp channels
+                    DDIF_TRY(add_dgrad(L, ci + ".kv.1", dkvT, &dkdw));
+                    const int nsplit = std::min(64, BB * Hl);
+                    need(T->n_dwpart, (size_t)nsplit * cd * 9);
+                    float** dwk0 = G(ci + ".kv.0.weight");
+                    const Tensor cimg = cdec[m.lev];
+                    const int ldk = dkdw.C;
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((cd + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), st, (const float*)cimg.p, cd,
+                                           (const float*)dkdw.p, ldk, BB, cd, Hl, Wl, nsplit, T->dwpart);
+                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((cd * 9 + 255) / 256), dim3(256), 0, st, (const double*)T->dwpart, nsplit, cd, *dwk0);
+                    });
+                }
+                // prenorm_x: xn = GroupNorm(cat[h, skip])  (no SiLU); then split the gradient of the cat
+                {
+                    const int HW = Hl * Wl, nchunk = HW < 32 ? HW : 32, Ca = m.in.C, Cb = skip.C;
+                    const float *gamma = V(ci + ".prenorm_x.weight"), *beta = V(ci + ".prenorm_x.bias");
+                    if (!gamma || !beta) return fail(DDIF_ERR_MISSING, "training: %s.prenorm_x missing", ci.c_str());
+                    need(T->n_a, npix * fea);     // cat[h, skip]
+                    need(T->n_tmp, npix * fea);   // its gradient
+                    need(T->n_cpart, (size_t)BB * nchunk * fea * 2);
+                    need(T->n_planes, (size_t)BB * fea * 2);
+                    float** dg = G(ci + ".prenorm_x.weight");
+                    float** dbt = G(ci + ".prenorm_x.bias");
+                    float* dskip = nullptr;
+                    DDIF_TRY(fbuf(&dx, numel(m.in)));
+                    DDIF_TRY(fbuf(&dskip, numel(skip)));
+                    const Tensor hin = m.in;
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(concat2_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)hin.p, Ca, (const float*)skip.p, Cb, npix, T->a);
+                        tk::gn_stats(st, T->a, BB, (size_t)HW * fea, nchunk, T->spart, T->ms);
+                        tk::gn_bwd(st, T->a, dxn, nullptr, T->ms, gamma, beta, BB, HW, fea, nchunk, 0, T->cpart, T->planes, T->S, *dg, *dbt, T->tmp);
+                        hipLaunchKernelGGL(split2_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)T->tmp, Ca, Cb, npix, (const float*)nullptr, (const float*)nullptr, dx, dskip);
+                    });
+                    if (m.skip_from < 0) return fail(DDIF_ERR_STATE, "training: decoder block without a skip source");
+                    skipg[m.skip_from] = dskip;
+                }
+                break;
+            }
+        }
+        g = dx;
+        seqs.push_back(std::move(L));
+    }
+
+    // ---- time embedding: d(rows) -> every FeatureWiseAffine Linear, noise_level_mlp (:59-64, 241-258)
+    {
+        const int ns = net->nslots, in4 = 4 * inner;
+        DDIF_TRY(fbuf(&T->dte, (size_t)BB * inner));
+        DDIF_TRY(fbuf(&T->dh1, (size_t)BB * in4));
+        DDIF_TRY(fbuf(&T->ds, (size_t)BB * in4));
+        DDIF_TRY(fbuf(&T->dwall, (size_t)ns * inner));
+        DDIF_TRY(fbuf(&T->dball, (size_t)ns));
+        float* pe = taux;                                   // [B][inner]
+        float* spre = taux + (size_t)BB * inner;            // [B][4 inner] pre-activation
+        float* hid = spre + (size_t)BB * in4;               // [B][4 inner] swish
+        float* te = hid + (size_t)BB * in4;                 // [B][inner]
+        float **gw1 = G("noise_level_mlp.1.weight"), **gb1 = G("noise_level_mlp.1.bias"), **gw3 = G("noise_level_mlp.3.weight"), **gb3 = G("noise_level_mlp.3.bias");
+        struct SlotG { float** w; float** b; int off, n; };
+        auto slots = std::make_shared<std::vector<SlotG>>();
+        for (auto& m : tmods)
+            if (m.kind == TrainMod::RES) slots->push_back(SlotG{G(m.key + ".noise_func.noise_func.0.weight"), G(m.key + ".noise_func.noise_func.0.bias"), m.slot, m.t[0].C});
+        Seq L;
+        const float *wall = net->wall, *w3 = net->w3, *w1 = net->w1;
+        float* dtb_ = dtb;
+        L.v.push_back([=](hipStream_t st) {
+            tk::linear_bwd(st, te, wall, dtb_, BB, inner, ns, T->dte, T->dwall, T->dball);
+            for (auto& sg : *slots) {
+                (void)hipMemcpyAsync(*sg.w, T->dwall + (size_t)sg.off * inner, (size_t)sg.n * inner * sizeof(float), hipMemcpyDeviceToDevice, st);
+                (void)hipMemcpyAsync(*sg.b, T->dball + sg.off, (size_t)sg.n * sizeof(float), hipMemcpyDeviceToDevice, st);
+            }
+            tk::linear_bwd(st, hid, w3, T->dte, BB, in4, inner, T->dh1, *gw3, *gb3);
+            tk::silu_bwd(st, spre, T->dh1, (size_t)BB * in4, T->ds);
+            tk::linear_bwd(st, pe, w1, T->ds, BB, inner, in4, nullptr, *gw1, *gb1);
+        });
+        seqs.push_back(std::move(L));
+    }
+
+    // ---- scratch
+    DDIF_TRY(fbuf(&T->a, T->n_a + 64));
+    DDIF_TRY(fbuf(&T->tmp, T->n_tmp + 64));
+    DDIF_TRY(fbuf(&T->partial, T->n_partial + 64));
+    DDIF_TRY(fbuf(&T->bpart, T->n_bpart + 64));
+    DDIF_TRY(fbuf(&T->ms, (size_t)BB * 2 + 64));
+    DDIF_TRY(fbuf(&T->S, (size_t)BB * 2 + 64));
+    DDIF_TRY(fbuf(&T->wpad, T->n_wpad + 64));
+    DDIF_TRY(fbuf(&T->dwflip, T->n_dwflip + 64));
+    DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 64));
+    DDIF_TRY(dalloc(&T->cpart, T->n_cpart + 64));
+    DDIF_TRY(dalloc(&T->planes, T->n_planes + 64));
+    DDIF_TRY(dalloc(&T->dwpart, T->n_dwpart + 64));
+
+    for (auto& L : seqs) {
+        auto sp = std::make_shared<Seq>(std::move(L));
+        bwd.push_back([sp](hipStream_t st) {
+            for (auto& f : sp->v) f(st);
+        });
+    }
+    return 0;
+#undef DDIF_TRY
+}
+
+// run after the forward (Plan::train_step, ddif_plan.cpp): loss, its gradient, the reverse program
+int Plan::train_backward(const float* target_nhwc, float upstream, float* loss_dev, hipStream_t s) {
+    const size_t n = (size_t)B * H * W * C;
+    tk::l1_fwd(s, net_out.p, target_nhwc, n, d_loss);
+    tk::l1_bwd(s, net_out.p, target_nhwc, n, upstream, d_net_out);
+    for (auto& f : bwd) f(s);
+    if (loss_dev) DDIF_HIPCHK(hipMemcpyAsync(loss_dev, d_loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+void Plan::train_set_stem_source(const float* sc_nhwc) { ts->stem_sc = sc_nhwc; }
+
+}  // namespace ddif

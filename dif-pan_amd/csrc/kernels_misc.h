@@ -524,7 +524,7 @@ __global__ void dropout_mask_kernel(float* mask, int B, int C, int HW, unsigned 
 __global__ __launch_bounds__(128) void time_embed_kernel(const float* tvals, const float* freqs, const float* w1,
                                                          const float* b1, const float* w3, const float* b3,
                                                          const float* wall, const float* ball, int inner, int nslots,
-                                                         float* out) {
+                                                         float* out, float* aux) {
     DDIF_DYN_SMEM(smem);
     float* pe = reinterpret_cast<float*>(smem);  // [inner]
     float* h1 = pe + inner;                      // [4*inner]
@@ -543,12 +543,19 @@ __global__ __launch_bounds__(128) void time_embed_kernel(const float* tvals, con
         for (int k = 0; k < inner; ++k) s = fmaf(w1[o * inner + k], pe[k], s);
         s += b1[o];
         h1[o] = dd_silu(s);
+        if (aux) {  // training: the reverse pass of the time MLP needs pe | pre-activation | hidden | temb  ([rows][.] arrays, back to back)
+            const size_t rows = gridDim.x;
+            aux[rows * inner + (size_t)r * 4 * inner + o] = s;
+            aux[rows * inner + rows * 4 * inner + (size_t)r * 4 * inner + o] = h1[o];
+        }
     }
+    if (aux && tid < inner) aux[(size_t)r * inner + tid] = pe[tid];
     __syncthreads();
     for (int o = tid; o < inner; o += blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < 4 * inner; ++k) s = fmaf(w3[o * 4 * inner + k], h1[k], s);
         te[o] = s + b3[o];
+        if (aux) aux[(size_t)gridDim.x * 9 * inner + (size_t)r * inner + o] = te[o];
     }
     __syncthreads();
     for (int o = tid; o < nslots; o += blockDim.x) {

@@ -15,6 +15,8 @@ struct RefreshRec {
     const float* src1;   // second source: concatenated along cin (attn_out | attn_res) or summed (bias pair); may be null
     float* dst;
     int cout, cin0, cin1, ks, ck, n_chunks;
+    int tr, fc0, fc1;    // tr = 1: the pack of the DGRAD conv of a forward conv W (Cout_f = cin0, Cin_f = fc0 [+ fc1 from src1]):
+                         //   W'[co'][ci'][tap] = W[ci'][co'][taps - 1 - tap]  (transposed, taps flipped); co' >= fc0 + fc1: zero padding
     long long n_out;     // floats written
     long long blk0;      // first thread block of this record (256 floats per block)
 };
@@ -42,6 +44,12 @@ __global__ __launch_bounds__(256) void refresh_blob_kernel(const RefreshRec* rec
     } else {
         const int taps = r.ks * r.ks, cin = r.cin0 + r.cin1;
         auto wval = [&](int co, int ci, int tap) -> float {
+            if (r.tr) {
+                if (ci >= r.cin0) return 0.f;
+                if (co < r.fc0) return r.src0[((size_t)ci * r.fc0 + co) * taps + (taps - 1 - tap)];
+                if (co < r.fc0 + r.fc1) return r.src1[((size_t)ci * r.fc1 + (co - r.fc0)) * taps + (taps - 1 - tap)];
+                return 0.f;
+            }
             if (co >= r.cout || ci >= cin) return 0.f;
             if (ci < r.cin0) return r.src0[((size_t)co * r.cin0 + ci) * taps + tap];
             return r.src1[((size_t)co * r.cin1 + (ci - r.cin0)) * taps + tap];

@@ -1,0 +1,503 @@
+// NHWC kernels of the native training step: the pieces of `loss.backward()` through UNetSR3
+// (reference models/sr3_dwt.py:169-219 under .train(), diffusion_engine.py:230-233) that are not convolutions.  Every activation of the
+// training program is [B, H, W, C] with C innermost -- the layout the conv kernels stage from -- so nothing is converted between ops
+// (round 2's op-by-op graph spent 10 % of its time in NCHW <-> NHWC transposes around every call).
+// All reductions: fixed order, no atomics -> bitwise reproducible gradients.
+#pragma once
+#include "ddif_dev.h"
+
+namespace ddif {
+
+// ---------------------------------------------------------------------------------------------------------------- FiLM (CondInjection, :395-396)
+// out = xc * (1 + scale) + shift with film = [scale | shift] per pixel ([B, HW, 2C]); emits the GroupNorm partial of out.
+// grid = (chunks, B), 256 threads, C % 4 == 0.
+__global__ __launch_bounds__(256) void film_apply_kernel(const float* xc, const float* film, int HW, int C, float* out, double* st_out) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [2][4]
+    const int b = blockIdx.y;
+    const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
+    const int c4n = C / 4;
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / c4n;
+        const int c = (int)(i - pix * c4n) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(xc + base + i * 4);
+        const float* f = film + ((size_t)b * HW + pix) * 2 * C;
+        const float4 sc = *reinterpret_cast<const float4*>(f + c);
+        const float4 sh = *reinterpret_cast<const float4*>(f + C + c);
+        float4 o;
+        o.x = v.x * (1.f + sc.x) + sh.x;
+        o.y = v.y * (1.f + sc.y) + sh.y;
+        o.z = v.z * (1.f + sc.z) + sh.z;
+        o.w = v.w * (1.f + sc.w) + sh.w;
+        *reinterpret_cast<float4*>(out + base + i * 4) = o;
+        s1 += ((double)o.x + o.y) + ((double)o.z + o.w);
+        s2 += ((double)o.x * o.x + (double)o.y * o.y) + ((double)o.z * o.z + (double)o.w * o.w);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) {
+        red[wave] = s1;
+        red[4 + wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && st_out) {
+        const size_t pi = ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        st_out[pi + 0] = (red[0] + red[1]) + (red[2] + red[3]);
+        st_out[pi + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+// dxc = dout (1 + scale);  dfilm = [dout * xc | dout]
+__global__ void film_bwd_nhwc_kernel(const float* xc, const float* film, const float* dout, size_t npix, int C, float* dxc, float* dfilm) {
+    const size_t total = npix * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C;
+        const int c = (int)(i - pix * C);
+        const float g = dout[i];
+        dxc[i] = g * (1.f + film[pix * 2 * C + c]);
+        dfilm[pix * 2 * C + c] = g * xc[i];
+        dfilm[pix * 2 * C + C + c] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- channel concat / split / pad
+__global__ void concat2_kernel(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out) {
+    const int C = Ca + Cb;
+    const size_t total = npix * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C;
+        const int c = (int)(i - pix * C);
+        out[i] = c < Ca ? a[pix * Ca + c] : b[pix * Cb + (c - Ca)];
+    }
+}
+// out_a = in[:, :Ca] (+ add_a), out_b = in[:, Ca:] (+ add_b): add_* nullable, same shapes as the outputs
+__global__ void split2_kernel(const float* in, int Ca, int Cb, size_t npix, const float* add_a, const float* add_b, float* out_a, float* out_b) {
+    const int C = Ca + Cb;
+    const size_t total = npix * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C;
+        const int c = (int)(i - pix * C);
+        const float v = in[i];
+        if (c < Ca) {
+            const size_t o = pix * Ca + c;
+            out_a[o] = add_a ? v + add_a[o] : v;
+        } else {
+            const size_t o = pix * Cb + (c - Ca);
+            out_b[o] = add_b ? v + add_b[o] : v;
+        }
+    }
+}
+// out[pix][0..Cp) = in[pix][0..C) then zeros
+__global__ void pad_channels_kernel(const float* in, int C, int Cp, size_t npix, float* out) {
+    const size_t total = npix * Cp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / Cp;
+        const int c = (int)(i - pix * Cp);
+        out[i] = c < C ? in[pix * C + c] : 0.f;
+    }
+}
+// weight gradient computed over zero-padded input channels (Cout, Cp, taps) -> (Cout, C, taps)
+__global__ void unpad_weight_kernel(const float* dwp, int Cout, int Cp, int C, int taps, float* dw) {
+    const size_t total = (size_t)Cout * C * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const int ci = (int)((i / taps) % C);
+        const int co = (int)(i / ((size_t)taps * C));
+        dw[i] = dwp[((size_t)co * Cp + ci) * taps + t];
+    }
+}
+// out = a + b, or a * scale[b] (per-sample row scale; nullable -> 1) -- elementwise helpers of the reverse pass
+__global__ void add2_kernel(const float* a, const float* b, size_t n, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+// out[pix][c] = a[pix * lda + c] + b[pix * ldb + c]   (operands that are channel slices of wider tensors)
+__global__ void add2_ld_kernel(const float* a, int lda, const float* b, int ldb, int C, size_t npix, float* out) {
+    const size_t total = npix * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C;
+        const int c = (int)(i - pix * C);
+        out[i] = a[pix * lda + c] + b[pix * ldb + c];
+    }
+}
+__global__ void scale_rows_kernel(const float* a, const float* scale, size_t per_sample, size_t total, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] * scale[i / per_sample];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- resampling around strided / upsampled convs
+// Downsample (conv3x3 stride 2): dX = stride-1 dgrad of dY with zeros inserted.  out (B, H, W, C) from dy (B, Ho, Wo, C)
+__global__ void zero_stuff_nhwc_kernel(const float* dy, int B, int C, int Ho, int Wo, int H, int W, float* out) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % W);
+        const int y = (int)((i / ((size_t)C * W)) % H);
+        const int b = (int)(i / ((size_t)C * W * H));
+        float v = 0.f;
+        if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo) v = dy[(((size_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
+        out[i] = v;
+    }
+}
+// Upsample (nearest x2 then conv3x3): x_up (B, 2H, 2W, C) for the weight gradient; d(x) = 2x2 sum-pool of d(x_up)
+__global__ void upsample2_nhwc_kernel(const float* x, int B, int C, int H, int W, float* out) {
+    const size_t total = (size_t)B * 4 * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int xx = (int)((i / C) % (2 * W));
+        const int yy = (int)((i / ((size_t)C * 2 * W)) % (2 * H));
+        const int b = (int)(i / ((size_t)C * 4 * W * H));
+        out[i] = x[(((size_t)b * H + (yy >> 1)) * W + (xx >> 1)) * C + c];
+    }
+}
+__global__ void sumpool2_nhwc_kernel(const float* dxu, int B, int C, int H, int W, float* dx) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % W);
+        const int y = (int)((i / ((size_t)C * W)) % H);
+        const int b = (int)(i / ((size_t)C * W * H));
+        const float* p = dxu + (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+        dx[i] = (p[0] + p[C]) + (p[(size_t)2 * W * C] + p[(size_t)2 * W * C + C]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- per-sample plane sums (time-bias gradient)
+// out[b * ld + c] = sum over the HW pixels of dy[b, :, c]  -- d(loss)/d(FeatureWiseAffine bias row) of sample b (:257).  One workgroup per
+// sample; threads = (pixel row r, channel c) side by side, combined through LDS in row order (as bias_grad_partial_kernel).
+__global__ __launch_bounds__(256) void plane_sum_nhwc_kernel(const float* dy, int HW, int C, int ld, float* out) {
+    DDIF_DYN_SMEM(smem_);
+    float* red = reinterpret_cast<float*>(smem_);  // [256]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* src = dy + (size_t)b * HW * C;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cw = C - c0 < 256 ? C - c0 : 256, rows = 256 / cw;
+        const int c = tid % cw, r = tid / cw;
+        float s = 0.f;
+        if (r < rows)
+            for (int p = r; p < HW; p += rows) s += src[(size_t)p * C + c0 + c];
+        red[tid] = s;
+        __syncthreads();
+        if (r == 0) {
+            for (int rr = 1; rr < rows; ++rr) s += red[rr * cw + c];
+            out[(size_t)b * ld + c0 + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- depthwise conv weight gradient (NHWC)
+// dw[c][k] = sum_{b,y,x} x[b, y + ky - 1, x + kx - 1, c] dy[b, y, x, c]   (q.0 / kv.0, :507-520).  x may carry padding channels (ldx >= C).
+// grid = (channel blocks of 32, nsplit row bands over B*H); partial [nsplit][C][9] fp64, then a fixed-order reduce.
+__global__ __launch_bounds__(256) void dw_wgrad_partial_nhwc_kernel(const float* x, int ldx, const float* dy, int ldy, int B, int C, int H, int W, int nsplit, double* partial) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [8][32][9]
+    const int tid = threadIdx.x, cl = tid & 31, r = tid >> 5;  // 8 pixel lanes x 32 channels
+    const int c = blockIdx.x * 32 + cl;
+    const bool cok = c < C;
+    const long long rows = (long long)B * H;
+    const long long r0 = rows * blockIdx.y / nsplit, r1 = rows * (blockIdx.y + 1) / nsplit;
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (long long row = r0; row < r1; ++row) {
+        const int b = (int)(row / H), y = (int)(row % H);
+        for (int xx = r; xx < W; xx += 8) {
+            if (!cok) continue;
+            const float g = dy[(((size_t)b * H + y) * W + xx) * ldy + c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int iy = y + k / 3 - 1, ix = xx + k % 3 - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[k] += (double)g * (double)x[(((size_t)b * H + iy) * W + ix) * ldx + c];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[(r * 32 + cl) * 9 + k] = acc[k];
+    __syncthreads();
+    if (r == 0 && cok) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            double s = 0.0;
+            for (int rr = 0; rr < 8; ++rr) s += red[(rr * 32 + cl) * 9 + k];
+            partial[((size_t)blockIdx.y * C + c) * 9 + k] = s;
+        }
+    }
+}
+__global__ void dw_wgrad_reduce_kernel(const double* partial, int nsplit, int C, float* dw /* (C,1,3,3) */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 9) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * C * 9 + i];
+    dw[i] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- SelfAttention core backward (NHWC)
+// qkv [B, n, 3C] with channel = head * 3d + {q: 0..d, k: d..2d, v: 2d..3d} (the reference's view(B, heads, 3d, n) + chunk, :347-348), dout / do
+// [B, n, C] with channel = head * d + c.  Same math and reduction order as selfattn_bwd_kernel (kernels_bwd_ops.h); only the addressing differs.
+__global__ __launch_bounds__(256) void selfattn_bwd_nhwc_kernel(const float* qkv, const float* dout, int heads, int d, int n, float sc, float* dqkv) {
+    DDIF_DYN_SMEM(smem_);
+    float* qs = reinterpret_cast<float*>(smem_);
+    float* ks = qs + d * n;
+    float* vs = ks + d * n;
+    float* gs = vs + d * n;   // do
+    float* as = gs + d * n;   // [n][n]
+    float* ds = as + n * n;   // [n][n]
+    float* rd = ds + n * n;   // [n] row dots
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int C3 = 3 * d * heads, C1 = d * heads;
+    const float* base = qkv + (size_t)b * n * C3 + hd * 3 * d;
+    const float* gbase = dout + (size_t)b * n * C1 + hd * d;
+    for (int i = tid; i < d * n; i += 256) {
+        const int c = i % d, p = i / d;  // channel fastest: contiguous reads
+        qs[c * n + p] = base[(size_t)p * C3 + c];
+        ks[c * n + p] = base[(size_t)p * C3 + d + c];
+        vs[c * n + p] = base[(size_t)p * C3 + 2 * d + c];
+        gs[c * n + p] = gbase[(size_t)p * C1 + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < n * n; i += 256) {  // scores and d(a)
+        const int p = i / n, q = i % n;
+        float s = 0.f, da = 0.f;
+        for (int c = 0; c < d; ++c) {
+            s = fmaf(qs[c * n + p], ks[c * n + q], s);
+            da = fmaf(gs[c * n + p], vs[c * n + q], da);
+        }
+        as[i] = s * sc;
+        ds[i] = da;
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {  // softmax of row p, then ds = a (da - sum a da)
+        float mx = -3.0e38f;
+        for (int q = 0; q < n; ++q) mx = fmaxf(mx, as[p * n + q]);
+        float sum = 0.f;
+        for (int q = 0; q < n; ++q) {
+            const float e = dd_exp(as[p * n + q] - mx);
+            as[p * n + q] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+        for (int q = 0; q < n; ++q) {
+            as[p * n + q] *= inv;
+            dot = fmaf(as[p * n + q], ds[p * n + q], dot);
+        }
+        rd[p] = dot;
+    }
+    __syncthreads();
+    float* dq = dqkv + (size_t)b * n * C3 + hd * 3 * d;
+    for (int i = tid; i < d * n; i += 256) {  // dv[c][q] = sum_p a[p][q] do[c][p]
+        const int c = i % d, q = i / d;
+        float s = 0.f;
+        for (int p = 0; p < n; ++p) s = fmaf(as[p * n + q], gs[c * n + p], s);
+        dq[(size_t)q * C3 + 2 * d + c] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n * n; i += 256) ds[i] = as[i] * (ds[i] - rd[i / n]);
+    __syncthreads();
+    for (int i = tid; i < d * n; i += 256) {
+        const int c = i % d, p = i / d;
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = 0; q < n; ++q) {
+            s1 = fmaf(ds[p * n + q], ks[c * n + q], s1);  // dq[c][p] = sc sum_q ds[p][q] k[c][q]
+            s2 = fmaf(ds[q * n + p], qs[c * n + q], s2);  // dk[c][p] = sc sum_q ds[q][p] q[c][q]
+        }
+        dq[(size_t)p * C3 + c] = s1 * sc;
+        dq[(size_t)p * C3 + d + c] = s2 * sc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- linear attention core (NHWC), :545-566
+// q_pre [B, HW, qd], kv_pre [B, HW, 2 qd] (k | v), channel = head * d + i; out / dout [B, HW, ld_o] (the first qd channels of each pixel).
+//   q = softmax over H of q_pre (per channel and column) / sqrt(d);  k = softmax over W of k_pre (per channel and row)
+//   ctx[a][e] = sum_n k[a][n] v[e][n];   o[e][n] = sum_a ctx[a][e] q[a][n]
+// One workgroup per (sample, head); W, H <= 64, d <= 32.  Same passes and reduction order as linattn_fwd / _bwd_kernel (kernels_bwd_ops.h).
+__global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pre, const float* kv_pre, int heads, int d, int H, int W, float sc, float* out, int ld_o) {
+    DDIF_DYN_SMEM(smem_);
+    float* qmx = reinterpret_cast<float*>(smem_);  // [d][W]
+    float* qsm = qmx + d * W;                      // [d][W]
+    float* ctx = qsm + d * W;                      // [d][d]
+    float* rk = ctx + d * d;                       // [d][W]
+    float* rv = rk + d * W;                        // [d][W]
+    float* kmx = rv + d * W;                       // [d][H] row max of k_pre (softmax over W)
+    float* ksm = kmx + d * H;                      // [d][H]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int qd = heads * d, HW = H * W;
+    const float* qb = q_pre + (size_t)b * HW * qd + hd * d;
+    const float* kb = kv_pre + (size_t)b * HW * 2 * qd + hd * d;
+    const float* vb = kb + qd;
+    float* ob = out + (size_t)b * HW * ld_o + hd * d;
+    for (int i = tid; i < d * W; i += 256) {  // column statistics of q_pre (softmax over H)
+        const int a = i % d, x = i / d;
+        float mx = -3.0e38f;
+        for (int y = 0; y < H; ++y) mx = fmaxf(mx, qb[(size_t)(y * W + x) * qd + a]);
+        float s = 0.f;
+        for (int y = 0; y < H; ++y) s += dd_exp(qb[(size_t)(y * W + x) * qd + a] - mx);
+        qmx[a * W + x] = mx;
+        qsm[a * W + x] = s;
+    }
+    for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre (softmax over W)
+        const int a = i % d, y = i / d;
+        float mx = -3.0e38f;
+        for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)(y * W + x) * 2 * qd + a]);
+        float sm = 0.f;
+        for (int x = 0; x < W; ++x) sm += dd_exp(kb[(size_t)(y * W + x) * 2 * qd + a] - mx);
+        kmx[a * H + y] = mx;
+        ksm[a * H + y] = sm;
+    }
+    for (int i = tid; i < d * d; i += 256) ctx[i] = 0.f;
+    __syncthreads();
+    for (int y = 0; y < H; ++y) {  // ctx: rows in order, one owner thread per (a, e)
+        for (int i = tid; i < d * W; i += 256) {
+            const int a = i % d, x = i / d;
+            const size_t p = (size_t)(y * W + x);
+            rk[a * W + x] = dd_exp(kb[p * 2 * qd + a] - kmx[a * H + y]) / ksm[a * H + y];
+            rv[a * W + x] = vb[p * 2 * qd + a];
+        }
+        __syncthreads();
+        for (int i = tid; i < d * d; i += 256) {
+            const int a = i / d, e = i % d;
+            float s1 = ctx[i];
+            for (int x = 0; x < W; ++x) s1 = fmaf(rk[a * W + x], rv[e * W + x], s1);
+            ctx[i] = s1;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < d * HW; i += 256) {  // o[e][n] = sum_a ctx[a][e] q[a][n]
+        const int e = i % d, p = i / d, x = p % W;
+        float s = 0.f;
+        for (int a = 0; a < d; ++a) {
+            const float qv = dd_exp(qb[(size_t)p * qd + a] - qmx[a * W + x]) / qsm[a * W + x] * sc;
+            s = fmaf(ctx[a * d + e], qv, s);
+        }
+        ob[(size_t)p * ld_o + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pre, const float* kv_pre, const float* dout, int ld_g, int heads, int d, int H, int W, float sc,
+                                                               float* dq_pre, float* dkv_pre) {
+    DDIF_DYN_SMEM(smem_);
+    float* qmx = reinterpret_cast<float*>(smem_);  // [d][W] column max of q_pre
+    float* qsm = qmx + d * W;                      // [d][W] column sum of exp
+    float* T = qsm + d * W;                        // [d][W] column sums of dq * q_sm
+    float* ctx = T + d * W;                        // [d][d]
+    float* dctx = ctx + d * d;                     // [d][d]
+    float* rk = dctx + d * d;                      // [d][W] k softmax of the current row
+    float* rv = rk + d * W;                        // [d][W]
+    float* rq = rv + d * W;                        // [d][W] q softmax * sc of the current row
+    float* rg = rq + d * W;                        // [d][W] do of the current row
+    float* rdk = rg + d * W;                       // [d][W] dk of the current row
+    float* rdot = rdk + d * W;                     // [d] row dots of the k softmax backward
+    float* kmx = rdot + d;                         // [d][H] row max of k_pre (softmax over W)
+    float* ksm = kmx + d * H;                      // [d][H] row sum of exp
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int qd = heads * d, HW = H * W;
+    const float* qb = q_pre + (size_t)b * HW * qd + hd * d;
+    const float* kb = kv_pre + (size_t)b * HW * 2 * qd + hd * d;
+    const float* vb = kb + qd;
+    const float* gb = dout + (size_t)b * HW * ld_g + hd * d;
+    float* dqb = dq_pre + (size_t)b * HW * qd + hd * d;
+    float* dkb = dkv_pre + (size_t)b * HW * 2 * qd + hd * d;
+    float* dvb = dkb + qd;
+    for (int i = tid; i < d * W; i += 256) {  // pass 1: column statistics of q_pre (softmax over H)
+        const int a = i % d, x = i / d;
+        float mx = -3.0e38f;
+        for (int y = 0; y < H; ++y) mx = fmaxf(mx, qb[(size_t)(y * W + x) * qd + a]);
+        float s = 0.f;
+        for (int y = 0; y < H; ++y) s += dd_exp(qb[(size_t)(y * W + x) * qd + a] - mx);
+        qmx[a * W + x] = mx;
+        qsm[a * W + x] = s;
+        T[a * W + x] = 0.f;
+    }
+    for (int i = tid; i < d * d; i += 256) {
+        ctx[i] = 0.f;
+        dctx[i] = 0.f;
+    }
+    for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre for every (channel, row)
+        const int a = i % d, y = i / d;
+        float mx = -3.0e38f;
+        for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)(y * W + x) * 2 * qd + a]);
+        float sm = 0.f;
+        for (int x = 0; x < W; ++x) sm += dd_exp(kb[(size_t)(y * W + x) * 2 * qd + a] - mx);
+        kmx[a * H + y] = mx;
+        ksm[a * H + y] = sm;
+    }
+    __syncthreads();
+    auto load_row = [&](int y) {  // k softmax (over this row), v, q softmax * sc, do  -> LDS
+        for (int i = tid; i < d * W; i += 256) {
+            const int a = i % d, x = i / d, l = a * W + x;
+            const size_t p = (size_t)(y * W + x);
+            rk[l] = dd_exp(kb[p * 2 * qd + a] - kmx[a * H + y]) / ksm[a * H + y];
+            rv[l] = vb[p * 2 * qd + a];
+            rq[l] = dd_exp(qb[p * qd + a] - qmx[l]) / qsm[l] * sc;
+            rg[l] = gb[p * ld_g + a];
+        }
+        __syncthreads();
+    };
+    for (int y = 0; y < H; ++y) {  // pass 2: ctx and dctx
+        load_row(y);
+        for (int i = tid; i < d * d; i += 256) {
+            const int a = i / d, e = i % d;
+            float s1 = ctx[i], s2 = dctx[i];
+            for (int x = 0; x < W; ++x) {
+                s1 = fmaf(rk[a * W + x], rv[e * W + x], s1);
+                s2 = fmaf(rq[a * W + x], rg[e * W + x], s2);
+            }
+            ctx[i] = s1;
+            dctx[i] = s2;
+        }
+        __syncthreads();
+    }
+    for (int y = 0; y < H; ++y) {  // pass 3
+        load_row(y);
+        for (int i = tid; i < d * W; i += 256) {
+            const int a = i % d, x = i / d, l = a * W + x;
+            float dq = 0.f, dk = 0.f, dv = 0.f;
+            for (int e = 0; e < d; ++e) {
+                dq = fmaf(ctx[a * d + e], rg[e * W + x], dq);    // dq[a][n] = sum_e ctx[a][e] do[e][n]
+                dk = fmaf(dctx[a * d + e], rv[e * W + x], dk);   // dk[a][n] = sum_e dctx[a][e] v[e][n]
+                dv = fmaf(dctx[e * d + a], rk[e * W + x], dv);   // dv[a][n] = sum_e dctx[e][a] k[e][n]
+            }
+            const size_t p = (size_t)(y * W + x);
+            dvb[p * 2 * qd + a] = dv;
+            rdk[l] = dk;
+            dq *= sc;  // d(q_sm) of o = ctx^T (q_sm * sc)
+            dqb[p * qd + a] = dq;
+            T[l] += dq * (rq[l] / sc);  // q_sm = rq / sc
+        }
+        __syncthreads();
+        for (int a = tid; a < d; a += 256) {
+            float s = 0.f;
+            for (int x = 0; x < W; ++x) s = fmaf(rdk[a * W + x], rk[a * W + x], s);
+            rdot[a] = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < d * W; i += 256) {
+            const int a = i % d, x = i / d, l = a * W + x;
+            dkb[(size_t)(y * W + x) * 2 * qd + a] = rk[l] * (rdk[l] - rdot[a]);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < d * W; i += 256) {  // pass 4: softmax-over-H backward of q
+        const int a = i % d, x = i / d, l = a * W + x;
+        for (int y = 0; y < H; ++y) {
+            const size_t el = (size_t)(y * W + x) * qd + a;
+            const float qs_ = dd_exp(qb[el] - qmx[l]) / qsm[l];
+            dqb[el] = qs_ * (dqb[el] - T[l]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- misc
+// flipped depthwise taps: w [9][C] (tap-major, the forward layout) -> [9][C] with tap k <- 8 - k: dX of a depthwise conv is the same
+// depthwise conv of dY with the taps reversed
+__global__ void flip_dw_taps_kernel(const float* w, int C, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * C) return;
+    const int k = i / C, c = i % C;
+    out[i] = w[(8 - k) * C + c];
+}
+
+}  // namespace ddif

@@ -87,6 +87,10 @@ class _Lib:
         d.ddif_plan_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
         d.ddif_plan_create_train.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
         d.ddif_plan_train_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+        d.ddif_plan_train_bind.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(vp)]
+        d.ddif_plan_train_num_grads.argtypes = [vp, C.POINTER(i32)]
+        d.ddif_plan_train_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        d.ddif_plan_train_forward_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         d.ddif_plan_train_site.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         d.ddif_plan_train_set_dropout.argtypes = [vp, i32, vp, vp]
         d.ddif_plan_train_set_droppath.argtypes = [vp, vp, vp]
@@ -368,6 +372,55 @@ class PlanHandle:
     def random_train_masks(self, seed: int, tile0: int, p_dropout: float, p_droppath: float):
         self.lib.check(self.lib.dll.ddif_plan_train_random_masks(self.h, int(seed), int(tile0), float(p_dropout), float(p_droppath),
                                                                  _stream(self.lib, self.net.device)), "ddif_plan_train_random_masks")
+
+    # -- native training step ---------------------------------------------------------------------------------------
+    def train_bind(self, named_grads):
+        """Name the gradient tensors the reverse pass writes: [(state-dict key, contiguous fp32 tensor of the parameter's shape)] for every
+        learnable tensor.  They must stay alive and in place while the plan is used."""
+        named_grads = list(named_grads)
+        n = len(named_grads)
+        for k, t in named_grads:
+            _check_tensor(self.lib, t, f"grad[{k}]")
+            if not t.is_contiguous():
+                raise DdifError(f"grad[{k}] must be contiguous")
+        keys = (C.c_char_p * n)(*[k.encode() for k, _ in named_grads])
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, t in named_grads])
+        self.lib.check(self.lib.dll.ddif_plan_train_bind(self.h, n, keys, ptrs), "ddif_plan_train_bind")
+        self._grads_keep = [t for _, t in named_grads]
+
+    def train_step(self, x0, noise, a, s, time, self_cond, want_pred=True):
+        """One iteration's device work: q_sample, train-mode forward, L1 loss, backward (gradients -> the bound tensors).
+        Returns (loss: 0-d device tensor, pred or None)."""
+        img = (self.B, self.net.out_channel, self.H, self.W)
+        for nm, t in (("x_start", x0), ("noise", noise)) + ((("self_cond", self_cond),) if self_cond is not None else ()):
+            _check_tensor(self.lib, t, nm)
+            _check_shape(t, nm, img)
+        x0, noise = x0.contiguous(), noise.contiguous()
+        sc = None if self_cond is None else self_cond.contiguous()
+        a = a.detach().to("cpu", torch.float32).contiguous()
+        s = s.detach().to("cpu", torch.float32).contiguous()
+        t = time.detach().to("cpu", torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x0.device)
+        pred = torch.empty_like(x0) if want_pred else None
+        self.lib.check(self.lib.dll.ddif_plan_train_step(
+            self.h, _ptr(x0), _ptr(noise), C.c_void_p(a.data_ptr()), C.c_void_p(s.data_ptr()), C.c_void_p(t.data_ptr()), _ptr(sc), _ptr(loss), _ptr(pred),
+            _stream(self.lib, x0.device)), "ddif_plan_train_step")
+        return loss, pred
+
+    def train_forward_backward(self, x, time, self_cond, target):
+        """Forward + L1 loss + backward on a given network input / target (parity tests).  Returns (loss, pred)."""
+        img = (self.B, self.net.out_channel, self.H, self.W)
+        for nm, t in (("x", x), ("target", target)) + ((("self_cond", self_cond),) if self_cond is not None else ()):
+            _check_tensor(self.lib, t, nm)
+            _check_shape(t, nm, img)
+        x, target = x.contiguous(), target.contiguous()
+        sc = None if self_cond is None else self_cond.contiguous()
+        t = time.detach().to("cpu", torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        pred = torch.empty_like(x)
+        self.lib.check(self.lib.dll.ddif_plan_train_forward_backward(self.h, _ptr(x), C.c_void_p(t.data_ptr()), _ptr(sc), _ptr(target), _ptr(loss), _ptr(pred),
+                                                                     _stream(self.lib, x.device)), "ddif_plan_train_forward_backward")
+        return loss, pred
 
     # -- cond ---------------------------------------------------------------------------------------------------
     def set_cond(self, cond: torch.Tensor, force: bool = False):

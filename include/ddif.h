@@ -204,6 +204,21 @@ DDIF_API int ddif_optim_step(ddif_optim_t h, float lr, float beta1, float beta2,
  * (ddif_plan_set_cond / ddif_plan_forward / ddif_plan_q_sample_forward) with the masks below applied; it starts with identity
  * masks.  Masks hold 0 or 1/(1-p) (what nn.Dropout multiplies by) / per-sample DropPath scales in {0, 1/(1-p)}. */
 DDIF_API int ddif_plan_create_train(ddif_plan_t* out, ddif_net_t net, int B, int H, int W);
+/* ---- native training step (reference diffusion_engine.py:230-233: `diff_loss, recon = diffusion(res, cond=cond); diff_loss.backward()`).
+ * A train-mode plan also holds the REVERSE launch program of the whole denoiser.  Per iteration:
+ *   ddif_net_refresh (weights changed)  ->  ddif_plan_set_cond  ->  masks (ddif_plan_train_random_masks / _set_dropout / _set_droppath)
+ *   ->  ddif_plan_train_step: x_t = a x0 + s noise, train-mode forward, L1 loss against x0, backward.
+ * ddif_plan_train_bind names the gradient tensors once: n (state-dict key, device pointer) pairs covering every learnable tensor, reference
+ * layouts (conv (Cout,Cin,k,k), Linear (out,in), vectors); the step WRITES them (no accumulation).  loss_dev: one device float (mean
+ * absolute error, F.l1_loss); pred (nullable): the network output (B,C,H,W).  a / s / t: HOST arrays of B floats (sqrt(alpha_bar_t),
+ * sqrt(1 - alpha_bar_t), t); self_cond nullable (B,C,H,W).  Deterministic: fixed-order reductions, no atomics. */
+DDIF_API int ddif_plan_train_bind(ddif_plan_t plan, int n, const char* const* keys, float* const* grads_dev);
+DDIF_API int ddif_plan_train_num_grads(ddif_plan_t plan, int* n);
+/* the same on a GIVEN network input and target (no q_sample): what the gradient parity tests drive with the reference's own tensors */
+DDIF_API int ddif_plan_train_forward_backward(ddif_plan_t plan, const float* x, const float* time_host, const float* self_cond, const float* target,
+                                              float* loss_dev, float* pred, void* stream);
+DDIF_API int ddif_plan_train_step(ddif_plan_t plan, const float* x0, const float* noise, const float* sqrt_ac_host, const float* sqrt_1mac_host,
+                                  const float* time_host, const float* self_cond, float* loss_dev, float* pred, void* stream);
 DDIF_API int ddif_plan_train_info(ddif_plan_t plan, int* n_dropout_sites, int* n_droppath_sites);  /* sites in execution order */
 DDIF_API int ddif_plan_train_site(ddif_plan_t plan, int site, int* C, int* H, int* W);             /* mask shape (B, C, H, W) */
 /* explicit masks (parity with a reference run whose masks were captured): mask (B,C,H,W) device; scales HOST [n_droppath][B] */

@@ -77,6 +77,51 @@ def test_training_step_gradients_match_the_reference(backend):
     print("worst relative grad-norm error over %d parameters: %.2e" % (len(names), worst))
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_native_training_step_gradients_match_the_reference(backend):
+    """The NATIVE reverse program (csrc/ddif_train.cpp, ddif_plan_train_forward_backward): train-mode forward over NHWC activations + L1 loss
+    + backward in one C-ABI call, against the real reference's `loss.backward()` golden -- output, loss, the gradient norm of all 702
+    parameters and the full gradients the golden carries.  Also: two runs give bit-identical gradients (fixed-order reductions)."""
+    from ddif_testlib import make_net
+
+    dev = _dev(backend)
+    g, ds, x, sc, target, cond, t, masks, paths = _case_inputs(gc.TRAIN_GRAD_CASES[0])
+    B, _, H, W = x.shape
+    net = make_net(ds, dev).train()
+    try:
+        plan = net.plan_for(B, H, W, dev, train=True)
+        net._net.refresh_from_device(net.named_parameters())  # fills the dgrad packs (and re-packs the forward weights on the device)
+        plan.set_cond(cond.to(dev), force=True)
+        plan.set_train_masks([m.to(dev) for m in masks], paths)
+        grads = {n: torch.full_like(p, float("nan")) for n, p in net.named_parameters()}
+        plan.train_bind(list(grads.items()))
+        loss, y = plan.train_forward_backward(x.to(dev), t, sc.to(dev), target.to(dev))
+        assert float((y.cpu() - torch.from_numpy(g["y"])).abs().max()) <= 2e-5
+        assert abs(float(loss) - float(g["loss"])) <= 1e-6
+        names = [str(n) for n in g["names"]]
+        assert set(names) == set(grads.keys())
+        worst = 0.0
+        for n, ref in zip(names, g["grad_norms"]):
+            got = float(grads[n].double().norm())
+            assert got == got, f"gradient of {n} was not written"
+            worst = max(worst, abs(got - float(ref)) / max(float(ref), 1e-4))
+            assert abs(got - float(ref)) <= 2e-4 * max(float(ref), 1e-4), (n, got, float(ref))
+        for k in g.files:
+            if k.startswith("grad::"):
+                ref = torch.from_numpy(g[k])
+                got = grads[k[6:]].cpu()
+                assert got.shape == ref.shape, k
+                err = float((got - ref).abs().max())
+                assert err <= 5e-5 * max(float(ref.abs().max()), 1e-5), (k, err, float(ref.abs().max()))
+        first = {n: v.clone() for n, v in grads.items()}
+        plan.train_forward_backward(x.to(dev), t, sc.to(dev), target.to(dev))
+        for n in first:
+            assert torch.equal(first[n], grads[n]), n
+        print("native step: worst relative grad-norm error over %d parameters: %.2e" % (len(names), worst))
+    finally:
+        net.eval()
+
+
 GPU_ONLY = [pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]  # a training step takes ~40 s on the host emulator: the CPU suite keeps the parity test above
 
 
