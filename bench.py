@@ -416,10 +416,7 @@ def bench_training(args, cf, rank, world, dev):
     runtime.PlanHandle.q_sample_forward = counted
 
     def one_step(timed=False):
-        for g in grads:
-            g.zero_()
-        loss, _ = d(res, cond=cond)
-        loss.backward()
+        loss, _ = d.train_step_into(res, cond, grads)  # q_sample + self-conditioning draw + forward + backward: gradients written into `grads`
         if world > 1:
             if timed:
                 ev[0].record()
@@ -466,7 +463,8 @@ def bench_training(args, cf, rank, world, dev):
                 "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                              "algorithmic_gflop_per_iteration": step_flop / 1e9,
                              "peak_note": "whole training iteration: algorithmic flops (3 x un-hoisted forward + self-conditioning forwards) / wall time vs the dense fp32 "
-                                          "matrix peak; the weight-gradient kernels run the exact fp32 MFMA, forward / dgrad convs the bf16x3 path"},
+                                          "matrix peak; the weight-gradient kernels run the exact fp32 MFMA, forward / dgrad convs the bf16x3 path",
+                             "path": "native reverse launch program (csrc/ddif_train.cpp, ddif_plan_train_step): NHWC end to end, device-side weight refresh"},
                 "build_id": build_id()}
         if world > 1:
             line["allreduce"] = {"bytes": 4 * n_param, "ms_per_iteration": comm_ms[0] / args.steps,

@@ -436,9 +436,13 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
     WgradGeom g;
     g.n_co = (Cout + 31) / 32;
     g.n_ci = (Cin + 31) / 32;
-    for (g.rb = 4; g.rb >= 1; g.rb >>= 1) {
+    // rows per band: the largest of {16, 8, 4, 2, 1} (<= H) whose two tiles fit DDIF_WGRAD_SMEM_KB (default 72 KB: two workgroups per CU, so one's
+    // band loads overlap the other's MFMAs; the low-resolution levels then stage a whole 8x8 sample or half a 16x16 one per band)
+    static const size_t lim = [] { const char* e = getenv("DDIF_WGRAD_SMEM_KB"); return (size_t)(e ? atoi(e) : 72) * 1024; }();
+    for (g.rb = 16; g.rb >= 1; g.rb >>= 1) {
+        if (g.rb > H && g.rb > 1) continue;
         g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
-        if (g.smem <= 150 * 1024) break;
+        if (g.smem <= lim || (g.rb == 1 && g.smem <= 150 * 1024)) break;
     }
     if (g.rb < 1) g.rb = 0;  // W too wide (caller checks)
     const int bands = B * ((H + (g.rb ? g.rb : 1) - 1) / (g.rb ? g.rb : 1));

@@ -39,7 +39,7 @@ void film_apply(hipStream_t s, const float* xc, const float* film, int B, int HW
     hipLaunchKernelGGL(film_apply_kernel, dim3(chunks, B), dim3(256), 64, s, xc, film, HW, C, out, st_out);
 }
 void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o) {
-    const size_t sm = (size_t)(4 * d * W + d * d + 2 * d * H) * sizeof(float);
+    const size_t sm = linattn_fwd_smem(d, H, W);
     hipLaunchKernelGGL(linattn_fwd_nhwc_kernel, dim3(B * heads), dim3(256), sm, s, q, kv, heads, d, H, W, 1.0f / std::sqrt((float)d), out, ld_o);
 }
 }  // namespace tk
@@ -85,6 +85,8 @@ int Plan::build_backward() {
     auto numel = [&](const Tensor& t) { return (size_t)BB * t.H * t.W * t.C; };
     auto fbuf = [&](float** p, size_t n) -> int { return dalloc(p, n); };
     DDIF_TRY(tk::wgrad_prepare());
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_bwd_nhwc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_fwd_nhwc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
 
     // ---- building blocks (each appends launches to a closure list `L` executed in order)
     using Launch = std::function<void(hipStream_t)>;
@@ -248,7 +250,12 @@ int Plan::build_backward() {
                 {
                     const int HW = h1.H * h1.W, C = h1.C, ld = net->nslots, slot = m.slot;
                     float* dst = dtb + slot;
-                    L.v.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plane_sum_nhwc_kernel, dim3(BB), dim3(256), 256 * sizeof(float), st, (const float*)dh1, HW, C, ld, dst); });
+                    const int nck = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+                    need(T->n_bpart, (size_t)BB * nck * C);
+                    L.v.push_back([=](hipStream_t st) {
+                        hipLaunchKernelGGL(plane_sum_partial_nhwc_kernel, dim3(nck, BB), dim3(256), 256 * sizeof(float), st, (const float*)dh1, HW, C, nck, T->bpart);
+                        hipLaunchKernelGGL(plane_sum_final_kernel, dim3((BB * C + 255) / 256), dim3(256), 0, st, (const float*)T->bpart, BB, C, nck, ld, dst);
+                    });
                 }
                 Tensor dh1T = h1;
                 dh1T.p = dh1;
@@ -454,7 +461,7 @@ int Plan::build_backward() {
                 DDIF_TRY(fbuf(&dq, numel(q)));
                 DDIF_TRY(fbuf(&dkv, numel(kv)));
                 {
-                    const size_t sm = (size_t)(8 * d * Wl + 2 * d * d + d + 2 * d * Hl) * sizeof(float);
+                    const size_t sm = linattn_bwd_smem(d, Hl, Wl);
                     const float sc = 1.0f / std::sqrt((float)d);
                     L.v.push_back([=](hipStream_t st) {
                         hipLaunchKernelGGL(linattn_bwd_nhwc_kernel, dim3(BB * 8), dim3(256), sm, st, (const float*)q.p, (const float*)kv.p, (const float*)dcat.p, ldc, 8, d, Hl, Wl, sc,
@@ -473,7 +480,7 @@ int Plan::build_backward() {
                     const float* w9 = V(ci + ".q.0.weight");  // [9][C], refreshed with the weights
                     need(T->n_dwflip, (size_t)9 * fea);
                     need(T->n_tmp, numel(xn));
-                    const int nsplit = std::min(64, BB * Hl);
+                    const int nsplit = std::min(512, BB * Hl);
                     need(T->n_dwpart, (size_t)nsplit * fea * 9);
                     float** dw0 = G(ci + ".q.0.weight");
                     const float* other = m.has_res ? dcat.p + fea : da;  // gradient of xn through attn_res (or the identity)
@@ -502,7 +509,7 @@ int Plan::build_backward() {
                     dkvT.st = nullptr;
                     Tensor dkdw;  // padded to Cp channels
                     DDIF_TRY(add_dgrad(L, ci + ".kv.1", dkvT, &dkdw));
-                    const int nsplit = std::min(64, BB * Hl);
+                    const int nsplit = std::min(512, BB * Hl);
                     need(T->n_dwpart, (size_t)nsplit * cd * 9);
                     float** dwk0 = G(ci + ".kv.0.weight");
                     const Tensor cimg = cdec[m.lev];
@@ -586,7 +593,7 @@ int Plan::build_backward() {
     DDIF_TRY(fbuf(&T->S, (size_t)BB * 2 + 64));
     DDIF_TRY(fbuf(&T->wpad, T->n_wpad + 64));
     DDIF_TRY(fbuf(&T->dwflip, T->n_dwflip + 64));
-    DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 64));
+    DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 512));
     DDIF_TRY(dalloc(&T->cpart, T->n_cpart + 64));
     DDIF_TRY(dalloc(&T->planes, T->n_planes + 64));
     DDIF_TRY(dalloc(&T->dwpart, T->n_dwpart + 64));
@@ -604,7 +611,11 @@ int Plan::build_backward() {
 // run after the forward (Plan::train_step, ddif_plan.cpp): loss, its gradient, the reverse program
 int Plan::train_backward(const float* target_nhwc, float upstream, float* loss_dev, hipStream_t s) {
     const size_t n = (size_t)B * H * W * C;
-    tk::l1_fwd(s, net_out.p, target_nhwc, n, d_loss);
+    {
+        const int nblk = 256;
+        hipLaunchKernelGGL(l1_partial_kernel, dim3(nblk), dim3(256), 256 * sizeof(double), s, (const float*)net_out.p, target_nhwc, n, ts->spart);
+        hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ts->spart, nblk, n, d_loss);
+    }
     tk::l1_bwd(s, net_out.p, target_nhwc, n, upstream, d_net_out);
     for (auto& f : bwd) f(s);
     if (loss_dev) DDIF_HIPCHK(hipMemcpyAsync(loss_dev, d_loss, sizeof(float), hipMemcpyDeviceToDevice, s));

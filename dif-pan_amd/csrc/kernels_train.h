@@ -308,18 +308,30 @@ __global__ __launch_bounds__(256) void selfattn_bwd_nhwc_kernel(const float* qkv
 }
 
 // ---------------------------------------------------------------------------------------------------------------- linear attention core (NHWC), :545-566
-// q_pre [B, HW, qd], kv_pre [B, HW, 2 qd] (k | v), channel = head * d + i; out / dout [B, HW, ld_o] (the first qd channels of each pixel).
+// q_pre [B, HW, qd], kv_pre [B, HW, 2 qd] (k | v), channel = head * d + i; out / dout [B, HW, ld] (the first qd channels of each pixel).
 //   q = softmax over H of q_pre (per channel and column) / sqrt(d);  k = softmax over W of k_pre (per channel and row)
 //   ctx[a][e] = sum_n k[a][n] v[e][n];   o[e][n] = sum_a ctx[a][e] q[a][n]
-// One workgroup per (sample, head); W, H <= 64, d <= 32.  Same passes and reduction order as linattn_fwd / _bwd_kernel (kernels_bwd_ops.h).
+// One workgroup per (sample, head); W, H <= 64, d <= 32.  The image is walked in BANDS of R rows (R * W <= LA_BAND pixels staged in LDS per
+// step) instead of row by row: 8 barriers instead of 128 at 64x64.  Every LDS cell has one owner thread and the bands / pixels are summed
+// in index order: deterministic.  (Same math as linattn_fwd / _bwd_kernel of kernels_bwd_ops.h, the NCHW forms behind the stateless C-ABI ops.)
+constexpr int LA_BAND = 4096;  // floats per staged band array: rows per band R = LA_BAND / (d * W)
+__host__ __device__ inline int la_rows(int d, int H, int W) {
+    int r = LA_BAND / (d * W);
+    if (r < 1) r = 1;
+    return r > H ? H : r;
+}
+inline size_t linattn_fwd_smem(int d, int H, int W) { return (size_t)(2 * d * W + d * d + 2 * d * la_rows(d, H, W) * W + 2 * d * H) * sizeof(float); }
+inline size_t linattn_bwd_smem(int d, int H, int W) { return (size_t)(3 * d * W + 2 * d * d + 5 * d * la_rows(d, H, W) * W + d * la_rows(d, H, W) + 2 * d * H) * sizeof(float); }
+
 __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pre, const float* kv_pre, int heads, int d, int H, int W, float sc, float* out, int ld_o) {
     DDIF_DYN_SMEM(smem_);
+    const int R = la_rows(d, H, W), RW = R * W;
     float* qmx = reinterpret_cast<float*>(smem_);  // [d][W]
     float* qsm = qmx + d * W;                      // [d][W]
     float* ctx = qsm + d * W;                      // [d][d]
-    float* rk = ctx + d * d;                       // [d][W]
-    float* rv = rk + d * W;                        // [d][W]
-    float* kmx = rv + d * W;                       // [d][H] row max of k_pre (softmax over W)
+    float* rk = ctx + d * d;                       // [d][RW]
+    float* rv = rk + d * RW;                       // [d][RW]
+    float* kmx = rv + d * RW;                      // [d][H] row max of k_pre (softmax over W)
     float* ksm = kmx + d * H;                      // [d][H]
     const int tid = threadIdx.x;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
@@ -348,18 +360,19 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
     }
     for (int i = tid; i < d * d; i += 256) ctx[i] = 0.f;
     __syncthreads();
-    for (int y = 0; y < H; ++y) {  // ctx: rows in order, one owner thread per (a, e)
-        for (int i = tid; i < d * W; i += 256) {
-            const int a = i % d, x = i / d;
-            const size_t p = (size_t)(y * W + x);
-            rk[a * W + x] = dd_exp(kb[p * 2 * qd + a] - kmx[a * H + y]) / ksm[a * H + y];
-            rv[a * W + x] = vb[p * 2 * qd + a];
+    for (int y0 = 0; y0 < H; y0 += R) {  // ctx: bands in order, one owner thread per (a, e)
+        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
+        for (int i = tid; i < d * npx; i += 256) {
+            const int a = i % d, pl = i / d, y = y0 + pl / W;
+            const size_t p = (size_t)y0 * W + pl;
+            rk[a * RW + pl] = dd_exp(kb[p * 2 * qd + a] - kmx[a * H + y]) / ksm[a * H + y];
+            rv[a * RW + pl] = vb[p * 2 * qd + a];
         }
         __syncthreads();
         for (int i = tid; i < d * d; i += 256) {
             const int a = i / d, e = i % d;
             float s1 = ctx[i];
-            for (int x = 0; x < W; ++x) s1 = fmaf(rk[a * W + x], rv[e * W + x], s1);
+            for (int pl = 0; pl < npx; ++pl) s1 = fmaf(rk[a * RW + pl], rv[e * RW + pl], s1);
             ctx[i] = s1;
         }
         __syncthreads();
@@ -375,21 +388,25 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
     }
 }
 
+// Backward (do given):  dctx[a][e] = sum_n q[a][n] do[e][n];  dq = ctx do;  dk = dctx v;  dv = dctx^T k;  then the two softmax backwards.
+// Pass 1: softmax statistics.  Pass 2 (bands): ctx, dctx.  Pass 3 (bands): dv (final), dk_pre (final: its softmax lives inside a row), dq (raw,
+// parked in the output) and the column sums T[a][x] = sum_y dq q.  Pass 4: dq_pre = q_sm (dq - T).
 __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pre, const float* kv_pre, const float* dout, int ld_g, int heads, int d, int H, int W, float sc,
                                                                float* dq_pre, float* dkv_pre) {
     DDIF_DYN_SMEM(smem_);
+    const int R = la_rows(d, H, W), RW = R * W;
     float* qmx = reinterpret_cast<float*>(smem_);  // [d][W] column max of q_pre
     float* qsm = qmx + d * W;                      // [d][W] column sum of exp
     float* T = qsm + d * W;                        // [d][W] column sums of dq * q_sm
     float* ctx = T + d * W;                        // [d][d]
     float* dctx = ctx + d * d;                     // [d][d]
-    float* rk = dctx + d * d;                      // [d][W] k softmax of the current row
-    float* rv = rk + d * W;                        // [d][W]
-    float* rq = rv + d * W;                        // [d][W] q softmax * sc of the current row
-    float* rg = rq + d * W;                        // [d][W] do of the current row
-    float* rdk = rg + d * W;                       // [d][W] dk of the current row
-    float* rdot = rdk + d * W;                     // [d] row dots of the k softmax backward
-    float* kmx = rdot + d;                         // [d][H] row max of k_pre (softmax over W)
+    float* rk = dctx + d * d;                      // [d][RW] k softmax of the band
+    float* rv = rk + d * RW;                       // [d][RW]
+    float* rq = rv + d * RW;                       // [d][RW] q softmax * sc
+    float* rg = rq + d * RW;                       // [d][RW] do
+    float* rdk = rg + d * RW;                      // [d][RW] dk
+    float* rdot = rdk + d * RW;                    // [d][R] row dots of the k softmax backward
+    float* kmx = rdot + d * R;                     // [d][H] row max of k_pre (softmax over W)
     float* ksm = kmx + d * H;                      // [d][H] row sum of exp
     const int tid = threadIdx.x;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
@@ -425,72 +442,133 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
         ksm[a * H + y] = sm;
     }
     __syncthreads();
-    auto load_row = [&](int y) {  // k softmax (over this row), v, q softmax * sc, do  -> LDS
-        for (int i = tid; i < d * W; i += 256) {
-            const int a = i % d, x = i / d, l = a * W + x;
-            const size_t p = (size_t)(y * W + x);
+    auto load_band = [&](int y0, int npx) {  // k softmax (over its row), v, q softmax * sc, do  -> LDS
+        for (int i = tid; i < d * npx; i += 256) {
+            const int a = i % d, pl = i / d, y = y0 + pl / W, x = pl % W, l = a * RW + pl;
+            const size_t p = (size_t)y0 * W + pl;
             rk[l] = dd_exp(kb[p * 2 * qd + a] - kmx[a * H + y]) / ksm[a * H + y];
             rv[l] = vb[p * 2 * qd + a];
-            rq[l] = dd_exp(qb[p * qd + a] - qmx[l]) / qsm[l] * sc;
+            rq[l] = dd_exp(qb[p * qd + a] - qmx[a * W + x]) / qsm[a * W + x] * sc;
             rg[l] = gb[p * ld_g + a];
         }
         __syncthreads();
     };
-    for (int y = 0; y < H; ++y) {  // pass 2: ctx and dctx
-        load_row(y);
+    for (int y0 = 0; y0 < H; y0 += R) {  // pass 2: ctx and dctx
+        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
+        load_band(y0, npx);
         for (int i = tid; i < d * d; i += 256) {
             const int a = i / d, e = i % d;
             float s1 = ctx[i], s2 = dctx[i];
-            for (int x = 0; x < W; ++x) {
-                s1 = fmaf(rk[a * W + x], rv[e * W + x], s1);
-                s2 = fmaf(rq[a * W + x], rg[e * W + x], s2);
+            for (int pl = 0; pl < npx; ++pl) {
+                s1 = fmaf(rk[a * RW + pl], rv[e * RW + pl], s1);
+                s2 = fmaf(rq[a * RW + pl], rg[e * RW + pl], s2);
             }
             ctx[i] = s1;
             dctx[i] = s2;
         }
         __syncthreads();
     }
-    for (int y = 0; y < H; ++y) {  // pass 3
-        load_row(y);
-        for (int i = tid; i < d * W; i += 256) {
-            const int a = i % d, x = i / d, l = a * W + x;
+    for (int y0 = 0; y0 < H; y0 += R) {  // pass 3
+        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
+        load_band(y0, npx);
+        for (int i = tid; i < d * npx; i += 256) {
+            const int a = i % d, pl = i / d, l = a * RW + pl;
             float dq = 0.f, dk = 0.f, dv = 0.f;
             for (int e = 0; e < d; ++e) {
-                dq = fmaf(ctx[a * d + e], rg[e * W + x], dq);    // dq[a][n] = sum_e ctx[a][e] do[e][n]
-                dk = fmaf(dctx[a * d + e], rv[e * W + x], dk);   // dk[a][n] = sum_e dctx[a][e] v[e][n]
-                dv = fmaf(dctx[e * d + a], rk[e * W + x], dv);   // dv[a][n] = sum_e dctx[e][a] k[e][n]
+                dq = fmaf(ctx[a * d + e], rg[e * RW + pl], dq);    // dq[a][n] = sum_e ctx[a][e] do[e][n]
+                dk = fmaf(dctx[a * d + e], rv[e * RW + pl], dk);   // dk[a][n] = sum_e dctx[a][e] v[e][n]
+                dv = fmaf(dctx[e * d + a], rk[e * RW + pl], dv);   // dv[a][n] = sum_e dctx[e][a] k[e][n]
             }
-            const size_t p = (size_t)(y * W + x);
+            const size_t p = (size_t)y0 * W + pl;
             dvb[p * 2 * qd + a] = dv;
             rdk[l] = dk;
-            dq *= sc;  // d(q_sm) of o = ctx^T (q_sm * sc)
-            dqb[p * qd + a] = dq;
-            T[l] += dq * (rq[l] / sc);  // q_sm = rq / sc
+            dqb[p * qd + a] = dq * sc;  // d(q_sm) of o = ctx^T (q_sm * sc)
         }
         __syncthreads();
-        for (int a = tid; a < d; a += 256) {
+        for (int i = tid; i < d * rows; i += 256) {  // row dots of the k softmax backward
+            const int a = i % d, r = i / d;
             float s = 0.f;
-            for (int x = 0; x < W; ++x) s = fmaf(rdk[a * W + x], rk[a * W + x], s);
-            rdot[a] = s;
+            for (int x = 0; x < W; ++x) s = fmaf(rdk[a * RW + r * W + x], rk[a * RW + r * W + x], s);
+            rdot[a * R + r] = s;
+        }
+        for (int i = tid; i < d * W; i += 256) {  // column sums T += dq * q_sm over the band's rows, in row order (one owner per (a, x))
+            const int a = i % d, x = i / d;
+            float t = T[a * W + x];
+            for (int r = 0; r < rows; ++r) {
+                const int pl = r * W + x;
+                t += dqb[((size_t)y0 * W + pl) * qd + a] * (rq[a * RW + pl] / sc);  // q_sm = rq / sc
+            }
+            T[a * W + x] = t;
         }
         __syncthreads();
-        for (int i = tid; i < d * W; i += 256) {
-            const int a = i % d, x = i / d, l = a * W + x;
-            dkb[(size_t)(y * W + x) * 2 * qd + a] = rk[l] * (rdk[l] - rdot[a]);
+        for (int i = tid; i < d * npx; i += 256) {
+            const int a = i % d, pl = i / d, l = a * RW + pl;
+            dkb[((size_t)y0 * W + pl) * 2 * qd + a] = rk[l] * (rdk[l] - rdot[a * R + pl / W]);
         }
         __syncthreads();
     }
-    for (int i = tid; i < d * W; i += 256) {  // pass 4: softmax-over-H backward of q
-        const int a = i % d, x = i / d, l = a * W + x;
-        for (int y = 0; y < H; ++y) {
-            const size_t el = (size_t)(y * W + x) * qd + a;
-            const float qs_ = dd_exp(qb[el] - qmx[l]) / qsm[l];
-            dqb[el] = qs_ * (dqb[el] - T[l]);
-        }
+    for (int i = tid; i < d * HW; i += 256) {  // pass 4: softmax-over-H backward of q
+        const int a = i % d, p = i / d, x = p % W;
+        const size_t el = (size_t)p * qd + a;
+        const float qs_ = dd_exp(qb[el] - qmx[a * W + x]) / qsm[a * W + x];
+        dqb[el] = qs_ * (dqb[el] - T[a * W + x]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- misc
+// F.l1_loss(pred, target), mean: per-workgroup fp64 partials, then a fixed-order sum (the single-workgroup form of kernels_bwd_ops.h costs
+// 1.7 ms on a batch-32 output)
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* pred, const float* target, size_t n, double* part) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) s += (double)fabsf(pred[i] - target[i]);
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) part[blockIdx.x] = red[0];
+}
+__global__ void l1_final_kernel(const double* part, int nblk, size_t n, float* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < nblk; ++k) s += part[k];
+        out[0] = (float)(s / (double)n);
+    }
+}
+// per-sample plane sums in two stages: part[b][chunk][c] over pixel chunks, then out[b * ld + c] (fixed order)
+__global__ __launch_bounds__(256) void plane_sum_partial_nhwc_kernel(const float* dy, int HW, int C, int nchunk, float* part) {
+    DDIF_DYN_SMEM(smem_);
+    float* red = reinterpret_cast<float*>(smem_);  // [256]
+    const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
+    const int per = (HW + nchunk - 1) / nchunk, p0 = ck * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const float* src = dy + (size_t)b * HW * C;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cw = C - c0 < 256 ? C - c0 : 256, rows = 256 / cw;
+        const int c = tid % cw, r = tid / cw;
+        float s = 0.f;
+        if (r < rows)
+            for (int p = p0 + r; p < p1; p += rows) s += src[(size_t)p * C + c0 + c];
+        red[tid] = s;
+        __syncthreads();
+        if (r == 0) {
+            for (int rr = 1; rr < rows; ++rr) s += red[rr * cw + c];
+            part[((size_t)b * nchunk + ck) * C + c0 + c] = s;
+        }
+        __syncthreads();
+    }
+}
+__global__ void plane_sum_final_kernel(const float* part, int B, int C, int nchunk, int ld, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * C + c];
+    out[(size_t)b * ld + c] = s;
+}
 // flipped depthwise taps: w [9][C] (tap-major, the forward layout) -> [9][C] with tap k <- 8 - k: dX of a depthwise conv is the same
 // depthwise conv of dY with the taps reversed
 __global__ void flip_dw_taps_kernel(const float* w, int C, float* out) {

@@ -62,6 +62,29 @@ def extract(a, t, x_shape):
     return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
 
 
+class _NativeTrainFn(torch.autograd.Function):
+    """Autograd node around `ddif_plan_train_step`: the library computes loss AND gradients in the forward call (one reverse launch program);
+    backward() hands the gradient tensors to torch scaled by the upstream gradient (1.0 for `loss.backward()`).  The gradient buffers belong
+    to the plan and are overwritten by the next step: torch accumulates them into `.grad` right away, as the reference's autograd does."""
+
+    @staticmethod
+    def forward(ctx, plan, x_start, noise, a, s, t, x_self_cond, gbuf, *params):
+        loss, pred = plan.train_step(x_start, noise, a, s, t, x_self_cond)
+        flat, views, offs = gbuf
+        ctx.snapshot = flat.clone()  # the plan's buffer is overwritten by the next step; this copy is what backward() hands out
+        ctx.meta = (offs, [v.shape for v in views])
+        ctx.mark_non_differentiable(pred)
+        return loss, pred
+
+    @staticmethod
+    def backward(ctx, gloss, _gpred):
+        flat = ctx.snapshot
+        if float(gloss) != 1.0:
+            flat = flat * gloss
+        offs, shapes = ctx.meta
+        return (None,) * 8 + tuple(flat[o:o + int(torch.Size(sh).numel())].view(sh) for o, sh in zip(offs, shapes))
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(
         self,
@@ -321,20 +344,97 @@ class GaussianDiffusion(nn.Module):
         return loss, pred
 
     def _train_step(self, x_start, noise, a, s, t, cond, x_self_cond):
-        """The differentiable pass of p_losses (:711-766): prediction through ddif.train.TrainGraph, L1 loss, and a torch autograd node
-        whose backward is the library's reverse pass -- `loss.backward()` then fills `.grad` of every parameter, as in the reference."""
-        from .. import functional as DF
-        from ..train import TrainGraph, TrainStepFn
+        """The differentiable pass of p_losses (:711-766) as ONE library call: q_sample, the train-mode forward over NHWC activations, the L1
+        loss and the reverse launch program of the whole denoiser (csrc/ddif_train.cpp, `ddif_plan_train_step`), behind a torch autograd
+        node -- `loss.backward()` then leaves `.grad` on every parameter, as in the reference (diffusion_engine.py:230-233).  The weights the
+        kernels read are re-packed from the parameter tensors on the device when they changed (`ddif_net_refresh`), the Dropout / DropPath
+        masks come from the library's counter-based generator keyed by (seed, site, GLOBAL tile index `self.train_tile0 + b`, element) --
+        so a batch split over ranks draws the masks the unsplit batch would -- or are the ones pinned with `model.set_train_masks`.
+        `DDIF_TRAIN_TAPE=1` selects round 2's op-by-op Python tape (ddif/train.py) instead (kept as a cross-check of the native program)."""
+        import os
 
         if self.loss_type != "l1":
             raise DdifError("training: only loss_type='l1' (the engine configuration) has a backward pass")
         if float(getattr(self, "p2_loss_weight_gamma", 0.0)) != 0.0:
             raise DdifError("training: p2 loss weighting is not implemented by the backward pass")
         model = self.model
-        graph = getattr(self, "_train_graph", None)
-        if graph is None:
-            graph = self._train_graph = TrainGraph(model.cfg, dropout=float(model.cfg["dropout"]), drop_path=model.DROP_PATH_PROB)
         named = [(n, p) for n, p in model.named_parameters()]
+        if os.environ.get("DDIF_TRAIN_TAPE", "0") == "1":
+            return self._train_step_tape(x_start, noise, a, s, t, cond, x_self_cond, named)
+        plan = self._native_plan(x_start, cond, named)
+        gb = getattr(plan, "_grad_bufs", None)
+        if gb is None:
+            # one flat buffer, one 64-float-aligned view per parameter: backward() hands torch a single clone of it
+            offs, total = [], 0
+            for _, p in named:
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64
+            flat = torch.empty((total,), dtype=torch.float32, device=x_start.device)
+            views = [flat[o:o + p.numel()].view(p.shape) for o, (_, p) in zip(offs, named)]
+            gb = plan._grad_bufs = (flat, views, offs)
+            plan._bound_ptrs = None
+        self._bind(plan, named, gb[1])
+        loss, pred = _NativeTrainFn.apply(plan, x_start, noise, a, s, t, x_self_cond, gb, *[p for _, p in named])
+        return loss, pred
+
+    def _native_plan(self, x_start, cond, named):
+        model = self.model
+        B, _, H, W = x_start.shape
+        plan = model.plan_for(B, H, W, x_start.device, train=True)
+        if not getattr(model._net, "device_refreshed", False):
+            model._net.refresh_from_device(named)  # first use after a host commit: fills the dgrad packs
+        plan.set_cond(cond)
+        pinned = getattr(model, "_train_masks", None)
+        if pinned is not None:
+            plan.set_train_masks(*pinned)
+        else:
+            # seed: `train_mask_seed` (set by a caller that wants masks independent of the ranks' own torch RNG: engine_google under DDP) advanced
+            # per pass, else a draw from torch's generator as nn.Dropout would make
+            base = getattr(self, "train_mask_seed", None)
+            if base is None:
+                seed = self._seed_from_torch()
+            else:
+                self._mask_calls = getattr(self, "_mask_calls", 0) + 1
+                seed = (int(base) + self._mask_calls) & ((1 << 62) - 1)
+            plan.random_train_masks(seed, int(getattr(self, "train_tile0", 0)), float(model.cfg["dropout"]), model.DROP_PATH_PROB)
+        return plan
+
+    @staticmethod
+    def _bind(plan, named, tensors):
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        if getattr(plan, "_bound_ptrs", None) != ptrs:
+            plan.train_bind([(n, g) for (n, _), g in zip(named, tensors)])
+            plan._bound_ptrs = ptrs
+
+    def train_step_into(self, x_start, cond, grads, noise=None):
+        """p_losses + loss.backward() of the reference (:692-766, diffusion_engine.py:230-233) with the gradients WRITTEN straight into `grads`
+        (one contiguous fp32 tensor per parameter, `model.parameters()` order) -- what `engine_google` hands to its fused optimizer; no
+        autograd node, no per-parameter accumulation launches.  Same random draws, in the same order, as p_losses.  Returns (loss, recon)."""
+        if self.loss_type != "l1" or float(getattr(self, "p2_loss_weight_gamma", 0.0)) != 0.0:
+            raise DdifError("training: only loss_type='l1' without p2 weighting has a backward pass")
+        model = self.model
+        if not getattr(model, "training", False):
+            raise DdifError("train_step_into needs the model in .train() mode")
+        b = x_start.shape[0]
+        t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        named = [(n, p) for n, p in model.named_parameters()]
+        a = self.sqrt_alphas_cumprod.detach().cpu()[t.cpu()]
+        s = self.sqrt_one_minus_alphas_cumprod.detach().cpu()[t.cpu()]
+        x_self_cond = None
+        if self.self_condition and random.random() < 0.5:
+            plan = self._native_plan(x_start, cond, named)
+            x_self_cond = plan.q_sample_forward(x_start, noise, a, s, t, None)  # no-grad pass of the reference (:703-709), its own masks
+        plan = self._native_plan(x_start, cond, named)
+        self._bind(plan, named, grads)
+        return plan.train_step(x_start, noise, a, s, t, x_self_cond)
+
+    def _train_step_tape(self, x_start, noise, a, s, t, cond, x_self_cond, named):
+        from .. import functional as DF
+        from ..train import TrainGraph, TrainStepFn
+
+        model = self.model
+        graph = TrainGraph(model.cfg, dropout=float(model.cfg["dropout"]), drop_path=model.DROP_PATH_PROB)  # one tape per call (gradient accumulation safe)
         names = tuple(n for n, _ in named)
         x_noisy = DF.q_sample(x_start, noise, a, s)
         pinned = getattr(model, "_train_masks", None)

@@ -154,18 +154,18 @@ def test_loss_backward_through_the_drop_in_fills_parameter_grads_and_the_optimiz
         torch.randint = lambda *a, **k: t.to(dev)
         random.random = lambda: 1.0  # no self-conditioning pass: the golden's self_cond is a given tensor, not a model output
         try:
-            from ddif.train import TrainGraph
+            from ddif.runtime import PlanHandle
 
-            fwd = TrainGraph.forward
+            step = PlanHandle.train_step
 
-            def spy(self, P, xx, tt, cc, self_cond=None, **kw):  # the golden ran with an explicit self_cond tensor and its own target
-                return fwd(self, P, xx, tt, cc, sc.to(dev), **kw)
+            def spy(self, x0, noise, a, s, time, self_cond, want_pred=True):  # the golden ran with an explicit self_cond tensor
+                return step(self, x0, noise, a, s, time, sc.to(dev), want_pred)
 
-            TrainGraph.forward = spy
+            PlanHandle.train_step = spy
             try:
                 loss, recon = d(x.to(dev), cond=cond.to(dev))
             finally:
-                TrainGraph.forward = fwd
+                PlanHandle.train_step = step
         finally:
             torch.randint, random.random = randint, rnd
             d.sqrt_alphas_cumprod.copy_(a_keep)
