@@ -491,7 +491,7 @@ int Plan::build_backward() {
                         hipLaunchKernelGGL(add2_ld_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)T->tmp, fea, other, ld_other, fea, npix, dxn);
                         hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((fea + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), st, (const float*)xn.p, fea,
                                            (const float*)ddwq, fea, BB, fea, Hl, Wl, nsplit, T->dwpart);
-                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((fea * 9 + 255) / 256), dim3(256), 0, st, (const double*)T->dwpart, nsplit, fea, *dw0);
+                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((fea * 9 + 7) / 8), dim3(256), 256 * sizeof(double), st, (const double*)T->dwpart, nsplit, fea, *dw0);
                     });
                 }
                 // kv = kv.1(kdw) + b;  kdw = depthwise3x3(cond; kv.0): weight gradients only (cond needs no gradient)
@@ -517,7 +517,7 @@ int Plan::build_backward() {
                     L.v.push_back([=](hipStream_t st) {
                         hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((cd + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), st, (const float*)cimg.p, cd,
                                            (const float*)dkdw.p, ldk, BB, cd, Hl, Wl, nsplit, T->dwpart);
-                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((cd * 9 + 255) / 256), dim3(256), 0, st, (const double*)T->dwpart, nsplit, cd, *dwk0);
+                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((cd * 9 + 7) / 8), dim3(256), 256 * sizeof(double), st, (const double*)T->dwpart, nsplit, cd, *dwk0);
                     });
                 }
                 // prenorm_x: xn = GroupNorm(cat[h, skip])  (no SiLU); then split the gradient of the cat

@@ -69,22 +69,35 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     for (int band = blockIdx.y; band < nbands; band += gridDim.y) {
         const int b = band / a.bands_y, y0 = (band % a.bands_y) * RB;
         __syncthreads();  // previous band fully consumed
-        // stage dY rows y0..y0+RB-1 (32 couts of this block) and X rows y0-1..y0+RB with a one-pixel zero border
-        for (int i = tid; i < RB * W * 8; i += 256) {
-            const int c4 = i & 7, p = i >> 3;
-            const int y = y0 + p / W, x = p % W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int co = cob * 32 + c4 * 4;
-            if (y < a.H && co < a.Cout) v = *reinterpret_cast<const float4*>(a.dy + (((size_t)b * a.H + y) * W + x) * a.Cout + co);
-            *reinterpret_cast<float4*>(&Ys[p * 32 + c4 * 4]) = v;
-        }
-        for (int i = tid; i < (RB + 2) * IW * 8; i += 256) {
-            const int c4 = i & 7, p = i >> 3;
-            const int y = y0 - 1 + p / IW, x = p % IW - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int ci = cib * 32 + c4 * 4;
-            if (y >= 0 && y < a.H && x >= 0 && x < W && ci < a.Cin) v = *reinterpret_cast<const float4*>(a.x + (((size_t)b * a.H + y) * W + x) * a.Cin + ci);
-            *reinterpret_cast<float4*>(&Xs[p * 32 + c4 * 4]) = v;
+        // stage dY rows y0..y0+RB-1 (32 couts of this block) and X rows y0-1..y0+RB with a one-pixel zero border.  Items (float4) are
+        // fetched EIGHT per thread at a time into registers before any is written to LDS: a load-then-store loop pays one memory latency
+        // per item (measured: the kernel ran at 5-10 % of its MFMA time, all of it waiting on these loads)
+        {
+            const int NY = RB * W * 8, NX = (RB + 2) * IW * 8, NTOT = NY + NX;
+            for (int base = 0; base < NTOT; base += 256 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + u * 256 + tid;
+                    const bool isy = i < NY;
+                    const int k = isy ? i : i - NY;
+                    const int c4 = k & 7, p = k >> 3;
+                    const int rowlen = isy ? W : IW;
+                    const int pr_ = p / rowlen, pc_ = p - pr_ * rowlen;
+                    const int y = isy ? y0 + pr_ : y0 - 1 + pr_, x = isy ? pc_ : pc_ - 1;
+                    const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
+                    const bool ok = (i < NTOT) & (y >= 0) & (y < a.H) & (x >= 0) & (x < W) & (cc < Cc);
+                    const float* src = isy ? a.dy : a.x;
+                    const size_t off = ok ? (((size_t)b * a.H + y) * W + x) * Cc + cc : 0;
+                    const float4 ld = *reinterpret_cast<const float4*>(src + off);  // (offset 0 is always readable)
+                    v[u] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + u * 256 + tid;
+                    if (i < NTOT) *reinterpret_cast<float4*>(&Ys[i * 4]) = v[u];  // Xs follows Ys: item i lives at float 4 i of the joint tile
+                }
+            }
         }
         __syncthreads();
         // pixel pairs of the band: pair q -> pixels (2q, 2q+1) in row-major order of the RB x W band; wave w takes q = w, w+4, ...

@@ -223,12 +223,21 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial_nhwc_kernel(const float*
         }
     }
 }
-__global__ void dw_wgrad_reduce_kernel(const double* partial, int nsplit, int C, float* dw /* (C,1,3,3) */) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * 9) return;
+// 32 lanes per output element (8 outputs per 256-thread workgroup): lane l sums splits l, l + 32, ...; the 32 partials are added in lane order
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const double* partial, int nsplit, int C, float* dw /* (C,1,3,3) */) {
+    DDIF_DYN_SMEM(smem_);
+    double* red = reinterpret_cast<double*>(smem_);  // [256]
+    const int tid = threadIdx.x, l = tid & 31, o = blockIdx.x * 8 + (tid >> 5);
     double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * C * 9 + i];
-    dw[i] = (float)s;
+    if (o < C * 9)
+        for (int k = l; k < nsplit; k += 32) s += partial[(size_t)k * C * 9 + o];
+    red[tid] = s;
+    __syncthreads();
+    if (l == 0 && o < C * 9) {
+        double t = 0.0;
+        for (int k = 0; k < 32; ++k) t += red[(tid & ~31) + k];
+        dw[o] = (float)t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- SelfAttention core backward (NHWC)
@@ -314,6 +323,23 @@ __global__ __launch_bounds__(256) void selfattn_bwd_nhwc_kernel(const float* qkv
 // One workgroup per (sample, head); W, H <= 64, d <= 32.  The image is walked in BANDS of R rows (R * W <= LA_BAND pixels staged in LDS per
 // step) instead of row by row: 8 barriers instead of 128 at 64x64.  Every LDS cell has one owner thread and the bands / pixels are summed
 // in index order: deterministic.  (Same math as linattn_fwd / _bwd_kernel of kernels_bwd_ops.h, the NCHW forms behind the stateless C-ABI ops.)
+// max / sum(exp(. - max)) of a strided line of <= 64 elements: the whole line is loaded into registers first (independent loads in flight
+// together -- a load-per-iteration loop pays one memory latency per element), then the two-pass arithmetic of torch.softmax
+__device__ __forceinline__ void la_line_stats(const float* p0, size_t stride, int n, float* mx_out, float* sm_out) {
+    float v[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) v[r] = p0[(size_t)(r < n ? r : n - 1) * stride];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) mx = fmaxf(mx, v[r]);  // the clamped tail repeats the last element
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 64; ++r)
+        if (r < n) s += dd_exp(v[r] - mx);
+    *mx_out = mx;
+    *sm_out = s;
+}
+
 constexpr int LA_BAND = 4096;  // floats per staged band array: rows per band R = LA_BAND / (d * W)
 __host__ __device__ inline int la_rows(int d, int H, int W) {
     int r = LA_BAND / (d * W);
@@ -342,21 +368,11 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
     float* ob = out + (size_t)b * HW * ld_o + hd * d;
     for (int i = tid; i < d * W; i += 256) {  // column statistics of q_pre (softmax over H)
         const int a = i % d, x = i / d;
-        float mx = -3.0e38f;
-        for (int y = 0; y < H; ++y) mx = fmaxf(mx, qb[(size_t)(y * W + x) * qd + a]);
-        float s = 0.f;
-        for (int y = 0; y < H; ++y) s += dd_exp(qb[(size_t)(y * W + x) * qd + a] - mx);
-        qmx[a * W + x] = mx;
-        qsm[a * W + x] = s;
+        la_line_stats(qb + (size_t)x * qd + a, (size_t)W * qd, H, &qmx[a * W + x], &qsm[a * W + x]);
     }
     for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre (softmax over W)
         const int a = i % d, y = i / d;
-        float mx = -3.0e38f;
-        for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)(y * W + x) * 2 * qd + a]);
-        float sm = 0.f;
-        for (int x = 0; x < W; ++x) sm += dd_exp(kb[(size_t)(y * W + x) * 2 * qd + a] - mx);
-        kmx[a * H + y] = mx;
-        ksm[a * H + y] = sm;
+        la_line_stats(kb + (size_t)y * W * 2 * qd + a, (size_t)2 * qd, W, &kmx[a * H + y], &ksm[a * H + y]);
     }
     for (int i = tid; i < d * d; i += 256) ctx[i] = 0.f;
     __syncthreads();
@@ -377,14 +393,22 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
         }
         __syncthreads();
     }
-    for (int i = tid; i < d * HW; i += 256) {  // o[e][n] = sum_a ctx[a][e] q[a][n]
-        const int e = i % d, p = i / d, x = p % W;
-        float s = 0.f;
-        for (int a = 0; a < d; ++a) {
-            const float qv = dd_exp(qb[(size_t)p * qd + a] - qmx[a * W + x]) / qsm[a * W + x] * sc;
-            s = fmaf(ctx[a * d + e], qv, s);
+    // o[e][n] = sum_a ctx[a][e] q[a][n]: the band buffer is free now -- stage q_sm * sc of a band of pixels once (every (pixel, a) value is
+    // needed by all d outputs of the pixel), then one thread per output element
+    for (int y0 = 0; y0 < H; y0 += R) {
+        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
+        for (int i = tid; i < d * npx; i += 256) {
+            const int a = i % d, pl = i / d, x = pl % W;
+            rk[a * RW + pl] = dd_exp(qb[((size_t)y0 * W + pl) * qd + a] - qmx[a * W + x]) / qsm[a * W + x] * sc;
         }
-        ob[(size_t)p * ld_o + e] = s;
+        __syncthreads();
+        for (int i = tid; i < d * npx; i += 256) {
+            const int e = i % d, pl = i / d;
+            float s = 0.f;
+            for (int a = 0; a < d; ++a) s = fmaf(ctx[a * d + e], rk[a * RW + pl], s);
+            ob[((size_t)y0 * W + pl) * ld_o + e] = s;
+        }
+        __syncthreads();
     }
 }
 
@@ -420,12 +444,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
     float* dvb = dkb + qd;
     for (int i = tid; i < d * W; i += 256) {  // pass 1: column statistics of q_pre (softmax over H)
         const int a = i % d, x = i / d;
-        float mx = -3.0e38f;
-        for (int y = 0; y < H; ++y) mx = fmaxf(mx, qb[(size_t)(y * W + x) * qd + a]);
-        float s = 0.f;
-        for (int y = 0; y < H; ++y) s += dd_exp(qb[(size_t)(y * W + x) * qd + a] - mx);
-        qmx[a * W + x] = mx;
-        qsm[a * W + x] = s;
+        la_line_stats(qb + (size_t)x * qd + a, (size_t)W * qd, H, &qmx[a * W + x], &qsm[a * W + x]);
         T[a * W + x] = 0.f;
     }
     for (int i = tid; i < d * d; i += 256) {
@@ -434,12 +453,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
     }
     for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre for every (channel, row)
         const int a = i % d, y = i / d;
-        float mx = -3.0e38f;
-        for (int x = 0; x < W; ++x) mx = fmaxf(mx, kb[(size_t)(y * W + x) * 2 * qd + a]);
-        float sm = 0.f;
-        for (int x = 0; x < W; ++x) sm += dd_exp(kb[(size_t)(y * W + x) * 2 * qd + a] - mx);
-        kmx[a * H + y] = mx;
-        ksm[a * H + y] = sm;
+        la_line_stats(kb + (size_t)y * W * 2 * qd + a, (size_t)2 * qd, W, &kmx[a * H + y], &ksm[a * H + y]);
     }
     __syncthreads();
     auto load_band = [&](int y0, int npx) {  // k softmax (over its row), v, q softmax * sc, do  -> LDS
@@ -507,11 +521,25 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
         }
         __syncthreads();
     }
-    for (int i = tid; i < d * HW; i += 256) {  // pass 4: softmax-over-H backward of q
-        const int a = i % d, p = i / d, x = p % W;
-        const size_t el = (size_t)p * qd + a;
-        const float qs_ = dd_exp(qb[el] - qmx[a * W + x]) / qsm[a * W + x];
-        dqb[el] = qs_ * (dqb[el] - T[a * W + x]);
+    const int NEL = d * HW;
+    for (int i0 = tid; i0 < NEL; i0 += 256 * 4) {  // pass 4: softmax-over-H backward of q (four elements per thread in flight)
+        float qv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256 < NEL ? i0 + u * 256 : tid;
+            const size_t el = (size_t)(i / d) * qd + i % d;
+            qv[u] = qb[el];
+            gv[u] = dqb[el];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            if (i < NEL) {
+                const int a = i % d, p = i / d, x = p % W;
+                const float qs_ = dd_exp(qv[u] - qmx[a * W + x]) / qsm[a * W + x];
+                dqb[(size_t)p * qd + a] = qs_ * (gv[u] - T[a * W + x]);
+            }
+        }
     }
 }
 

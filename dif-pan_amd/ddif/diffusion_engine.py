@@ -333,6 +333,7 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
     opt = _rt.FusedAdamW(params, grads, ema, lr=lr_d, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
     iterations = int(pretrain_iterations) if pretrain_iterations is not None else 0
     history, records = [], []
+    resume_tiles = 0
     names = [n for n, _ in net.named_parameters()]
     if resume_state is not None:
         st = torch.load(resume_state, map_location="cpu", weights_only=False) if isinstance(resume_state, (str, os.PathLike)) else resume_state
@@ -344,6 +345,8 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
         opt.load_state_dict(st["optimizer"])
         iterations = int(st["iterations"])
         train.epoch = int(st.get("epoch", 0))
+        resume_tiles = int(st.get("tile_counter", 0))
+        diffusion._mask_calls = int(st.get("mask_calls", 0))
         torch.set_rng_state(st["rng"]["torch"])
         _random.setstate(st["rng"]["python"])
         if dev.type == "cuda" and st["rng"].get("cuda") is not None:
@@ -382,13 +385,14 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
         torch.save(model_sd, os.path.join(save_dir, f"diffusion_{name}_iter_{it}.pth"))      # bare state_dicts, reference :333-340
         torch.save(ema_sd, os.path.join(save_dir, f"ema_diffusion_{name}_iter_{it}.pth"))
         torch.save({"model": model_sd, "ema": ema_sd, "optimizer": opt.state_dict(), "iterations": it, "epoch": train.epoch,
+                    "tile_counter": tile_counter, "mask_calls": int(getattr(diffusion, "_mask_calls", 0)),
                     "rng": {"torch": torch.get_rng_state(), "python": _random.getstate(),
                             "cuda": torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None}},
                    os.path.join(save_dir, f"train_state_{name}_iter_{it}.pth"))
 
     net.train()
     native = os.environ.get("DDIF_TRAIN_TAPE", "0") != "1"
-    tile_counter = 0
+    tile_counter = resume_tiles
     if world > 1:
         diffusion.train_mask_seed = (int(data_seed) + 1) * 1_000_003  # same mask stream on every rank, keyed by GLOBAL tile index below
     while iterations < max_iterations:
