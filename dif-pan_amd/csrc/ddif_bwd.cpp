@@ -146,7 +146,7 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
             hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)c.Cout * c.Cin), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
                                c.Cout, c.Cin, dw);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)c.Cout * c.Cin * 9), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)c.n_co * c.n_ci * 9 * 1024), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
                                c.Cout, c.Cin, dw);
     }
     if (db) {
@@ -473,7 +473,7 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     if (centre)
         hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)Cout * Cin * 9), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)g.n_co * g.n_ci * 9 * 1024), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
 }
 void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db) {
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nbchunk), dim3(256), 256 * sizeof(float), s, dy, npix, Cout, nbchunk, bpart);

@@ -139,6 +139,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// fixed-order sum over the K splits with EIGHT loads in flight (a load-per-iteration loop pays one memory latency per split)
+__device__ __forceinline__ float wgrad_sum_splits(const float* p, size_t stride, int nsplit) {
+    float acc = 0.f;
+    for (int k0 = 0; k0 < nsplit; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k0 + u < nsplit ? p[(size_t)(k0 + u) * stride] : 0.f;
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    return acc;
+}
 // 1x1 form: dW (Cout, Cin) from the centre-tap blocks only
 __global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw) {
     const size_t total = (size_t)Cout * Cin;
@@ -146,23 +157,19 @@ __global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int
         const int ci = (int)(i % Cin), co = (int)(i / Cin);
         const int blk = (co / 32) * n_ci + ci / 32;
         const size_t off = ((size_t)blk * 9 + 4) * 1024 + (size_t)(co % 32) * 32 + ci % 32;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * nblk * 9 * 1024 + off];
-        dw[i] = s;
+        dw[i] = wgrad_sum_splits(partial + off, (size_t)nblk * 9 * 1024, nsplit);
     }
 }
-// dW (OIHW) = fixed-order sum of the partial blocks; one thread per weight element
+// dW (OIHW) = fixed-order sum of the partial blocks.  Threads walk the PARTIAL layout ([block][tap][co % 32][ci % 32]: coalesced reads, which
+// are nsplit x the writes); each writes its one weight element
 __global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw) {
-    const size_t total = (size_t)Cout * Cin * 9;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i % 9);
-        const int ci = (int)((i / 9) % Cin);
-        const int co = (int)(i / ((size_t)9 * Cin));
-        const int blk = (co / 32) * n_ci + ci / 32;
-        const size_t off = ((size_t)blk * 9 + t) * 1024 + (size_t)(co % 32) * 32 + ci % 32;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * nblk * 9 * 1024 + off];
-        dw[i] = s;
+    const size_t total = (size_t)nblk * 9 * 1024;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
+        const int t = (int)((j >> 10) % 9), blk = (int)(j / (9 * 1024));
+        const int co = (blk / n_ci) * 32 + r, ci = (blk % n_ci) * 32 + c;
+        if (co >= Cout || ci >= Cin) continue;
+        dw[((size_t)co * Cin + ci) * 9 + t] = wgrad_sum_splits(partial + j, total, nsplit);
     }
 }
 

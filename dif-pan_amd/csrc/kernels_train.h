@@ -378,11 +378,25 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
     __syncthreads();
     for (int y0 = 0; y0 < H; y0 += R) {  // ctx: bands in order, one owner thread per (a, e)
         const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
-        for (int i = tid; i < d * npx; i += 256) {
-            const int a = i % d, pl = i / d, y = y0 + pl / W;
-            const size_t p = (size_t)y0 * W + pl;
-            rk[a * RW + pl] = dd_exp(kb[p * 2 * qd + a] - kmx[a * H + y]) / ksm[a * H + y];
-            rv[a * RW + pl] = vb[p * 2 * qd + a];
+        const int nit = d * npx;
+        for (int i0 = tid; i0 < nit; i0 += 256 * 4) {  // four items' loads in flight per thread
+            float kv_[4], vv_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 < nit ? i0 + u * 256 : tid;
+                const size_t p = (size_t)y0 * W + i / d;
+                kv_[u] = kb[p * 2 * qd + i % d];
+                vv_[u] = vb[p * 2 * qd + i % d];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < nit) {
+                    const int a = i % d, pl = i / d, y = y0 + pl / W;
+                    rk[a * RW + pl] = dd_exp(kv_[u] - kmx[a * H + y]) / ksm[a * H + y];
+                    rv[a * RW + pl] = vv_[u];
+                }
+            }
         }
         __syncthreads();
         for (int i = tid; i < d * d; i += 256) {
@@ -397,9 +411,22 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
     // needed by all d outputs of the pixel), then one thread per output element
     for (int y0 = 0; y0 < H; y0 += R) {
         const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
-        for (int i = tid; i < d * npx; i += 256) {
-            const int a = i % d, pl = i / d, x = pl % W;
-            rk[a * RW + pl] = dd_exp(qb[((size_t)y0 * W + pl) * qd + a] - qmx[a * W + x]) / qsm[a * W + x] * sc;
+        const int nit = d * npx;
+        for (int i0 = tid; i0 < nit; i0 += 256 * 4) {
+            float qv_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 < nit ? i0 + u * 256 : tid;
+                qv_[u] = qb[((size_t)y0 * W + i / d) * qd + i % d];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < nit) {
+                    const int a = i % d, pl = i / d, x = pl % W;
+                    rk[a * RW + pl] = dd_exp(qv_[u] - qmx[a * W + x]) / qsm[a * W + x] * sc;
+                }
+            }
         }
         __syncthreads();
         for (int i = tid; i < d * npx; i += 256) {
@@ -457,13 +484,30 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
     }
     __syncthreads();
     auto load_band = [&](int y0, int npx) {  // k softmax (over its row), v, q softmax * sc, do  -> LDS
-        for (int i = tid; i < d * npx; i += 256) {
-            const int a = i % d, pl = i / d, y = y0 + pl / W, x = pl % W, l = a * RW + pl;
-            const size_t p = (size_t)y0 * W + pl;
-            rk[l] = dd_exp(kb[p * 2 * qd + a] - kmx[a * H + y]) / ksm[a * H + y];
-            rv[l] = vb[p * 2 * qd + a];
-            rq[l] = dd_exp(qb[p * qd + a] - qmx[a * W + x]) / qsm[a * W + x] * sc;
-            rg[l] = gb[p * ld_g + a];
+        const int nit = d * npx;
+        for (int i0 = tid; i0 < nit; i0 += 256 * 4) {  // four items' loads (16 in all) in flight per thread
+            float kv_[4], vv_[4], qv_[4], gv_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 < nit ? i0 + u * 256 : tid;
+                const size_t p = (size_t)y0 * W + i / d;
+                const int a = i % d;
+                kv_[u] = kb[p * 2 * qd + a];
+                vv_[u] = vb[p * 2 * qd + a];
+                qv_[u] = qb[p * qd + a];
+                gv_[u] = gb[p * ld_g + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < nit) {
+                    const int a = i % d, pl = i / d, y = y0 + pl / W, x = pl % W, l = a * RW + pl;
+                    rk[l] = dd_exp(kv_[u] - kmx[a * H + y]) / ksm[a * H + y];
+                    rv[l] = vv_[u];
+                    rq[l] = dd_exp(qv_[u] - qmx[a * W + x]) / qsm[a * W + x] * sc;
+                    rg[l] = gv_[u];
+                }
+            }
         }
         __syncthreads();
     };
