@@ -115,7 +115,7 @@ int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device)
         c.nbchunk = (int)std::min<size_t>(512, std::max<size_t>(1, (size_t)B * H * W / 16));  // >= 16 pixels per chunk
         TRY(c.plan.dalloc(&c.bpart, (size_t)c.nbchunk * Cout));
         if (!rc && c.wg_smem > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.wg_smem) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.wg_smem) != hipSuccess)
             rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_create: hipFuncSetAttribute failed");
     }
     return rc;
@@ -141,7 +141,7 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
         a.bands_y = (c.H + c.rb - 1) / c.rb;
         a.partial = c.partial;
         a.centre_only = c.centre_only ? 1 : 0;
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
         if (c.centre_only)
             hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)c.Cout * c.Cin), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
                                c.Cout, c.Cin, dw);
@@ -439,11 +439,21 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
     // rows per band: the largest of {16, 8, 4, 2, 1} (<= H) whose two tiles fit DDIF_WGRAD_SMEM_KB (default 72 KB: two workgroups per CU, so one's
     // band loads overlap the other's MFMAs; the low-resolution levels then stage a whole 8x8 sample or half a 16x16 one per band)
     static const size_t lim = [] { const char* e = getenv("DDIF_WGRAD_SMEM_KB"); return (size_t)(e ? atoi(e) : 72) * 1024; }();
-    for (g.rb = 16; g.rb >= 1; g.rb >>= 1) {
+    g.pf = 0;
+    for (g.rb = 16; g.rb >= 1; g.rb >>= 1) {  // first choice: a band whose float4 items fit the kernel's prefetch registers (WG_PF per thread)
         if (g.rb > H && g.rb > 1) continue;
-        g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
-        if (g.smem <= lim || (g.rb == 1 && g.smem <= 150 * 1024)) break;
+        if (((size_t)g.rb * W + (size_t)(g.rb + 2) * (W + 2)) * 8 <= (size_t)WG_PF * 256) {
+            g.pf = 1;
+            break;
+        }
     }
+    if (!g.pf)
+        for (g.rb = 16; g.rb >= 1; g.rb >>= 1) {
+            if (g.rb > H && g.rb > 1) continue;
+            g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
+            if (g.smem <= lim || (g.rb == 1 && g.smem <= 150 * 1024)) break;
+        }
+    if (g.rb >= 1) g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
     if (g.rb < 1) g.rb = 0;  // W too wide (caller checks)
     const int bands = B * ((H + (g.rb ? g.rb : 1) - 1) / (g.rb ? g.rb : 1));
     int want = (2 * 256) / (g.n_co * g.n_ci);
@@ -456,7 +466,8 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
     return g;
 }
 int wgrad_prepare() {
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return 0;
 }
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw) {
@@ -469,7 +480,8 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     a.bands_y = (H + g.rb - 1) / g.rb;
     a.partial = partial;
     a.centre_only = centre ? 1 : 0;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
+    if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
+    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     if (centre)
         hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
     else

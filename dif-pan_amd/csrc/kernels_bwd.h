@@ -49,6 +49,11 @@ struct WgradArgs {
 };
 
 // grid = (n_co * n_ci, NSPLIT); block 256.  LDS: dY band [rb*W][32] + X band [(rb+2)*(W+2)][32] + reduction scratch [4][1024].
+// PF = 1 (bands of <= WG_PF * 256 float4 items, chosen by the host): the NEXT band is fetched into registers while the current one is in
+// the MFMA loop -- a band's loads are then hidden instead of serialised in front of its MFMAs.  PF = 0: any band size, loads in batches
+// of eight before the LDS writes.
+constexpr int WG_PF = 12;
+template <int PF>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     DDIF_DYN_SMEM(smem);
     const int W = a.W, IW = W + 2;
@@ -60,46 +65,65 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     const int h = lane >> 5, j = lane & 31;
     const int cob = blockIdx.x / a.n_ci, cib = blockIdx.x % a.n_ci;
     const int nbands = a.B * a.bands_y;
+    const int NY = RB * W * 8, NX = (RB + 2) * IW * 8, NTOT = NY + NX;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // item i of a band (float4): i < NY -> dY row y0 + p / W, 32 couts of this block; else X rows y0 - 1 .. y0 + RB with a one-pixel zero border
+    auto load_item = [&](int b, int y0, int i) -> float4 {
+        const bool isy = i < NY;
+        const int k = isy ? i : i - NY;
+        const int c4 = k & 7, p = k >> 3;
+        const int rowlen = isy ? W : IW;
+        const int pr_ = p / rowlen, pc_ = p - pr_ * rowlen;
+        const int y = isy ? y0 + pr_ : y0 - 1 + pr_, x = isy ? pc_ : pc_ - 1;
+        const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
+        const bool ok = (i < NTOT) & (y >= 0) & (y < a.H) & (x >= 0) & (x < W) & (cc < Cc);
+        const float* src = isy ? a.dy : a.x;
+        const size_t off = ok ? (((size_t)b * a.H + y) * W + x) * Cc + cc : 0;
+        const float4 ld = *reinterpret_cast<const float4*>(src + off);  // (offset 0 is always readable)
+        return ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    [[maybe_unused]] float4 pf[PF ? WG_PF : 1];
+    if constexpr (PF) {
+        if ((int)blockIdx.y < nbands) {
+            const int b = blockIdx.y / a.bands_y, y0 = (blockIdx.y % a.bands_y) * RB;
+#pragma unroll
+            for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b, y0, u * 256 + tid);
+        }
+    }
     for (int band = blockIdx.y; band < nbands; band += gridDim.y) {
         const int b = band / a.bands_y, y0 = (band % a.bands_y) * RB;
         __syncthreads();  // previous band fully consumed
-        // stage dY rows y0..y0+RB-1 (32 couts of this block) and X rows y0-1..y0+RB with a one-pixel zero border.  Items (float4) are
-        // fetched EIGHT per thread at a time into registers before any is written to LDS: a load-then-store loop pays one memory latency
-        // per item (measured: the kernel ran at 5-10 % of its MFMA time, all of it waiting on these loads)
-        {
-            const int NY = RB * W * 8, NX = (RB + 2) * IW * 8, NTOT = NY + NX;
+        if constexpr (PF) {
+#pragma unroll
+            for (int u = 0; u < WG_PF; ++u) {
+                const int i = u * 256 + tid;
+                if (i < NTOT) *reinterpret_cast<float4*>(&Ys[i * 4]) = pf[u];  // Xs follows Ys: item i lives at float 4 i of the joint tile
+            }
+            __syncthreads();
+            const int nb = band + gridDim.y;
+            if (nb < nbands) {  // workgroup-uniform: the next band's loads fly during this band's MFMAs
+                const int b2 = nb / a.bands_y, y2 = (nb % a.bands_y) * RB;
+#pragma unroll
+                for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b2, y2, u * 256 + tid);
+            }
+        } else {
             for (int base = 0; base < NTOT; base += 256 * 8) {
                 float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base + u * 256 + tid;
-                    const bool isy = i < NY;
-                    const int k = isy ? i : i - NY;
-                    const int c4 = k & 7, p = k >> 3;
-                    const int rowlen = isy ? W : IW;
-                    const int pr_ = p / rowlen, pc_ = p - pr_ * rowlen;
-                    const int y = isy ? y0 + pr_ : y0 - 1 + pr_, x = isy ? pc_ : pc_ - 1;
-                    const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
-                    const bool ok = (i < NTOT) & (y >= 0) & (y < a.H) & (x >= 0) & (x < W) & (cc < Cc);
-                    const float* src = isy ? a.dy : a.x;
-                    const size_t off = ok ? (((size_t)b * a.H + y) * W + x) * Cc + cc : 0;
-                    const float4 ld = *reinterpret_cast<const float4*>(src + off);  // (offset 0 is always readable)
-                    v[u] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int u = 0; u < 8; ++u) v[u] = load_item(b, y0, base + u * 256 + tid);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = base + u * 256 + tid;
-                    if (i < NTOT) *reinterpret_cast<float4*>(&Ys[i * 4]) = v[u];  // Xs follows Ys: item i lives at float 4 i of the joint tile
+                    if (i < NTOT) *reinterpret_cast<float4*>(&Ys[i * 4]) = v[u];
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         // pixel pairs of the band: pair q -> pixels (2q, 2q+1) in row-major order of the RB x W band; wave w takes q = w, w+4, ...
         const int npix = RB * W, npairs = (npix + 1) / 2;
         for (int q = wave; q < npairs; q += 4) {

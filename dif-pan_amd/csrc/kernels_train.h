@@ -399,10 +399,19 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
             }
         }
         __syncthreads();
-        for (int i = tid; i < d * d; i += 256) {
+        for (int i = tid; i < d * d; i += 256) {  // (R W and every array offset are multiples of 4 floats: 16-byte LDS reads, 4 pixels per step)
             const int a = i / d, e = i % d;
             float s1 = ctx[i];
-            for (int pl = 0; pl < npx; ++pl) s1 = fmaf(rk[a * RW + pl], rv[e * RW + pl], s1);
+            const float4* pk = reinterpret_cast<const float4*>(rk + a * RW);
+            const float4* pv = reinterpret_cast<const float4*>(rv + e * RW);
+#pragma unroll 4
+            for (int q4 = 0; q4 < npx / 4; ++q4) {
+                const float4 k4 = pk[q4], v4 = pv[q4];
+                s1 = fmaf(k4.x, v4.x, s1);
+                s1 = fmaf(k4.y, v4.y, s1);
+                s1 = fmaf(k4.z, v4.z, s1);
+                s1 = fmaf(k4.w, v4.w, s1);
+            }
             ctx[i] = s1;
         }
         __syncthreads();
@@ -517,9 +526,21 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
         for (int i = tid; i < d * d; i += 256) {
             const int a = i / d, e = i % d;
             float s1 = ctx[i], s2 = dctx[i];
-            for (int pl = 0; pl < npx; ++pl) {
-                s1 = fmaf(rk[a * RW + pl], rv[e * RW + pl], s1);
-                s2 = fmaf(rq[a * RW + pl], rg[e * RW + pl], s2);
+            const float4* pk = reinterpret_cast<const float4*>(rk + a * RW);
+            const float4* pv = reinterpret_cast<const float4*>(rv + e * RW);
+            const float4* pq = reinterpret_cast<const float4*>(rq + a * RW);
+            const float4* pg = reinterpret_cast<const float4*>(rg + e * RW);
+#pragma unroll 2
+            for (int q4 = 0; q4 < npx / 4; ++q4) {  // 16-byte LDS reads, 4 pixels per step (same summation order)
+                const float4 k4 = pk[q4], v4 = pv[q4], q4v = pq[q4], g4 = pg[q4];
+                s1 = fmaf(k4.x, v4.x, s1);
+                s2 = fmaf(q4v.x, g4.x, s2);
+                s1 = fmaf(k4.y, v4.y, s1);
+                s2 = fmaf(q4v.y, g4.y, s2);
+                s1 = fmaf(k4.z, v4.z, s1);
+                s2 = fmaf(q4v.z, g4.z, s2);
+                s1 = fmaf(k4.w, v4.w, s1);
+                s2 = fmaf(q4v.w, g4.w, s2);
             }
             ctx[i] = s1;
             dctx[i] = s2;
