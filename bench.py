@@ -181,15 +181,17 @@ def main():
     if strong:
         # one scene of `total` tiles (the same on every rank), this rank's contiguous block of it; noise keyed by the tile's index in the scene
         total = B
-        ny = int(round(total ** 0.5))
-        if ny * ny != total or total % world:
-            raise SystemExit("gf2_dpm50: %d scene tiles must be a square number divisible by %d GPUs" % (total, world))
+        from ddif.sharding import scene_grid
+
+        ny, nx = scene_grid(total)
+        if total % world:
+            raise SystemExit("gf2_dpm50: %d scene tiles must be divisible by %d GPUs" % (total, world))
         lo, hi = shard_range(total, rank, world)
         tiles = synth_tiles(total, C, P, H, H, seed=100, order=order)
         tiles = {k: v[lo:hi].contiguous() for k, v in tiles.items()}
         B, tile0 = hi - lo, lo
     else:
-        total, ny = world * B, 0
+        total, ny, nx = world * B, 0, 0
         tiles = synth_tiles(B, C, P, H, H, seed=100 + rank, order=order)
         tile0 = rank * B
     log("network built (%d params), %d synthetic tiles on this rank" % (sum(p.numel() for p in net.parameters()), B))
@@ -230,7 +232,7 @@ def main():
             dist.all_gather_into_tensor(gathered, sr)  # the only exchange: every rank ends with all tiles
             sr = gathered
         if strong:
-            return stitch_tiles(sr, ny, ny)  # (C, 512, 512): the fused scene
+            return stitch_tiles(sr, ny, nx)  # (C, 512, 512): the fused scene
         return sr
 
     for w in range(args.warmup):
@@ -293,7 +295,7 @@ def main():
     if cf["sampler"] == "dpmpp2m":
         metric = cf["metric"] % n_evals
         workload = "GF2 pansharpening, one %dx%d scene = %d tiles of %dx%dx%d split over %d GPU(s) (%d per GPU), DPM-Solver++ 2M %d NFE (T=%d schedule), all-gather + stitch, fp32" % (
-            ny * H, ny * H, total, H, H, C, world, B, n_evals, T)
+            ny * H, nx * H, total, H, H, C, world, B, n_evals, T)
     else:
         metric = cf["metric"] % T
         workload = "%s, batch %d of %dx%dx%d tiles per GPU, T=%d DDPM p_sample, fp32" % ("WV3 pansharpening" if cf["ds"] == "wv3" else "CAVE MHIF", B, H, H, C, T)

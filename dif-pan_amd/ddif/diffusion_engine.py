@@ -171,20 +171,31 @@ def test_fn(test_data_path=None, weight_path=None, schedule_type="cosine", batch
                 mets.append(_rt.metrics(gt, sr, 4.0).cpu().numpy())  # SAM / ERGAS / PSNR / CC on the GPU (reference :449)
             preds.append((sr.cpu().numpy() * division).clip(0, division))
     else:
-        for i in range(0, lms_all.shape[0], batch_size):
-            raw_l, raw_p = lms_all[i:i + batch_size].to(device), pan_all[i:i + batch_size].to(device)
+        # whole scenes through the network, as the reference does (:373-377).  The kernels address a tensor with 32-bit byte offsets: a batch
+        # whose largest activation would reach 4 GiB is refused by the library -- the batch is then halved (loudly) and retried
+        i, bs = 0, batch_size
+        while i < lms_all.shape[0]:
+            raw_l, raw_p = lms_all[i:i + bs].to(device), pan_all[i:i + bs].to(device)
             cond = _rt.cond_assemble(raw_l, raw_p, float(division), wave_order)
             lms = cond[:, :C]
-            if sampler == "ddim_sample":
-                sr = diffusion(cond, mode="ddim_sample", section_counts=section_counts)  # respaces the schedule in place, once (SURVEY D-2)
-            else:
-                sr = diffusion(cond, mode="ddpm_sample")
+            try:
+                if sampler == "ddim_sample":
+                    sr = diffusion(cond, mode="ddim_sample", section_counts=section_counts)  # respaces the schedule in place, once (SURVEY D-2)
+                else:
+                    sr = diffusion(cond, mode="ddpm_sample")
+            except DdifError as e:
+                if "4 GiB" in str(e) and bs > 1:
+                    bs = max(1, bs // 2)
+                    print(f"[ddif] test_fn: a batch of {raw_l.shape[0]} scenes of {H}x{W} exceeds the 4 GiB tensor limit; retrying with batch_size={bs}")
+                    continue
+                raise
             sr = (sr + lms).clip(0, 1)  # reference :446-447
             if gt_all is not None:
-                gt = gt_all[i:i + batch_size].to(device)
+                gt = gt_all[i:i + bs].to(device)
                 scores.append(psnr(gt.cpu(), sr.cpu()))
                 mets.append(_rt.metrics(gt, sr, 4.0).cpu().numpy())
             preds.append((sr.cpu().numpy() * division).clip(0, division))
+            i += raw_l.shape[0]
     out = dict(sr=np.concatenate(preds, axis=0), psnr=scores,
                metrics=(np.concatenate(mets, axis=0) if mets else np.zeros((0, 4), np.float32)))  # columns: SAM, ERGAS, PSNR (ref. sign), CC
     if save_path is not None:

@@ -59,3 +59,39 @@ def sample_sharded(diffusion, cond_all: torch.Tensor, mode: str = "ddpm_sample",
     out = torch.empty((cond_all.shape[0],) + tuple(sr.shape[1:]), dtype=sr.dtype, device=sr.device)
     dist.all_gather_into_tensor(out, sr.contiguous())
     return out
+
+
+def scene_grid(n_tiles: int) -> Tuple[int, int]:
+    """(ny, nx) with ny * nx == n_tiles and ny the largest divisor <= sqrt(n_tiles): 64 -> 8 x 8, 32 -> 4 x 8, 8 -> 2 x 4."""
+    ny = int(n_tiles ** 0.5)
+    while ny > 1 and n_tiles % ny:
+        ny -= 1
+    return max(1, ny), n_tiles // max(1, ny)
+
+
+def sample_scene_dpmpp(net, diffusion, cond_all: torch.Tensor, x_T_all: torch.Tensor, steps: int = 50, order: int = 2, grid=None) -> torch.Tensor:
+    """BASELINE configs[2]: ONE scene = `cond_all` (n_tiles, 2C+4P, h, w; the same on every rank) sampled with DPM-Solver++ multistep, the tiles
+    split in contiguous blocks over the ranks of the default process group (strong scaling: n_tiles / world per GPU), one all-gather, then the
+    stitch.  `x_T_all` (n_tiles, C, h, w) is the scene's initial noise (the same on every rank; each rank uses its block), so the fused scene does
+    not depend on the number of GPUs.  Returns the fused scene (C, ny h, nx w) on every rank.  The reference feeds the whole scene through
+    the network instead (diffusion_engine.py:373-377) -- tiles never mix inside it, so the tiled run is the same computation per tile."""
+    from .solver.dpm_solver import DPM_Solver, ImageSpaceClamp, NoiseScheduleVP, model_wrapper
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = cond_all.shape[0]
+    ny, nx = grid if grid is not None else scene_grid(n)
+    lo, hi = shard_range(n, rank, world)
+    cond = cond_all[lo:hi].contiguous()
+    C = diffusion.channels
+    lms = cond[:, :C].contiguous()
+    ns = NoiseScheduleVP("discrete", betas=diffusion.betas)
+    fn = model_wrapper(net, ns, model_type="x_start", guidance_type="classifier-free", guidance_scale=1.0, condition=cond)
+    solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(lms, 0.0, 1.0))
+    res = solver.sample(x_T_all[lo:hi].contiguous(), steps=steps, order=order, skip_type="time_uniform", method="multistep")
+    sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
+    if world > 1:
+        out = torch.empty((n,) + tuple(sr.shape[1:]), dtype=sr.dtype, device=sr.device)
+        dist.all_gather_into_tensor(out, sr.contiguous())
+        sr = out
+    return stitch_tiles(sr, ny, nx)

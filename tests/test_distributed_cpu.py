@@ -139,3 +139,61 @@ def test_epoch_permutation_is_sharded_by_rank():
         seen.append(e0)
     flat = sum(seen, [])
     assert len(set(flat)) == 9  # 10 // 3 * 3 samples, each exactly once
+
+
+# ---------------------------------------------------------------------------------------------------------------- BASELINE configs[2]: one scene, strong scaling
+def _run_scene(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HIPEMU_THREADS="4")
+    torch.set_num_threads(2)
+    use_emulator()
+    from ddif.sharding import sample_scene_dpmpp
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds, H, T = "gf2", 8, 1000
+    C = gc.DATASETS[ds][0]
+    cond = gc.tiles_for(ds, 4, H, H, seed=23)["cond"]
+    xT = torch.randn(4, C, H, H, generator=torch.Generator().manual_seed(24))
+    net = make_net(ds, "cpu")
+    d = make_diffusion(net, C, T, H, "cpu")
+    scene = sample_scene_dpmpp(net, d, cond, xT, steps=3, order=2)
+    if rank == 0:
+        q.put(scene.numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_strong_scaling_scene_is_independent_of_the_rank_count():
+    """`bench.py --config gf2_dpm50` (one scene, tiles split over the ranks, all-gather + stitch): 2 ranks x 2 tiles == 1 rank x 4 tiles, bit for bit."""
+    def spawn(world, port):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_run_scene, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = q.get(timeout=900)
+        for p in procs:
+            p.join(timeout=900)
+            assert p.exitcode == 0
+        return torch.from_numpy(out)
+
+    one, two = spawn(1, 29631), spawn(2, 29632)
+    assert one.shape == (4, 16, 16) and torch.equal(one, two)
+    from ddif.sharding import scene_grid
+
+    assert scene_grid(64) == (8, 8) and scene_grid(32) == (4, 8) and scene_grid(8) == (2, 4) and scene_grid(7) == (1, 7)
+
+
+def test_bench_self_launcher_spawns_ranks_and_propagates_failure():
+    """`bench.py --gpus 2` with no WORLD_SIZE launches torch.distributed.run as a CHILD (the parent never imports torch or touches a GPU) and
+    relays the outcome.  Without GPUs here the ranks refuse to run (no CPU fallback): the parent must report the launch and exit non-zero."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert "launching 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a GPU" in r.stderr and r.stdout.strip() == ""

@@ -35,8 +35,17 @@ cp gpurun_out/${tag}_hbm_traffic.json profiles/ 2>/dev/null   # so that the benc
 python3 bench.py > gpurun_out/${tag}_bench_T1000_B64.json 2> gpurun_out/${tag}_bench_T1000_B64.log
 cat gpurun_out/${tag}_bench_T1000_B64.json
 python3 bench.py --config gf2_dpm50 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_gf2_dpm50.json 2> gpurun_out/${tag}_bench_gf2_dpm50.log
+# what one rank of an N-GPU strong-scaling run of the same scene holds: 32 / 16 / 8 tiles (N = 2 / 4 / 8), measured on this one GPU
+for b in 32 16 8; do
+  python3 bench.py --config gf2_dpm50 --batch $b --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_gf2_dpm50_tiles$b.json 2> /dev/null
+done
 python3 bench.py --config cave128_t2000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${tag}_bench_cave128_t2000.json 2> gpurun_out/${tag}_bench_cave128_t2000.log
-python3 bench.py --config wv3_train_b32 --steps 10 --warmup 3 > gpurun_out/${tag}_bench_wv3_train_b32.json 2> gpurun_out/${tag}_bench_wv3_train_b32.log
+python3 bench.py --config wv3_train_b32 --steps 10 --warmup 3 --cpu-seconds 15 > gpurun_out/${tag}_bench_wv3_train_b32.json 2> gpurun_out/${tag}_bench_wv3_train_b32.log
+cd /tmp
+rm -rf /tmp/prof_train_$tag
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train_$tag -o p -- python3 $R/bench.py --config wv3_train_b32 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> /tmp/prof_train_$tag.log
+cp $(find /tmp/prof_train_$tag -name "*kernel_stats.csv") $R/gpurun_out/${tag}_train_kernel_stats.csv
+cd $R
 python3 - <<PY
 import json
 try:
@@ -44,7 +53,7 @@ try:
     print("wv3_train_b32", r["value"], r["unit"], "ms/iteration", r["ms_per_step"])
 except Exception as e:
     print("wv3_train_b32 failed", e)
-for n in ("gf2_dpm50", "cave128_t2000"):
+for n in ("gf2_dpm50", "gf2_dpm50_tiles32", "gf2_dpm50_tiles16", "gf2_dpm50_tiles8", "cave128_t2000"):
     try:
         r = json.load(open("gpurun_out/${tag}_bench_%s.json" % n))
         print(n, r["value"], r["unit"], "ms/job", r["ms_per_step"], "job TF", r["roofline"]["whole_step"]["tflops"])
