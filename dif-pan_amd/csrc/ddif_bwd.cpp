@@ -442,7 +442,7 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
     g.pf = 0;
     for (g.rb = 16; g.rb >= 1; g.rb >>= 1) {  // first choice: a band whose float4 items fit the kernel's prefetch registers (WG_PF per thread)
         if (g.rb > H && g.rb > 1) continue;
-        if (((size_t)g.rb * W + (size_t)(g.rb + 2) * (W + 2)) * 8 <= (size_t)WG_PF * 512) {  // 512 threads (8 waves) x WG_PF items
+        if (((size_t)g.rb * W + (size_t)(g.rb + 2) * (W + 2)) * 8 <= (size_t)WG_PF * 256) {
             g.pf = 1;
             break;
         }
@@ -453,12 +453,11 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
             g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
             if (g.smem <= lim || (g.rb == 1 && g.smem <= 150 * 1024)) break;
         }
-    if (g.rb >= 1) g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + (g.pf ? 8192 : 4096)) * sizeof(float);
+    if (g.rb >= 1) g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
     if (g.rb < 1) g.rb = 0;  // W too wide (caller checks)
     const int bands = B * ((H + (g.rb ? g.rb : 1) - 1) / (g.rb ? g.rb : 1));
-    int want = ((g.pf ? 1 : 2) * 256) / (g.n_co * g.n_ci);  // pf: eight-wave workgroups, one per CU
+    int want = (2 * 256) / (g.n_co * g.n_ci);
     if (want < 1) want = 1;
-    if (g.pf && bands >= 4 && want > bands / 2) want = bands / 2;  // at least two bands per workgroup: something to prefetch
     if (want > bands) want = bands;
     if (want > 256) want = 256;
     g.nsplit = want;
@@ -468,7 +467,7 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
 }
 int wgrad_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return 0;
 }
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw) {
@@ -481,7 +480,7 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     a.bands_y = (H + g.rb - 1) / g.rb;
     a.partial = partial;
     a.centre_only = centre ? 1 : 0;
-    if (g.pf) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 8>), dim3(g.n_co * g.n_ci, g.nsplit), dim3(512), g.smem, s, a);
+    if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     if (centre)
         hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);

@@ -52,18 +52,15 @@ struct WgradArgs {
 // PF = 1 (bands of <= WG_PF * 256 float4 items, chosen by the host): the NEXT band is fetched into registers while the current one is in
 // the MFMA loop -- a band's loads are then hidden instead of serialised in front of its MFMAs.  PF = 0: any band size, loads in batches
 // of eight before the LDS writes.
-// NW wavefronts per workgroup: 8 with PF (a 4-row band of a 64-wide image is then 7.7 us of MFMAs on the CU's four SIMDs -- longer than the
-// loads of the next band take to land; with 4 waves and one-row bands the prefetch distance was 1.9 us and the loads were exposed again).
 constexpr int WG_PF = 12;
-template <int PF, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void conv3x3_wgrad_kernel(WgradArgs a) {
-    constexpr int NT = 64 * NW;
+template <int PF>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     DDIF_DYN_SMEM(smem);
     const int W = a.W, IW = W + 2;
     const int RB = a.rb;
     float* Ys = reinterpret_cast<float*>(smem);  // [RB*W][32]
     float* Xs = Ys + RB * W * 32;                 // [(RB+2)*IW][32]
-    float* Rs = Xs + (RB + 2) * IW * 32;          // [NW waves][16 regs][64 lanes]
+    float* Rs = Xs + (RB + 2) * IW * 32;          // [4 waves][16 regs][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int cob = blockIdx.x / a.n_ci, cib = blockIdx.x % a.n_ci;
@@ -95,7 +92,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_wgrad_kernel(WgradArgs a) {
         if ((int)blockIdx.y < nbands) {
             const int b = blockIdx.y / a.bands_y, y0 = (blockIdx.y % a.bands_y) * RB;
 #pragma unroll
-            for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b, y0, u * NT + tid);
+            for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b, y0, u * 256 + tid);
         }
     }
     for (int band = blockIdx.y; band < nbands; band += gridDim.y) {
@@ -104,7 +101,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_wgrad_kernel(WgradArgs a) {
         if constexpr (PF) {
 #pragma unroll
             for (int u = 0; u < WG_PF; ++u) {
-                const int i = u * NT + tid;
+                const int i = u * 256 + tid;
                 if (i < NTOT) *reinterpret_cast<float4*>(&Ys[i * 4]) = pf[u];  // Xs follows Ys: item i lives at float 4 i of the joint tile
             }
             __syncthreads();
@@ -112,16 +109,16 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_wgrad_kernel(WgradArgs a) {
             if (nb < nbands) {  // workgroup-uniform: the next band's loads fly during this band's MFMAs
                 const int b2 = nb / a.bands_y, y2 = (nb % a.bands_y) * RB;
 #pragma unroll
-                for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b2, y2, u * NT + tid);
+                for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b2, y2, u * 256 + tid);
             }
         } else {
-            for (int base = 0; base < NTOT; base += NT * 8) {
+            for (int base = 0; base < NTOT; base += 256 * 8) {
                 float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = load_item(b, y0, base + u * NT + tid);
+                for (int u = 0; u < 8; ++u) v[u] = load_item(b, y0, base + u * 256 + tid);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int i = base + u * NT + tid;
+                    const int i = base + u * 256 + tid;
                     if (i < NTOT) *reinterpret_cast<float4*>(&Ys[i * 4]) = v[u];
                 }
             }
@@ -129,7 +126,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_wgrad_kernel(WgradArgs a) {
         }
         // pixel pairs of the band: pair q -> pixels (2q, 2q+1) in row-major order of the RB x W band; wave w takes q = w, w+4, ...
         const int npix = RB * W, npairs = (npix + 1) / 2;
-        for (int q = wave; q < npairs; q += NW) {
+        for (int q = wave; q < npairs; q += 4) {
             const int pr = 2 * q + h;         // this lane half's pixel (k index of the MFMA)
             const bool pv = pr < npix;        // odd pixel count: the last pair's second pixel does not exist
             const int p = pv ? pr : npix - 1;
@@ -154,13 +151,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) Rs[(wave * 16 + r) * 64 + lane] = acc[t][r];
         __syncthreads();
-        // 1024 outputs / NT threads: element e = (r, lane): row (co) = (r&3) + 8*(r>>2) + 4*(lane>>5), col (ci) = lane & 31
+        // 1024 outputs / 256 threads: element e = (r, lane): row (co) = (r&3) + 8*(r>>2) + 4*(lane>>5), col (ci) = lane & 31
 #pragma unroll
-        for (int k = 0; k < 1024 / NT; ++k) {
-            const int e = tid + k * NT;
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + k * 256;
             const int r = e >> 6, l = e & 63;
-            float s = (Rs[(0 * 16 + r) * 64 + l] + Rs[(1 * 16 + r) * 64 + l]) + (Rs[(2 * 16 + r) * 64 + l] + Rs[(3 * 16 + r) * 64 + l]);
-            if constexpr (NW == 8) s += (Rs[(4 * 16 + r) * 64 + l] + Rs[(5 * 16 + r) * 64 + l]) + (Rs[(6 * 16 + r) * 64 + l] + Rs[(7 * 16 + r) * 64 + l]);
+            const float s = (Rs[(0 * 16 + r) * 64 + l] + Rs[(1 * 16 + r) * 64 + l]) + (Rs[(2 * 16 + r) * 64 + l] + Rs[(3 * 16 + r) * 64 + l]);
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
             outp[t * 1024 + row * 32 + col] = s;
         }
