@@ -141,6 +141,7 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
         a.bands_y = (c.H + c.rb - 1) / c.rb;
         a.partial = c.partial;
         a.centre_only = c.centre_only ? 1 : 0;
+        a.wshift = -1;
         hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
         if (c.centre_only)
             hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)c.Cout * c.Cin), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
@@ -480,6 +481,9 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     a.bands_y = (H + g.rb - 1) / g.rb;
     a.partial = partial;
     a.centre_only = centre ? 1 : 0;
+    a.wshift = -1;
+    for (int k = 0; k < 16; ++k)
+        if ((1 << k) == W) a.wshift = k;
     if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     if (centre)

@@ -572,7 +572,8 @@ int Plan::build_backward() {
         const float *wall = net->wall, *w3 = net->w3, *w1 = net->w1;
         float* dtb_ = dtb;
         L.v.push_back([=](hipStream_t st) {
-            tk::linear_bwd(st, te, wall, dtb_, BB, inner, ns, T->dte, T->dwall, T->dball);
+            hipLaunchKernelGGL(time_dte_kernel, dim3(BB), dim3(256), 256 * sizeof(float), st, (const float*)dtb_, wall, ns, inner, T->dte);
+            tk::linear_bwd(st, te, wall, dtb_, BB, inner, ns, nullptr, T->dwall, T->dball);
             for (auto& sg : *slots) {
                 (void)hipMemcpyAsync(*sg.w, T->dwall + (size_t)sg.off * inner, (size_t)sg.n * inner * sizeof(float), hipMemcpyDeviceToDevice, st);
                 (void)hipMemcpyAsync(*sg.b, T->dball + sg.off, (size_t)sg.n * sizeof(float), hipMemcpyDeviceToDevice, st);

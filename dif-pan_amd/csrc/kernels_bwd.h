@@ -46,6 +46,7 @@ struct WgradArgs {
     int bands_y;       // ceil(H / rb)
     float* partial;    // [gridDim.y][n_co * n_ci][9][32 co][32 ci]
     int centre_only;   // 1x1 convs riding this kernel: only tap 4 (the centre) is contracted and written
+    int wshift;        // log2(W) when W is a power of two, else -1
 };
 
 // grid = (n_co * n_ci, NSPLIT); block 256.  LDS: dY band [rb*W][32] + X band [(rb+2)*(W+2)][32] + reduction scratch [4][1024].
@@ -88,12 +89,44 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
         return ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     [[maybe_unused]] float4 pf[PF ? WG_PF : 1];
+    // PF: the geometry of this thread's items is the same for every band -- only (b, y0) move.  Precomputed once: element offset relative to
+    // pixel (b, y0, 0) of the item's tensor, its row relative to y0, and whether it can ever be valid (column / channel inside).  Per band an
+    // item then costs an add, two compares and a select instead of two integer divisions (the exact-fp32 MFMA shares the vector datapath:
+    // this address arithmetic ran INSTEAD of MFMAs, ~1.3 us per one-row band against 1.9 us of matrix work)
+    [[maybe_unused]] int it_off[PF ? WG_PF : 1], it_row[PF ? WG_PF : 1];
+    [[maybe_unused]] unsigned it_ok = 0, it_isy = 0;
     if constexpr (PF) {
-        if ((int)blockIdx.y < nbands) {
-            const int b = blockIdx.y / a.bands_y, y0 = (blockIdx.y % a.bands_y) * RB;
 #pragma unroll
-            for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b, y0, u * 256 + tid);
+        for (int u = 0; u < WG_PF; ++u) {
+            const int i = u * 256 + tid;
+            const bool isy = i < NY;
+            const int k = isy ? i : i - NY;
+            const int c4 = k & 7, p = k >> 3;
+            const int rowlen = isy ? W : IW;
+            const int pr_ = p / rowlen, pc_ = p - pr_ * rowlen;
+            const int x = isy ? pc_ : pc_ - 1;
+            const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
+            const bool ok = (i < NTOT) & (x >= 0) & (x < W) & (cc < Cc);
+            it_row[u] = isy ? pr_ : pr_ - 1;
+            it_off[u] = ok ? (it_row[u] * W + x) * Cc + cc : 0;
+            it_ok |= (ok ? 1u : 0u) << u;
+            it_isy |= (isy ? 1u : 0u) << u;
         }
+    }
+    auto fetch_band = [&](int b, int y0) {
+        const size_t by = ((size_t)b * a.H + y0) * W * a.Cout, bx = ((size_t)b * a.H + y0) * W * a.Cin;
+#pragma unroll
+        for (int u = 0; u < (PF ? WG_PF : 1); ++u) {
+            const int y = y0 + it_row[u];
+            const bool isy = (it_isy >> u) & 1u;
+            const bool ok = ((it_ok >> u) & 1u) & (y >= 0) & (y < a.H);
+            const float* src = isy ? a.dy + by : a.x + bx;
+            const float4 ld = *reinterpret_cast<const float4*>(ok ? src + it_off[u] : a.dy);  // (a.dy itself is always readable)
+            pf[u] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if constexpr (PF) {
+        if ((int)blockIdx.y < nbands) fetch_band(blockIdx.y / a.bands_y, (blockIdx.y % a.bands_y) * RB);
     }
     for (int band = blockIdx.y; band < nbands; band += gridDim.y) {
         const int b = band / a.bands_y, y0 = (band % a.bands_y) * RB;
@@ -106,11 +139,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             }
             __syncthreads();
             const int nb = band + gridDim.y;
-            if (nb < nbands) {  // workgroup-uniform: the next band's loads fly during this band's MFMAs
-                const int b2 = nb / a.bands_y, y2 = (nb % a.bands_y) * RB;
-#pragma unroll
-                for (int u = 0; u < WG_PF; ++u) pf[u] = load_item(b2, y2, u * 256 + tid);
-            }
+            if (nb < nbands) fetch_band(nb / a.bands_y, (nb % a.bands_y) * RB);  // workgroup-uniform: the next band's loads fly during this band's MFMAs
         } else {
             for (int base = 0; base < NTOT; base += 256 * 8) {
                 float4 v[8];
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             const int pr = 2 * q + h;         // this lane half's pixel (k index of the MFMA)
             const bool pv = pr < npix;        // odd pixel count: the last pair's second pixel does not exist
             const int p = pv ? pr : npix - 1;
-            const int py = p / W, px = p % W;
+            const int py = a.wshift >= 0 ? (p >> a.wshift) : p / W, px = p - py * W;  // W is a power of two at every level of the engine network
             const float av = pv ? Ys[p * 32 + j] : 0.f;  // A[i = co j][k = h]
             if (a.centre_only) {
                 acc[4] = DDIF_MFMA_32x32x2(av, Xs[((py + 1) * IW + px + 1) * 32 + j], acc[4]);

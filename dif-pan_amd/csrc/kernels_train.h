@@ -347,7 +347,7 @@ __host__ __device__ inline int la_rows(int d, int H, int W) {
     return r > H ? H : r;
 }
 inline size_t linattn_fwd_smem(int d, int H, int W) { return (size_t)(2 * d * W + d * d + 2 * d * la_rows(d, H, W) * W + 2 * d * H) * sizeof(float); }
-inline size_t linattn_bwd_smem(int d, int H, int W) { return (size_t)(3 * d * W + 2 * d * d + 5 * d * la_rows(d, H, W) * W + d * la_rows(d, H, W) + 2 * d * H) * sizeof(float); }
+inline size_t linattn_bwd_smem(int d, int H, int W) { return (size_t)(3 * d * W + 2 * d * d + 6 * d * la_rows(d, H, W) * W + d * la_rows(d, H, W) + 2 * d * H) * sizeof(float); }
 
 __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pre, const float* kv_pre, int heads, int d, int H, int W, float sc, float* out, int ld_o) {
     DDIF_DYN_SMEM(smem_);
@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
     float* rq = rv + d * RW;                       // [d][RW] q softmax * sc
     float* rg = rq + d * RW;                       // [d][RW] do
     float* rdk = rg + d * RW;                      // [d][RW] dk
-    float* rdot = rdk + d * RW;                    // [d][R] row dots of the k softmax backward
+    float* rdq = rdk + d * RW;                     // [d][RW] dq (raw): the column sums T read it back from here, not from memory
+    float* rdot = rdq + d * RW;                    // [d][R] row dots of the k softmax backward
     float* kmx = rdot + d * R;                     // [d][H] row max of k_pre (softmax over W)
     float* ksm = kmx + d * H;                      // [d][H] row sum of exp
     const int tid = threadIdx.x;
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
             const size_t p = (size_t)y0 * W + pl;
             dvb[p * 2 * qd + a] = dv;
             rdk[l] = dk;
+            rdq[l] = dq * sc;
             dqb[p * qd + a] = dq * sc;  // d(q_sm) of o = ctx^T (q_sm * sc)
         }
         __syncthreads();
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
             float t = T[a * W + x];
             for (int r = 0; r < rows; ++r) {
                 const int pl = r * W + x;
-                t += dqb[((size_t)y0 * W + pl) * qd + a] * (rq[a * RW + pl] / sc);  // q_sm = rq / sc
+                t += rdq[a * RW + pl] * (rq[a * RW + pl] / sc);  // q_sm = rq / sc
             }
             T[a * W + x] = t;
         }
@@ -630,6 +632,23 @@ __global__ void l1_final_kernel(const double* part, int nblk, size_t n, float* o
         double s = 0.0;
         for (int k = 0; k < nblk; ++k) s += part[k];
         out[0] = (float)(s / (double)n);
+    }
+}
+// time MLP, top layer: dte[b][k] = sum_o dtb[b][o] wall[o][k]  (o over all 2272 FeatureWiseAffine outputs).  One workgroup per sample; thread
+// (group g = tid / inner, k = tid % inner) sums the outputs o = g, g + G, ...; the G partials are added in group order
+__global__ __launch_bounds__(256) void time_dte_kernel(const float* dtb, const float* wall, int ns, int inner, float* dte) {
+    DDIF_DYN_SMEM(smem_);
+    float* red = reinterpret_cast<float*>(smem_);  // [256]
+    const int b = blockIdx.x, tid = threadIdx.x, G = 256 / inner, g = tid / inner, k = tid % inner;
+    float s = 0.f;
+    if (g < G)
+        for (int o = g; o < ns; o += G) s = fmaf(dtb[(size_t)b * ns + o], wall[(size_t)o * inner + k], s);
+    red[tid] = s;
+    __syncthreads();
+    if (tid < inner) {
+        float t = 0.f;
+        for (int gg = 0; gg < G; ++gg) t += red[gg * inner + tid];
+        dte[(size_t)b * inner + tid] = t;
     }
 }
 // per-sample plane sums in two stages: part[b][chunk][c] over pixel chunks, then out[b * ld + c] (fixed order)
