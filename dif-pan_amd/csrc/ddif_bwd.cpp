@@ -433,7 +433,7 @@ namespace ddif {
 namespace tk {
 void silu_fwd(hipStream_t s, const float* x, size_t n, float* y) { hipLaunchKernelGGL(silu_fwd_kernel, grid_for(n), dim3(256), 0, s, x, n, y); }
 void silu_bwd(hipStream_t s, const float* x, const float* da, size_t n, float* dx) { hipLaunchKernelGGL(silu_bwd_kernel, grid_for(n), dim3(256), 0, s, x, da, n, dx); }
-WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_init
+WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre) {  // as convbwd_init
     WgradGeom g;
     g.n_co = (Cout + 31) / 32;
     g.n_ci = (Cin + 31) / 32;
@@ -441,20 +441,29 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
     // band loads overlap the other's MFMAs; the low-resolution levels then stage a whole 8x8 sample or half a 16x16 one per band)
     static const size_t lim = [] { const char* e = getenv("DDIF_WGRAD_SMEM_KB"); return (size_t)(e ? atoi(e) : 72) * 1024; }();
     g.pf = 0;
-    for (g.rb = 16; g.rb >= 1; g.rb >>= 1) {  // first choice: a band whose float4 items fit the kernel's prefetch registers (WG_PF per thread)
-        if (g.rb > H && g.rb > 1) continue;
-        if (((size_t)g.rb * W + (size_t)(g.rb + 2) * (W + 2)) * 8 <= (size_t)WG_PF * 256) {
+    g.centre = centre ? 1 : 0;
+    const int halo = centre ? 0 : 1;
+    for (g.rb = H < 16 ? H : 16; g.rb >= 1; --g.rb) {  // first choice: the largest band whose float4 items fit the kernel's prefetch registers (WG_PF per thread)
+        if (((size_t)g.rb * W + (size_t)(g.rb + 2 * halo) * (W + 2 * halo)) * 8 <= (size_t)WG_PF * 256) {
             g.pf = 1;
             break;
         }
     }
+    if (g.pf) {  // the smallest band with the same number of bands per image: no rows of padding work beyond what the count forces
+        const int nb = (H + g.rb - 1) / g.rb;
+        while (g.rb > 1 && (H + (g.rb - 1) - 1) / (g.rb - 1) == nb) --g.rb;
+    }
+    if (!g.pf) g.centre = 0;  // the halo-free form exists for the prefetching kernel only
     if (!g.pf)
         for (g.rb = 16; g.rb >= 1; g.rb >>= 1) {
             if (g.rb > H && g.rb > 1) continue;
             g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
             if (g.smem <= lim || (g.rb == 1 && g.smem <= 150 * 1024)) break;
         }
-    if (g.rb >= 1) g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
+    if (g.rb >= 1) {
+        const int hl = g.centre ? 0 : 1;
+        g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2 * hl) * (W + 2 * hl) * 32 + 4096) * sizeof(float);
+    }
     if (g.rb < 1) g.rb = 0;  // W too wide (caller checks)
     const int bands = B * ((H + (g.rb ? g.rb : 1) - 1) / (g.rb ? g.rb : 1));
     int want = (2 * 256) / (g.n_co * g.n_ci);
@@ -469,6 +478,7 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W) {  // as convbwd_in
 int wgrad_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return 0;
 }
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw) {
@@ -484,7 +494,10 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     a.wshift = -1;
     for (int k = 0; k < 16; ++k)
         if ((1 << k) == W) a.wshift = k;
-    if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
+    static const bool dump = getenv("DDIF_WGRAD_DUMP") != nullptr;  // development aid: geometry of every launch, in order (match against a kernel trace)
+    if (dump) fprintf(stderr, "[wgrad] B=%d H=%d W=%d Cin=%d Cout=%d centre=%d rb=%d nsplit=%d blocks=%d pf=%d smem=%zu\n", B, H, W, Cin, Cout, (int)centre, g.rb, g.nsplit, g.n_co * g.n_ci, g.pf, g.smem);
+    if (g.pf && g.centre && centre) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 1>), dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
+    else if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     if (centre)
         hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);

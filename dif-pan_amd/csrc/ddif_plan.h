@@ -56,8 +56,8 @@ void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int head
 // kernels_bwd.h  (ddif_bwd.cpp)
 void silu_fwd(hipStream_t s, const float* x, size_t n, float* y);
 void silu_bwd(hipStream_t s, const float* x, const float* da, size_t n, float* dx);
-struct WgradGeom { int n_co = 0, n_ci = 0, nsplit = 0, rb = 0, nbchunk = 0, pf = 0; size_t smem = 0, partial_floats = 0; };
-WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W);
+struct WgradGeom { int n_co = 0, n_ci = 0, nsplit = 0, rb = 0, nbchunk = 0, pf = 0, centre = 0; size_t smem = 0, partial_floats = 0; };
+WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre = false);
 int wgrad_prepare();
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw);
 void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db);

@@ -114,7 +114,7 @@ int Plan::build_backward() {
     // weight (+ bias) gradient of a conv with input x [B,H,W,Cin] (Cin % 4 == 0) and output gradient dy [B,H,W,Cout]
     auto add_wgrad = [&](Seq& L, const float* x, int Cin, const float* dy, int Cout, int H_, int W_, int ks, float** dw, float** db) -> int {
         if (Cin % 4 || Cout % 4) return fail(DDIF_ERR_INVALID, "training: weight gradient needs 4 | channels (got %d -> %d)", Cin, Cout);
-        const tk::WgradGeom g = tk::wgrad_geom(BB, Cin, Cout, H_, W_);
+        const tk::WgradGeom g = tk::wgrad_geom(BB, Cin, Cout, H_, W_, ks == 1);
         if (g.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", W_);
         need(T->n_partial, g.partial_floats);
         need(T->n_bpart, (size_t)g.nbchunk * Cout);
@@ -147,7 +147,7 @@ int Plan::build_backward() {
         float** db = has_bias ? G(ckey + ".bias") : nullptr;
         // (the scratch pointer T->a is read when the launch runs, not now)
         if (pro && !a_mat) {
-            const tk::WgradGeom g = tk::wgrad_geom(BB, C, dy.C, x.H, x.W);
+            const tk::WgradGeom g = tk::wgrad_geom(BB, C, dy.C, x.H, x.W, ks == 1);
             if (g.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", x.W);
             need(T->n_partial, g.partial_floats);
             need(T->n_bpart, (size_t)g.nbchunk * dy.C);

@@ -53,20 +53,23 @@ struct WgradArgs {
 // PF = 1 (bands of <= WG_PF * 256 float4 items, chosen by the host): the NEXT band is fetched into registers while the current one is in
 // the MFMA loop -- a band's loads are then hidden instead of serialised in front of its MFMAs.  PF = 0: any band size, loads in batches
 // of eight before the LDS writes.
-constexpr int WG_PF = 12;
-template <int PF>
+// CENTRE = 1 (1x1 convs, only with PF): the X band is the SAME pixel set as the dY band -- no halo rows / columns are fetched or staged (the
+// 3x3 form loaded three rows of X to use one: the 1x1 weight gradients ran at 3-9 % of their matrix time, profiles/r03_k_wgrad_by_shape.txt)
+constexpr int WG_PF = 13;
+template <int PF, int CENTRE = 0>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     DDIF_DYN_SMEM(smem);
-    const int W = a.W, IW = W + 2;
+    constexpr int HALO = CENTRE ? 0 : 1;
+    const int W = a.W, IW = W + 2 * HALO;
     const int RB = a.rb;
     float* Ys = reinterpret_cast<float*>(smem);  // [RB*W][32]
-    float* Xs = Ys + RB * W * 32;                 // [(RB+2)*IW][32]
-    float* Rs = Xs + (RB + 2) * IW * 32;          // [4 waves][16 regs][64 lanes]
+    float* Xs = Ys + RB * W * 32;                 // [(RB+2)*IW][32]  (CENTRE: [RB*W][32])
+    float* Rs = Xs + (RB + 2 * HALO) * IW * 32;   // [4 waves][16 regs][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int cob = blockIdx.x / a.n_ci, cib = blockIdx.x % a.n_ci;
     const int nbands = a.B * a.bands_y;
-    const int NY = RB * W * 8, NX = (RB + 2) * IW * 8, NTOT = NY + NX;
+    const int NY = RB * W * 8, NX = (RB + 2 * HALO) * IW * 8, NTOT = NY + NX;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
         const int c4 = k & 7, p = k >> 3;
         const int rowlen = isy ? W : IW;
         const int pr_ = p / rowlen, pc_ = p - pr_ * rowlen;
-        const int y = isy ? y0 + pr_ : y0 - 1 + pr_, x = isy ? pc_ : pc_ - 1;
+        const int y = isy ? y0 + pr_ : y0 - HALO + pr_, x = isy ? pc_ : pc_ - HALO;
         const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
         const bool ok = (i < NTOT) & (y >= 0) & (y < a.H) & (x >= 0) & (x < W) & (cc < Cc);
         const float* src = isy ? a.dy : a.x;
@@ -104,10 +107,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             const int c4 = k & 7, p = k >> 3;
             const int rowlen = isy ? W : IW;
             const int pr_ = p / rowlen, pc_ = p - pr_ * rowlen;
-            const int x = isy ? pc_ : pc_ - 1;
+            const int x = isy ? pc_ : pc_ - HALO;
             const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
             const bool ok = (i < NTOT) & (x >= 0) & (x < W) & (cc < Cc);
-            it_row[u] = isy ? pr_ : pr_ - 1;
+            it_row[u] = isy ? pr_ : pr_ - HALO;
             it_off[u] = ok ? (it_row[u] * W + x) * Cc + cc : 0;
             it_ok |= (ok ? 1u : 0u) << u;
             it_isy |= (isy ? 1u : 0u) << u;
@@ -161,6 +164,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             const int p = pv ? pr : npix - 1;
             const int py = a.wshift >= 0 ? (p >> a.wshift) : p / W, px = p - py * W;  // W is a power of two at every level of the engine network
             const float av = pv ? Ys[p * 32 + j] : 0.f;  // A[i = co j][k = h]
+            if constexpr (CENTRE) {
+                acc[4] = DDIF_MFMA_32x32x2(av, pv ? Xs[p * 32 + j] : 0.f, acc[4]);
+                continue;
+            }
             if (a.centre_only) {
                 acc[4] = DDIF_MFMA_32x32x2(av, Xs[((py + 1) * IW + px + 1) * 32 + j], acc[4]);
                 continue;
