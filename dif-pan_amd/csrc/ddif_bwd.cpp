@@ -444,14 +444,23 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre) {  // 
     g.centre = centre ? 1 : 0;
     const int halo = centre ? 0 : 1;
     for (g.rb = H < 16 ? H : 16; g.rb >= 1; --g.rb) {  // first choice: the largest band whose float4 items fit the kernel's prefetch registers (WG_PF per thread)
-        if (((size_t)g.rb * W + (size_t)(g.rb + 2 * halo) * (W + 2 * halo)) * 8 <= (size_t)WG_PF * 256) {
+        if (((size_t)g.rb * W + (size_t)(g.rb + 2 * halo) * (W + 2 * halo)) * 8 <= (size_t)(centre ? WG_PF_CENTRE : WG_PF) * 256) {
             g.pf = 1;
             break;
         }
     }
-    if (g.pf) {  // the smallest band with the same number of bands per image: no rows of padding work beyond what the count forces
-        const int nb = (H + g.rb - 1) / g.rb;
-        while (g.rb > 1 && (H + (g.rb - 1) - 1) / (g.rb - 1) == nb) --g.rb;
+    if (g.pf) {  // among the bands that fit: fewest rows processed (padding rows of the last band count) + half a row of per-band overhead
+        int best = g.rb;
+        double best_cost = 1e30;
+        for (int r = g.rb; r >= 1; --r) {
+            const int nb = (H + r - 1) / r;
+            const double cost = (double)nb * r + 0.5 * nb;
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                best = r;
+            }
+        }
+        g.rb = best;
     }
     if (!g.pf) g.centre = 0;  // the halo-free form exists for the prefetching kernel only
     if (!g.pf)
@@ -469,7 +478,7 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre) {  // 
     int want = (2 * 256) / (g.n_co * g.n_ci);
     if (want < 1) want = 1;
     if (want > bands) want = bands;
-    if (want > 256) want = 256;
+    if (want > 512) want = 512;
     g.nsplit = want;
     g.partial_floats = (size_t)g.nsplit * g.n_co * g.n_ci * 9 * 1024;
     g.nbchunk = (int)std::min<size_t>(512, std::max<size_t>(1, (size_t)B * H * W / 16));

@@ -55,11 +55,12 @@ struct WgradArgs {
 // of eight before the LDS writes.
 // CENTRE = 1 (1x1 convs, only with PF): the X band is the SAME pixel set as the dY band -- no halo rows / columns are fetched or staged (the
 // 3x3 form loaded three rows of X to use one: the 1x1 weight gradients ran at 3-9 % of their matrix time, profiles/r03_k_wgrad_by_shape.txt)
-constexpr int WG_PF = 13;
+constexpr int WG_PF = 9, WG_PF_CENTRE = 13;  // prefetch registers (float4 per thread): 3x3 keeps 144 accumulators and must stay at 2 waves / SIMD
 template <int PF, int CENTRE = 0>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     DDIF_DYN_SMEM(smem);
     constexpr int HALO = CENTRE ? 0 : 1;
+    constexpr int NPF = CENTRE ? WG_PF_CENTRE : WG_PF;
     const int W = a.W, IW = W + 2 * HALO;
     const int RB = a.rb;
     float* Ys = reinterpret_cast<float*>(smem);  // [RB*W][32]
@@ -91,16 +92,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
         const float4 ld = *reinterpret_cast<const float4*>(src + off);  // (offset 0 is always readable)
         return ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    [[maybe_unused]] float4 pf[PF ? WG_PF : 1];
+    [[maybe_unused]] float4 pf[PF ? NPF : 1];
     // PF: the geometry of this thread's items is the same for every band -- only (b, y0) move.  Precomputed once: element offset relative to
     // pixel (b, y0, 0) of the item's tensor, its row relative to y0, and whether it can ever be valid (column / channel inside).  Per band an
     // item then costs an add, two compares and a select instead of two integer divisions (the exact-fp32 MFMA shares the vector datapath:
     // this address arithmetic ran INSTEAD of MFMAs, ~1.3 us per one-row band against 1.9 us of matrix work)
-    [[maybe_unused]] int it_off[PF ? WG_PF : 1], it_row[PF ? WG_PF : 1];
+    [[maybe_unused]] int it_off[PF ? NPF : 1], it_row[PF ? NPF : 1];
     [[maybe_unused]] unsigned it_ok = 0, it_isy = 0;
     if constexpr (PF) {
 #pragma unroll
-        for (int u = 0; u < WG_PF; ++u) {
+        for (int u = 0; u < NPF; ++u) {
             const int i = u * 256 + tid;
             const bool isy = i < NY;
             const int k = isy ? i : i - NY;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     auto fetch_band = [&](int b, int y0) {
         const size_t by = ((size_t)b * a.H + y0) * W * a.Cout, bx = ((size_t)b * a.H + y0) * W * a.Cin;
 #pragma unroll
-        for (int u = 0; u < (PF ? WG_PF : 1); ++u) {
+        for (int u = 0; u < (PF ? NPF : 1); ++u) {
             const int y = y0 + it_row[u];
             const bool isy = (it_isy >> u) & 1u;
             const bool ok = ((it_ok >> u) & 1u) & (y >= 0) & (y < a.H);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
         __syncthreads();  // previous band fully consumed
         if constexpr (PF) {
 #pragma unroll
-            for (int u = 0; u < WG_PF; ++u) {
+            for (int u = 0; u < NPF; ++u) {
                 const int i = u * 256 + tid;
                 if (i < NTOT) *reinterpret_cast<float4*>(&Ys[i * 4]) = pf[u];  // Xs follows Ys: item i lives at float 4 i of the joint tile
             }
