@@ -40,7 +40,7 @@ void film_apply(hipStream_t s, const float* xc, const float* film, int B, int HW
 }
 void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o) {
     const size_t sm = linattn_fwd_smem(d, H, W);
-    hipLaunchKernelGGL(linattn_fwd_nhwc_kernel, dim3(B * heads), dim3(256), sm, s, q, kv, heads, d, H, W, 1.0f / std::sqrt((float)d), out, ld_o);
+    hipLaunchKernelGGL(linattn_fwd_nhwc_kernel, dim3(B * heads), dim3(LA_NT), sm, s, q, kv, heads, d, H, W, 1.0f / std::sqrt((float)d), out, ld_o);
 }
 }  // namespace tk
 
@@ -464,7 +464,7 @@ int Plan::build_backward() {
                     const size_t sm = linattn_bwd_smem(d, Hl, Wl);
                     const float sc = 1.0f / std::sqrt((float)d);
                     L.v.push_back([=](hipStream_t st) {
-                        hipLaunchKernelGGL(linattn_bwd_nhwc_kernel, dim3(BB * 8), dim3(256), sm, st, (const float*)q.p, (const float*)kv.p, (const float*)dcat.p, ldc, 8, d, Hl, Wl, sc,
+                        hipLaunchKernelGGL(linattn_bwd_nhwc_kernel, dim3(BB * 8), dim3(LA_NT), sm, st, (const float*)q.p, (const float*)kv.p, (const float*)dcat.p, ldc, 8, d, Hl, Wl, sc,
                                            dq, dkv);
                     });
                 }

@@ -340,6 +340,7 @@ __device__ __forceinline__ void la_line_stats(const float* p0, size_t stride, in
     *sm_out = s;
 }
 
+constexpr int LA_NT = 1024;   // threads per workgroup: one workgroup per (sample, head) is all the parallelism there is (256 at batch 32) -> 16 waves per CU
 constexpr int LA_BAND = 4096;  // floats per staged band array: rows per band R = LA_BAND / (d * W)
 __host__ __device__ inline int la_rows(int d, int H, int W) {
     int r = LA_BAND / (d * W);
@@ -349,7 +350,7 @@ __host__ __device__ inline int la_rows(int d, int H, int W) {
 inline size_t linattn_fwd_smem(int d, int H, int W) { return (size_t)(2 * d * W + d * d + 2 * d * la_rows(d, H, W) * W + 2 * d * H) * sizeof(float); }
 inline size_t linattn_bwd_smem(int d, int H, int W) { return (size_t)(3 * d * W + 2 * d * d + 6 * d * la_rows(d, H, W) * W + d * la_rows(d, H, W) + 2 * d * H) * sizeof(float); }
 
-__global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pre, const float* kv_pre, int heads, int d, int H, int W, float sc, float* out, int ld_o) {
+__global__ __launch_bounds__(LA_NT) void linattn_fwd_nhwc_kernel(const float* q_pre, const float* kv_pre, int heads, int d, int H, int W, float sc, float* out, int ld_o) {
     DDIF_DYN_SMEM(smem_);
     const int R = la_rows(d, H, W), RW = R * W;
     float* qmx = reinterpret_cast<float*>(smem_);  // [d][W]
@@ -366,31 +367,31 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
     const float* kb = kv_pre + (size_t)b * HW * 2 * qd + hd * d;
     const float* vb = kb + qd;
     float* ob = out + (size_t)b * HW * ld_o + hd * d;
-    for (int i = tid; i < d * W; i += 256) {  // column statistics of q_pre (softmax over H)
+    for (int i = tid; i < d * W; i += LA_NT) {  // column statistics of q_pre (softmax over H)
         const int a = i % d, x = i / d;
         la_line_stats(qb + (size_t)x * qd + a, (size_t)W * qd, H, &qmx[a * W + x], &qsm[a * W + x]);
     }
-    for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre (softmax over W)
+    for (int i = tid; i < d * H; i += LA_NT) {  // row statistics of k_pre (softmax over W)
         const int a = i % d, y = i / d;
         la_line_stats(kb + (size_t)y * W * 2 * qd + a, (size_t)2 * qd, W, &kmx[a * H + y], &ksm[a * H + y]);
     }
-    for (int i = tid; i < d * d; i += 256) ctx[i] = 0.f;
+    for (int i = tid; i < d * d; i += LA_NT) ctx[i] = 0.f;
     __syncthreads();
     for (int y0 = 0; y0 < H; y0 += R) {  // ctx: bands in order, one owner thread per (a, e)
         const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
         const int nit = d * npx;
-        for (int i0 = tid; i0 < nit; i0 += 256 * 4) {  // four items' loads in flight per thread
+        for (int i0 = tid; i0 < nit; i0 += LA_NT * 4) {  // four items' loads in flight per thread
             float kv_[4], vv_[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256 < nit ? i0 + u * 256 : tid;
+                const int i = i0 + u * LA_NT < nit ? i0 + u * LA_NT : tid;
                 const size_t p = (size_t)y0 * W + i / d;
                 kv_[u] = kb[p * 2 * qd + i % d];
                 vv_[u] = vb[p * 2 * qd + i % d];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
+                const int i = i0 + u * LA_NT;
                 if (i < nit) {
                     const int a = i % d, pl = i / d, y = y0 + pl / W;
                     rk[a * RW + pl] = dd_exp(kv_[u] - kmx[a * H + y]) / ksm[a * H + y];
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
             }
         }
         __syncthreads();
-        for (int i = tid; i < d * d; i += 256) {  // (R W and every array offset are multiples of 4 floats: 16-byte LDS reads, 4 pixels per step)
+        for (int i = tid; i < d * d; i += LA_NT) {  // (R W and every array offset are multiples of 4 floats: 16-byte LDS reads, 4 pixels per step)
             const int a = i / d, e = i % d;
             float s1 = ctx[i];
             const float4* pk = reinterpret_cast<const float4*>(rk + a * RW);
@@ -421,16 +422,16 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
     for (int y0 = 0; y0 < H; y0 += R) {
         const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
         const int nit = d * npx;
-        for (int i0 = tid; i0 < nit; i0 += 256 * 4) {
+        for (int i0 = tid; i0 < nit; i0 += LA_NT * 4) {
             float qv_[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256 < nit ? i0 + u * 256 : tid;
+                const int i = i0 + u * LA_NT < nit ? i0 + u * LA_NT : tid;
                 qv_[u] = qb[((size_t)y0 * W + i / d) * qd + i % d];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
+                const int i = i0 + u * LA_NT;
                 if (i < nit) {
                     const int a = i % d, pl = i / d, x = pl % W;
                     rk[a * RW + pl] = dd_exp(qv_[u] - qmx[a * W + x]) / qsm[a * W + x] * sc;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
             }
         }
         __syncthreads();
-        for (int i = tid; i < d * npx; i += 256) {
+        for (int i = tid; i < d * npx; i += LA_NT) {
             const int e = i % d, pl = i / d;
             float s = 0.f;
             for (int a = 0; a < d; ++a) s = fmaf(ctx[a * d + e], rk[a * RW + pl], s);
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_nhwc_kernel(const float* q_pr
 // Backward (do given):  dctx[a][e] = sum_n q[a][n] do[e][n];  dq = ctx do;  dk = dctx v;  dv = dctx^T k;  then the two softmax backwards.
 // Pass 1: softmax statistics.  Pass 2 (bands): ctx, dctx.  Pass 3 (bands): dv (final), dk_pre (final: its softmax lives inside a row), dq (raw,
 // parked in the output) and the column sums T[a][x] = sum_y dq q.  Pass 4: dq_pre = q_sm (dq - T).
-__global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pre, const float* kv_pre, const float* dout, int ld_g, int heads, int d, int H, int W, float sc,
+__global__ __launch_bounds__(LA_NT) void linattn_bwd_nhwc_kernel(const float* q_pre, const float* kv_pre, const float* dout, int ld_g, int heads, int d, int H, int W, float sc,
                                                                float* dq_pre, float* dkv_pre) {
     DDIF_DYN_SMEM(smem_);
     const int R = la_rows(d, H, W), RW = R * W;
@@ -479,27 +480,27 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
     float* dqb = dq_pre + (size_t)b * HW * qd + hd * d;
     float* dkb = dkv_pre + (size_t)b * HW * 2 * qd + hd * d;
     float* dvb = dkb + qd;
-    for (int i = tid; i < d * W; i += 256) {  // pass 1: column statistics of q_pre (softmax over H)
+    for (int i = tid; i < d * W; i += LA_NT) {  // pass 1: column statistics of q_pre (softmax over H)
         const int a = i % d, x = i / d;
         la_line_stats(qb + (size_t)x * qd + a, (size_t)W * qd, H, &qmx[a * W + x], &qsm[a * W + x]);
         T[a * W + x] = 0.f;
     }
-    for (int i = tid; i < d * d; i += 256) {
+    for (int i = tid; i < d * d; i += LA_NT) {
         ctx[i] = 0.f;
         dctx[i] = 0.f;
     }
-    for (int i = tid; i < d * H; i += 256) {  // row statistics of k_pre for every (channel, row)
+    for (int i = tid; i < d * H; i += LA_NT) {  // row statistics of k_pre for every (channel, row)
         const int a = i % d, y = i / d;
         la_line_stats(kb + (size_t)y * W * 2 * qd + a, (size_t)2 * qd, W, &kmx[a * H + y], &ksm[a * H + y]);
     }
     __syncthreads();
     auto load_band = [&](int y0, int npx) {  // k softmax (over its row), v, q softmax * sc, do  -> LDS
         const int nit = d * npx;
-        for (int i0 = tid; i0 < nit; i0 += 256 * 4) {  // four items' loads (16 in all) in flight per thread
+        for (int i0 = tid; i0 < nit; i0 += LA_NT * 4) {  // four items' loads (16 in all) in flight per thread
             float kv_[4], vv_[4], qv_[4], gv_[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256 < nit ? i0 + u * 256 : tid;
+                const int i = i0 + u * LA_NT < nit ? i0 + u * LA_NT : tid;
                 const size_t p = (size_t)y0 * W + i / d;
                 const int a = i % d;
                 kv_[u] = kb[p * 2 * qd + a];
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
+                const int i = i0 + u * LA_NT;
                 if (i < nit) {
                     const int a = i % d, pl = i / d, y = y0 + pl / W, x = pl % W, l = a * RW + pl;
                     rk[l] = dd_exp(kv_[u] - kmx[a * H + y]) / ksm[a * H + y];
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
     for (int y0 = 0; y0 < H; y0 += R) {  // pass 2: ctx and dctx
         const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
         load_band(y0, npx);
-        for (int i = tid; i < d * d; i += 256) {
+        for (int i = tid; i < d * d; i += LA_NT) {
             const int a = i / d, e = i % d;
             float s1 = ctx[i], s2 = dctx[i];
             const float4* pk = reinterpret_cast<const float4*>(rk + a * RW);
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
     for (int y0 = 0; y0 < H; y0 += R) {  // pass 3
         const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
         load_band(y0, npx);
-        for (int i = tid; i < d * npx; i += 256) {
+        for (int i = tid; i < d * npx; i += LA_NT) {
             const int a = i % d, pl = i / d, l = a * RW + pl;
             float dq = 0.f, dk = 0.f, dv = 0.f;
             for (int e = 0; e < d; ++e) {
@@ -566,13 +567,13 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
             dqb[p * qd + a] = dq * sc;  // d(q_sm) of o = ctx^T (q_sm * sc)
         }
         __syncthreads();
-        for (int i = tid; i < d * rows; i += 256) {  // row dots of the k softmax backward
+        for (int i = tid; i < d * rows; i += LA_NT) {  // row dots of the k softmax backward
             const int a = i % d, r = i / d;
             float s = 0.f;
             for (int x = 0; x < W; ++x) s = fmaf(rdk[a * RW + r * W + x], rk[a * RW + r * W + x], s);
             rdot[a * R + r] = s;
         }
-        for (int i = tid; i < d * W; i += 256) {  // column sums T += dq * q_sm over the band's rows, in row order (one owner per (a, x))
+        for (int i = tid; i < d * W; i += LA_NT) {  // column sums T += dq * q_sm over the band's rows, in row order (one owner per (a, x))
             const int a = i % d, x = i / d;
             float t = T[a * W + x];
             for (int r = 0; r < rows; ++r) {
@@ -582,25 +583,25 @@ __global__ __launch_bounds__(256) void linattn_bwd_nhwc_kernel(const float* q_pr
             T[a * W + x] = t;
         }
         __syncthreads();
-        for (int i = tid; i < d * npx; i += 256) {
+        for (int i = tid; i < d * npx; i += LA_NT) {
             const int a = i % d, pl = i / d, l = a * RW + pl;
             dkb[((size_t)y0 * W + pl) * 2 * qd + a] = rk[l] * (rdk[l] - rdot[a * R + pl / W]);
         }
         __syncthreads();
     }
     const int NEL = d * HW;
-    for (int i0 = tid; i0 < NEL; i0 += 256 * 4) {  // pass 4: softmax-over-H backward of q (four elements per thread in flight)
+    for (int i0 = tid; i0 < NEL; i0 += LA_NT * 4) {  // pass 4: softmax-over-H backward of q (four elements per thread in flight)
         float qv[4], gv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256 < NEL ? i0 + u * 256 : tid;
+            const int i = i0 + u * LA_NT < NEL ? i0 + u * LA_NT : tid;
             const size_t el = (size_t)(i / d) * qd + i % d;
             qv[u] = qb[el];
             gv[u] = dqb[el];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256;
+            const int i = i0 + u * LA_NT;
             if (i < NEL) {
                 const int a = i % d, p = i / d, x = p % W;
                 const float qs_ = dd_exp(qv[u] - qmx[a * W + x]) / qsm[a * W + x];
