@@ -142,13 +142,14 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
         a.partial = c.partial;
         a.centre_only = c.centre_only ? 1 : 0;
         a.wshift = -1;
+        a.bpartial = nullptr;
         hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
         if (c.centre_only)
             hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)c.Cout * c.Cin), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
-                               c.Cout, c.Cin, dw);
+                               c.Cout, c.Cin, dw, (const float*)nullptr, (float*)nullptr);
         else
             hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)c.n_co * c.n_ci * 9 * 1024), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
-                               c.Cout, c.Cin, dw);
+                               c.Cout, c.Cin, dw, (const float*)nullptr, (float*)nullptr);
     }
     if (db) {
         hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 256 * sizeof(float), s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
@@ -490,7 +491,8 @@ int wgrad_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return 0;
 }
-void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw) {
+void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw, float* bpart,
+           float* db) {
     WgradArgs a{};
     a.x = x;
     a.dy = dy;
@@ -503,15 +505,18 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     a.wshift = -1;
     for (int k = 0; k < 16; ++k)
         if ((1 << k) == W) a.wshift = k;
+    a.bpartial = (db && bpart) ? bpart : nullptr;  // bias gradient fused: per-split column sums from the kernel, finished by the reduce kernel
     static const bool dump = getenv("DDIF_WGRAD_DUMP") != nullptr;  // development aid: geometry of every launch, in order (match against a kernel trace)
     if (dump) fprintf(stderr, "[wgrad] B=%d H=%d W=%d Cin=%d Cout=%d centre=%d rb=%d nsplit=%d blocks=%d pf=%d smem=%zu\n", B, H, W, Cin, Cout, (int)centre, g.rb, g.nsplit, g.n_co * g.n_ci, g.pf, g.smem);
     if (g.pf && g.centre && centre) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 1>), dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     if (centre)
-        hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
+        hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw,
+                           (const float*)a.bpartial, db);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)g.n_co * g.n_ci * 9 * 1024), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)g.n_co * g.n_ci * 9 * 1024), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw,
+                           (const float*)a.bpartial, db);
 }
 void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db) {
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nbchunk), dim3(256), 256 * sizeof(float), s, dy, npix, Cout, nbchunk, bpart);
@@ -531,8 +536,7 @@ void gn_act(hipStream_t s, const float* x, const float* ms, const float* gamma, 
 void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta, int B, int HW, int C, int nchunk,
             int silu, double* cpart, double* planes, float* S, float* dgamma, float* dbeta, float* dx) {
     hipLaunchKernelGGL(gnb_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, x, da, mask, ms, gamma, beta, HW, C, nchunk, silu, cpart);
-    hipLaunchKernelGGL(gnb_bwd_planes_kernel, grid_for((size_t)B * C), dim3(256), 0, s, (const double*)cpart, B, nchunk, C, planes);
-    hipLaunchKernelGGL(gnb_bwd_finalize_kernel, dim3((C + B + 255) / 256), dim3(256), 0, s, (const double*)planes, gamma, B, C, dgamma, dbeta, S);
+    hipLaunchKernelGGL(gnb_bwd_planes_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)cpart, gamma, B, nchunk, C, planes, dgamma, dbeta, S);
     if (dx) hipLaunchKernelGGL(gnb_bwd_dx_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, da, mask, ms, gamma, beta, (const float*)S, HW, C, silu, dx);
 }
 }  // namespace tk

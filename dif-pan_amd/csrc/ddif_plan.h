@@ -59,7 +59,8 @@ void silu_bwd(hipStream_t s, const float* x, const float* da, size_t n, float* d
 struct WgradGeom { int n_co = 0, n_ci = 0, nsplit = 0, rb = 0, nbchunk = 0, pf = 0, centre = 0; size_t smem = 0, partial_floats = 0; };
 WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre = false);
 int wgrad_prepare();
-void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw);
+void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw,
+           float* bpart = nullptr, float* db = nullptr);  // db: the bias gradient too (bpart: >= nsplit * n_co * 32 floats of scratch)
 void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db);
 void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart, float* ms);
 void gn_act(hipStream_t s, const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out);

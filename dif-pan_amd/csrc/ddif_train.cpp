@@ -13,6 +13,7 @@
 // Gradients are written (not accumulated) into caller-bound tensors in the reference's parameter layouts (ddif_plan_train_bind).
 // Everything is deterministic: fixed-order reductions, no atomics.
 #include <algorithm>
+#include <cstring>
 
 #include "ddif_plan.h"
 #include "kernels_train.h"
@@ -51,6 +52,8 @@ struct Plan::TrainScratch {
     const float* stem_sc = nullptr;  // set by train_step: the self-conditioning source of THIS iteration (sc_in or x_in)
     // time MLP backward
     float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr;
+    SlotScatter* slot_tab = nullptr;
+    std::vector<SlotScatter> slot_host;
 };
 
 int Plan::train_bind(int n, const char* const* keys, float* const* grads) {
@@ -117,12 +120,8 @@ int Plan::build_backward() {
         const tk::WgradGeom g = tk::wgrad_geom(BB, Cin, Cout, H_, W_, ks == 1);
         if (g.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", W_);
         need(T->n_partial, g.partial_floats);
-        need(T->n_bpart, (size_t)g.nbchunk * Cout);
-        const size_t npix = (size_t)BB * H_ * W_;
-        L.v.push_back([=](hipStream_t st) {
-            tk::wgrad(st, x, dy, BB, H_, W_, Cin, Cout, g, ks == 1, T->partial, *dw);
-            if (db) tk::bias_grad(st, dy, npix, Cout, g.nbchunk, T->bpart, *db);
-        });
+        need(T->n_bpart, (size_t)g.nsplit * g.n_co * 32);
+        L.v.push_back([=](hipStream_t st) { tk::wgrad(st, x, dy, BB, H_, W_, Cin, Cout, g, ks == 1, T->partial, *dw, T->bpart, db ? *db : nullptr); });
         return 0;
     };
     // backward of  [GroupNorm (+SiLU) (+mask)] -> conv  (one `Block` of the reference, :288-300, and the other normalised convs)
@@ -150,13 +149,9 @@ int Plan::build_backward() {
             const tk::WgradGeom g = tk::wgrad_geom(BB, C, dy.C, x.H, x.W, ks == 1);
             if (g.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", x.W);
             need(T->n_partial, g.partial_floats);
-            need(T->n_bpart, (size_t)g.nbchunk * dy.C);
-            const size_t npix = (size_t)BB * HW;
+            need(T->n_bpart, (size_t)g.nsplit * g.n_co * 32);
             const int Co = dy.C, H_ = x.H, W_ = x.W;
-            L.v.push_back([=](hipStream_t st) {
-                tk::wgrad(st, T->a, dy.p, BB, H_, W_, C, Co, g, ks == 1, T->partial, *dw);
-                if (db) tk::bias_grad(st, dy.p, npix, Co, g.nbchunk, T->bpart, *db);
-            });
+            L.v.push_back([=](hipStream_t st) { tk::wgrad(st, T->a, dy.p, BB, H_, W_, C, Co, g, ks == 1, T->partial, *dw, T->bpart, db ? *db : nullptr); });
         } else {
             DDIF_TRY(add_wgrad(L, a_mat ? a_mat : x.p, C, dy.p, dy.C, x.H, x.W, ks, dw, db));
         }
@@ -335,14 +330,7 @@ int Plan::build_backward() {
                 dz.C = Co;
                 dz.H = H_;
                 dz.W = W_;
-                DDIF_TRY(add_wgrad(L, m.in.p, C, dyz, Co, H_, W_, 3, G(m.key + ".weight"), nullptr));
-                {
-                    const tk::WgradGeom gg = tk::wgrad_geom(BB, C, Co, Ho, Wo);
-                    need(T->n_bpart, (size_t)gg.nbchunk * Co);
-                    float** db = G(m.key + ".bias");
-                    const size_t npix = (size_t)BB * Ho * Wo;
-                    L.v.push_back([=](hipStream_t st) { tk::bias_grad(st, dy, npix, Co, gg.nbchunk, T->bpart, *db); });
-                }
+                DDIF_TRY(add_wgrad(L, m.in.p, C, dyz, Co, H_, W_, 3, G(m.key + ".weight"), G(m.key + ".bias")));  // (the inserted zeros add nothing to the bias sums)
                 Tensor dxT;
                 DDIF_TRY(add_dgrad(L, m.key, dz, &dxT));
                 dx = dxT.p;
@@ -359,14 +347,10 @@ int Plan::build_backward() {
                     const tk::WgradGeom gg = tk::wgrad_geom(BB, C, Co, 2 * H_, 2 * W_);
                     if (gg.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", 2 * W_);
                     need(T->n_partial, gg.partial_floats);
-                    need(T->n_bpart, (size_t)gg.nbchunk * Co);
+                    need(T->n_bpart, (size_t)gg.nsplit * gg.n_co * 32);
                     float** dw = G(m.key + ".weight");
                     float** db = G(m.key + ".bias");
-                    const size_t npix = (size_t)BB * 4 * H_ * W_;
-                    L.v.push_back([=](hipStream_t st) {
-                        tk::wgrad(st, T->tmp, dy, BB, 2 * H_, 2 * W_, C, Co, gg, false, T->partial, *dw);
-                        tk::bias_grad(st, dy, npix, Co, gg.nbchunk, T->bpart, *db);
-                    });
+                    L.v.push_back([=](hipStream_t st) { tk::wgrad(st, T->tmp, dy, BB, 2 * H_, 2 * W_, C, Co, gg, false, T->partial, *dw, T->bpart, *db); });
                 }
                 Tensor dxu;
                 DDIF_TRY(add_dgrad(L, m.key, dyT, &dxu));
@@ -392,14 +376,13 @@ int Plan::build_backward() {
                     const tk::WgradGeom gg = tk::wgrad_geom(BB, Cp, Co, H_, W_);
                     if (gg.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", W_);
                     need(T->n_partial, gg.partial_floats);
-                    need(T->n_bpart, (size_t)gg.nbchunk * Co);
+                    need(T->n_bpart, (size_t)gg.nsplit * gg.n_co * 32);
                     need(T->n_wpad, (size_t)Co * Cp * 9);
                     float** dw = G(m.key + ".weight");
                     float** db = G(m.key + ".bias");
                     L.v.push_back([=](hipStream_t st) {
-                        tk::wgrad(st, T->a, dy, BB, H_, W_, Cp, Co, gg, false, T->partial, T->wpad);
+                        tk::wgrad(st, T->a, dy, BB, H_, W_, Cp, Co, gg, false, T->partial, T->wpad, T->bpart, *db);
                         hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)Co * Cin * 9), dim3(256), 0, st, (const float*)T->wpad, Co, Cp, Cin, 9, *dw);
-                        tk::bias_grad(st, dy, npix, Co, gg.nbchunk, T->bpart, *db);
                     });
                 }
                 dx = nullptr;
@@ -559,6 +542,11 @@ int Plan::build_backward() {
         DDIF_TRY(fbuf(&T->ds, (size_t)BB * in4));
         DDIF_TRY(fbuf(&T->dwall, (size_t)ns * inner));
         DDIF_TRY(fbuf(&T->dball, (size_t)ns));
+        {
+            float* raw = nullptr;
+            DDIF_TRY(fbuf(&raw, 64 * sizeof(SlotScatter) / sizeof(float) + 16));
+            T->slot_tab = reinterpret_cast<SlotScatter*>(raw);
+        }
         float* pe = taux;                                   // [B][inner]
         float* spre = taux + (size_t)BB * inner;            // [B][4 inner] pre-activation
         float* hid = spre + (size_t)BB * in4;               // [B][4 inner] swish
@@ -574,9 +562,16 @@ int Plan::build_backward() {
         L.v.push_back([=](hipStream_t st) {
             hipLaunchKernelGGL(time_dte_kernel, dim3(BB), dim3(256), 256 * sizeof(float), st, (const float*)dtb_, wall, ns, inner, T->dte);
             tk::linear_bwd(st, te, wall, dtb_, BB, inner, ns, nullptr, T->dwall, T->dball);
-            for (auto& sg : *slots) {
-                (void)hipMemcpyAsync(*sg.w, T->dwall + (size_t)sg.off * inner, (size_t)sg.n * inner * sizeof(float), hipMemcpyDeviceToDevice, st);
-                (void)hipMemcpyAsync(*sg.b, T->dball + sg.off, (size_t)sg.n * sizeof(float), hipMemcpyDeviceToDevice, st);
+            {   // the table is rebuilt only when the bound gradient tensors moved
+                std::vector<SlotScatter> tab;
+                for (auto& sg : *slots) tab.push_back(SlotScatter{*sg.w, *sg.b, sg.off, sg.n});
+                if (T->slot_host.size() != tab.size() || memcmp(T->slot_host.data(), tab.data(), tab.size() * sizeof(SlotScatter)) != 0) {
+                    (void)hipMemcpyAsync(T->slot_tab, tab.data(), tab.size() * sizeof(SlotScatter), hipMemcpyHostToDevice, st);
+                    (void)hipStreamSynchronize(st);  // `tab` is a local: the copy must have read it (rare: first step / re-bind)
+                    T->slot_host = tab;
+                }
+                hipLaunchKernelGGL(slot_scatter_kernel, dim3((unsigned)tab.size()), dim3(256), 0, st, (const SlotScatter*)T->slot_tab, (int)tab.size(), (const float*)T->dwall,
+                                   (const float*)T->dball, inner);
             }
             tk::linear_bwd(st, hid, w3, T->dte, BB, in4, inner, T->dh1, *gw3, *gb3);
             tk::silu_bwd(st, spre, T->dh1, (size_t)BB * in4, T->ds);

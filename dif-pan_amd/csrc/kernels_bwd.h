@@ -47,6 +47,7 @@ struct WgradArgs {
     float* partial;    // [gridDim.y][n_co * n_ci][9][32 co][32 ci]
     int centre_only;   // 1x1 convs riding this kernel: only tap 4 (the centre) is contracted and written
     int wshift;        // log2(W) when W is a power of two, else -1
+    float* bpartial;   // nullable: [gridDim.y][n_co * 32] per-split column sums of dY (the BIAS gradient's partials), written by the ci-block-0 workgroups
 };
 
 // grid = (n_co * n_ci, NSPLIT); block 256.  LDS: dY band [rb*W][32] + X band [(rb+2)*(W+2)][32] + reduction scratch [4][1024].
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bacc = 0.f;  // bias gradient: this thread's (pixel lane tid / 32, channel tid % 32) column sum over the workgroup's bands
 
     // item i of a band (float4): i < NY -> dY row y0 + p / W, 32 couts of this block; else X rows y0 - 1 .. y0 + RB with a one-pixel zero border
     auto load_item = [&](int b, int y0, int i) -> float4 {
@@ -157,8 +159,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
             }
             __syncthreads();
         }
-        // pixel pairs of the band: pair q -> pixels (2q, 2q+1) in row-major order of the RB x W band; wave w takes q = w, w+4, ...
         const int npix = RB * W, npairs = (npix + 1) / 2;
+        if (a.bpartial && cib == 0) {  // workgroup-uniform: bias gradient = column sums of the dY band already sitting in LDS (rows past the image are zero)
+            const int c = tid & 31;
+            float sb = 0.f;
+            for (int p = tid >> 5; p < npix; p += 8) sb += Ys[p * 32 + c];
+            bacc += sb;
+        }
+        // pixel pairs of the band: pair q -> pixels (2q, 2q+1) in row-major order of the RB x W band; wave w takes q = w, w+4, ...
         for (int q = wave; q < npairs; q += 4) {
             const int pr = 2 * q + h;         // this lane half's pixel (k index of the MFMA)
             const bool pv = pr < npix;        // odd pixel count: the last pair's second pixel does not exist
@@ -178,6 +186,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
                 const float bv = Xs[((py + t / 3) * IW + px + t % 3) * 32 + j];  // B[k = h][j = ci]: X at (y + ky - 1, x + kx - 1)
                 acc[t] = DDIF_MFMA_32x32x2(av, bv, acc[t]);
             }
+        }
+    }
+    if (a.bpartial && cib == 0) {  // the eight pixel lanes of every channel, in lane order
+        __syncthreads();
+        Rs[tid] = bacc;
+        __syncthreads();
+        if (tid < 32) {
+            float sb = 0.f;
+            for (int r = 0; r < 8; ++r) sb += Rs[r * 32 + tid];
+            a.bpartial[(size_t)blockIdx.y * (gridDim.x / a.n_ci) * 32 + cob * 32 + tid] = sb;
         }
     }
     // combine the four waves tap by tap in fixed order, write this workgroup's partial block
@@ -212,7 +230,13 @@ __device__ __forceinline__ float wgrad_sum_splits(const float* p, size_t stride,
     return acc;
 }
 // 1x1 form: dW (Cout, Cin) from the centre-tap blocks only
-__global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw) {
+// (both reduce kernels also finish the bias gradient when bpartial / db are given: db[c] = fixed-order sum over the splits)
+__device__ __forceinline__ void wgrad_reduce_bias(const float* bpartial, int nsplit, int n_co, int Cout, float* db) {
+    if (!bpartial || !db || blockIdx.x != 0) return;
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) db[c] = wgrad_sum_splits(bpartial + c, (size_t)n_co * 32, nsplit);
+}
+__global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial, float* db) {
+    wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db);
     const size_t total = (size_t)Cout * Cin;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ci = (int)(i % Cin), co = (int)(i / Cin);
@@ -223,7 +247,8 @@ __global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int
 }
 // dW (OIHW) = fixed-order sum of the partial blocks.  Threads walk the PARTIAL layout ([block][tap][co % 32][ci % 32]: coalesced reads, which
 // are nsplit x the writes); each writes its one weight element
-__global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw) {
+__global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial, float* db) {
+    wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db);
     const size_t total = (size_t)nblk * 9 * 1024;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
@@ -458,6 +483,43 @@ __global__ void gnb_bwd_finalize_kernel(const double* pl, const float* gamma, in
         }
         S[b * 2 + 0] = (float)(s1 / ((double)C));  // divided by HW in the consumer (N = C * HW)
         S[b * 2 + 1] = (float)(s2 / ((double)C));
+    }
+}
+// The two steps above in ONE launch for the training step (B * C <= a few thousand: a single 1024-thread workgroup walks the planes, keeps
+// them in memory for phase 2 behind a barrier; same sums in the same order).  Saves one launch + its gap per GroupNorm (97 per iteration).
+__global__ __launch_bounds__(1024) void gnb_bwd_planes_finalize_kernel(const double* cpart, const float* gamma, int B, int nchunk, int C, double* pl, float* dgamma,
+                                                                       float* dbeta, float* S) {
+    const int tid = threadIdx.x, n = B * C;
+    for (int i = tid; i < n; i += 1024) {
+        const size_t b = i / C, c = i % C;
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            s0 += cpart[((b * nchunk + k) * C + c) * 2 + 0];
+            s1 += cpart[((b * nchunk + k) * C + c) * 2 + 1];
+        }
+        pl[(size_t)i * 2 + 0] = s0;
+        pl[(size_t)i * 2 + 1] = s1;
+    }
+    __syncthreads();  // (global writes of this workgroup are visible to it after the barrier)
+    for (int i = tid; i < C + B; i += 1024) {
+        if (i < C) {
+            double g = 0.0, bt = 0.0;
+            for (int b = 0; b < B; ++b) {
+                bt += pl[((size_t)b * C + i) * 2 + 0];
+                g += pl[((size_t)b * C + i) * 2 + 1];
+            }
+            if (dgamma) dgamma[i] = (float)g;
+            if (dbeta) dbeta[i] = (float)bt;
+        } else {
+            const int b = i - C;
+            double s1 = 0.0, s2 = 0.0;
+            for (int c = 0; c < C; ++c) {
+                s1 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 0];
+                s2 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 1];
+            }
+            S[b * 2 + 0] = (float)(s1 / ((double)C));
+            S[b * 2 + 1] = (float)(s2 / ((double)C));
+        }
     }
 }
 __global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta,

@@ -652,6 +652,16 @@ __global__ __launch_bounds__(256) void time_dte_kernel(const float* dtb, const f
         dte[(size_t)b * inner + tid] = t;
     }
 }
+// FeatureWiseAffine gradients: rows [off, off + n) of dwall ([nslots][inner]) / dball ([nslots]) copied into each block's own (n, inner) /
+// (n) gradient tensors -- one launch over a table instead of two device copies per block (64 per iteration)
+struct SlotScatter { float* w; float* b; int off, n; };
+__global__ void slot_scatter_kernel(const SlotScatter* tab, int nslot_blocks, const float* dwall, const float* dball, int inner) {
+    const int k = blockIdx.x;
+    if (k >= nslot_blocks) return;
+    const SlotScatter s = tab[k];
+    for (int i = threadIdx.x; i < s.n * inner; i += blockDim.x) s.w[i] = dwall[(size_t)s.off * inner + i];
+    for (int i = threadIdx.x; i < s.n; i += blockDim.x) s.b[i] = dball[s.off + i];
+}
 // per-sample plane sums in two stages: part[b][chunk][c] over pixel chunks, then out[b * ld + c] (fixed order)
 __global__ __launch_bounds__(256) void plane_sum_partial_nhwc_kernel(const float* dy, int HW, int C, int nchunk, float* part) {
     DDIF_DYN_SMEM(smem_);
