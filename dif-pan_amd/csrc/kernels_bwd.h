@@ -485,43 +485,6 @@ __global__ void gnb_bwd_finalize_kernel(const double* pl, const float* gamma, in
         S[b * 2 + 1] = (float)(s2 / ((double)C));
     }
 }
-// The two steps above in ONE launch for the training step (B * C <= a few thousand: a single 1024-thread workgroup walks the planes, keeps
-// them in memory for phase 2 behind a barrier; same sums in the same order).  Saves one launch + its gap per GroupNorm (97 per iteration).
-__global__ __launch_bounds__(1024) void gnb_bwd_planes_finalize_kernel(const double* cpart, const float* gamma, int B, int nchunk, int C, double* pl, float* dgamma,
-                                                                       float* dbeta, float* S) {
-    const int tid = threadIdx.x, n = B * C;
-    for (int i = tid; i < n; i += 1024) {
-        const size_t b = i / C, c = i % C;
-        double s0 = 0.0, s1 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-            s0 += cpart[((b * nchunk + k) * C + c) * 2 + 0];
-            s1 += cpart[((b * nchunk + k) * C + c) * 2 + 1];
-        }
-        pl[(size_t)i * 2 + 0] = s0;
-        pl[(size_t)i * 2 + 1] = s1;
-    }
-    __syncthreads();  // (global writes of this workgroup are visible to it after the barrier)
-    for (int i = tid; i < C + B; i += 1024) {
-        if (i < C) {
-            double g = 0.0, bt = 0.0;
-            for (int b = 0; b < B; ++b) {
-                bt += pl[((size_t)b * C + i) * 2 + 0];
-                g += pl[((size_t)b * C + i) * 2 + 1];
-            }
-            if (dgamma) dgamma[i] = (float)g;
-            if (dbeta) dbeta[i] = (float)bt;
-        } else {
-            const int b = i - C;
-            double s1 = 0.0, s2 = 0.0;
-            for (int c = 0; c < C; ++c) {
-                s1 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 0];
-                s2 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 1];
-            }
-            S[b * 2 + 0] = (float)(s1 / ((double)C));
-            S[b * 2 + 1] = (float)(s2 / ((double)C));
-        }
-    }
-}
 __global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta,
                                                          const float* S, int HW, int C, int silu, float* dx) {
     const int b = blockIdx.y;
