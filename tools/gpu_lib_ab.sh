@@ -1,18 +1,25 @@
 #!/bin/bash
-# usage: tools/gpu_lib_ab.sh <tag> <other-lib.so>  -- parity tests on the default build, then a same-box A/B of the default build against another build
-# of libddif (bench.py --lib): T = 200 job time twice each, alternating, and one op-timing run each
+# usage: tools/gpu_lib_ab.sh <tag> <other lib (path relative to the repo)>  -- same-box A/B of the default library against another build of it:
+# job time at T = 200 (twice each, interleaved) and one op-by-op timing of each
 tag=$1; other=$2
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-(timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_batch64.py -m gpu -q -x -k "not T1000" 2>&1 | tail -4) > $R/gpurun_out/${tag}_tests.log 2>&1
-cat $R/gpurun_out/${tag}_tests.log
-for v in new old new old; do
-  L=""; [ $v = old ] && L="--lib $other"
-  python3 bench.py $L --steps 2 --warmup 1 --T 200 --no-cpu-baseline > $R/gpurun_out/${tag}_bench_$v.json 2> $R/gpurun_out/${tag}_bench_$v.log
-  python3 - <<PY
-import json
-r=json.load(open("$R/gpurun_out/${tag}_bench_$v.json"))
-c={x["class"][:12]:round(x["ms_per_step"],3) for x in r["roofline"]["whole_step"]["classes"]}
-print("$v ms/denoise-step", round(r["ms_per_step"]/r["config"]["T"],4), c)
-PY
+for rep in 1 2; do
+  for v in default other; do
+    if [ $v = other ]; then L="--lib $R/$other"; else L=""; fi
+    python3 bench.py --steps 2 --warmup 1 --T 200 --no-cpu-baseline $L > gpurun_out/${tag}_${v}_$rep.json 2> /dev/null
+    python3 -c "
+import json; r=json.load(open('gpurun_out/${tag}_${v}_$rep.json')); print('$v', $rep, 'ms/denoise %.3f' % r['roofline']['whole_step']['ms_per_denoising_step'], [(c['class'][:12], round(c['ms_per_step'],3)) for c in (r['roofline']['whole_step']['classes'] or [])])"
+  done
 done
+DDIF_OP_TIMING=$R/gpurun_out/${tag}_op_default.csv python3 bench.py --steps 1 --warmup 1 --T 40 --no-cpu-baseline > /dev/null 2>&1
+DDIF_OP_TIMING=$R/gpurun_out/${tag}_op_other.csv python3 bench.py --steps 1 --warmup 1 --T 40 --no-cpu-baseline --lib $R/$other > /dev/null 2>&1
+python3 - <<PY
+import csv
+a = list(csv.DictReader(open("gpurun_out/${tag}_op_default.csv"))); b = list(csv.DictReader(open("gpurun_out/${tag}_op_other.csv")))
+tot = [0, 0]
+for x, y in zip(a, b):
+    ua, ub = float(x["us"]), float(y["us"]); tot[0] += ua; tot[1] += ub
+    if abs(ua - ub) > 0.08 * ua: print("%-64s %-26s %7.1f -> %7.1f us" % (x["op"][:64], x["kernel"][:26], ua, ub))
+print("sum of ops: %.1f -> %.1f us" % tuple(tot))
+PY
