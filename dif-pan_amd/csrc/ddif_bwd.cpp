@@ -512,11 +512,11 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     else if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     if (centre)
-        hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)Cout * Cin), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw,
-                           (const float*)a.bpartial, db);
+        hipLaunchKernelGGL(wgrad_reduce_centre_kernel, dim3(grid_for((size_t)Cout * Cin).x + (a.bpartial ? 1 : 0)), dim3(256), 0, s, (const float*)partial, g.nsplit,
+                           g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw, (const float*)a.bpartial, db);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)g.n_co * g.n_ci * 9 * 1024), dim3(256), 0, s, (const float*)partial, g.nsplit, g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw,
-                           (const float*)a.bpartial, db);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t)g.n_co * g.n_ci * 9 * 1024).x + (a.bpartial ? 1 : 0)), dim3(256), 0, s, (const float*)partial, g.nsplit,
+                           g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw, (const float*)a.bpartial, db);
 }
 void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db) {
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nbchunk), dim3(256), 256 * sizeof(float), s, dy, npix, Cout, nbchunk, bpart);

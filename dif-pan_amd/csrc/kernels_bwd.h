@@ -231,14 +231,17 @@ __device__ __forceinline__ float wgrad_sum_splits(const float* p, size_t stride,
 }
 // 1x1 form: dW (Cout, Cin) from the centre-tap blocks only
 // (both reduce kernels also finish the bias gradient when bpartial / db are given: db[c] = fixed-order sum over the splits)
-__device__ __forceinline__ void wgrad_reduce_bias(const float* bpartial, int nsplit, int n_co, int Cout, float* db) {
-    if (!bpartial || !db || blockIdx.x != 0) return;
+// (the launch carries ONE extra workgroup -- the last -- for the bias; returns true for that workgroup)
+__device__ __forceinline__ bool wgrad_reduce_bias(const float* bpartial, int nsplit, int n_co, int Cout, float* db) {
+    if (!bpartial || !db || blockIdx.x != gridDim.x - 1) return false;
     for (int c = threadIdx.x; c < Cout; c += blockDim.x) db[c] = wgrad_sum_splits(bpartial + c, (size_t)n_co * 32, nsplit);
+    return true;
 }
 __global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial, float* db) {
-    wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db);
+    if (wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db)) return;
+    const size_t nb_main = (bpartial && db) ? gridDim.x - 1 : gridDim.x;
     const size_t total = (size_t)Cout * Cin;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nb_main * blockDim.x) {
         const int ci = (int)(i % Cin), co = (int)(i / Cin);
         const int blk = (co / 32) * n_ci + ci / 32;
         const size_t off = ((size_t)blk * 9 + 4) * 1024 + (size_t)(co % 32) * 32 + ci % 32;
@@ -248,9 +251,10 @@ __global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int
 // dW (OIHW) = fixed-order sum of the partial blocks.  Threads walk the PARTIAL layout ([block][tap][co % 32][ci % 32]: coalesced reads, which
 // are nsplit x the writes); each writes its one weight element
 __global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial, float* db) {
-    wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db);
+    if (wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db)) return;
+    const size_t nb_main = (bpartial && db) ? gridDim.x - 1 : gridDim.x;
     const size_t total = (size_t)nblk * 9 * 1024;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += nb_main * blockDim.x) {
         const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
         const int t = (int)((j >> 10) % 9), blk = (int)(j / (9 * 1024));
         const int co = (blk / n_ci) * 32 + r, ci = (blk % n_ci) * 32 + c;
