@@ -460,9 +460,20 @@ __global__ void gnb_bwd_planes_kernel(const double* cpart, int B, int nchunk, in
     if (i >= (size_t)B * C) return;
     const size_t b = i / C, c = i % C;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        s0 += cpart[((b * nchunk + k) * C + c) * 2 + 0];
-        s1 += cpart[((b * nchunk + k) * C + c) * 2 + 1];
+    for (int k0 = 0; k0 < nchunk; k0 += 8) {  // eight chunks' loads in flight, summed in chunk order
+        double v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u < nchunk ? k0 + u : nchunk - 1;
+            v0[u] = cpart[((b * nchunk + k) * C + c) * 2 + 0];
+            v1[u] = cpart[((b * nchunk + k) * C + c) * 2 + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nchunk) {
+                s0 += v0[u];
+                s1 += v1[u];
+            }
     }
     pl[i * 2 + 0] = s0;
     pl[i * 2 + 1] = s1;
@@ -472,18 +483,41 @@ __global__ void gnb_bwd_finalize_kernel(const double* pl, const float* gamma, in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) {
         double g = 0.0, bt = 0.0;
-        for (int b = 0; b < B; ++b) {
-            bt += pl[((size_t)b * C + i) * 2 + 0];
-            g += pl[((size_t)b * C + i) * 2 + 1];
+        for (int b0 = 0; b0 < B; b0 += 8) {  // eight samples' loads in flight, summed in sample order
+            double v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u < B ? b0 + u : B - 1;
+                v0[u] = pl[((size_t)b * C + i) * 2 + 0];
+                v1[u] = pl[((size_t)b * C + i) * 2 + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b0 + u < B) {
+                    bt += v0[u];
+                    g += v1[u];
+                }
         }
         if (dgamma) dgamma[i] = (float)g;
         if (dbeta) dbeta[i] = (float)bt;
     } else if (i < C + B) {
         const int b = i - C;
         double s1 = 0.0, s2 = 0.0;
-        for (int c = 0; c < C; ++c) {
-            s1 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 0];
-            s2 += (double)gamma[c] * pl[((size_t)b * C + c) * 2 + 1];
+        for (int c0 = 0; c0 < C; c0 += 8) {  // C is a multiple of 4; the clamped tail is masked
+            double v0[8], v1[8], gm[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u < C ? c0 + u : C - 1;
+                gm[u] = (double)gamma[c];
+                v0[u] = pl[((size_t)b * C + c) * 2 + 0];
+                v1[u] = pl[((size_t)b * C + c) * 2 + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < C) {
+                    s1 += gm[u] * v0[u];
+                    s2 += gm[u] * v1[u];
+                }
         }
         S[b * 2 + 0] = (float)(s1 / ((double)C));  // divided by HW in the consumer (N = C * HW)
         S[b * 2 + 1] = (float)(s2 / ((double)C));

@@ -62,15 +62,24 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
             gb = a.beta[c] - mean * ga;
         }
         if (cb) __syncthreads();
-        for (int pix = tid >> 5; pix < IH * IW; pix += 8) {
-            const int iy = oy0 - 1 + pix / IW, ix = ox0 - 1 + pix % IW;
-            float v = 0.f;
-            if (cok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                const size_t sp = ((size_t)b * a.H + iy) * a.W + ix;
-                v = (c < a.c0) ? a.in0[sp * a.c0 + c] : a.in1[sp * a.c1 + (c - a.c0)];
-                if (a.use_gn) v = fmaf(v, ga, gb);
+        // (the 180 halo pixels of this thread's channel, eight loads in flight at a time: a load-then-store loop pays one memory latency per pixel)
+        for (int p0 = tid >> 5; p0 < IH * IW; p0 += 64) {
+            float v[8];
+            bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pix = p0 + 8 * u;
+                const int iy = oy0 - 1 + pix / IW, ix = ox0 - 1 + pix % IW;
+                ok[u] = cok && pix < IH * IW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                const size_t sp = ok[u] ? ((size_t)b * a.H + iy) * a.W + ix : (size_t)b * a.H * a.W;
+                const int cc = ok[u] ? c : 0;
+                v[u] = (cc < a.c0) ? a.in0[sp * a.c0 + cc] : a.in1[sp * a.c1 + (cc - a.c0)];
             }
-            As[pix * CK + cl] = v;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pix = p0 + 8 * u;
+                if (pix < IH * IW) As[pix * CK + cl] = ok[u] ? (a.use_gn ? fmaf(v[u], ga, gb) : v[u]) : 0.f;
+            }
         }
         __syncthreads();
         float wv[9];
