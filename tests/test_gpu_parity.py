@@ -241,10 +241,11 @@ def test_p_losses_forward_matches_reference_golden(case, monkeypatch):
     assert _maxerr(recon, torch.from_numpy(g["recon"])) <= 2e-5
 
 
-@pytest.mark.parametrize("shape", [(1, 128, 128), (2, 8, 8), (1, 72, 200)], ids=["128x128", "8x8", "72x200"])
+@pytest.mark.parametrize("shape", [(1, 128, 128), (2, 8, 8), (1, 72, 200), (1, 256, 256)], ids=["128x128", "8x8", "72x200", "256x256-whole-scene"])
 def test_forward_matches_oracle_other_sizes(shape):
     """Sizes beyond the golden set: 128x128 (CAVE-sized, 256 bottleneck tokens -> multi-block attention), the smallest
-    legal tile, and a non-square scene with partial tiles; expected values from the pinned CPU oracle."""
+    legal tile, a non-square scene with partial tiles, and a WHOLE 256x256 scene through one plan as the reference feeds it
+    (diffusion_engine.py:373-377; 1024 bottleneck tokens); expected values from the pinned CPU oracle."""
     B, H, W = shape
     ds = "wv3"
     g = torch.Generator().manual_seed(H * 1000 + W)
