@@ -47,9 +47,6 @@ ConvVariant variant_for_cfg(int cfg) {
             case 7: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 1>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = true; break;
             case 8: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
             case 9: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = true; break;
-            // 10 (experiment, DDIF_WSB=1): 8x16 x 32 on four waves with ONE weight buffer (69 KB of LDS) and a register cap of 256 -> two workgroups
-            // resident per CU, one's epilogue / fill under the other's MFMA loop
-            case 10: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 2>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 2>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
             default: break;
         }
     }
@@ -142,8 +139,6 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
         return base;
     }
     if (ks == 3 && vec == 1 && stride == 1 && x3) {
-        static const int wsb = [] { const char* e = getenv("DDIF_WSB"); return e ? atoi(e) : 0; }();
-        if (wsb && wide && Hout >= 32 && Wout >= 32) return 10;
         if (wide && Hout >= 32 && Wout >= 32) return 7;
         if (wide || Cout <= 32) return 8;
         return 9;

@@ -104,7 +104,7 @@ enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_
 // result (not bitwise the fmaf chain), 198 instead of 512 matrix cycles per slab, and the matrix core runs beside the
 // VALU instead of on it.  LDS holds three bf16 planes per operand (96 B per pixel and 16-channel chunk + 16 B pad).
 template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0, int MATH = 0>
-__global__ __launch_bounds__(64 * WM * WN, (MATH == 2) ? 2 : 1) void conv_mfma_kernel(ConvArgs a) {  // MATH = 2: two workgroups per CU must FIT (<= 256 unified registers)
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
