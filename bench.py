@@ -377,7 +377,7 @@ def bench_training(args, cf, rank, world, dev):
 
     from ddif import runtime
     from ddif.diffusion.diffusion_ddpm_pan import GaussianDiffusion, make_beta_schedule
-    from ddif.diffusion_engine import average_gradients, broadcast_parameters
+    from ddif.diffusion_engine import average_gradients, broadcast_parameters, gradient_bucket
     from ddif.layout import engine_cfg
     from ddif.models.sr3_dwt import UNetSR3
     from ddif.synth import synth_state_dict, synth_tiles
@@ -396,7 +396,7 @@ def bench_training(args, cf, rank, world, dev):
     cond = tiles["cond"].to(dev)
     res = (tiles["gt"].to(dev) - cond[:, :C]).contiguous()
     params = [p for p in net.parameters()]
-    grads = [torch.zeros_like(p) for p in params]
+    _, grads = gradient_bucket(params)
     for p, g in zip(params, grads):
         p.grad = g
     ema = [p.detach().clone() for p in params]

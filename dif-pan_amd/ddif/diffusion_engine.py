@@ -243,18 +243,50 @@ def _open_set(path_or_data):
     return {k: np.asarray(f[k]) for k in ("pan", "lms", "gt")}
 
 
+_BUCKET_ALIGN = 64  # floats: every gradient starts on a 256-byte boundary, as a separately allocated tensor would (vector stores in the kernels)
+
+
+def gradient_bucket(params):
+    """One flat fp32 buffer holding every parameter's gradient (each on a 256-byte boundary; the gaps stay zero), and the per-parameter
+    views into it.  The native training step and the fused optimizer work on the views (raw pointers), the DDP all-reduce on the flat
+    buffer: no concatenation, no copy back."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += -(-p.numel() // _BUCKET_ALIGN) * _BUCKET_ALIGN
+    flat = torch.zeros(off, dtype=torch.float32, device=params[0].device)
+    return flat, [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+
+
+def _flat_of(grads):
+    """The flat tensor `grads` are the views of (gradient_bucket, in order), or None."""
+    base = grads[0]._base
+    if base is None or base.dim() != 1:
+        return None
+    off = 0
+    for g in grads:
+        if g._base is not base or g.storage_offset() != off or not g.is_contiguous():
+            return None
+        off += -(-g.numel() // _BUCKET_ALIGN) * _BUCKET_ALIGN
+    return base if off == base.numel() else None
+
+
 def average_gradients(grads, world: int):
     """DDP of config 5 (one process per GPU, `torch.distributed`; backend "nccl" = RCCL over xGMI): the gradients of all ranks are averaged
     in ONE flat bucket (7.1 M floats = 28 MB for the engine network: a single ring all-reduce, bandwidth-bound on the xGMI links rather
-    than latency-bound on 702 small ones).  In place: the fused optimizer keeps the gradient pointers."""
+    than latency-bound on 702 small ones).  In place: the fused optimizer keeps the gradient pointers.  Gradients allocated by
+    `gradient_bucket` are reduced where they lie; any other list goes through a temporary concatenation."""
     import torch.distributed as dist
 
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    bucket = _flat_of(grads)
+    flat = bucket if bucket is not None else torch.cat([g.reshape(-1) for g in grads])
     if dist.get_backend() == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective
     else:  # gloo (the CPU tests) has no AVG
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat /= world
+    if bucket is not None:
+        return
     off = 0
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -334,7 +366,7 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
     train = _Batches(_open_set(train_dataset_path), batch_size, shuffle=True, rank=rank, world=world, seed=data_seed)
     valid = _Batches(_open_set(valid_dataset_path), 16, shuffle=False) if valid_dataset_path is not None else None
     params = [p for p in net.parameters()]
-    grads = [torch.zeros_like(p) for p in params]
+    _, grads = gradient_bucket(params)
     for p, g in zip(params, grads):
         p.grad = g  # autograd accumulates in place: the fused optimizer keeps these pointers
     if world > 1:

@@ -84,6 +84,15 @@ def _run_train(rank, world, port, q):
     if world > 1:
         E.average_gradients(g, world)
         assert torch.equal(g[0], torch.full((3, 2), 1.5)) and torch.equal(g[1], torch.full((5,), 15.0))
+        # gradients allocated as views of one bucket are reduced where they lie (no concatenation, same pointers afterwards)
+        flat, views = E.gradient_bucket([torch.empty(3, 2), torch.empty(5)])
+        assert E._flat_of(views) is flat and E._flat_of(g) is None
+        ptrs = [v.data_ptr() for v in views]
+        views[0].fill_(float(rank + 1))
+        views[1].fill_(10.0 * (rank + 1))
+        E.average_gradients(views, world)
+        assert torch.equal(views[0], torch.full((3, 2), 1.5)) and torch.equal(views[1], torch.full((5,), 15.0))
+        assert [v.data_ptr() for v in views] == ptrs and torch.equal(flat[:6], torch.full((6,), 1.5)) and flat.numel() == 128
     # one training iteration of engine_google as DDP runs it: the SAME two-sample set on both ranks (the per-epoch permutation is sharded by
     # rank: one sample each) and DIFFERENT torch seeds per rank (different default initialisation, different masks): the rank-0 broadcast
     # must make the replicas identical before the step, the gradient average must keep them identical after it
