@@ -187,8 +187,8 @@ int ddif_convbwd_run(ddif_convbwd_t h, const float* x, const float* w, const flo
 namespace ddif {
 struct BlockBwd {
     ConvBwd conv;      // owns the NHWC staging buffers: conv.x_nhwc = a (the conv's input), conv.dy_nhwc = dY, conv.dx = dA
-    float *x_nhwc = nullptr, *mask_nhwc = nullptr, *dx_nhwc = nullptr, *ms = nullptr, *S = nullptr;
-    double *spart = nullptr, *cpart = nullptr, *planes = nullptr;
+    float *x_nhwc = nullptr, *mask_nhwc = nullptr, *dx_nhwc = nullptr, *S = nullptr;
+    double *spart = nullptr, *cpart = nullptr;
     float* w3 = nullptr;  // ks == 1: the 1x1 weights embedded in a 3x3 tensor for the dgrad conv
     int nchunk = 32, ks = 3, pro = DDIF_BWD_PRO_GN_SILU, resample = DDIF_BWD_PLAIN;
     int H = 0, W = 0;  // of the op's INPUT x (the conv runs at 2H x 2W under DDIF_BWD_UP2)
@@ -235,11 +235,9 @@ int ddif_blockbwd_create_ex(ddif_blockbwd_t* out, int B, int Cin, int Cout, int 
     TRY(pl.dalloc(&k.x_nhwc, n));
     TRY(pl.dalloc(&k.mask_nhwc, n));
     TRY(pl.dalloc(&k.dx_nhwc, n));
-    TRY(pl.dalloc(&k.ms, (size_t)B * 2));
     TRY(pl.dalloc(&k.S, (size_t)B * 2));
     TRY(pl.dalloc(&k.spart, (size_t)B * k.nchunk * 2));
     TRY(pl.dalloc(&k.cpart, (size_t)B * k.nchunk * Cin * 2));
-    TRY(pl.dalloc(&k.planes, (size_t)B * Cin * 2));
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (rc) return rc;
     *out = h.release();
@@ -282,8 +280,7 @@ int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, con
     if (gn) {
         // forward recompute: GroupNorm statistics of x, then a = Dropout(SiLU(GroupNorm(x))) -- the conv's input, needed by wgrad
         hipLaunchKernelGGL(ddif::gnb_stats_kernel, dim3(k.nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, (const float*)k.x_nhwc, (size_t)HW * Ci, k.nchunk, k.spart);
-        hipLaunchKernelGGL(ddif::gnb_finalize_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)k.spart, k.nchunk, (double)HW * Ci, B, k.ms);
-        hipLaunchKernelGGL(ddif::gnb_act_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, (const float*)k.ms, gamma, beta, m, HW, Ci, silu, c.x_nhwc);
+        hipLaunchKernelGGL(ddif::gnb_act_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, (const double*)k.spart, k.nchunk, gamma, beta, m, HW, Ci, silu, c.x_nhwc);
     } else if (act) {
         hipLaunchKernelGGL(ddif::silu_fwd_kernel, ddif::grid_for(n), dim3(256), 0, s, (const float*)k.x_nhwc, n, c.x_nhwc);
     }
@@ -300,13 +297,13 @@ int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, con
     const float* da = c.dx.p;
     if (gn) {
         // GroupNorm (+ SiLU + dropout) backward
-        hipLaunchKernelGGL(ddif::gnb_bwd_partial_kernel, dim3(k.nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, (const float*)k.x_nhwc, da, m, (const float*)k.ms,
-                           gamma, beta, HW, Ci, k.nchunk, silu, k.cpart);
-        hipLaunchKernelGGL(ddif::gnb_bwd_planes_kernel, ddif::grid_for((size_t)B * Ci), dim3(256), 0, s, (const double*)k.cpart, B, k.nchunk, Ci, k.planes);
-        hipLaunchKernelGGL(ddif::gnb_bwd_finalize_kernel, dim3((Ci + B + 255) / 256), dim3(256), 0, s, (const double*)k.planes, gamma, B, Ci, dgamma, dbeta, k.S);
+        hipLaunchKernelGGL(ddif::gnb_bwd_partial_kernel, dim3(k.nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, (const float*)k.x_nhwc, da, m, (const double*)k.spart,
+                           k.nchunk, gamma, beta, HW, Ci, k.nchunk, silu, k.cpart);
+        hipLaunchKernelGGL(ddif::gnb_bwd_reduce_kernel, dim3((Ci + 31) / 32 + B), dim3(ddif::GNB_RED_NT), 2 * ddif::GNB_RED_NT * sizeof(double), s, (const double*)k.cpart, gamma, B, k.nchunk, Ci, dgamma, dbeta,
+                           k.S);
         if (dx) {
-            hipLaunchKernelGGL(ddif::gnb_bwd_dx_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, da, m, (const float*)k.ms, gamma, beta, (const float*)k.S, HW, Ci,
-                               silu, k.dx_nhwc);
+            hipLaunchKernelGGL(ddif::gnb_bwd_dx_kernel, ew, dim3(256), 0, s, (const float*)k.x_nhwc, da, m, (const double*)k.spart, k.nchunk, gamma, beta, (const float*)k.S,
+                               (const float*)nullptr, HW, Ci, silu, k.dx_nhwc);
             hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), ddif::TR_SMEM, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
         }
     } else if (dx) {
@@ -522,24 +519,23 @@ void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchun
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nbchunk), dim3(256), 256 * sizeof(float), s, dy, npix, Cout, nbchunk, bpart);
     hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(Cout), dim3(64), 64 * sizeof(float), s, (const float*)bpart, nbchunk, Cout, db);
 }
-void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart, float* ms) {
+void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart) {
     hipLaunchKernelGGL(gnb_stats_kernel, dim3(nchunk, B), dim3(256), 2 * 256 * sizeof(double), s, x, per_sample, nchunk, spart);
-    hipLaunchKernelGGL(gnb_finalize_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)spart, nchunk, (double)per_sample, B, ms);
 }
 static inline dim3 ew_grid2(int B, int HW, int C) {
     const size_t nq = ((size_t)HW * C / 4 + 255) / 256;
     return dim3((unsigned)(nq > 64 ? 64 : (nq < 1 ? 1 : nq)), (unsigned)B);
 }
-void gn_act(hipStream_t s, const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out) {
-    hipLaunchKernelGGL(gnb_act_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, ms, gamma, beta, mask, HW, C, silu, out);
+// `st` [B][np][2]: the partials of x -- gn_stats' output or, in the training step, what the forward producer of x left behind (no second read of x)
+void gn_act(hipStream_t s, const float* x, const double* st, int np, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out) {
+    hipLaunchKernelGGL(gnb_act_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, st, np, gamma, beta, mask, HW, C, silu, out);
 }
-void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta, int B, int HW, int C, int nchunk,
-            int silu, double* cpart, double* planes, float* S, float* dgamma, float* dbeta, float* dx) {
-    hipLaunchKernelGGL(gnb_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, x, da, mask, ms, gamma, beta, HW, C, nchunk, silu, cpart);
-    // (one launch for both steps -- a single 1024-thread workgroup -- measured 46 us against 10 + 15 us for the pair: removed)
-    hipLaunchKernelGGL(gnb_bwd_planes_kernel, grid_for((size_t)B * C), dim3(256), 0, s, (const double*)cpart, B, nchunk, C, planes);
-    hipLaunchKernelGGL(gnb_bwd_finalize_kernel, dim3((C + B + 255) / 256), dim3(256), 0, s, (const double*)planes, gamma, B, C, dgamma, dbeta, S);
-    if (dx) hipLaunchKernelGGL(gnb_bwd_dx_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, da, mask, ms, gamma, beta, (const float*)S, HW, C, silu, dx);
+void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma, const float* beta, int B, int HW, int C,
+            int nchunk, int silu, double* cpart, float* S, float* dgamma, float* dbeta, const float* res, float* dx) {
+    hipLaunchKernelGGL(gnb_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, x, da, mask, st, np, gamma, beta, HW, C, nchunk, silu, cpart);
+    // (plane sums + finalize as ONE single-workgroup launch measured 46 us against 10 + 15 us for the pair; as (C / 32 + B) workgroups of 1024 threads it is one launch)
+    hipLaunchKernelGGL(gnb_bwd_reduce_kernel, dim3((C + 31) / 32 + B), dim3(GNB_RED_NT), 2 * GNB_RED_NT * sizeof(double), s, (const double*)cpart, gamma, B, nchunk, C, dgamma, dbeta, S);
+    if (dx) hipLaunchKernelGGL(gnb_bwd_dx_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, da, mask, st, np, gamma, beta, (const float*)S, res, HW, C, silu, dx);
 }
 }  // namespace tk
 }  // namespace ddif

@@ -193,6 +193,20 @@ int ddif_plan_train_set_droppath(ddif_plan_t plan, const float* scales_host, voi
     DDIF_GUARD_END
 }
 
+int ddif_plan_train_get_dropout(ddif_plan_t plan, int site, float* mask, void* stream) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_get_dropout");
+    return plan->p.train_get_dropout(site, mask, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
+int ddif_plan_train_get_droppath(ddif_plan_t plan, float* scales_dev, void* stream) {
+    DDIF_GUARD_BEGIN
+    DDIF_PLAN_ENTER(plan, "ddif_plan_train_get_droppath");
+    return plan->p.train_get_droppath(scales_dev, (hipStream_t)stream);
+    DDIF_GUARD_END
+}
+
 int ddif_plan_train_random_masks(ddif_plan_t plan, uint64_t seed, uint64_t tile0, float p_dropout, float p_droppath, void* stream) {
     DDIF_GUARD_BEGIN
     DDIF_PLAN_ENTER(plan, "ddif_plan_train_random_masks");

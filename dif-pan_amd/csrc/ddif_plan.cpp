@@ -301,6 +301,8 @@ int Plan::build() {
     cdec.clear();
     drop_sites.clear();
     path_sites.clear();
+    mask_recs = nullptr;
+    n_mask_recs = 0;
     n_conv3 = n_conv3_x3 = 0;
     tb_rows = 0;
     tb = tvals = nullptr;
@@ -1746,17 +1748,51 @@ int Plan::train_set_droppath(const float* scales_host, hipStream_t s) {
         DDIF_HIPCHK(hipMemcpyAsync(path_sites[k], scales_host + k * B, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
     return 0;
 }
+int Plan::train_get_dropout(int site, float* mask_nchw, hipStream_t s) {
+    if (!train_mode) return fail(DDIF_ERR_STATE, "not a train-mode plan (ddif_plan_create_train)");
+    if (site < 0 || site >= (int)drop_sites.size() || !mask_nchw) return fail(DDIF_ERR_INVALID, "ddif_plan_train_get_dropout: bad site %d of %d", site, (int)drop_sites.size());
+    const DropSite& d = drop_sites[site];
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid((size_t)B * d.H * d.W * d.C), dim3(256), 0, s, (const float*)d.mask, B, d.C, d.H * d.W, mask_nchw);
+    DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+int Plan::train_get_droppath(float* scales_dev, hipStream_t s) {
+    if (!train_mode) return fail(DDIF_ERR_STATE, "not a train-mode plan (ddif_plan_create_train)");
+    if (!scales_dev) return fail(DDIF_ERR_INVALID, "ddif_plan_train_get_droppath: NULL");
+    for (size_t k = 0; k < path_sites.size(); ++k)
+        DDIF_HIPCHK(hipMemcpyAsync(scales_dev + k * B, path_sites[k], (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
 int Plan::train_random_masks(uint64_t seed, uint64_t tile0, float p_drop, float p_path, hipStream_t s) {
     if (!train_mode) return fail(DDIF_ERR_STATE, "not a train-mode plan (ddif_plan_create_train)");
     if (!(p_drop >= 0.f && p_drop < 1.f && p_path >= 0.f && p_path < 1.f)) return fail(DDIF_ERR_INVALID, "drop probabilities must be in [0, 1)");
-    for (size_t k = 0; k < drop_sites.size(); ++k) {
-        const DropSite& d = drop_sites[k];
-        hipLaunchKernelGGL(dropout_mask_kernel, ew_grid((size_t)B * d.H * d.W * d.C), dim3(256), 0, s, d.mask, B, d.C, d.H * d.W, (unsigned long long)seed, (unsigned)k,
-                           (unsigned long long)tile0, 1.f - p_drop);
+    if (!mask_recs) {  // the table of sites (fixed for the life of the plan): dropout sites first, DropPath sites after them, numbered in that order
+        std::vector<MaskRec> tab;
+        unsigned long long blk = 0;
+        auto push = [&](float* m, int C_, int HW_, int path) {
+            MaskRec r{};
+            r.mask = m;
+            r.C = C_;
+            r.HW = HW_;
+            r.site = (unsigned)tab.size();
+            r.path = path;
+            r.blk0 = blk;
+            const size_t units = (HW_ & 3) == 0 ? (size_t)B * (HW_ >> 2) * C_ : (size_t)B * HW_ * C_;
+            blk += (units + MASK_QPB - 1) / MASK_QPB;
+            tab.push_back(r);
+        };
+        for (const DropSite& d : drop_sites) push(d.mask, d.C, d.H * d.W, 0);
+        for (float* p : path_sites) push(p, 1, 1, 1);
+        if (tab.empty()) return 0;
+        float* raw = nullptr;
+        if (int e = dalloc(&raw, (tab.size() * sizeof(MaskRec) + sizeof(float) - 1) / sizeof(float))) return e;
+        DDIF_HIPCHK(hipMemcpy(raw, tab.data(), tab.size() * sizeof(MaskRec), hipMemcpyHostToDevice));
+        mask_recs = raw;
+        n_mask_recs = (int)tab.size();
+        mask_blocks = blk;
     }
-    for (size_t k = 0; k < path_sites.size(); ++k)  // one "pixel" per sample: the same generator, site numbers after the dropout sites
-        hipLaunchKernelGGL(dropout_mask_kernel, dim3(1), dim3(64), 0, s, path_sites[k], B, 1, 1, (unsigned long long)seed, (unsigned)(drop_sites.size() + k),
-                           (unsigned long long)tile0, 1.f - p_path);
+    hipLaunchKernelGGL(train_masks_kernel, dim3((unsigned)mask_blocks), dim3(256), 0, s, reinterpret_cast<const MaskRec*>(mask_recs), n_mask_recs, B,
+                       (unsigned long long)seed, (unsigned long long)tile0, 1.f - p_drop, 1.f - p_path);
     DDIF_HIPCHK(hipGetLastError());
     return 0;
 }

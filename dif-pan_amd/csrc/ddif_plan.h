@@ -62,10 +62,10 @@ int wgrad_prepare();
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw,
            float* bpart = nullptr, float* db = nullptr);  // db: the bias gradient too (bpart: >= nsplit * n_co * 32 floats of scratch)
 void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db);
-void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart, float* ms);
-void gn_act(hipStream_t s, const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out);
-void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta, int B, int HW, int C, int nchunk,
-            int silu, double* cpart, double* planes, float* S, float* dgamma, float* dbeta, float* dx);
+void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart);
+void gn_act(hipStream_t s, const float* x, const double* st, int np, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out);
+void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma, const float* beta, int B, int HW, int C,
+            int nchunk, int silu, double* cpart, float* S, float* dgamma, float* dbeta, const float* res, float* dx);
 // kernels_bwd_ops.h  (ddif_bwd_ops.cpp)
 void linear_bwd(hipStream_t s, const float* x, const float* w, const float* dy, int B, int nin, int nout, float* dx, float* dw, float* db);
 void l1_fwd(hipStream_t s, const float* pred, const float* target, size_t n, float* out);
@@ -114,6 +114,9 @@ struct Plan {
     struct DropSite { float* mask; int C, H, W; };
     std::vector<DropSite> drop_sites;      // NHWC masks (0 or 1/(1-p)), one per Block with dropout, in execution order
     std::vector<float*> path_sites;        // per-sample DropPath scales [B], one per FastAttnCondInjection, in execution order
+    float* mask_recs = nullptr;            // device table of every site for the one-launch mask generator (kernels_misc.h MaskRec), built on first use
+    int n_mask_recs = 0;
+    unsigned long long mask_blocks = 0;
     size_t bytes_allocated = 0;
 
     // fixed buffers
@@ -222,6 +225,8 @@ struct Plan {
 
     int train_set_dropout(int site, const float* mask_nchw, hipStream_t s);
     int train_set_droppath(const float* scales_host, hipStream_t s);
+    int train_get_dropout(int site, float* mask_nchw, hipStream_t s);
+    int train_get_droppath(float* scales_dev, hipStream_t s);
     int train_random_masks(uint64_t seed, uint64_t tile0, float p_drop, float p_path, hipStream_t s);
     int set_cond(const float* cond, hipStream_t s);
     int forward(const float* x, const float* t_host, const float* sc, float* out, hipStream_t s);

@@ -46,9 +46,9 @@ void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int head
 }  // namespace tk
 
 struct Plan::TrainScratch {
-    float *a = nullptr, *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *bpart = nullptr, *ms = nullptr, *S = nullptr, *wpad = nullptr, *dwflip = nullptr;
-    double *spart = nullptr, *cpart = nullptr, *planes = nullptr, *dwpart = nullptr;
-    size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_planes = 0, n_wpad = 0, n_dwpart = 0, n_dwflip = 0;
+    float *a = nullptr, *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *bpart = nullptr, *S = nullptr, *wpad = nullptr, *dwflip = nullptr;
+    double *spart = nullptr, *cpart = nullptr, *dwpart = nullptr;
+    size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_wpad = 0, n_dwpart = 0, n_dwflip = 0;
     const float* stem_sc = nullptr;  // set by train_step: the self-conditioning source of THIS iteration (sc_in or x_in)
     // time MLP backward
     float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr;
@@ -126,21 +126,34 @@ int Plan::build_backward() {
     };
     // backward of  [GroupNorm (+SiLU) (+mask)] -> conv  (one `Block` of the reference, :288-300, and the other normalised convs)
     //   pro: 0 none, 1 GroupNorm, 2 GroupNorm + SiLU.  a_mat: the conv's input if the forward materialised it (block2's dropped activation).
+    //   res: a gradient to add to dx (the residual path of a ResnetBlock / SelfAttention), folded into GroupNorm's dx launch.
     auto add_block_bwd = [&](Seq& L, Tensor x, int pro, const std::string& nkey, const float* mask, const float* a_mat, const std::string& ckey, int ks, bool has_bias,
-                             Tensor dy, bool need_dx, float** dx_out) -> int {
+                             Tensor dy, bool need_dx, float** dx_out, const float* res = nullptr) -> int {
         const int HW = x.H * x.W, C = x.C;
         const size_t n = numel(x);
         const int nchunk = HW < 32 ? HW : 32;
         const float *gamma = nullptr, *beta = nullptr;
+        const double* fst = nullptr;
+        int fnp = 0;
         if (pro) {
             gamma = V(nkey + ".weight");
             beta = V(nkey + ".bias");
             if (!gamma || !beta) return fail(DDIF_ERR_MISSING, "training: %s weights missing", nkey.c_str());
             need(T->n_cpart, (size_t)BB * nchunk * C * 2);
-            need(T->n_planes, (size_t)BB * C * 2);
             if (!a_mat) need(T->n_a, n);
-            L.v.push_back([=](hipStream_t st) { tk::gn_stats(st, x.p, BB, (size_t)HW * C, nchunk, T->spart, T->ms); });
-            if (!a_mat) L.v.push_back([=](hipStream_t st) { tk::gn_act(st, x.p, T->ms, gamma, beta, mask, BB, HW, C, pro == 2, T->a); });
+            // statistics of x: the fp64 partials its forward producer left behind (no second read of x); recomputed if there are none
+            if (x.st && x.np > 0 && !getenv("DDIF_TRAIN_GN_RESTAT")) {
+                fst = x.st;
+                fnp = x.np;
+            } else {
+                fnp = nchunk;
+                L.v.push_back([=](hipStream_t st) { tk::gn_stats(st, x.p, BB, (size_t)HW * C, nchunk, T->spart); });
+            }
+            if (!a_mat) {
+                const double* fs = fst;
+                const int fn = fnp;
+                L.v.push_back([=](hipStream_t st) { tk::gn_act(st, x.p, fs ? fs : T->spart, fn, gamma, beta, mask, BB, HW, C, pro == 2, T->a); });
+            }
         }
         float** dw = G(ckey + ".weight");
         float** db = has_bias ? G(ckey + ".bias") : nullptr;
@@ -160,6 +173,7 @@ int Plan::build_backward() {
         DDIF_TRY(add_dgrad(L, ckey, dy, &da));
         if (da.C != C) return fail(DDIF_ERR_STATE, "training: dgrad of %s yields %d channels, expected %d", ckey.c_str(), da.C, C);
         if (!pro) {
+            if (res) return fail(DDIF_ERR_STATE, "training: residual fusion needs the GroupNorm form of the block");
             *dx_out = da.p;
             return 0;
         }
@@ -168,7 +182,7 @@ int Plan::build_backward() {
         float** dg = G(nkey + ".weight");
         float** dbt = G(nkey + ".bias");
         L.v.push_back([=](hipStream_t st) {
-            tk::gn_bwd(st, x.p, da.p, mask, T->ms, gamma, beta, BB, HW, C, nchunk, pro == 2, T->cpart, T->planes, T->S, *dg, *dbt, dx);
+            tk::gn_bwd(st, x.p, da.p, mask, fst ? fst : T->spart, fnp, gamma, beta, BB, HW, C, nchunk, pro == 2, T->cpart, T->S, *dg, *dbt, res, dx);
         });
         *dx_out = dx;
         return 0;
@@ -255,10 +269,7 @@ int Plan::build_backward() {
                 Tensor dh1T = h1;
                 dh1T.p = dh1;
                 dh1T.st = nullptr;
-                float* dx1 = nullptr;
-                DDIF_TRY(add_block_bwd(L, m.in, 2, rb + ".block1.block.0", nullptr, nullptr, rb + ".block1.block.3", 3, true, dh1T, true, &dx1));
-                DDIF_TRY(fbuf(&dx, numel(m.in)));
-                add_add2(L, dx1, dy, numel(m.in), dx);  // + the residual path
+                DDIF_TRY(add_block_bwd(L, m.in, 2, rb + ".block1.block.0", nullptr, nullptr, rb + ".block1.block.3", 3, true, dh1T, true, &dx, dy));  // + the residual path
                 break;
             }
             case TrainMod::ATTN: {
@@ -279,10 +290,7 @@ int Plan::build_backward() {
                 Tensor dq = qkv;
                 dq.p = dqkv;
                 dq.st = nullptr;
-                float* dx1 = nullptr;
-                DDIF_TRY(add_block_bwd(L, m.in, 1, m.key + ".norm", nullptr, nullptr, m.key + ".qkv", 1, false, dq, true, &dx1));
-                DDIF_TRY(fbuf(&dx, numel(m.in)));
-                add_add2(L, dx1, dy, numel(m.in), dx);
+                DDIF_TRY(add_block_bwd(L, m.in, 1, m.key + ".norm", nullptr, nullptr, m.key + ".qkv", 1, false, dq, true, &dx, dy));  // + the residual path
                 break;
             }
             case TrainMod::FILM: {
@@ -511,7 +519,6 @@ int Plan::build_backward() {
                     need(T->n_a, npix * fea);     // cat[h, skip]
                     need(T->n_tmp, npix * fea);   // its gradient
                     need(T->n_cpart, (size_t)BB * nchunk * fea * 2);
-                    need(T->n_planes, (size_t)BB * fea * 2);
                     float** dg = G(ci + ".prenorm_x.weight");
                     float** dbt = G(ci + ".prenorm_x.bias");
                     float* dskip = nullptr;
@@ -520,8 +527,8 @@ int Plan::build_backward() {
                     const Tensor hin = m.in;
                     L.v.push_back([=](hipStream_t st) {
                         hipLaunchKernelGGL(concat2_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)hin.p, Ca, (const float*)skip.p, Cb, npix, T->a);
-                        tk::gn_stats(st, T->a, BB, (size_t)HW * fea, nchunk, T->spart, T->ms);
-                        tk::gn_bwd(st, T->a, dxn, nullptr, T->ms, gamma, beta, BB, HW, fea, nchunk, 0, T->cpart, T->planes, T->S, *dg, *dbt, T->tmp);
+                        tk::gn_stats(st, T->a, BB, (size_t)HW * fea, nchunk, T->spart);
+                        tk::gn_bwd(st, T->a, dxn, nullptr, T->spart, nchunk, gamma, beta, BB, HW, fea, nchunk, 0, T->cpart, T->S, *dg, *dbt, nullptr, T->tmp);
                         hipLaunchKernelGGL(split2_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)T->tmp, Ca, Cb, npix, (const float*)nullptr, (const float*)nullptr, dx, dskip);
                     });
                     if (m.skip_from < 0) return fail(DDIF_ERR_STATE, "training: decoder block without a skip source");
@@ -585,13 +592,11 @@ int Plan::build_backward() {
     DDIF_TRY(fbuf(&T->tmp, T->n_tmp + 64));
     DDIF_TRY(fbuf(&T->partial, T->n_partial + 64));
     DDIF_TRY(fbuf(&T->bpart, T->n_bpart + 64));
-    DDIF_TRY(fbuf(&T->ms, (size_t)BB * 2 + 64));
     DDIF_TRY(fbuf(&T->S, (size_t)BB * 2 + 64));
     DDIF_TRY(fbuf(&T->wpad, T->n_wpad + 64));
     DDIF_TRY(fbuf(&T->dwflip, T->n_dwflip + 64));
     DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 512));
     DDIF_TRY(dalloc(&T->cpart, T->n_cpart + 64));
-    DDIF_TRY(dalloc(&T->planes, T->n_planes + 64));
     DDIF_TRY(dalloc(&T->dwpart, T->n_dwpart + 64));
 
     for (auto& L : seqs) {

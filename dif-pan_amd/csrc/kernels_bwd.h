@@ -374,25 +374,15 @@ __global__ __launch_bounds__(256) void gnb_stats_kernel(const float* x, size_t p
         part[((size_t)b * nchunk + blockIdx.x) * 2 + 1] = red[256];
     }
 }
-__global__ void gnb_finalize_stats_kernel(const double* part, int nchunk, double n, int B, float* ms /* [B][2]: mean, rstd */) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        s1 += part[((size_t)b * nchunk + k) * 2 + 0];
-        s2 += part[((size_t)b * nchunk + k) * 2 + 1];
-    }
-    const double mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    ms[b * 2 + 0] = (float)mean;
-    ms[b * 2 + 1] = (float)(1.0 / sqrt(var + DDIF_GN_EPS));
-}
+// The consumers below take the fp64 partials {sum, sum of squares} [B][np][2] themselves -- the ones gnb_stats_kernel wrote or, in the training
+// step, the ones the FORWARD producer of x left behind (Tensor::st) -- and every wavefront finalises mean / rstd for itself
+// (gn_finalize_wave, the same code the forward prologues run): no statistics launch of its own, no second read of x.
 // a = silu(gamma x_hat + beta) * mask     grid = (chunks, B)
-__global__ __launch_bounds__(256) void gnb_act_kernel(const float* x, const float* ms, const float* gamma, const float* beta, const float* mask, int HW, int C,
-                                                      int silu, float* out) {
+__global__ __launch_bounds__(256) void gnb_act_kernel(const float* x, const double* st, int np, const float* gamma, const float* beta, const float* mask, int HW,
+                                                      int C, int silu, float* out) {
     const int b = blockIdx.y;
-    const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
+    float mean, rstd;
+    gn_finalize_wave(st, np, nullptr, 0, b, (double)C * HW, &mean, &rstd);
     const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
@@ -414,13 +404,14 @@ __device__ __forceinline__ float gnb_dy(float xh, float g, float bt, float da, f
     return da * m * (s * (1.f + y * (1.f - s)));
 }
 // per (sample, pixel chunk, channel): {sum dy, sum dy x_hat}.  grid = (nchunk, B); thread = (pixel row r, channel quad q)
-__global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma,
+__global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma,
                                                               const float* beta, int HW, int C, int nchunk, int silu, double* cpart /* [B][nchunk][C][2] */) {
     DDIF_DYN_SMEM(smem_);
     double* red = reinterpret_cast<double*>(smem_);  // [256][8]
     const int b = blockIdx.y, tid = threadIdx.x;
     const int C4 = C / 4, rows = 256 / C4 > 0 ? 256 / C4 : 1;
-    const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
+    float mean, rstd;
+    gn_finalize_wave(st, np, nullptr, 0, b, (double)C * HW, &mean, &rstd);
     const int per = (HW + nchunk - 1) / nchunk;
     const int p0 = blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
     for (int q0 = 0; q0 < C4; q0 += 256) {  // C > 1024: several passes over channel quads
@@ -454,79 +445,95 @@ __global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, co
         __syncthreads();
     }
 }
-// plane sums pl[b][c][2] = sum over chunks; one thread per (b, c)
-__global__ void gnb_bwd_planes_kernel(const double* cpart, int B, int nchunk, int C, double* pl) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * C) return;
-    const size_t b = i / C, c = i % C;
+// Everything that follows the per-chunk partials, in ONE launch of 1024-thread workgroups (it replaces a plane-sum launch and a finalize launch):
+//   workgroups [0, ceil(C / 32)):  dgamma[c] = sum_{b,k} cpart[b][k][c][1], dbeta[c] = sum_{b,k} cpart[b][k][c][0]  for 32 channels each
+//                                  (thread = (channel, one of 32 interleaved (b, k) slices), eight loads in flight, fixed-order LDS tree over the slices)
+//   workgroups [nC, nC + B):       S[b] = {sum_{c,k} gamma[c] cpart[b][k][c][0], .. [1]} / C   (divided by HW in the consumer: N = C * HW)
+// fp64, fixed order: bitwise reproducible.
+constexpr int GNB_RED_NT = 1024;
+__global__ __launch_bounds__(GNB_RED_NT) void gnb_bwd_reduce_kernel(const double* cpart, const float* gamma, int B, int nchunk, int C, float* dgamma, float* dbeta,
+                                                                     float* S /* [B][2] */) {
+    DDIF_DYN_SMEM(smem_);
+    double(*red)[GNB_RED_NT] = reinterpret_cast<double(*)[GNB_RED_NT]>(smem_);  // [2][GNB_RED_NT]
+    const int tid = threadIdx.x;
+    const int nC = (C + 31) / 32;
     double s0 = 0.0, s1 = 0.0;
-    for (int k0 = 0; k0 < nchunk; k0 += 8) {  // eight chunks' loads in flight, summed in chunk order
-        double v0[8], v1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u < nchunk ? k0 + u : nchunk - 1;
-            v0[u] = cpart[((b * nchunk + k) * C + c) * 2 + 0];
-            v1[u] = cpart[((b * nchunk + k) * C + c) * 2 + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k0 + u < nchunk) {
-                s0 += v0[u];
-                s1 += v1[u];
-            }
-    }
-    pl[i * 2 + 0] = s0;
-    pl[i * 2 + 1] = s1;
-}
-// threads [0, C): dgamma / dbeta (sum over samples);  threads [C, C + B): S1_b, S2_b (sum over channels, weighted by gamma)
-__global__ void gnb_bwd_finalize_kernel(const double* pl, const float* gamma, int B, int C, float* dgamma, float* dbeta, float* S /* [B][2] */) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < C) {
-        double g = 0.0, bt = 0.0;
-        for (int b0 = 0; b0 < B; b0 += 8) {  // eight samples' loads in flight, summed in sample order
+    if ((int)blockIdx.x < nC) {
+        const int c = blockIdx.x * 32 + (tid & 31), sl = tid >> 5;  // slice sl takes the pairs (b, k) = sl, sl + 32, ...
+        const int npair = B * nchunk;
+        const int cc = c < C ? c : C - 1;
+        for (int p0 = sl; p0 < npair; p0 += 32 * 8) {
             double v0[8], v1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int b = b0 + u < B ? b0 + u : B - 1;
-                v0[u] = pl[((size_t)b * C + i) * 2 + 0];
-                v1[u] = pl[((size_t)b * C + i) * 2 + 1];
+                const int pr = p0 + 32 * u < npair ? p0 + 32 * u : sl;
+                v0[u] = cpart[((size_t)pr * C + cc) * 2 + 0];
+                v1[u] = cpart[((size_t)pr * C + cc) * 2 + 1];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (b0 + u < B) {
-                    bt += v0[u];
-                    g += v1[u];
+                if (p0 + 32 * u < npair) {
+                    s0 += v0[u];
+                    s1 += v1[u];
                 }
         }
-        if (dgamma) dgamma[i] = (float)g;
-        if (dbeta) dbeta[i] = (float)bt;
-    } else if (i < C + B) {
-        const int b = i - C;
-        double s1 = 0.0, s2 = 0.0;
-        for (int c0 = 0; c0 < C; c0 += 8) {  // C is a multiple of 4; the clamped tail is masked
-            double v0[8], v1[8], gm[8];
+        red[0][tid] = s0;
+        red[1][tid] = s1;
+        __syncthreads();
+        for (int st = 16; st >= 1; st >>= 1) {  // over the 32 slices (tid >> 5), channel kept in the low 5 bits
+            if (sl < st) {
+                red[0][tid] += red[0][tid + st * 32];
+                red[1][tid] += red[1][tid + st * 32];
+            }
+            __syncthreads();
+        }
+        if (sl == 0 && c < C) {
+            if (dbeta) dbeta[c] = (float)red[0][tid];
+            if (dgamma) dgamma[c] = (float)red[1][tid];
+        }
+    } else {
+        const int b = blockIdx.x - nC;
+        const int n = nchunk * C;  // entries (k, c) of sample b, c fastest
+        const double* base = cpart + (size_t)b * n * 2;
+        for (int i0 = tid; i0 < n; i0 += GNB_RED_NT * 4) {
+            double v0[4], v1[4], gm[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + u < C ? c0 + u : C - 1;
-                gm[u] = (double)gamma[c];
-                v0[u] = pl[((size_t)b * C + c) * 2 + 0];
-                v1[u] = pl[((size_t)b * C + c) * 2 + 1];
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + GNB_RED_NT * u < n ? i0 + GNB_RED_NT * u : tid % n;
+                gm[u] = (double)gamma[i % C];
+                v0[u] = base[(size_t)i * 2 + 0];
+                v1[u] = base[(size_t)i * 2 + 1];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c0 + u < C) {
-                    s1 += gm[u] * v0[u];
-                    s2 += gm[u] * v1[u];
+            for (int u = 0; u < 4; ++u)
+                if (i0 + GNB_RED_NT * u < n) {
+                    s0 += gm[u] * v0[u];
+                    s1 += gm[u] * v1[u];
                 }
         }
-        S[b * 2 + 0] = (float)(s1 / ((double)C));  // divided by HW in the consumer (N = C * HW)
-        S[b * 2 + 1] = (float)(s2 / ((double)C));
+        red[0][tid] = s0;
+        red[1][tid] = s1;
+        __syncthreads();
+        for (int st = GNB_RED_NT / 2; st >= 1; st >>= 1) {
+            if (tid < st) {
+                red[0][tid] += red[0][tid + st];
+                red[1][tid] += red[1][tid + st];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            S[b * 2 + 0] = (float)(red[0][0] / ((double)C));
+            S[b * 2 + 1] = (float)(red[1][0] / ((double)C));
+        }
     }
 }
-__global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* da, const float* mask, const float* ms, const float* gamma, const float* beta,
-                                                         const float* S, int HW, int C, int silu, float* dx) {
+// dx = rstd (gamma dy - m1 - x_hat m2)  (+ res: the gradient arriving over the residual path of a ResnetBlock / SelfAttention, added here instead
+// of by a launch of its own)
+__global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma,
+                                                         const float* beta, const float* S, const float* res, int HW, int C, int silu, float* dx) {
     const int b = blockIdx.y;
-    const float mean = ms[b * 2], rstd = ms[b * 2 + 1];
+    float mean, rstd;
+    gn_finalize_wave(st, np, nullptr, 0, b, (double)C * HW, &mean, &rstd);
     const float m1 = S[b * 2] / (float)HW, m2 = S[b * 2 + 1] / (float)HW;
     const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -539,6 +546,13 @@ __global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const f
             const float xh = ((&xv.x)[k] - mean) * rstd;
             const float dy = gnb_dy(xh, gamma[c + k], beta[c + k], (&dv.x)[k], mask ? mask[base + i * 4 + k] : 1.f, silu);
             o[k] = rstd * (gamma[c + k] * dy - m1 - xh * m2);
+        }
+        if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + base + i * 4);
+            o[0] += rv.x;
+            o[1] += rv.y;
+            o[2] += rv.z;
+            o[3] += rv.w;
         }
         *reinterpret_cast<float4*>(dx + base + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }

@@ -456,7 +456,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 // the dropout sits between the GroupNorm + SiLU prologue and the conv, so the activation is materialised once:
 //   y = silu(GroupNorm(x)) * mask        gn_silu_drop_kernel   (mask holds 0 or 1/(1-p); y is also what wgrad will need)
 //   out = f * scale[b] + res             droppath_add_kernel   (scale[b] in {0, 1/(1-p)}; emits the GroupNorm partial of out)
-//   mask generation                      dropout_mask_kernel   (Philox keyed by (seed, site, NCHW element): split-invariant)
+//   mask generation                      train_masks_kernel    (every site in one launch; Philox keyed by (seed, site, NCHW element): split-invariant)
 // grid = (chunks, B), 256 threads, float4 over C (C % 4 == 0).
 __global__ __launch_bounds__(256) void gn_silu_drop_kernel(const float* x, const double* st, int np, const float* gamma, const float* beta,
                                                            const float* mask, int HW, int C, float* y) {
@@ -511,18 +511,60 @@ __global__ __launch_bounds__(256) void droppath_add_kernel(const float* f, const
     }
 }
 
-// mask (NHWC) of one dropout site: element index = its NCHW position in the (tile0 + b)-th tile, like the sampler noise
-__global__ void dropout_mask_kernel(float* mask, int B, int C, int HW, unsigned long long seed, unsigned site, unsigned long long tile0, float keep) {
-    const size_t total = (size_t)B * HW * C;
-    const float inv = 1.0f / keep;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
-        unsigned o[4];
-        const unsigned long long e = ((tile0 + b) * C + c) * HW + p;
-        philox4x32_10((unsigned)e, (unsigned)(e >> 32), site, 0xD0F0u, (unsigned)seed, (unsigned)(seed >> 32), o);
-        const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        mask[i] = u < keep ? inv : 0.f;
+// Masks of ALL dropout / DropPath sites of a train-mode plan in one launch.  Element e of a site = its NCHW position in the (tile0 + b)-th
+// tile, like the sampler noise, so a batch split over ranks or calls draws the same masks.  One Philox4x32-10 block serves the four
+// elements 4q .. 4q+3 (counter = (q, site), key = seed): with 4 | H*W these are four neighbouring pixels of one channel plane.
+struct MaskRec {
+    float* mask;              // NHWC [B][HW][C]
+    int C, HW;
+    unsigned site;
+    int path;                 // 1: a DropPath site (keep = keep_path)
+    unsigned long long blk0;  // first workgroup of this site
+};
+constexpr int MASK_QPB = 1024;  // Philox blocks (4 elements each) per workgroup
+__global__ __launch_bounds__(256) void train_masks_kernel(const MaskRec* recs, int n_recs, int B, unsigned long long seed, unsigned long long tile0, float keep_drop,
+                                                          float keep_path) {
+    int lo = 0, hi = n_recs - 1;
+    while (lo < hi) {  // the last record whose first workgroup is <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (recs[mid].blk0 <= blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const MaskRec r = recs[lo];
+    const float keep = r.path ? keep_path : keep_drop, inv = 1.0f / keep;
+    const size_t q0 = ((size_t)blockIdx.x - r.blk0) * MASK_QPB;
+    if ((r.HW & 3) == 0) {
+        const int HW4 = r.HW >> 2;
+        const size_t nq = (size_t)B * HW4 * r.C;
+        for (int k = threadIdx.x; k < MASK_QPB; k += 256) {
+            const size_t i = q0 + k;  // (b, p4, c), c fastest: neighbouring lanes write neighbouring channels
+            if (i >= nq) break;
+            const int c = (int)(i % r.C);
+            const size_t p4 = (i / r.C) % HW4, b = i / ((size_t)r.C * HW4);
+            const unsigned long long q = ((tile0 + b) * r.C + c) * HW4 + p4;  // = e >> 2 of the four elements
+            unsigned o[4];
+            philox4x32_10((unsigned)q, (unsigned)(q >> 32), r.site, 0xD0F0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+            float* dst = r.mask + ((size_t)b * r.HW + p4 * 4) * r.C + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = ((float)(o[j] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                dst[(size_t)j * r.C] = u < keep ? inv : 0.f;
+            }
+        }
+    } else {  // general shape (DropPath: one element per sample): element e takes word e & 3 of block e >> 2
+        const size_t n = (size_t)B * r.HW * r.C;
+        for (int k = threadIdx.x; k < MASK_QPB; k += 256) {
+            const size_t i = q0 + k;
+            if (i >= n) break;
+            const int c = (int)(i % r.C);
+            const size_t p = (i / r.C) % r.HW, b = i / ((size_t)r.C * r.HW);
+            const unsigned long long e = ((tile0 + b) * r.C + c) * r.HW + p, q = e >> 2;
+            unsigned o[4];
+            philox4x32_10((unsigned)q, (unsigned)(q >> 32), r.site, 0xD0F0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+            const unsigned w = (e & 3) == 0 ? o[0] : ((e & 3) == 1 ? o[1] : ((e & 3) == 2 ? o[2] : o[3]));
+            const float u = ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            r.mask[i] = u < keep ? inv : 0.f;
+        }
     }
 }
 

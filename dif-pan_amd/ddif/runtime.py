@@ -95,6 +95,8 @@ class _Lib:
         d.ddif_plan_train_set_dropout.argtypes = [vp, i32, vp, vp]
         d.ddif_plan_train_set_droppath.argtypes = [vp, vp, vp]
         d.ddif_plan_train_random_masks.argtypes = [vp, u64, u64, f32, f32, vp]
+        d.ddif_plan_train_get_dropout.argtypes = [vp, i32, vp, vp]
+        d.ddif_plan_train_get_droppath.argtypes = [vp, vp, vp]
         d.ddif_plan_destroy.argtypes = [vp]
         d.ddif_plan_destroy.restype = None
         d.ddif_plan_set_cond.argtypes = [vp, vp, vp]
@@ -372,6 +374,21 @@ class PlanHandle:
     def random_train_masks(self, seed: int, tile0: int, p_dropout: float, p_droppath: float):
         self.lib.check(self.lib.dll.ddif_plan_train_random_masks(self.h, int(seed), int(tile0), float(p_dropout), float(p_droppath),
                                                                  _stream(self.lib, self.net.device)), "ddif_plan_train_random_masks")
+
+    def train_masks(self):
+        """The masks in force: ([dropout mask (B,C,H,W) per site], DropPath scales (n_sites, B)) -- what `set_train_masks` accepts."""
+        shapes, npth = self.train_sites()
+        dev = torch.device(self.net.device)
+        st = _stream(self.lib, dev)
+        masks = []
+        for k, shp in enumerate(shapes):
+            m = torch.empty((self.B,) + shp, dtype=torch.float32, device=dev)
+            self.lib.check(self.lib.dll.ddif_plan_train_get_dropout(self.h, k, _ptr(m), st), "ddif_plan_train_get_dropout")
+            masks.append(m)
+        sc = torch.empty((npth, self.B), dtype=torch.float32, device=dev)
+        if npth:
+            self.lib.check(self.lib.dll.ddif_plan_train_get_droppath(self.h, _ptr(sc), st), "ddif_plan_train_get_droppath")
+        return masks, sc
 
     # -- native training step ---------------------------------------------------------------------------------------
     def train_bind(self, named_grads):

@@ -226,6 +226,9 @@ DDIF_API int ddif_plan_train_set_dropout(ddif_plan_t plan, int site, const float
 DDIF_API int ddif_plan_train_set_droppath(ddif_plan_t plan, const float* scales_host, void* stream);
 /* fresh masks from the counter-based generator, keyed by (seed, site, tile0 + sample, element): independent of the batch split */
 DDIF_API int ddif_plan_train_random_masks(ddif_plan_t plan, uint64_t seed, uint64_t tile0, float p_dropout, float p_droppath, void* stream);
+/* read the masks in force back (what nn.Dropout / DropPath would have drawn): mask (B,C,H,W) device; scales DEVICE [n_droppath][B] */
+DDIF_API int ddif_plan_train_get_dropout(ddif_plan_t plan, int site, float* mask, void* stream);
+DDIF_API int ddif_plan_train_get_droppath(ddif_plan_t plan, float* scales_dev, void* stream);
 
 /* Backward of nn.Conv2d(Cin, Cout, 3, padding=1) as autograd computes it under loss.backward() (diffusion_engine.py:233):
  *   dx = conv_transpose(dy, w), dw[co,ci,ky,kx] = sum dy[b,co,y,x] * x[b,ci,y+ky-1,x+kx-1], db[co] = sum dy[b,co,y,x].

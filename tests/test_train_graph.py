@@ -189,6 +189,48 @@ def test_loss_backward_through_the_drop_in_fills_parameter_grads_and_the_optimiz
         net.set_train_masks(None, None)
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_library_masks_are_split_invariant_reproducible_and_keep_the_right_fraction(backend):
+    """Dropout / DropPath masks drawn by the library (one launch for every site, Philox keyed by (seed, site, global tile, NCHW element)):
+    the masks of tiles 1..2 drawn in a batch of three equal those drawn by a plan of two tiles starting at tile 1 (what a DDP rank holding
+    the second shard draws), the same seed gives the same masks, another seed other ones, values are 0 or 1/(1-p), and about 1-p are kept."""
+    from ddif_testlib import make_net
+
+    dev = _dev(backend)
+    net = make_net("wv3", dev)
+    net.train()
+    try:
+        big = net.plan_for(3, 16, 16, dev, train=True)
+        small = net.plan_for(2, 16, 16, dev, train=True)
+        big.random_train_masks(1234, 0, 0.2, 0.2)
+        small.random_train_masks(1234, 1, 0.2, 0.2)
+        mb, pb = big.train_masks()
+        ms, ps = small.train_masks()
+        assert len(mb) == len(ms) > 20 and pb.shape[0] == ps.shape[0] > 0
+        kept = total = 0
+        for a, b in zip(mb, ms):
+            assert torch.equal(a[1:], b)
+            vals = torch.unique(a)
+            assert all(abs(float(v)) < 1e-12 or abs(float(v) - 1.25) < 1e-6 for v in vals)
+            kept += int((a > 0).sum())
+            total += a.numel()
+        assert torch.equal(pb[:, 1:], ps)
+        assert abs(kept / total - 0.8) < 0.01
+        assert not any(torch.equal(mb[0], m) for m in mb[1:] if m.shape == mb[0].shape)  # sites draw different masks
+        big.random_train_masks(1234, 0, 0.2, 0.2)
+        mb2, pb2 = big.train_masks()
+        assert all(torch.equal(a, b) for a, b in zip(mb, mb2)) and torch.equal(pb, pb2)
+        big.random_train_masks(1235, 0, 0.2, 0.2)
+        mb3, _ = big.train_masks()
+        assert not torch.equal(mb[0], mb3[0])
+        # a pinned set of masks goes back in unchanged
+        big.set_train_masks(mb, pb)
+        mb4, pb4 = big.train_masks()
+        assert all(torch.equal(a, b) for a, b in zip(mb, mb4)) and torch.equal(pb, pb4)
+    finally:
+        net.eval()
+
+
 def _raw_set(n, C, H, seed):
     """raw-count arrays like the reference's h5 training files: gt / lms at H x H, pan at H x H (values in [0, 2047])"""
     from ddif.synth import synth_tiles
