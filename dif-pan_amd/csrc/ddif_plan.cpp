@@ -1455,7 +1455,7 @@ int Plan::ensure_tb(int rows) {
 
 int Plan::time_rows(const float* t_host, int rows, hipStream_t s) {
     if (int e = ensure_tb(rows)) return e;
-    DDIF_HIPCHK(hipMemcpyAsync(tvals, t_host, (size_t)rows * sizeof(float), hipMemcpyHostToDevice, s));
+    DDIF_HIPCHK(hipMemcpyAsync(tvals, t_host, (size_t)rows * sizeof(float), hipMemcpyDefault, s));  // host or device source
     const int inner = net->cfg.inner_channel;
     hipLaunchKernelGGL(time_embed_kernel, dim3(rows), dim3(128), (size_t)6 * inner * sizeof(float), s, (const float*)tvals,
                        net->freqs, net->w1, net->b1, net->w3, net->b3, net->wall, net->ball, inner, net->nslots, tb, (float*)nullptr);
@@ -1466,7 +1466,7 @@ static int check_sampler_net(const Net* n);
 
 int Plan::time_rows_aux(const float* t_host, int rows, float* aux, hipStream_t s) {
     if (int e = ensure_tb(rows)) return e;
-    DDIF_HIPCHK(hipMemcpyAsync(tvals, t_host, (size_t)rows * sizeof(float), hipMemcpyHostToDevice, s));
+    DDIF_HIPCHK(hipMemcpyAsync(tvals, t_host, (size_t)rows * sizeof(float), hipMemcpyDefault, s));  // host or device source
     const int inner = net->cfg.inner_channel;
     hipLaunchKernelGGL(time_embed_kernel, dim3(rows), dim3(128), (size_t)6 * inner * sizeof(float), s, (const float*)tvals,
                        net->freqs, net->w1, net->b1, net->w3, net->b3, net->wall, net->ball, inner, net->nslots, tb, aux);
@@ -1501,8 +1501,8 @@ int Plan::train_step(const float* x0, const float* noise, const float* a_h, cons
     if (int e = check_sampler_net(net)) return e;
     const int HW = H * W;
     const size_t n = (size_t)B * HW * C;
-    DDIF_HIPCHK(hipMemcpyAsync(small, a_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
-    DDIF_HIPCHK(hipMemcpyAsync(small + B, s_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    DDIF_HIPCHK(hipMemcpyAsync(small, a_h, (size_t)B * sizeof(float), hipMemcpyDefault, s));  // host or device source
+    DDIF_HIPCHK(hipMemcpyAsync(small + B, s_h, (size_t)B * sizeof(float), hipMemcpyDefault, s));
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, x0, B, C, HW, 0, C, img[0]);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, noise, B, C, HW, 0, C, img[1]);
     hipLaunchKernelGGL(q_sample_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[0], (const float*)img[1], (const float*)small, (const float*)(small + B), B, (size_t)HW * C, x_in.p);
@@ -1875,8 +1875,8 @@ int Plan::q_sample_forward(const float* x0, const float* noise, const float* a_h
     if (int e = check_sampler_net(net)) return e;
     const int HW = H * W;
     const size_t n = (size_t)B * HW * C;
-    DDIF_HIPCHK(hipMemcpyAsync(small, a_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
-    DDIF_HIPCHK(hipMemcpyAsync(small + B, s_h, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    DDIF_HIPCHK(hipMemcpyAsync(small, a_h, (size_t)B * sizeof(float), hipMemcpyDefault, s));  // host or device source
+    DDIF_HIPCHK(hipMemcpyAsync(small + B, s_h, (size_t)B * sizeof(float), hipMemcpyDefault, s));
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, x0, B, C, HW, 0, C, img[0]);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, noise, B, C, HW, 0, C, img[1]);
     hipLaunchKernelGGL(q_sample_kernel, ew_grid(n), dim3(256), 0, s, (const float*)img[0], (const float*)img[1], (const float*)small, (const float*)(small + B), B, (size_t)HW * C, x_in.p);

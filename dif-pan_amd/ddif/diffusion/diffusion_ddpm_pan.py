@@ -306,6 +306,14 @@ class GaussianDiffusion(nn.Module):
             [0.0 if j == 0 else float(sigma[j]) for j in order], x_T, noise, 0 if seed is None else seed, tile0, clamp, dev)
 
     # ------------------------------------------------------------------------------------------------ training
+    def _schedule_rows(self, t):
+        """sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t) of the drawn timesteps, gathered where `t` lives: on the GPU nothing comes back to the host
+        (a `.cpu()` here would drain the stream once per training iteration)."""
+        tab_a, tab_s = self.sqrt_alphas_cumprod.detach(), self.sqrt_one_minus_alphas_cumprod.detach()
+        if tab_a.device != t.device:
+            tab_a, tab_s = tab_a.to(t.device), tab_s.to(t.device)
+        return tab_a[t], tab_s[t]
+
     def p_losses(self, x_start, noise=None, cond=None):
         """Reference :692-766, forward half: q_sample + (optional self-conditioning pass) + prediction + loss value.
         With the model in .train() mode both passes run the train-mode launch program (Dropout in every ResnetBlock,
@@ -329,8 +337,7 @@ class GaussianDiffusion(nn.Module):
             else:
                 plan.random_train_masks(self._seed_from_torch(), 0, float(self.model.cfg["dropout"]), self.model.DROP_PATH_PROB)
 
-        a = self.sqrt_alphas_cumprod.detach().cpu()[t.cpu()]
-        s = self.sqrt_one_minus_alphas_cumprod.detach().cpu()[t.cpu()]
+        a, s = self._schedule_rows(t)
         x_self_cond = None
         if self.self_condition and random.random() < 0.5:
             masks()
@@ -419,8 +426,7 @@ class GaussianDiffusion(nn.Module):
         t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
         noise = default(noise, lambda: torch.randn_like(x_start))
         named = [(n, p) for n, p in model.named_parameters()]
-        a = self.sqrt_alphas_cumprod.detach().cpu()[t.cpu()]
-        s = self.sqrt_one_minus_alphas_cumprod.detach().cpu()[t.cpu()]
+        a, s = self._schedule_rows(t)
         x_self_cond = None
         if self.self_condition and random.random() < 0.5:
             plan = self._native_plan(x_start, cond, named)

@@ -316,7 +316,7 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
                   schedule_type="cosine", n_steps=3_000, max_iterations=400_000, device="cuda:0", batch_size=128,
                   lr_d=1e-4, show_recon=False, pretrain_weight=None, pretrain_iterations=None, *, constrain_channel=None,
                   add_n_channel=1, ema_start_iter=20_000, valid_every=5_000, save_dir=None, save_every=5_000, resume_state=None,
-                  data_seed=0, log=print):
+                  data_seed=0, log=print, log_every=1):
     """Reference engine_google (:52-348): the training loop.  Same keyword names and defaults; `train_dataset_path` / `valid_dataset_path`
     may also be dicts {"pan", "lms", "gt"} of raw-count arrays (h5py is not part of this image).  Per iteration, as in the reference
     (:218-241): cond assembly (one kernel), `diff_loss, recon = diffusion(hr - lms, cond=cond)`, `diff_loss.backward()` (the library's
@@ -328,7 +328,8 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
     `ddif_metrics`.  Every `save_every` iterations (rank 0): `diffusion_{name}_iter_{N}.pth` and `ema_diffusion_{name}_iter_{N}.pth` as bare
     state_dicts like the reference (:333-340; `test_fn(weight_path=...)` loads either) plus `train_state_{name}_iter_{N}.pth` with the
     optimizer moments, step, iteration and RNG states; `resume_state=<that file>` continues such a run bit-identically.
-    Plotting, tensorboard and .mat dumps of the reference are out of scope.  Returns a dict with the loss history, the validation records,
+    `log_every` (not in the reference, default 1 = its behaviour): read the losses back and log every k-th iteration only -- the iteration
+    itself never synchronises with the host.  Plotting, tensorboard and .mat dumps of the reference are out of scope.  Returns a dict with the loss history, the validation records,
     the model, the diffusion wrapper and the EMA weights."""
     import random as _random
 
@@ -376,6 +377,13 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
     opt = _rt.FusedAdamW(params, grads, ema, lr=lr_d, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
     iterations = int(pretrain_iterations) if pretrain_iterations is not None else 0
     history, records = [], []
+    pending = []  # losses of the iterations since the last read-back (device scalars)
+
+    def flush_losses():
+        if pending:
+            history.extend(float(v) for v in torch.stack(pending).cpu())
+            pending.clear()
+
     resume_tiles = 0
     names = [n for n, _ in net.named_parameters()]
     if resume_state is not None:
@@ -458,19 +466,27 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
             opt.lr = lr_at(iterations, lr_d)
             # EmaUpdater.update(iterations) runs BEFORE `iterations += 1` (reference :239-242): copy while that 0-based count <= start_iter, lerp after
             mode = 2 if iterations > ema_start_iter else 1
-            gn = opt.step(max_grad_norm=0.003, ema_mode=mode, ema_decay=0.995, return_norm=True)
+            # the reference prints the loss every iteration (one host read-back each); `log_every=k` reads the losses back k at a time instead,
+            # so the stream is not drained in between (the step itself has no other synchronisation)
+            want_log = log_every <= 1 or (iterations + 1) % log_every == 0 or iterations + 1 >= max_iterations
+            gn = opt.step(max_grad_norm=0.003, ema_mode=mode, ema_decay=0.995, return_norm=want_log)
             iterations += 1
             net.mark_weights_dirty()  # the fused step wrote the parameters through raw pointers
-            history.append(float(diff_loss.detach()))
-            log(f"[iter {iterations}/{max_iterations}: d_lr {opt.lr: .6f}] - denoise loss {history[-1]:.6f} (grad norm {gn:.4f})")
+            pending.append(diff_loss.detach())
+            if want_log:
+                flush_losses()
+                log(f"[iter {iterations}/{max_iterations}: d_lr {opt.lr: .6f}] - denoise loss {history[-1]:.6f} (grad norm {gn:.4f})")
             if valid is not None and valid_every and iterations % valid_every == 0:
+                flush_losses()
                 rec = validate()
                 records.append((iterations, rec))
                 log(f"[iter {iterations}] validation: {rec}")
             if save_dir and save_every and iterations % save_every == 0 and rank == 0:
+                flush_losses()
                 save(iterations)
             if iterations >= max_iterations:
                 break
+    flush_losses()
     net.eval()
     return {"loss": history, "validation": records, "model": net, "diffusion": diffusion, "ema": ema, "iterations": iterations,
             "optimizer": opt}

@@ -320,6 +320,15 @@ class NetHandle:
             pass
 
 
+def _row(v, device):
+    """A per-sample row (sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t), t) as B contiguous floats: left on `device` when it already is there (the
+    library copies it on the stream -- no host round trip, no synchronisation), else on the host."""
+    v = v.detach()
+    if v.device == device and device.type == "cuda":
+        return v.to(torch.float32).contiguous()
+    return v.to("cpu", torch.float32).contiguous()
+
+
 class PlanHandle:
     """ddif_plan_t for batches of B tiles of H x W."""
 
@@ -414,9 +423,7 @@ class PlanHandle:
             _check_shape(t, nm, img)
         x0, noise = x0.contiguous(), noise.contiguous()
         sc = None if self_cond is None else self_cond.contiguous()
-        a = a.detach().to("cpu", torch.float32).contiguous()
-        s = s.detach().to("cpu", torch.float32).contiguous()
-        t = time.detach().to("cpu", torch.float32).contiguous()
+        a, s, t = _row(a, x0.device), _row(s, x0.device), _row(time, x0.device)
         loss = torch.empty((), dtype=torch.float32, device=x0.device)
         pred = torch.empty_like(x0) if want_pred else None
         self.lib.check(self.lib.dll.ddif_plan_train_step(
@@ -535,9 +542,7 @@ class PlanHandle:
             _check_shape(t, nm, img)
         x0, noise = x0.contiguous(), noise.contiguous()
         sc = None if self_cond is None else self_cond.contiguous()
-        a = a.detach().to("cpu", torch.float32).contiguous()
-        s = s.detach().to("cpu", torch.float32).contiguous()
-        t = time.detach().to("cpu", torch.float32).contiguous()
+        a, s, t = _row(a, x0.device), _row(s, x0.device), _row(time, x0.device)
         out = torch.empty_like(x0)
         self.lib.check(self.lib.dll.ddif_plan_q_sample_forward(
             self.h, _ptr(x0), _ptr(noise), C.c_void_p(a.data_ptr()), C.c_void_p(s.data_ptr()), C.c_void_p(t.data_ptr()),

@@ -151,7 +151,8 @@ DDIF_API int ddif_plan_sample_dpmpp(ddif_plan_t plan, const ddif_dpm_tables* tab
                            float clamp_hi, int do_clamp, float* out, void* stream);
 
 /* GaussianDiffusion.p_losses forward half (diffusion/diffusion_ddpm_pan.py:692-732), eval mode, pred_mode x_start:
- * x_t = a[b]*x0 + s[b]*noise; pred = net(x_t, t, cond, self_cond); returns pred (recon_x0). a, s, time: HOST. */
+ * x_t = a[b]*x0 + s[b]*noise; pred = net(x_t, t, cond, self_cond); returns pred (recon_x0). a, s, time: B floats each, HOST or DEVICE
+ * memory (copied on `stream`: a training loop that draws t on the device hands them over without a host round trip). */
 DDIF_API int ddif_plan_q_sample_forward(ddif_plan_t plan, const float* x0, const float* noise, const float* sqrt_ac_host,
                                const float* sqrt_1mac_host, const float* time_host, const float* self_cond,
                                float* pred, void* stream);
@@ -210,8 +211,8 @@ DDIF_API int ddif_plan_create_train(ddif_plan_t* out, ddif_net_t net, int B, int
  *   ->  ddif_plan_train_step: x_t = a x0 + s noise, train-mode forward, L1 loss against x0, backward.
  * ddif_plan_train_bind names the gradient tensors once: n (state-dict key, device pointer) pairs covering every learnable tensor, reference
  * layouts (conv (Cout,Cin,k,k), Linear (out,in), vectors); the step WRITES them (no accumulation).  loss_dev: one device float (mean
- * absolute error, F.l1_loss); pred (nullable): the network output (B,C,H,W).  a / s / t: HOST arrays of B floats (sqrt(alpha_bar_t),
- * sqrt(1 - alpha_bar_t), t); self_cond nullable (B,C,H,W).  Deterministic: fixed-order reductions, no atomics. */
+ * absolute error, F.l1_loss); pred (nullable): the network output (B,C,H,W).  a / s / t: arrays of B floats (sqrt(alpha_bar_t),
+ * sqrt(1 - alpha_bar_t), t) in HOST or DEVICE memory (device: no synchronisation per iteration); self_cond nullable (B,C,H,W).  Deterministic: fixed-order reductions, no atomics. */
 DDIF_API int ddif_plan_train_bind(ddif_plan_t plan, int n, const char* const* keys, float* const* grads_dev);
 DDIF_API int ddif_plan_train_num_grads(ddif_plan_t plan, int* n);
 /* the same on a GIVEN network input and target (no q_sample): what the gradient parity tests drive with the reference's own tensors */
