@@ -144,12 +144,14 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
         a.wshift = -1;
         a.bpartial = nullptr;
         hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
+        const int rrows = c.n_co * c.n_ci * 32 * (c.centre_only ? 1 : 9);
+        const unsigned rgrid = (unsigned)(rrows < 2048 ? rrows : 2048);
         if (c.centre_only)
-            hipLaunchKernelGGL(wgrad_reduce_centre_kernel, grid_for((size_t)c.Cout * c.Cin), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
-                               c.Cout, c.Cin, dw, (const float*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL(wgrad_reduce_centre_kernel, dim3(rgrid), dim3(256), 256 * sizeof(float), s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci, c.Cout,
+                               c.Cin, dw, (const float*)nullptr, (float*)nullptr);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel, grid_for((size_t)c.n_co * c.n_ci * 9 * 1024), dim3(256), 0, s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci,
-                               c.Cout, c.Cin, dw, (const float*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 256 * sizeof(float), s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci, c.Cout, c.Cin,
+                               dw, (const float*)nullptr, (float*)nullptr);
     }
     if (db) {
         hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 256 * sizeof(float), s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);
@@ -508,12 +510,16 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     if (g.pf && g.centre && centre) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 1>), dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
+    // one workgroup per row of 32 input channels of the partial layout (capped), + one for the bias
+    const int nblk = g.n_co * g.n_ci;
+    const int rows = centre ? nblk * 32 : nblk * 9 * 32;
+    const unsigned rgrid = (unsigned)(rows < 2048 ? rows : 2048) + (a.bpartial ? 1u : 0u);
     if (centre)
-        hipLaunchKernelGGL(wgrad_reduce_centre_kernel, dim3(grid_for((size_t)Cout * Cin).x + (a.bpartial ? 1 : 0)), dim3(256), 0, s, (const float*)partial, g.nsplit,
-                           g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw, (const float*)a.bpartial, db);
+        hipLaunchKernelGGL(wgrad_reduce_centre_kernel, dim3(rgrid), dim3(256), 256 * sizeof(float), s, (const float*)partial, g.nsplit, nblk, g.n_ci, Cout, Cin, dw,
+                           (const float*)a.bpartial, db);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t)g.n_co * g.n_ci * 9 * 1024).x + (a.bpartial ? 1 : 0)), dim3(256), 0, s, (const float*)partial, g.nsplit,
-                           g.n_co * g.n_ci, g.n_ci, Cout, Cin, dw, (const float*)a.bpartial, db);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 256 * sizeof(float), s, (const float*)partial, g.nsplit, nblk, g.n_ci, Cout, Cin, dw,
+                           (const float*)a.bpartial, db);
 }
 void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchunk, float* bpart, float* db) {
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nbchunk), dim3(256), 256 * sizeof(float), s, dy, npix, Cout, nbchunk, bpart);

@@ -218,48 +218,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// fixed-order sum over the K splits with EIGHT loads in flight (a load-per-iteration loop pays one memory latency per split)
-__device__ __forceinline__ float wgrad_sum_splits(const float* p, size_t stride, int nsplit) {
+// Fixed-order sum over the K splits, shared by the eight 32-thread SLICES of a 256-thread workgroup: thread (slice sl = tid >> 5, lane c = tid & 31)
+// adds the splits sl, sl + 8, ... of element c with eight loads in flight (a load-per-iteration loop pays one memory latency per split; one
+// thread per element pays nsplit / 8 of them -- 64 at 512 splits -- on a grid of a few dozen workgroups), the slices are combined through LDS
+// in slice order.  Every thread of the workgroup must call it (two barriers); slice 0 returns the sum.
+__device__ __forceinline__ float wgrad_sum_splits8(const float* p, bool valid, size_t stride, int nsplit, float* red /* [256] */) {
+    const int tid = threadIdx.x, sl = tid >> 5;
     float acc = 0.f;
-    for (int k0 = 0; k0 < nsplit; k0 += 8) {
-        float v[8];
+    if (valid)
+        for (int k0 = sl; k0 < nsplit; k0 += 64) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = k0 + u < nsplit ? p[(size_t)(k0 + u) * stride] : 0.f;
-        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            for (int u = 0; u < 8; ++u) v[u] = k0 + 8 * u < nsplit ? p[(size_t)(k0 + 8 * u) * stride] : 0.f;
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+    red[tid] = acc;
+    __syncthreads();
+    float tot = 0.f;
+    if (sl == 0) {
+        const int c = tid;
+        tot = ((red[c] + red[c + 32]) + (red[c + 64] + red[c + 96])) + ((red[c + 128] + red[c + 160]) + (red[c + 192] + red[c + 224]));
     }
-    return acc;
+    __syncthreads();
+    return tot;
 }
-// 1x1 form: dW (Cout, Cin) from the centre-tap blocks only
 // (both reduce kernels also finish the bias gradient when bpartial / db are given: db[c] = fixed-order sum over the splits)
 // (the launch carries ONE extra workgroup -- the last -- for the bias; returns true for that workgroup)
-__device__ __forceinline__ bool wgrad_reduce_bias(const float* bpartial, int nsplit, int n_co, int Cout, float* db) {
+__device__ __forceinline__ bool wgrad_reduce_bias(const float* bpartial, int nsplit, int n_co, int Cout, float* db, float* red) {
     if (!bpartial || !db || blockIdx.x != gridDim.x - 1) return false;
-    for (int c = threadIdx.x; c < Cout; c += blockDim.x) db[c] = wgrad_sum_splits(bpartial + c, (size_t)n_co * 32, nsplit);
+    for (int c0 = 0; c0 < Cout; c0 += 32) {
+        const int c = c0 + (threadIdx.x & 31);
+        const float v = wgrad_sum_splits8(bpartial + c, c < Cout, (size_t)n_co * 32, nsplit, red);
+        if (threadIdx.x < 32 && c < Cout) db[c] = v;
+    }
     return true;
 }
-__global__ void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial, float* db) {
-    if (wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db)) return;
-    const size_t nb_main = (bpartial && db) ? gridDim.x - 1 : gridDim.x;
-    const size_t total = (size_t)Cout * Cin;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nb_main * blockDim.x) {
-        const int ci = (int)(i % Cin), co = (int)(i / Cin);
-        const int blk = (co / 32) * n_ci + ci / 32;
-        const size_t off = ((size_t)blk * 9 + 4) * 1024 + (size_t)(co % 32) * 32 + ci % 32;
-        dw[i] = wgrad_sum_splits(partial + off, (size_t)nblk * 9 * 1024, nsplit);
+// 1x1 form: dW (Cout, Cin) from the centre-tap blocks only.  A workgroup takes rows of 32 input channels of the PARTIAL layout
+// ([block][tap][co % 32][ci % 32]) at a time.
+__global__ __launch_bounds__(256) void wgrad_reduce_centre_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial,
+                                                                  float* db) {
+    DDIF_DYN_SMEM(smem_);
+    float* red = reinterpret_cast<float*>(smem_);  // [256]
+    if (wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db, red)) return;
+    const int nb_main = (bpartial && db) ? gridDim.x - 1 : gridDim.x;
+    const int nrows = nblk * 32;  // (block, co % 32)
+    for (int row = blockIdx.x; row < nrows; row += nb_main) {
+        const int blk = row >> 5, r = row & 31, c = threadIdx.x & 31;
+        const int co = (blk / n_ci) * 32 + r, ci = (blk % n_ci) * 32 + c;
+        const bool ok = co < Cout && ci < Cin;
+        const float v = wgrad_sum_splits8(partial + ((size_t)blk * 9 + 4) * 1024 + (size_t)r * 32 + c, ok, (size_t)nblk * 9 * 1024, nsplit, red);
+        if (threadIdx.x < 32 && ok) dw[(size_t)co * Cin + ci] = v;
     }
 }
-// dW (OIHW) = fixed-order sum of the partial blocks.  Threads walk the PARTIAL layout ([block][tap][co % 32][ci % 32]: coalesced reads, which
-// are nsplit x the writes); each writes its one weight element
-__global__ void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial, float* db) {
-    if (wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db)) return;
-    const size_t nb_main = (bpartial && db) ? gridDim.x - 1 : gridDim.x;
-    const size_t total = (size_t)nblk * 9 * 1024;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += nb_main * blockDim.x) {
-        const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
-        const int t = (int)((j >> 10) % 9), blk = (int)(j / (9 * 1024));
+// dW (OIHW) = fixed-order sum of the partial blocks, the same way: a workgroup per row (block, tap, co % 32) of 32 input channels
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int nsplit, int nblk, int n_ci, int Cout, int Cin, float* dw, const float* bpartial, float* db) {
+    DDIF_DYN_SMEM(smem_);
+    float* red = reinterpret_cast<float*>(smem_);  // [256]
+    if (wgrad_reduce_bias(bpartial, nsplit, nblk / n_ci, Cout, db, red)) return;
+    const int nb_main = (bpartial && db) ? gridDim.x - 1 : gridDim.x;
+    const int nrows = nblk * 9 * 32;
+    const size_t total = (size_t)nrows * 32;
+    for (int row = blockIdx.x; row < nrows; row += nb_main) {
+        const int c = threadIdx.x & 31, r = row & 31;
+        const int t = (row >> 5) % 9, blk = row / (9 * 32);
         const int co = (blk / n_ci) * 32 + r, ci = (blk % n_ci) * 32 + c;
-        if (co >= Cout || ci >= Cin) continue;
-        dw[((size_t)co * Cin + ci) * 9 + t] = wgrad_sum_splits(partial + j, total, nsplit);
+        const bool ok = co < Cout && ci < Cin;
+        const float v = wgrad_sum_splits8(partial + (size_t)row * 32 + c, ok, total, nsplit, red);
+        if (threadIdx.x < 32 && ok) dw[((size_t)co * Cin + ci) * 9 + t] = v;
     }
 }
 
