@@ -1050,6 +1050,7 @@ int Plan::build_impl() {
             const float *pn_g = V(ci + ".prenorm_x.weight"), *pn_b = V(ci + ".prenorm_x.bias"), *q0w = V(ci + ".q.0.weight");
             if (!pn_g || !pn_b || !q0w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
             Tensor xn, dwq, q, o, a, f0, f1, f2, f3c, f3, kdw_pad;
+            float *la_ctx = nullptr, *la_part = nullptr;
             DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl, true));
             DDIF_TRY(alloc_tensor(&dwq, fea, Hl, Wl, true));
             {
@@ -1098,7 +1099,13 @@ int Plan::build_impl() {
                 op.flop = 4.0 * B * 8 * d * d * (double)Hl * Wl;
                 op.bytes = 16.0 * B * Hl * Wl * fea;
                 Tensor qq = q, kk = kv, oo = o;
-                op.run = [qq, kk, oo, BB, d, Hl, Wl, fea](hipStream_t s, const StepCtx&) { tk::linattn_fwd(s, qq.p, kk.p, BB, 8, d, Hl, Wl, oo.p, fea); };
+                if ((Hl > Wl ? Hl : Wl) * fea > 8192 || d > 32 || d % 4)
+                    return fail(DDIF_ERR_INVALID, "%s: train-mode linear attention holds one image line x %d channels in LDS: lines of more than %d pixels are not supported",
+                                ci.c_str(), fea, 8192 / fea);
+                DDIF_TRY(dalloc(&la_ctx, (size_t)B * fea * d));
+                DDIF_TRY(dalloc(&la_part, tk::linattn_part_floats(B, Hl, Wl, fea, d)));
+                float *cx = la_ctx, *pt = la_part;
+                op.run = [qq, kk, oo, BB, d, Hl, Wl, fea, cx, pt](hipStream_t s, const StepCtx&) { tk::linattn_fwd(s, qq.p, kk.p, BB, 8, d, Hl, Wl, oo.p, fea, cx, pt); };
                 step.push_back(std::move(op));
             }
             const bool has_res = pmixt->cin == 2 * fea;
@@ -1185,6 +1192,8 @@ int Plan::build_impl() {
             m.t[10] = f1;
             m.t[11] = f2;
             m.scale = scale;
+            m.ctx = la_ctx;
+            m.la_part = la_part;
             m.has_res = has_res;
             m.skip_from = skip_from;
             m.lev = lev;

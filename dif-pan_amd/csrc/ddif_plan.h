@@ -52,7 +52,11 @@ namespace tk {
 // kernels_train.h  (ddif_train.cpp)
 void film_apply(hipStream_t s, const float* xc, const float* film, int B, int HW, int C, float* out, double* st_out, int chunks);
 int film_chunks(int HW, int C);
-void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o);
+size_t linattn_part_floats(int B, int H, int W, int C, int d);
+void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o, float* ctx, float* part);
+void linattn_bwd(hipStream_t s, const float* q, const float* kv, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dkv,
+                 float* dctx, float* part);
+int linattn_prepare();
 // kernels_bwd.h  (ddif_bwd.cpp)
 void silu_fwd(hipStream_t s, const float* x, size_t n, float* y);
 void silu_bwd(hipStream_t s, const float* x, const float* da, size_t n, float* dx);
@@ -197,6 +201,8 @@ struct Plan {
         Tensor t[12];                // module-specific saved tensors (see ddif_train.cpp)
         float* mask = nullptr;       // RES: dropout mask of block2 (NHWC)
         float* scale = nullptr;      // DEC: per-sample DropPath scales
+        float* ctx = nullptr;        // DEC: linear-attention context [B][fea * d] of the forward (read by the reverse pass)
+        float* la_part = nullptr;    // DEC: per-workgroup partial contexts (scratch of this block's launches)
         int slot = -1;               // RES: offset of the block's FeatureWiseAffine row in a time-bias row
         int lev = 0;
         bool has_res = false;        // DEC: attn_res is a conv (fea != dim_out)

@@ -17,6 +17,7 @@
 
 #include "ddif_plan.h"
 #include "kernels_train.h"
+#include "kernels_linattn.h"
 
 namespace ddif {
 
@@ -39,9 +40,33 @@ int film_chunks(int HW, int C) {
 void film_apply(hipStream_t s, const float* xc, const float* film, int B, int HW, int C, float* out, double* st_out, int chunks) {
     hipLaunchKernelGGL(film_apply_kernel, dim3(chunks, B), dim3(256), 64, s, xc, film, HW, C, out, st_out);
 }
-void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o) {
-    const size_t sm = linattn_fwd_smem(d, H, W);
-    hipLaunchKernelGGL(linattn_fwd_nhwc_kernel, dim3(B * heads), dim3(LA_NT), sm, s, q, kv, heads, d, H, W, 1.0f / std::sqrt((float)d), out, ld_o);
+// linear attention of the train-mode forward: k side (partial contexts per row group) -> reduce -> q side.  ctx [B][C * d] is kept for the reverse pass
+size_t linattn_part_floats(int B, int H, int W, int C, int d) {
+    const int gk = la_groups(W, C, H), gq = la_groups(H, C, W);
+    return (size_t)B * (gk > gq ? gk : gq) * C * d;
+}
+void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o, float* ctx, float* part) {
+    const int C = heads * d, gk = la_groups(W, C, H), gq = la_groups(H, C, W);
+    hipLaunchKernelGGL(la_kside_fwd_kernel, dim3(gk, B), dim3(LA_THREADS), la_kside_fwd_smem(H, W, C), s, kv, H, W, C, d, part);
+    hipLaunchKernelGGL(la_reduce_kernel, tgrid((size_t)B * C * d), dim3(256), 0, s, (const float*)part, B, gk, C * d, ctx);
+    hipLaunchKernelGGL(la_qside_fwd_kernel, dim3(gq, B), dim3(LA_THREADS), la_qside_fwd_smem(H, W, C, d), s, q, (const float*)ctx, H, W, C, d, 1.0f / std::sqrt((float)d), out,
+                       ld_o);
+}
+// reverse: q side (dq_pre + partial dctx per column group) -> reduce -> k side (dk_pre, dv)
+void linattn_bwd(hipStream_t s, const float* q, const float* kv, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dkv,
+                 float* dctx, float* part) {
+    const int C = heads * d, gk = la_groups(W, C, H), gq = la_groups(H, C, W);
+    hipLaunchKernelGGL(la_qside_bwd_kernel, dim3(gq, B), dim3(LA_THREADS), la_qside_bwd_smem(H, W, C, d), s, q, dout, ld_g, ctx, H, W, C, d, 1.0f / std::sqrt((float)d), dq,
+                       part);
+    hipLaunchKernelGGL(la_reduce_kernel, tgrid((size_t)B * C * d), dim3(256), 0, s, (const float*)part, B, gq, C * d, dctx);
+    hipLaunchKernelGGL(la_kside_bwd_kernel, dim3(gk, B), dim3(LA_THREADS), la_kside_bwd_smem(H, W, C, d), s, kv, (const float*)dctx, H, W, C, d, dkv);
+}
+int linattn_prepare() {
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(la_kside_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(la_qside_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(la_qside_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(la_kside_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    return 0;
 }
 }  // namespace tk
 
@@ -51,7 +76,8 @@ struct Plan::TrainScratch {
     size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_wpad = 0, n_dwpart = 0, n_dwflip = 0;
     const float* stem_sc = nullptr;  // set by train_step: the self-conditioning source of THIS iteration (sc_in or x_in)
     // time MLP backward
-    float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr;
+    float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr, *dctx = nullptr;
+    size_t n_dctx = 0;
     SlotScatter* slot_tab = nullptr;
     std::vector<SlotScatter> slot_host;
 };
@@ -88,8 +114,7 @@ int Plan::build_backward() {
     auto numel = [&](const Tensor& t) { return (size_t)BB * t.H * t.W * t.C; };
     auto fbuf = [&](float** p, size_t n) -> int { return dalloc(p, n); };
     DDIF_TRY(tk::wgrad_prepare());
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_bwd_nhwc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_fwd_nhwc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    DDIF_TRY(tk::linattn_prepare());
 
     // ---- building blocks (each appends launches to a closure list `L` executed in order)
     using Launch = std::function<void(hipStream_t)>;
@@ -452,12 +477,11 @@ int Plan::build_backward() {
                 DDIF_TRY(fbuf(&dq, numel(q)));
                 DDIF_TRY(fbuf(&dkv, numel(kv)));
                 {
-                    const size_t sm = linattn_bwd_smem(d, Hl, Wl);
-                    const float sc = 1.0f / std::sqrt((float)d);
-                    L.v.push_back([=](hipStream_t st) {
-                        hipLaunchKernelGGL(linattn_bwd_nhwc_kernel, dim3(BB * 8), dim3(LA_NT), sm, st, (const float*)q.p, (const float*)kv.p, (const float*)dcat.p, ldc, 8, d, Hl, Wl, sc,
-                                           dq, dkv);
-                    });
+                    if (!m.ctx || !m.la_part) return fail(DDIF_ERR_STATE, "training: %s has no saved attention context", ci.c_str());
+                    need(T->n_dctx, (size_t)BB * fea * d);
+                    const float* ctx = m.ctx;
+                    float* part = m.la_part;
+                    L.v.push_back([=](hipStream_t st) { tk::linattn_bwd(st, q.p, kv.p, dcat.p, ldc, ctx, BB, 8, d, Hl, Wl, dq, dkv, T->dctx, part); });
                 }
                 // q = q.1(dwq) + b;  dwq = depthwise3x3(xn; q.0)
                 Tensor dqT = q;
@@ -595,6 +619,7 @@ int Plan::build_backward() {
     DDIF_TRY(fbuf(&T->S, (size_t)BB * 2 + 64));
     DDIF_TRY(fbuf(&T->wpad, T->n_wpad + 64));
     DDIF_TRY(fbuf(&T->dwflip, T->n_dwflip + 64));
+    DDIF_TRY(fbuf(&T->dctx, T->n_dctx + 64));
     DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 512));
     DDIF_TRY(dalloc(&T->cpart, T->n_cpart + 64));
     DDIF_TRY(dalloc(&T->dwpart, T->n_dwpart + 64));
@@ -627,3 +652,41 @@ int Plan::train_backward(const float* target_nhwc, float upstream, float* loss_d
 void Plan::train_set_stem_source(const float* sc_nhwc) { ts->stem_sc = sc_nhwc; }
 
 }  // namespace ddif
+
+// ---------------------------------------------------------------------------------------------------------------- C ABI: the NHWC linear attention core alone
+static int la_check(const char* what, int B, int qd, int H, int W, int heads) {
+    if (B < 1 || heads < 1 || qd < heads || qd % heads || H < 1 || W < 1) return ddif::fail(DDIF_ERR_INVALID, "%s: bad argument", what);
+    const int d = qd / heads;
+    if (d > 32 || d % 4) return ddif::fail(DDIF_ERR_INVALID, "%s: head dim <= 32 and 4 | head dim only", what);
+    if ((H > W ? H : W) * qd > ddif::LA_TILE_MAX) return ddif::fail(DDIF_ERR_INVALID, "%s: max(H, W) * channels must not exceed %d", what, ddif::LA_TILE_MAX);
+    return 0;
+}
+int64_t ddif_linattn_nhwc_workspace(int B, int qd, int H, int W, int heads) {
+    if (la_check("ddif_linattn_nhwc_workspace", B, qd, H, W, heads)) return -1;
+    const int d = qd / heads;
+    return (int64_t)(2 * (size_t)B * qd * d + ddif::tk::linattn_part_floats(B, H, W, qd, d));
+}
+int ddif_linattn_nhwc_fwd(const float* q_pre, const float* kv_pre, int B, int qd, int H, int W, int heads, float* out, float* workspace, void* stream) {
+    if (int e = la_check("ddif_linattn_nhwc_fwd", B, qd, H, W, heads)) return e;
+    if (!q_pre || !kv_pre || !out || !workspace) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_nhwc_fwd: NULL argument");
+    if (int e = ddif::tk::linattn_prepare()) return e;
+    const int d = qd / heads;
+    float* ctx = workspace;
+    float* part = workspace + 2 * (size_t)B * qd * d;
+    ddif::tk::linattn_fwd((hipStream_t)stream, q_pre, kv_pre, B, heads, d, H, W, out, qd, ctx, part);
+    if (hipGetLastError() != hipSuccess) return ddif::fail(DDIF_ERR_HIP, "ddif_linattn_nhwc_fwd: launch failed");
+    return 0;
+}
+int ddif_linattn_nhwc_bwd(const float* q_pre, const float* kv_pre, const float* dout, int B, int qd, int H, int W, int heads, float* dq_pre, float* dkv_pre, float* workspace,
+                          void* stream) {
+    if (int e = la_check("ddif_linattn_nhwc_bwd", B, qd, H, W, heads)) return e;
+    if (!q_pre || !kv_pre || !dout || !dq_pre || !dkv_pre || !workspace) return ddif::fail(DDIF_ERR_INVALID, "ddif_linattn_nhwc_bwd: NULL argument");
+    if (int e = ddif::tk::linattn_prepare()) return e;
+    const int d = qd / heads;
+    float* ctx = workspace;
+    float* dctx = workspace + (size_t)B * qd * d;
+    float* part = workspace + 2 * (size_t)B * qd * d;
+    ddif::tk::linattn_bwd((hipStream_t)stream, q_pre, kv_pre, dout, qd, ctx, B, heads, d, H, W, dq_pre, dkv_pre, dctx, part);
+    if (hipGetLastError() != hipSuccess) return ddif::fail(DDIF_ERR_HIP, "ddif_linattn_nhwc_bwd: launch failed");
+    return 0;
+}

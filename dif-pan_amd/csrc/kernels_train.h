@@ -316,300 +316,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_nhwc_kernel(const float* qkv
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- linear attention core (NHWC), :545-566
-// q_pre [B, HW, qd], kv_pre [B, HW, 2 qd] (k | v), channel = head * d + i; out / dout [B, HW, ld] (the first qd channels of each pixel).
-//   q = softmax over H of q_pre (per channel and column) / sqrt(d);  k = softmax over W of k_pre (per channel and row)
-//   ctx[a][e] = sum_n k[a][n] v[e][n];   o[e][n] = sum_a ctx[a][e] q[a][n]
-// One workgroup per (sample, head); W, H <= 64, d <= 32.  The image is walked in BANDS of R rows (R * W <= LA_BAND pixels staged in LDS per
-// step) instead of row by row: 8 barriers instead of 128 at 64x64.  Every LDS cell has one owner thread and the bands / pixels are summed
-// in index order: deterministic.  (Same math as linattn_fwd / _bwd_kernel of kernels_bwd_ops.h, the NCHW forms behind the stateless C-ABI ops.)
-// max / sum(exp(. - max)) of a strided line of <= 64 elements: the whole line is loaded into registers first (independent loads in flight
-// together -- a load-per-iteration loop pays one memory latency per element), then the two-pass arithmetic of torch.softmax
-__device__ __forceinline__ void la_line_stats(const float* p0, size_t stride, int n, float* mx_out, float* sm_out) {
-    float v[64];
-#pragma unroll
-    for (int r = 0; r < 64; ++r) v[r] = p0[(size_t)(r < n ? r : n - 1) * stride];
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int r = 0; r < 64; ++r) mx = fmaxf(mx, v[r]);  // the clamped tail repeats the last element
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 64; ++r)
-        if (r < n) s += dd_exp(v[r] - mx);
-    *mx_out = mx;
-    *sm_out = s;
-}
-
-constexpr int LA_NT = 1024;   // threads per workgroup: one workgroup per (sample, head) is all the parallelism there is (256 at batch 32) -> 16 waves per CU
-constexpr int LA_BAND = 4096;  // floats per staged band array: rows per band R = LA_BAND / (d * W)
-__host__ __device__ inline int la_rows(int d, int H, int W) {
-    int r = LA_BAND / (d * W);
-    if (r < 1) r = 1;
-    return r > H ? H : r;
-}
-inline size_t linattn_fwd_smem(int d, int H, int W) { return (size_t)(2 * d * W + d * d + 2 * d * la_rows(d, H, W) * W + 2 * d * H) * sizeof(float); }
-inline size_t linattn_bwd_smem(int d, int H, int W) { return (size_t)(3 * d * W + 2 * d * d + 6 * d * la_rows(d, H, W) * W + d * la_rows(d, H, W) + 2 * d * H) * sizeof(float); }
-
-__global__ __launch_bounds__(LA_NT) void linattn_fwd_nhwc_kernel(const float* q_pre, const float* kv_pre, int heads, int d, int H, int W, float sc, float* out, int ld_o) {
-    DDIF_DYN_SMEM(smem_);
-    const int R = la_rows(d, H, W), RW = R * W;
-    float* qmx = reinterpret_cast<float*>(smem_);  // [d][W]
-    float* qsm = qmx + d * W;                      // [d][W]
-    float* ctx = qsm + d * W;                      // [d][d]
-    float* rk = ctx + d * d;                       // [d][RW]
-    float* rv = rk + d * RW;                       // [d][RW]
-    float* kmx = rv + d * RW;                      // [d][H] row max of k_pre (softmax over W)
-    float* ksm = kmx + d * H;                      // [d][H]
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
-    const int qd = heads * d, HW = H * W;
-    const float* qb = q_pre + (size_t)b * HW * qd + hd * d;
-    const float* kb = kv_pre + (size_t)b * HW * 2 * qd + hd * d;
-    const float* vb = kb + qd;
-    float* ob = out + (size_t)b * HW * ld_o + hd * d;
-    for (int i = tid; i < d * W; i += LA_NT) {  // column statistics of q_pre (softmax over H)
-        const int a = i % d, x = i / d;
-        la_line_stats(qb + (size_t)x * qd + a, (size_t)W * qd, H, &qmx[a * W + x], &qsm[a * W + x]);
-    }
-    for (int i = tid; i < d * H; i += LA_NT) {  // row statistics of k_pre (softmax over W)
-        const int a = i % d, y = i / d;
-        la_line_stats(kb + (size_t)y * W * 2 * qd + a, (size_t)2 * qd, W, &kmx[a * H + y], &ksm[a * H + y]);
-    }
-    for (int i = tid; i < d * d; i += LA_NT) ctx[i] = 0.f;
-    __syncthreads();
-    for (int y0 = 0; y0 < H; y0 += R) {  // ctx: bands in order, one owner thread per (a, e)
-        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
-        const int nit = d * npx;
-        for (int i0 = tid; i0 < nit; i0 += LA_NT * 4) {  // four items' loads in flight per thread
-            float kv_[4], vv_[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * LA_NT < nit ? i0 + u * LA_NT : tid;
-                const size_t p = (size_t)y0 * W + i / d;
-                kv_[u] = kb[p * 2 * qd + i % d];
-                vv_[u] = vb[p * 2 * qd + i % d];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * LA_NT;
-                if (i < nit) {
-                    const int a = i % d, pl = i / d, y = y0 + pl / W;
-                    rk[a * RW + pl] = dd_exp(kv_[u] - kmx[a * H + y]) / ksm[a * H + y];
-                    rv[a * RW + pl] = vv_[u];
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < d * d; i += LA_NT) {  // (R W and every array offset are multiples of 4 floats: 16-byte LDS reads, 4 pixels per step)
-            const int a = i / d, e = i % d;
-            float s1 = ctx[i];
-            const float4* pk = reinterpret_cast<const float4*>(rk + a * RW);
-            const float4* pv = reinterpret_cast<const float4*>(rv + e * RW);
-#pragma unroll 4
-            for (int q4 = 0; q4 < npx / 4; ++q4) {
-                const float4 k4 = pk[q4], v4 = pv[q4];
-                s1 = fmaf(k4.x, v4.x, s1);
-                s1 = fmaf(k4.y, v4.y, s1);
-                s1 = fmaf(k4.z, v4.z, s1);
-                s1 = fmaf(k4.w, v4.w, s1);
-            }
-            ctx[i] = s1;
-        }
-        __syncthreads();
-    }
-    // o[e][n] = sum_a ctx[a][e] q[a][n]: the band buffer is free now -- stage q_sm * sc of a band of pixels once (every (pixel, a) value is
-    // needed by all d outputs of the pixel), then one thread per output element
-    for (int y0 = 0; y0 < H; y0 += R) {
-        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
-        const int nit = d * npx;
-        for (int i0 = tid; i0 < nit; i0 += LA_NT * 4) {
-            float qv_[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * LA_NT < nit ? i0 + u * LA_NT : tid;
-                qv_[u] = qb[((size_t)y0 * W + i / d) * qd + i % d];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * LA_NT;
-                if (i < nit) {
-                    const int a = i % d, pl = i / d, x = pl % W;
-                    rk[a * RW + pl] = dd_exp(qv_[u] - qmx[a * W + x]) / qsm[a * W + x] * sc;
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < d * npx; i += LA_NT) {
-            const int e = i % d, pl = i / d;
-            float s = 0.f;
-            for (int a = 0; a < d; ++a) s = fmaf(ctx[a * d + e], rk[a * RW + pl], s);
-            ob[((size_t)y0 * W + pl) * ld_o + e] = s;
-        }
-        __syncthreads();
-    }
-}
-
-// Backward (do given):  dctx[a][e] = sum_n q[a][n] do[e][n];  dq = ctx do;  dk = dctx v;  dv = dctx^T k;  then the two softmax backwards.
-// Pass 1: softmax statistics.  Pass 2 (bands): ctx, dctx.  Pass 3 (bands): dv (final), dk_pre (final: its softmax lives inside a row), dq (raw,
-// parked in the output) and the column sums T[a][x] = sum_y dq q.  Pass 4: dq_pre = q_sm (dq - T).
-__global__ __launch_bounds__(LA_NT) void linattn_bwd_nhwc_kernel(const float* q_pre, const float* kv_pre, const float* dout, int ld_g, int heads, int d, int H, int W, float sc,
-                                                               float* dq_pre, float* dkv_pre) {
-    DDIF_DYN_SMEM(smem_);
-    const int R = la_rows(d, H, W), RW = R * W;
-    float* qmx = reinterpret_cast<float*>(smem_);  // [d][W] column max of q_pre
-    float* qsm = qmx + d * W;                      // [d][W] column sum of exp
-    float* T = qsm + d * W;                        // [d][W] column sums of dq * q_sm
-    float* ctx = T + d * W;                        // [d][d]
-    float* dctx = ctx + d * d;                     // [d][d]
-    float* rk = dctx + d * d;                      // [d][RW] k softmax of the band
-    float* rv = rk + d * RW;                       // [d][RW]
-    float* rq = rv + d * RW;                       // [d][RW] q softmax * sc
-    float* rg = rq + d * RW;                       // [d][RW] do
-    float* rdk = rg + d * RW;                      // [d][RW] dk
-    float* rdq = rdk + d * RW;                     // [d][RW] dq (raw): the column sums T read it back from here, not from memory
-    float* rdot = rdq + d * RW;                    // [d][R] row dots of the k softmax backward
-    float* kmx = rdot + d * R;                     // [d][H] row max of k_pre (softmax over W)
-    float* ksm = kmx + d * H;                      // [d][H] row sum of exp
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
-    const int qd = heads * d, HW = H * W;
-    const float* qb = q_pre + (size_t)b * HW * qd + hd * d;
-    const float* kb = kv_pre + (size_t)b * HW * 2 * qd + hd * d;
-    const float* vb = kb + qd;
-    const float* gb = dout + (size_t)b * HW * ld_g + hd * d;
-    float* dqb = dq_pre + (size_t)b * HW * qd + hd * d;
-    float* dkb = dkv_pre + (size_t)b * HW * 2 * qd + hd * d;
-    float* dvb = dkb + qd;
-    for (int i = tid; i < d * W; i += LA_NT) {  // pass 1: column statistics of q_pre (softmax over H)
-        const int a = i % d, x = i / d;
-        la_line_stats(qb + (size_t)x * qd + a, (size_t)W * qd, H, &qmx[a * W + x], &qsm[a * W + x]);
-        T[a * W + x] = 0.f;
-    }
-    for (int i = tid; i < d * d; i += LA_NT) {
-        ctx[i] = 0.f;
-        dctx[i] = 0.f;
-    }
-    for (int i = tid; i < d * H; i += LA_NT) {  // row statistics of k_pre for every (channel, row)
-        const int a = i % d, y = i / d;
-        la_line_stats(kb + (size_t)y * W * 2 * qd + a, (size_t)2 * qd, W, &kmx[a * H + y], &ksm[a * H + y]);
-    }
-    __syncthreads();
-    auto load_band = [&](int y0, int npx) {  // k softmax (over its row), v, q softmax * sc, do  -> LDS
-        const int nit = d * npx;
-        for (int i0 = tid; i0 < nit; i0 += LA_NT * 4) {  // four items' loads (16 in all) in flight per thread
-            float kv_[4], vv_[4], qv_[4], gv_[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * LA_NT < nit ? i0 + u * LA_NT : tid;
-                const size_t p = (size_t)y0 * W + i / d;
-                const int a = i % d;
-                kv_[u] = kb[p * 2 * qd + a];
-                vv_[u] = vb[p * 2 * qd + a];
-                qv_[u] = qb[p * qd + a];
-                gv_[u] = gb[p * ld_g + a];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * LA_NT;
-                if (i < nit) {
-                    const int a = i % d, pl = i / d, y = y0 + pl / W, x = pl % W, l = a * RW + pl;
-                    rk[l] = dd_exp(kv_[u] - kmx[a * H + y]) / ksm[a * H + y];
-                    rv[l] = vv_[u];
-                    rq[l] = dd_exp(qv_[u] - qmx[a * W + x]) / qsm[a * W + x] * sc;
-                    rg[l] = gv_[u];
-                }
-            }
-        }
-        __syncthreads();
-    };
-    for (int y0 = 0; y0 < H; y0 += R) {  // pass 2: ctx and dctx
-        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
-        load_band(y0, npx);
-        for (int i = tid; i < d * d; i += LA_NT) {
-            const int a = i / d, e = i % d;
-            float s1 = ctx[i], s2 = dctx[i];
-            const float4* pk = reinterpret_cast<const float4*>(rk + a * RW);
-            const float4* pv = reinterpret_cast<const float4*>(rv + e * RW);
-            const float4* pq = reinterpret_cast<const float4*>(rq + a * RW);
-            const float4* pg = reinterpret_cast<const float4*>(rg + e * RW);
-#pragma unroll 2
-            for (int q4 = 0; q4 < npx / 4; ++q4) {  // 16-byte LDS reads, 4 pixels per step (same summation order)
-                const float4 k4 = pk[q4], v4 = pv[q4], q4v = pq[q4], g4 = pg[q4];
-                s1 = fmaf(k4.x, v4.x, s1);
-                s2 = fmaf(q4v.x, g4.x, s2);
-                s1 = fmaf(k4.y, v4.y, s1);
-                s2 = fmaf(q4v.y, g4.y, s2);
-                s1 = fmaf(k4.z, v4.z, s1);
-                s2 = fmaf(q4v.z, g4.z, s2);
-                s1 = fmaf(k4.w, v4.w, s1);
-                s2 = fmaf(q4v.w, g4.w, s2);
-            }
-            ctx[i] = s1;
-            dctx[i] = s2;
-        }
-        __syncthreads();
-    }
-    for (int y0 = 0; y0 < H; y0 += R) {  // pass 3
-        const int rows = H - y0 < R ? H - y0 : R, npx = rows * W;
-        load_band(y0, npx);
-        for (int i = tid; i < d * npx; i += LA_NT) {
-            const int a = i % d, pl = i / d, l = a * RW + pl;
-            float dq = 0.f, dk = 0.f, dv = 0.f;
-            for (int e = 0; e < d; ++e) {
-                dq = fmaf(ctx[a * d + e], rg[e * RW + pl], dq);    // dq[a][n] = sum_e ctx[a][e] do[e][n]
-                dk = fmaf(dctx[a * d + e], rv[e * RW + pl], dk);   // dk[a][n] = sum_e dctx[a][e] v[e][n]
-                dv = fmaf(dctx[e * d + a], rk[e * RW + pl], dv);   // dv[a][n] = sum_e dctx[e][a] k[e][n]
-            }
-            const size_t p = (size_t)y0 * W + pl;
-            dvb[p * 2 * qd + a] = dv;
-            rdk[l] = dk;
-            rdq[l] = dq * sc;
-            dqb[p * qd + a] = dq * sc;  // d(q_sm) of o = ctx^T (q_sm * sc)
-        }
-        __syncthreads();
-        for (int i = tid; i < d * rows; i += LA_NT) {  // row dots of the k softmax backward
-            const int a = i % d, r = i / d;
-            float s = 0.f;
-            for (int x = 0; x < W; ++x) s = fmaf(rdk[a * RW + r * W + x], rk[a * RW + r * W + x], s);
-            rdot[a * R + r] = s;
-        }
-        for (int i = tid; i < d * W; i += LA_NT) {  // column sums T += dq * q_sm over the band's rows, in row order (one owner per (a, x))
-            const int a = i % d, x = i / d;
-            float t = T[a * W + x];
-            for (int r = 0; r < rows; ++r) {
-                const int pl = r * W + x;
-                t += rdq[a * RW + pl] * (rq[a * RW + pl] / sc);  // q_sm = rq / sc
-            }
-            T[a * W + x] = t;
-        }
-        __syncthreads();
-        for (int i = tid; i < d * npx; i += LA_NT) {
-            const int a = i % d, pl = i / d, l = a * RW + pl;
-            dkb[((size_t)y0 * W + pl) * 2 * qd + a] = rk[l] * (rdk[l] - rdot[a * R + pl / W]);
-        }
-        __syncthreads();
-    }
-    const int NEL = d * HW;
-    for (int i0 = tid; i0 < NEL; i0 += LA_NT * 4) {  // pass 4: softmax-over-H backward of q (four elements per thread in flight)
-        float qv[4], gv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * LA_NT < NEL ? i0 + u * LA_NT : tid;
-            const size_t el = (size_t)(i / d) * qd + i % d;
-            qv[u] = qb[el];
-            gv[u] = dqb[el];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * LA_NT;
-            if (i < NEL) {
-                const int a = i % d, p = i / d, x = p % W;
-                const float qs_ = dd_exp(qv[u] - qmx[a * W + x]) / qsm[a * W + x];
-                dqb[(size_t)p * qd + a] = qs_ * (gv[u] - T[a * W + x]);
-            }
-        }
-    }
-}
+// (the linear attention core of the decoder blocks, :545-566, lives in kernels_linattn.h)
 
 // ---------------------------------------------------------------------------------------------------------------- misc
 // F.l1_loss(pred, target), mean: per-workgroup fp64 partials, then a fixed-order sum (the single-workgroup form of kernels_bwd_ops.h costs

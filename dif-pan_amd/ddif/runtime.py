@@ -147,6 +147,10 @@ class _Lib:
         d.ddif_film_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
         d.ddif_selfattn_core_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_linattn_core_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        d.ddif_linattn_nhwc_workspace.argtypes = [i32, i32, i32, i32, i32]
+        d.ddif_linattn_nhwc_workspace.restype = C.c_int64
+        d.ddif_linattn_nhwc_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        d.ddif_linattn_nhwc_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         d.ddif_linear_bwd.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
         d.ddif_groupnorm_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
         d.ddif_swish_bwd.argtypes = [vp, vp, C.c_int64, vp, vp]
@@ -878,3 +882,26 @@ def groupnorm_backward(x, gamma, dy):
     lib.check(lib.dll.ddif_groupnorm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), B, Cc, H, W, _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream(lib, x.device)),
               "ddif_groupnorm_bwd")
     return dx, dg, db
+
+
+def linattn_nhwc(q_pre, kv_pre, heads=8):
+    """The linear attention core as the native training step runs it: q_pre (B,H,W,qd), kv_pre (B,H,W,2qd), NHWC.  Returns (out (B,H,W,qd),
+    workspace) -- the workspace carries the contexts `linattn_nhwc_backward` needs."""
+    B, H, W, qd = q_pre.shape
+    lib, (q_pre, kv_pre) = _ops_prepare([("q_pre", q_pre, (B, H, W, qd)), ("kv_pre", kv_pre, (B, H, W, 2 * qd))])
+    n = lib.dll.ddif_linattn_nhwc_workspace(B, qd, H, W, heads)
+    if n < 0:
+        lib.check(int(n), "ddif_linattn_nhwc_workspace")  # negative = refused: the message is in ddif_last_error
+    ws = torch.empty((n,), dtype=torch.float32, device=q_pre.device)
+    out = torch.empty_like(q_pre)
+    lib.check(lib.dll.ddif_linattn_nhwc_fwd(_ptr(q_pre), _ptr(kv_pre), B, qd, H, W, heads, _ptr(out), _ptr(ws), _stream(lib, q_pre.device)), "ddif_linattn_nhwc_fwd")
+    return out, ws
+
+
+def linattn_nhwc_backward(q_pre, kv_pre, dout, workspace, heads=8):
+    B, H, W, qd = q_pre.shape
+    lib, (q_pre, kv_pre, dout) = _ops_prepare([("q_pre", q_pre, (B, H, W, qd)), ("kv_pre", kv_pre, (B, H, W, 2 * qd)), ("dout", dout, (B, H, W, qd))])
+    dq, dkv = torch.empty_like(q_pre), torch.empty_like(kv_pre)
+    lib.check(lib.dll.ddif_linattn_nhwc_bwd(_ptr(q_pre), _ptr(kv_pre), _ptr(dout), B, qd, H, W, heads, _ptr(dq), _ptr(dkv), _ptr(workspace),
+                                            _stream(lib, q_pre.device)), "ddif_linattn_nhwc_bwd")
+    return dq, dkv

@@ -315,6 +315,13 @@ DDIF_API int ddif_add_scaled(const float* a, const float* f, const float* alpha,
 DDIF_API int ddif_linear_fwd(const float* x, const float* w, const float* bias, int B, int nin, int nout, float* y, void* stream);
 DDIF_API int ddif_selfattn_core_fwd(const float* qkv, int B, int C, int H, int W, int heads, float* out, void* stream);
 DDIF_API int ddif_linattn_core_fwd(const float* q_pre, const float* kv_pre, int B, int qd, int H, int W, int heads, float* out, void* stream);
+/* The same core in the layout and form the native training step runs it (csrc/kernels_linattn.h): q_pre (B,H,W,qd), kv_pre (B,H,W,2qd) = [k | v],
+ * out / dout (B,H,W,qd), all NHWC.  workspace (device floats, ddif_linattn_nhwc_workspace of them): the forward leaves the per-sample contexts in
+ * its head, the backward of the SAME inputs reads them there.  max(H, W) * qd <= 8192, head dim <= 32. */
+DDIF_API int64_t ddif_linattn_nhwc_workspace(int B, int qd, int H, int W, int heads);
+DDIF_API int ddif_linattn_nhwc_fwd(const float* q_pre, const float* kv_pre, int B, int qd, int H, int W, int heads, float* out, float* workspace, void* stream);
+DDIF_API int ddif_linattn_nhwc_bwd(const float* q_pre, const float* kv_pre, const float* dout, int B, int qd, int H, int W, int heads, float* dq_pre, float* dkv_pre,
+                                   float* workspace, void* stream);
 /* q_sample (diffusion/diffusion_ddpm_pan.py:668-681): out = a[b] * x0 + s[b] * noise; a, s = B device floats */
 DDIF_API int ddif_q_sample(const float* x0, const float* noise, const float* a, const float* s, int B, int64_t per_sample, float* out, void* stream);
 /* F.l1_loss(pred, target), mean reduction: out = one device float */

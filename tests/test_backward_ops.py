@@ -109,6 +109,40 @@ def test_linear_attention_core_backward(backend, shape):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64), (1, 96, 64, 64), (2, 128, 32, 32), (1, 192, 16, 16), (2, 256, 8, 8), (1, 64, 10, 12), (1, 128, 40, 24)],
+                         ids=["64@64", "96@64", "128@32", "192@16", "256@8", "64@10x12", "128@40x24"])
+def test_linear_attention_core_nhwc_forward_and_backward(backend, shape):
+    """The same core in the form the native training step runs (csrc/kernels_linattn.h: row / column workgroups, contexts summed from
+    per-workgroup partials) at the shapes of the batch-32 step's decoder blocks and at ragged ones (line groups with a short tail):
+    output and both gradients against torch autograd in fp64."""
+    from ddif import runtime
+
+    dev = _dev(backend)
+    B, qd, H, W = shape
+    heads, d = 8, qd // 8
+    g = torch.Generator().manual_seed(sum(shape))
+    q_pre = (2.0 * torch.randn(B, H, W, qd, generator=g, dtype=torch.float64)).requires_grad_()
+    kv_pre = (2.0 * torch.randn(B, H, W, 2 * qd, generator=g, dtype=torch.float64)).requires_grad_()
+    dout = torch.randn(B, H, W, qd, generator=g, dtype=torch.float64)
+    k, v = kv_pre[..., :qd], kv_pre[..., qd:]
+    q = q_pre.softmax(dim=1).reshape(B, H * W, heads, d) * (1.0 / math.sqrt(d))
+    k = k.softmax(dim=2).reshape(B, H * W, heads, d)
+    ctx = torch.einsum("bnha,bnhe->bhae", k, v.reshape(B, H * W, heads, d))
+    out = torch.einsum("bhae,bnha->bnhe", ctx, q).reshape(B, H, W, qd)
+    out.backward(dout)
+    f32 = lambda t: t.detach().to(torch.float32).to(dev)
+    got, ws = runtime.linattn_nhwc(f32(q_pre), f32(kv_pre))
+    _close(got, out.detach().float(), "out", 1e-5)
+    dq, dkv = runtime.linattn_nhwc_backward(f32(q_pre), f32(kv_pre), f32(dout), ws)
+    _close(dq, q_pre.grad.float(), "dq_pre", 2e-5)
+    _close(dkv, kv_pre.grad.float(), "dkv_pre", 2e-5)
+    # deterministic: a second run gives the same bits
+    got2, ws2 = runtime.linattn_nhwc(f32(q_pre), f32(kv_pre))
+    dq2, dkv2 = runtime.linattn_nhwc_backward(f32(q_pre), f32(kv_pre), f32(dout), ws2)
+    assert torch.equal(got, got2) and torch.equal(dq, dq2) and torch.equal(dkv, dkv2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_time_mlp_backward_chain(backend):
     """noise_level_mlp = Linear(32,128) -> Swish -> Linear(128,32) and one FeatureWiseAffine Linear(32, C) (models/sr3_dwt.py:59-64,
     241-258; oracle.time_embedding), chained from the library's linear / swish backward ops."""
