@@ -180,6 +180,14 @@ static inline dim3 ew_grid(size_t n) {
     return dim3((unsigned)g);
 }
 
+// depthwise 3x3 launch: the channel-quad kernel whenever both sources have 4 | channels (every feature tensor), the scalar one for the 11-channel cond images
+static inline void launch_dw3x3(hipStream_t s, const DwArgs& a) {
+    const dim3 grid(a.B * a.tiles_x * a.tiles_y);
+    if (a.c0 % 4 == 0 && a.c1 % 4 == 0) hipLaunchKernelGGL(dw3x3_q4_kernel, grid, dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+    else hipLaunchKernelGGL(dw3x3_kernel, grid, dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+}
+
+
 // ------------------------------------------------------------------------------------------------ allocation
 Plan::~Plan() {
     drop_graphs();
@@ -1002,7 +1010,7 @@ int Plan::build_impl() {
                 op.flop = 2.0 * 9 * B * Hl * Wl * cd;
                 op.bytes = 8.0 * B * Hl * Wl * cd;
                 op.run = [a, BB](hipStream_t s, const StepCtx&) {
-                    hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+                    launch_dw3x3(s, a);
                 };
                 pre.push_back(std::move(op));
             }
@@ -1080,7 +1088,7 @@ int Plan::build_impl() {
                 op.flop = 2.0 * 9 * B * Hl * Wl * fea;
                 op.bytes = 12.0 * B * Hl * Wl * fea;
                 op.run = [da, BB](hipStream_t s, const StepCtx&) {
-                    hipLaunchKernelGGL(dw3x3_kernel, dim3(BB * da.tiles_x * da.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, da);
+                    launch_dw3x3(s, da);
                 };
                 step.push_back(std::move(op));
             }
@@ -1494,7 +1502,7 @@ void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, con
     a.out_dw = out;
     a.tiles_x = (W + 15) / 16;
     a.tiles_y = (H + 7) / 8;
-    hipLaunchKernelGGL(dw3x3_kernel, dim3(B * a.tiles_x * a.tiles_y), dim3(256), 10 * 18 * 32 * sizeof(float), s, a);
+    launch_dw3x3(s, a);
 }
 }  // namespace tk
 

@@ -306,7 +306,7 @@ int Plan::build_backward() {
                 float* dqkv = nullptr;
                 DDIF_TRY(fbuf(&dqkv, numel(qkv)));
                 {
-                    const size_t sm = (size_t)(4 * d * n + 2 * n * n + n) * sizeof(float);
+                    const size_t sm = (size_t)(4 * d * (n + 1) + 2 * n * (n + 1) + n) * sizeof(float);
                     const float sc = 1.0f / std::sqrt((float)C);
                     L.v.push_back([=](hipStream_t st) {
                         hipLaunchKernelGGL(selfattn_bwd_nhwc_kernel, dim3(BB * 8), dim3(256), sm, st, (const float*)qkv.p, (const float*)do_, 8, d, n, sc, dqkv);

@@ -100,6 +100,88 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
     }
 }
 
+// The same op on QUADS of channels (4 | c0, 4 | c1): one 16-byte access and one set of index arithmetic per four elements -- the scalar form above
+// spends ~3600 vector instructions per wavefront on addressing (rocprofv3 SQ_INSTS_VALU) and is instruction-bound, not memory-bound.  Same tile
+// (8x16 pixels, 32-channel chunks = 8 quads), same arithmetic per element (bit-identical results).
+__global__ __launch_bounds__(256) void dw3x3_q4_kernel(DwArgs a) {
+    constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, CK = 32, NIT = (IH * IW * 8 + 255) / 256;
+    DDIF_DYN_SMEM(smem);
+    float* As = reinterpret_cast<float*>(smem);  // [IH*IW][CK]
+    const int tid = threadIdx.x;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles, t = blockIdx.x % tiles;
+    const int oy0 = (t / a.tiles_x) * TH, ox0 = (t % a.tiles_x) * TW;
+    const int C = a.c0 + a.c1;
+    float mean = 0.f, rstd = 1.f;
+    if (a.use_gn) {
+        if (tid < 64) {
+            gn_finalize_wave(a.st0, a.np0, a.st1, a.np1, b, (double)C * a.H * a.W, &mean, &rstd);
+            if (tid == 0) {
+                As[0] = mean;
+                As[1] = rstd;
+            }
+        }
+        __syncthreads();
+        mean = As[0];
+        rstd = As[1];
+        __syncthreads();
+    }
+    const int q = tid & 7;  // this thread's quad of the chunk, in both phases (256 % 8 == 0)
+    const size_t img = (size_t)b * a.H * a.W;
+    for (int cb = 0; cb < C; cb += CK) {
+        const int c = cb + q * 4;
+        const bool cok = c < C;
+        float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), gb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.use_gn && cok) {
+            const float4 g = *reinterpret_cast<const float4*>(a.gamma + c), bt = *reinterpret_cast<const float4*>(a.beta + c);
+            ga = make_float4(g.x * rstd, g.y * rstd, g.z * rstd, g.w * rstd);
+            gb = make_float4(bt.x - mean * ga.x, bt.y - mean * ga.y, bt.z - mean * ga.z, bt.w - mean * ga.w);
+        }
+        const float* src = (c < a.c0) ? a.in0 + c : a.in1 + (c - a.c0);
+        const int ld = (c < a.c0) ? a.c0 : a.c1;
+        if (cb) __syncthreads();
+        float4 v[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {  // all of this thread's halo loads in flight together
+            const int pix = (tid >> 3) + 32 * u;
+            const int iy = oy0 - 1 + pix / IW, ix = ox0 - 1 + pix % IW;
+            ok[u] = cok && pix < IH * IW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            v[u] = ok[u] ? *reinterpret_cast<const float4*>(src + (img + (size_t)iy * a.W + ix) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int pix = (tid >> 3) + 32 * u;
+            if (pix < IH * IW) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[u]) o = a.use_gn ? make_float4(fmaf(v[u].x, ga.x, gb.x), fmaf(v[u].y, ga.y, gb.y), fmaf(v[u].z, ga.z, gb.z), fmaf(v[u].w, ga.w, gb.w)) : v[u];
+                *reinterpret_cast<float4*>(As + pix * CK + q * 4) = o;
+            }
+        }
+        __syncthreads();
+        float4 wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = cok ? *reinterpret_cast<const float4*>(a.w + k * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = (tid >> 3) + 32 * u;  // 0 .. 127
+            const int ty = p / TW, tx = p % TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float4 x = *reinterpret_cast<const float4*>(As + ((ty + k / 3) * IW + tx + k % 3) * CK + q * 4);
+                s = make_float4(fmaf(x.x, wv[k].x, s.x), fmaf(x.y, wv[k].y, s.y), fmaf(x.z, wv[k].z, s.z), fmaf(x.w, wv[k].w, s.w));
+            }
+            if (cok && oy < a.H && ox < a.W) {
+                const size_t op = ((img + (size_t)oy * a.W + ox)) * C + c;
+                *reinterpret_cast<float4*>(a.out_dw + op) = s;
+                if (a.out_xn) *reinterpret_cast<float4*>(a.out_xn + op) = *reinterpret_cast<const float4*>(As + ((ty + 1) * IW + tx + 1) * CK + q * 4);
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // The same op for samples of <= 256 pixels (the 8x8 / 16x16 levels): one workgroup per (32-channel chunk, sample) holds
 // the WHOLE normalised image of its chunk (+ zero border) in LDS, float4 channel groups, one pass.  Emits dw3x3(xn) and

@@ -245,13 +245,14 @@ __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const double* part
 // [B, n, C] with channel = head * d + c.  Same math and reduction order as selfattn_bwd_kernel (kernels_bwd_ops.h); only the addressing differs.
 __global__ __launch_bounds__(256) void selfattn_bwd_nhwc_kernel(const float* qkv, const float* dout, int heads, int d, int n, float sc, float* dqkv) {
     DDIF_DYN_SMEM(smem_);
+    const int n1 = n + 1;      // LDS row stride: with n = 64 a stride of n puts a whole column into ONE bank (64-way conflicts in the row softmax)
     float* qs = reinterpret_cast<float*>(smem_);
-    float* ks = qs + d * n;
-    float* vs = ks + d * n;
-    float* gs = vs + d * n;   // do
-    float* as = gs + d * n;   // [n][n]
-    float* ds = as + n * n;   // [n][n]
-    float* rd = ds + n * n;   // [n] row dots
+    float* ks = qs + d * n1;
+    float* vs = ks + d * n1;
+    float* gs = vs + d * n1;   // do
+    float* as = gs + d * n1;   // [n][n1]
+    float* ds = as + n * n1;   // [n][n1]
+    float* rd = ds + n * n1;   // [n] row dots
     const int tid = threadIdx.x;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int C3 = 3 * d * heads, C1 = d * heads;
@@ -259,37 +260,37 @@ __global__ __launch_bounds__(256) void selfattn_bwd_nhwc_kernel(const float* qkv
     const float* gbase = dout + (size_t)b * n * C1 + hd * d;
     for (int i = tid; i < d * n; i += 256) {
         const int c = i % d, p = i / d;  // channel fastest: contiguous reads
-        qs[c * n + p] = base[(size_t)p * C3 + c];
-        ks[c * n + p] = base[(size_t)p * C3 + d + c];
-        vs[c * n + p] = base[(size_t)p * C3 + 2 * d + c];
-        gs[c * n + p] = gbase[(size_t)p * C1 + c];
+        qs[c * n1 + p] = base[(size_t)p * C3 + c];
+        ks[c * n1 + p] = base[(size_t)p * C3 + d + c];
+        vs[c * n1 + p] = base[(size_t)p * C3 + 2 * d + c];
+        gs[c * n1 + p] = gbase[(size_t)p * C1 + c];
     }
     __syncthreads();
     for (int i = tid; i < n * n; i += 256) {  // scores and d(a)
         const int p = i / n, q = i % n;
         float s = 0.f, da = 0.f;
         for (int c = 0; c < d; ++c) {
-            s = fmaf(qs[c * n + p], ks[c * n + q], s);
-            da = fmaf(gs[c * n + p], vs[c * n + q], da);
+            s = fmaf(qs[c * n1 + p], ks[c * n1 + q], s);
+            da = fmaf(gs[c * n1 + p], vs[c * n1 + q], da);
         }
-        as[i] = s * sc;
-        ds[i] = da;
+        as[p * n1 + q] = s * sc;
+        ds[p * n1 + q] = da;
     }
     __syncthreads();
     for (int p = tid; p < n; p += 256) {  // softmax of row p, then ds = a (da - sum a da)
         float mx = -3.0e38f;
-        for (int q = 0; q < n; ++q) mx = fmaxf(mx, as[p * n + q]);
+        for (int q = 0; q < n; ++q) mx = fmaxf(mx, as[p * n1 + q]);
         float sum = 0.f;
         for (int q = 0; q < n; ++q) {
-            const float e = dd_exp(as[p * n + q] - mx);
-            as[p * n + q] = e;
+            const float e = dd_exp(as[p * n1 + q] - mx);
+            as[p * n1 + q] = e;
             sum += e;
         }
         const float inv = 1.0f / sum;
         float dot = 0.f;
         for (int q = 0; q < n; ++q) {
-            as[p * n + q] *= inv;
-            dot = fmaf(as[p * n + q], ds[p * n + q], dot);
+            as[p * n1 + q] *= inv;
+            dot = fmaf(as[p * n1 + q], ds[p * n1 + q], dot);
         }
         rd[p] = dot;
     }
@@ -298,18 +299,21 @@ __global__ __launch_bounds__(256) void selfattn_bwd_nhwc_kernel(const float* qkv
     for (int i = tid; i < d * n; i += 256) {  // dv[c][q] = sum_p a[p][q] do[c][p]
         const int c = i % d, q = i / d;
         float s = 0.f;
-        for (int p = 0; p < n; ++p) s = fmaf(as[p * n + q], gs[c * n + p], s);
+        for (int p = 0; p < n; ++p) s = fmaf(as[p * n1 + q], gs[c * n1 + p], s);
         dq[(size_t)q * C3 + 2 * d + c] = s;
     }
     __syncthreads();
-    for (int i = tid; i < n * n; i += 256) ds[i] = as[i] * (ds[i] - rd[i / n]);
+    for (int i = tid; i < n * n; i += 256) {
+        const int p = i / n, q = i % n;
+        ds[p * n1 + q] = as[p * n1 + q] * (ds[p * n1 + q] - rd[p]);
+    }
     __syncthreads();
     for (int i = tid; i < d * n; i += 256) {
         const int c = i % d, p = i / d;
         float s1 = 0.f, s2 = 0.f;
         for (int q = 0; q < n; ++q) {
-            s1 = fmaf(ds[p * n + q], ks[c * n + q], s1);  // dq[c][p] = sc sum_q ds[p][q] k[c][q]
-            s2 = fmaf(ds[q * n + p], qs[c * n + q], s2);  // dk[c][p] = sc sum_q ds[q][p] q[c][q]
+            s1 = fmaf(ds[p * n1 + q], ks[c * n1 + q], s1);  // dq[c][p] = sc sum_q ds[p][q] k[c][q]
+            s2 = fmaf(ds[q * n1 + p], qs[c * n1 + q], s2);  // dk[c][p] = sc sum_q ds[q][p] q[c][q]
         }
         dq[(size_t)p * C3 + c] = s1 * sc;
         dq[(size_t)p * C3 + d + c] = s2 * sc;
