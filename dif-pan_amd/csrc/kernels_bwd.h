@@ -69,7 +69,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     float* Rs = Xs + (RB + 2 * HALO) * IW * 32;   // [4 waves][16 regs][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int cob = blockIdx.x / a.n_ci, cib = blockIdx.x % a.n_ci;
+    // XCD-aware numbering: workgroups are dispatched round-robin over the 8 XCDs (a private L2 each), x fastest.  The gridDim.x workgroups of one
+    // K split read the SAME bands of X and dY (each (ci, co) block pair re-reads them), so they are renumbered to land on ONE XCD back to back:
+    // a band then comes out of HBM once and its re-reads out of that L2 (the 1x1 weight gradients of the wide layers moved 2.7 x their
+    // algorithmic bytes before).  Needs 8 | gridDim.y (the host rounds the split count).
+    int wg_x = blockIdx.x, wg_y = blockIdx.y;
+    if ((gridDim.y & 7) == 0 && gridDim.x > 1) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, k = L >> 3;
+        const int q = k / (int)gridDim.x;
+        wg_y = q * 8 + (L & 7);
+        wg_x = k - q * (int)gridDim.x;
+    }
+    const int cob = wg_x / a.n_ci, cib = wg_x % a.n_ci;
     const int nbands = a.B * a.bands_y;
     const int NY = RB * W * 8, NX = (RB + 2 * HALO) * IW * 8, NTOT = NY + NX;
     f32x16 acc[9];
@@ -132,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         }
     };
     if constexpr (PF) {
-        if ((int)blockIdx.y < nbands) fetch_band(blockIdx.y / a.bands_y, (blockIdx.y % a.bands_y) * RB);
+        if (wg_y < nbands) fetch_band(wg_y / a.bands_y, (wg_y % a.bands_y) * RB);
     }
-    for (int band = blockIdx.y; band < nbands; band += gridDim.y) {
+    for (int band = wg_y; band < nbands; band += gridDim.y) {
         const int b = band / a.bands_y, y0 = (band % a.bands_y) * RB;
         __syncthreads();  // previous band fully consumed
         if constexpr (PF) {
@@ -195,11 +206,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         if (tid < 32) {
             float sb = 0.f;
             for (int r = 0; r < 8; ++r) sb += Rs[r * 32 + tid];
-            a.bpartial[(size_t)blockIdx.y * (gridDim.x / a.n_ci) * 32 + cob * 32 + tid] = sb;
+            a.bpartial[(size_t)wg_y * (gridDim.x / a.n_ci) * 32 + cob * 32 + tid] = sb;
         }
     }
     // combine the four waves tap by tap in fixed order, write this workgroup's partial block
-    float* outp = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 1024;
+    float* outp = a.partial + ((size_t)wg_y * gridDim.x + wg_x) * 9 * 1024;
     for (int t = 0; t < 9; ++t) {
         if (a.centre_only && t != 4) continue;  // workgroup-uniform
         __syncthreads();

@@ -199,17 +199,37 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial_nhwc_kernel(const float*
     double acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-    for (long long row = r0; row < r1; ++row) {
-        const int b = (int)(row / H), y = (int)(row % H);
-        for (int xx = r; xx < W; xx += 8) {
-            if (!cok) continue;
-            const float g = dy[(((size_t)b * H + y) * W + xx) * ldy + c];
+    // this thread's pixels, in order: (row, xx) with xx = r, r + 8, ... inside a row, then the next row.  FOUR pixels' ten loads each are issued
+    // before any of them is used (a load-then-accumulate loop pays one memory latency per pixel); the accumulation order is unchanged.
+    long long row = r < W ? r0 : r1;  // (pixel lanes beyond a narrow row have nothing to do)
+    int xx = r;
+    while (row < r1) {
+        float g[4], xv[4][9];
+        bool ok[4];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int iy = y + k / 3 - 1, ix = xx + k % 3 - 1;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[k] += (double)g * (double)x[(((size_t)b * H + iy) * W + ix) * ldx + c];
+        for (int u = 0; u < 4; ++u) {
+            ok[u] = cok && row < r1;
+            if (ok[u]) {
+                const int b = (int)(row / H), y = (int)(row % H);
+                g[u] = dy[(((size_t)b * H + y) * W + xx) * ldy + c];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int iy = y + k / 3 - 1, ix = xx + k % 3 - 1;
+                    xv[u][k] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * H + iy) * W + ix) * ldx + c] : 0.f;
+                }
+            }
+            xx += 8;
+            if (xx >= W) {
+                xx = r;
+                ++row;
             }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] += (double)g[u] * (double)xv[u][k];  // (a tap outside the image adds +0.0)
+            }
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) red[(r * 32 + cl) * 9 + k] = acc[k];
