@@ -479,7 +479,6 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre) {  // 
     if (want < 1) want = 1;
     if (want > bands) want = bands;
     if (want > 512) want = 512;
-    if (want >= 8) want &= ~7;  // 8 | splits: the kernel numbers its workgroups XCD-aware (kernels_bwd.h)
     g.nsplit = want;
     g.partial_floats = (size_t)g.nsplit * g.n_co * g.n_ci * 9 * 1024;
     g.nbchunk = (int)std::min<size_t>(512, std::max<size_t>(1, (size_t)B * H * W / 16));
