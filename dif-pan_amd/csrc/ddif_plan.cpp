@@ -1113,7 +1113,14 @@ int Plan::build_impl() {
                 DDIF_TRY(dalloc(&la_ctx, (size_t)B * fea * d));
                 DDIF_TRY(dalloc(&la_part, tk::linattn_part_floats(B, Hl, Wl, fea, d)));
                 float *cx = la_ctx, *pt = la_part;
-                op.run = [qq, kk, oo, BB, d, Hl, Wl, fea, cx, pt](hipStream_t s, const StepCtx&) { tk::linattn_fwd(s, qq.p, kk.p, BB, 8, d, Hl, Wl, oo.p, fea, cx, pt); };
+                {   // cond-only half: softmax_W(k), context = k v^T per head (sr3_dwt.py:541,546,563) -- part of set_cond, like the eval plan's
+                    Op pc;
+                    pc.name = "linattn_ctx (train)";
+                    pc.bytes = 8.0 * B * Hl * Wl * fea;
+                    pc.run = [kk, BB, d, Hl, Wl, cx, pt](hipStream_t s, const StepCtx&) { tk::linattn_ctx(s, kk.p, BB, 8, d, Hl, Wl, cx, pt); };
+                    pre.push_back(std::move(pc));
+                }
+                op.run = [qq, oo, BB, d, Hl, Wl, fea, cx](hipStream_t s, const StepCtx&) { tk::linattn_apply(s, qq.p, cx, BB, 8, d, Hl, Wl, oo.p, fea); };
                 step.push_back(std::move(op));
             }
             const bool has_res = pmixt->cin == 2 * fea;

@@ -54,6 +54,8 @@ void film_apply(hipStream_t s, const float* xc, const float* film, int B, int HW
 int film_chunks(int HW, int C);
 size_t linattn_part_floats(int B, int H, int W, int C, int d);
 void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o, float* ctx, float* part);
+void linattn_ctx(hipStream_t s, const float* kv, int B, int heads, int d, int H, int W, float* ctx, float* part);
+void linattn_apply(hipStream_t s, const float* q, const float* ctx, int B, int heads, int d, int H, int W, float* out, int ld_o);
 void linattn_bwd(hipStream_t s, const float* q, const float* kv, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dkv,
                  float* dctx, float* part);
 int linattn_prepare();

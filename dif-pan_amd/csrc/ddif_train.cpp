@@ -45,12 +45,20 @@ size_t linattn_part_floats(int B, int H, int W, int C, int d) {
     const int gk = la_groups(W, C, H), gq = la_groups(H, C, W);
     return (size_t)B * (gk > gq ? gk : gq) * C * d;
 }
-void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o, float* ctx, float* part) {
-    const int C = heads * d, gk = la_groups(W, C, H), gq = la_groups(H, C, W);
+// the context depends on kv = kv.1(kv.0(cond)) only: the training plan computes it with the cond-only program (ddif_plan_set_cond), once per iteration,
+// and both forward passes of the iteration (self-conditioning, main) only run the q side
+void linattn_ctx(hipStream_t s, const float* kv, int B, int heads, int d, int H, int W, float* ctx, float* part) {
+    const int C = heads * d, gk = la_groups(W, C, H);
     hipLaunchKernelGGL(la_kside_fwd_kernel, dim3(gk, B), dim3(LA_THREADS), la_kside_fwd_smem(H, W, C), s, kv, H, W, C, d, part);
     hipLaunchKernelGGL(la_reduce_kernel, tgrid((size_t)B * C * d), dim3(256), 0, s, (const float*)part, B, gk, C * d, ctx);
-    hipLaunchKernelGGL(la_qside_fwd_kernel, dim3(gq, B), dim3(LA_THREADS), la_qside_fwd_smem(H, W, C, d), s, q, (const float*)ctx, H, W, C, d, 1.0f / std::sqrt((float)d), out,
-                       ld_o);
+}
+void linattn_apply(hipStream_t s, const float* q, const float* ctx, int B, int heads, int d, int H, int W, float* out, int ld_o) {
+    const int C = heads * d, gq = la_groups(H, C, W);
+    hipLaunchKernelGGL(la_qside_fwd_kernel, dim3(gq, B), dim3(LA_THREADS), la_qside_fwd_smem(H, W, C, d), s, q, ctx, H, W, C, d, 1.0f / std::sqrt((float)d), out, ld_o);
+}
+void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int heads, int d, int H, int W, float* out, int ld_o, float* ctx, float* part) {
+    linattn_ctx(s, kv, B, heads, d, H, W, ctx, part);
+    linattn_apply(s, q, ctx, B, heads, d, H, W, out, ld_o);
 }
 // reverse: q side (dq_pre + partial dctx per column group) -> reduce -> k side (dk_pre, dv)
 void linattn_bwd(hipStream_t s, const float* q, const float* kv, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dkv,
