@@ -1498,8 +1498,9 @@ int Plan::time_rows_aux(const float* t_host, int rows, float* aux, hipStream_t s
 }
 
 namespace tk {
-void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, const float* w9c, float* out) {
+void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, const float* w9c, float* out, bool flip) {
     DwArgs a{};
+    a.flip = flip ? 1 : 0;
     a.in0 = in;
     a.c0 = C;
     a.B = B;

@@ -77,7 +77,7 @@ void linear_bwd(hipStream_t s, const float* x, const float* w, const float* dy, 
 void l1_fwd(hipStream_t s, const float* pred, const float* target, size_t n, float* out);
 void l1_bwd(hipStream_t s, const float* pred, const float* target, size_t n, float upstream, float* dpred);
 // kernels_misc.h  (ddif_plan.cpp)
-void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, const float* w9c, float* out);  // depthwise conv, weights [9][C]
+void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, const float* w9c, float* out, bool flip = false);  // depthwise conv, weights [9][C]
 }  // namespace tk
 struct AttnBlockArgs;
 int attn_block_prepare();                                                        // ddif_lr.cpp (kernels_attn.h)

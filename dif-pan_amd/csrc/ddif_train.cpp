@@ -79,9 +79,9 @@ int linattn_prepare() {
 }  // namespace tk
 
 struct Plan::TrainScratch {
-    float *a = nullptr, *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *bpart = nullptr, *S = nullptr, *wpad = nullptr, *dwflip = nullptr;
+    float *a = nullptr, *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *bpart = nullptr, *S = nullptr, *wpad = nullptr;
     double *spart = nullptr, *cpart = nullptr, *dwpart = nullptr;
-    size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_wpad = 0, n_dwpart = 0, n_dwflip = 0;
+    size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_wpad = 0, n_dwpart = 0;
     const float* stem_sc = nullptr;  // set by train_step: the self-conditioning source of THIS iteration (sc_in or x_in)
     // time MLP backward
     float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr, *dctx = nullptr;
@@ -501,7 +501,6 @@ int Plan::build_backward() {
                 DDIF_TRY(fbuf(&dxn, numel(xn)));
                 {
                     const float* w9 = V(ci + ".q.0.weight");  // [9][C], refreshed with the weights
-                    need(T->n_dwflip, (size_t)9 * fea);
                     need(T->n_tmp, numel(xn));
                     const int nsplit = std::min(512, BB * Hl);
                     need(T->n_dwpart, (size_t)nsplit * fea * 9);
@@ -509,8 +508,7 @@ int Plan::build_backward() {
                     const float* other = m.has_res ? dcat.p + fea : da;  // gradient of xn through attn_res (or the identity)
                     const int ld_other = m.has_res ? ldc : Co;
                     L.v.push_back([=](hipStream_t st) {
-                        hipLaunchKernelGGL(flip_dw_taps_kernel, dim3((9 * fea + 255) / 256), dim3(256), 0, st, w9, fea, T->dwflip);
-                        tk::dw3x3_plain(st, ddwq, fea, BB, Hl, Wl, T->dwflip, T->tmp);  // d(xn) through the depthwise conv
+                        tk::dw3x3_plain(st, ddwq, fea, BB, Hl, Wl, w9, T->tmp, true);  // d(xn) through the depthwise conv: the same kernel on mirrored taps
                         hipLaunchKernelGGL(add2_ld_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)T->tmp, fea, other, ld_other, fea, npix, dxn);
                         hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((fea + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), st, (const float*)xn.p, fea,
                                            (const float*)ddwq, fea, BB, fea, Hl, Wl, nsplit, T->dwpart);
@@ -626,7 +624,6 @@ int Plan::build_backward() {
     DDIF_TRY(fbuf(&T->bpart, T->n_bpart + 64));
     DDIF_TRY(fbuf(&T->S, (size_t)BB * 2 + 64));
     DDIF_TRY(fbuf(&T->wpad, T->n_wpad + 64));
-    DDIF_TRY(fbuf(&T->dwflip, T->n_dwflip + 64));
     DDIF_TRY(fbuf(&T->dctx, T->n_dctx + 64));
     DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 512));
     DDIF_TRY(dalloc(&T->cpart, T->n_cpart + 64));

@@ -27,6 +27,7 @@ struct DwArgs {
     int tiles_x, tiles_y;
     int use_gn;
     int b0;              // gn_dw3x3_small_kernel: batch window (blockIdx.y counts from b0)
+    int flip;            // dw3x3(_q4)_kernel: taps mirrored (w[8 - k]): the input gradient of the same depthwise conv
 };
 
 __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
         __syncthreads();
         float wv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wv[k] = cok ? a.w[k * C + c] : 0.f;
+        for (int k = 0; k < 9; ++k) wv[k] = cok ? a.w[(a.flip ? 8 - k : k) * C + c] : 0.f;
         for (int p = tid >> 5; p < TH * TW; p += 8) {
             const int ty = p / TW, tx = p % TW;
             const int oy = oy0 + ty, ox = ox0 + tx;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void dw3x3_q4_kernel(DwArgs a) {
         __syncthreads();
         float4 wv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wv[k] = cok ? *reinterpret_cast<const float4*>(a.w + k * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 9; ++k) wv[k] = cok ? *reinterpret_cast<const float4*>(a.w + (a.flip ? 8 - k : k) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = (tid >> 3) + 32 * u;  // 0 .. 127

@@ -31,15 +31,16 @@ __global__ __launch_bounds__(256) void refresh_blob_kernel(const RefreshRec* rec
         else hi = mid - 1;
     }
     const RefreshRec r = recs[lo];
-    const long long idx = (blk - r.blk0) * 256 + threadIdx.x;
-    if (idx >= r.n_out) return;
+    const long long idx64 = (blk - r.blk0) * 256 + threadIdx.x;
+    if (idx64 >= r.n_out) return;
+    const unsigned idx = (unsigned)idx64;  // a record writes < 2^31 floats: 32-bit index arithmetic below (a 64-bit division is ~100 instructions, six per element)
     if (r.kind == RF_COPY) {
         r.dst[idx] = r.src0[idx];
     } else if (r.kind == RF_SUM) {
         r.dst[idx] = r.src0[idx] + r.src1[idx];
     } else if (r.kind == RF_DW) {  // (C,1,3,3) -> [9][C]
         const int C = r.cout;
-        const int k = (int)(idx / C), c = (int)(idx - (long long)k * C);
+        const unsigned k = idx / (unsigned)C, c = idx - k * (unsigned)C;
         r.dst[idx] = r.src0[(size_t)c * 9 + k];
     } else {
         const int taps = r.ks * r.ks, cin = r.cin0 + r.cin1;
@@ -57,38 +58,38 @@ __global__ __launch_bounds__(256) void refresh_blob_kernel(const RefreshRec* rec
         if (r.kind == RF_PACK_F32) {
             // [n-block][chunk][tap][k8][half h][cout j][4 cins]   (ddif_net.cpp pack_conv)
             const int K8 = r.ck / 8;
-            long long t = idx;
+            unsigned t = idx;
             const int i = (int)(t & 3);
             t >>= 2;
             const int j = (int)(t & 31);
             t >>= 5;
             const int h = (int)(t & 1);
             t >>= 1;
-            const int k8 = (int)(t % K8);
-            t /= K8;
-            const int tap = (int)(t % taps);
-            t /= taps;
-            const int ch = (int)(t % r.n_chunks);
-            const int nbi = (int)(t / r.n_chunks);
+            const int k8 = (int)(t % (unsigned)K8);
+            t /= (unsigned)K8;
+            const int tap = (int)(t % (unsigned)taps);
+            t /= (unsigned)taps;
+            const int ch = (int)(t % (unsigned)r.n_chunks);
+            const int nbi = (int)(t / (unsigned)r.n_chunks);
             r.dst[idx] = wval(nbi * 32 + j, ch * r.ck + k8 * 8 + 4 * h + i, tap);
         } else {
             // [n-block][chunk][tap][k16][plane][half h][cout j][8 bf16]: one float = two bf16 (t = 2q, 2q + 1)   (pack_conv_x3)
             const int K16 = r.ck / 16;
-            long long t = idx;
+            unsigned t = idx;
             const int q = (int)(t & 3);
             t >>= 2;
             const int j = (int)(t & 31);
             t >>= 5;
             const int h = (int)(t & 1);
             t >>= 1;
-            const int pl = (int)(t % 3);
-            t /= 3;
-            const int k16 = (int)(t % K16);
-            t /= K16;
-            const int tap = (int)(t % taps);
-            t /= taps;
-            const int ch = (int)(t % r.n_chunks);
-            const int nbi = (int)(t / r.n_chunks);
+            const int pl = (int)(t % 3u);
+            t /= 3u;
+            const int k16 = (int)(t % (unsigned)K16);
+            t /= (unsigned)K16;
+            const int tap = (int)(t % (unsigned)taps);
+            t /= (unsigned)taps;
+            const int ch = (int)(t % (unsigned)r.n_chunks);
+            const int nbi = (int)(t / (unsigned)r.n_chunks);
             unsigned out = 0;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {

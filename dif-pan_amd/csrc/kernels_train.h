@@ -423,13 +423,4 @@ __global__ void plane_sum_final_kernel(const float* part, int B, int C, int nchu
     for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * C + c];
     out[(size_t)b * ld + c] = s;
 }
-// flipped depthwise taps: w [9][C] (tap-major, the forward layout) -> [9][C] with tap k <- 8 - k: dX of a depthwise conv is the same
-// depthwise conv of dY with the taps reversed
-__global__ void flip_dw_taps_kernel(const float* w, int C, float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 9 * C) return;
-    const int k = i / C, c = i % C;
-    out[i] = w[(8 - k) * C + c];
-}
-
 }  // namespace ddif
