@@ -380,6 +380,60 @@ def test_engine_google_trains_on_after_validation_checkpoints_and_resumes(backen
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
+def test_native_step_equals_the_op_by_op_tape_at_the_benchmark_tile_size(backend, monkeypatch):
+    """The reference golden pins the native step at 16 x 16 tiles.  At the benchmark's 64 x 64 (other band / line-group geometries of the
+    weight-gradient, linear-attention and depthwise kernels, all four resolution levels at their real sizes) the native forward + reverse
+    program is compared with round 2's op-by-op tape (`DDIF_TRAIN_TAPE=1`: the stateless NCHW ops of csrc/kernels_bwd_ops.h, each pinned
+    against autograd in tests/test_backward_ops.py) on the same inputs, timesteps and pinned masks: loss, prediction and the gradient of every
+    one of the 702 parameters."""
+    from ddif_testlib import make_diffusion, make_net
+
+    dev = _dev(backend)
+    B, C, H = 2, 8, 64
+    gen = torch.Generator().manual_seed(123)
+    net = make_net("wv3", dev)
+    d = make_diffusion(net, C, 500, H, dev)
+    d.loss_type = "l1"
+    x0 = torch.rand(B, C, H, H, generator=gen).to(dev)
+    noise = torch.randn(B, C, H, H, generator=gen).to(dev)
+    sc = torch.randn(B, C, H, H, generator=gen).to(dev)
+    cond = gc.tiles_for("wv3", B, H, H, seed=9)["cond"].to(dev)
+    t = torch.tensor([37, 411], device=dev)
+    a, s = d._schedule_rows(t)
+    net.train()
+    try:
+        plan = net.plan_for(B, H, H, dev, train=True)
+        plan.random_train_masks(77, 0, 0.2, 0.2)
+        masks, paths = plan.train_masks()
+        net.set_train_masks([m.clone() for m in masks], paths.clone())
+
+        def run(tape):
+            monkeypatch.setenv("DDIF_TRAIN_TAPE", "1" if tape else "0")
+            for p in net.parameters():
+                p.grad = None
+            loss, pred = d._train_step(x0, noise, a, s, t, cond, sc)
+            loss.backward()
+            return float(loss.detach()), pred.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+        l_nat, p_nat, g_nat = run(False)
+        l_tape, p_tape, g_tape = run(True)
+        assert abs(l_nat - l_tape) <= 1e-6 * max(1.0, abs(l_tape))
+        assert float((p_nat - p_tape).abs().max()) <= 5e-5
+        worst = 0.0
+        for n, gt in g_tape.items():
+            gn = g_nat[n]
+            assert gn.shape == gt.shape and torch.isfinite(gn).all(), n
+            den = float(gt.norm())
+            err = float((gn - gt).norm()) / den if den > 0 else float(gn.norm())
+            worst = max(worst, err)
+            assert err <= 2e-4, (n, err)
+        print("worst relative gradient difference native vs tape at 64x64:", worst)
+    finally:
+        net.eval()
+        net.set_train_masks(None, None)
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_reference_optimizer_lines_run_unchanged_on_the_drop_in(backend):
     """diffusion_engine.py:205-241 verbatim in spirit: torch.optim.AdamW over `denoise_fn.parameters()`, `opt.zero_grad()`,
     `diff_loss.backward()`, `clip_grad_norm_(…, 0.003)`, `opt.step()` -- two iterations; the loss must be finite, the clipped gradient norm
