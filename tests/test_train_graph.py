@@ -419,15 +419,18 @@ def test_native_step_equals_the_op_by_op_tape_at_the_benchmark_tile_size(backend
         l_tape, p_tape, g_tape = run(True)
         assert abs(l_nat - l_tape) <= 1e-6 * max(1.0, abs(l_tape))
         assert float((p_nat - p_tape).abs().max()) <= 5e-5
+        # (some gradients are analytically zero -- a bias in front of a softmax over a whole line, q.1.bias / the k half of kv.1.bias: both paths
+        # return rounding noise there -- so the bar is relative to the tensor's own norm plus a floor relative to the largest gradient of the step)
+        gmax = max(float(g.norm()) for g in g_tape.values())
         worst = 0.0
         for n, gt in g_tape.items():
             gn = g_nat[n]
             assert gn.shape == gt.shape and torch.isfinite(gn).all(), n
-            den = float(gt.norm())
-            err = float((gn - gt).norm()) / den if den > 0 else float(gn.norm())
-            worst = max(worst, err)
-            assert err <= 2e-4, (n, err)
-        print("worst relative gradient difference native vs tape at 64x64:", worst)
+            diff, den = float((gn - gt).norm()), float(gt.norm())
+            assert diff <= 2e-4 * den + 2e-6 * gmax, (n, diff, den, gmax)
+            if den > 1e-3 * gmax:
+                worst = max(worst, diff / den)
+        print("worst relative gradient difference native vs tape at 64x64 (tensors above 1e-3 of the largest norm):", worst)
     finally:
         net.eval()
         net.set_train_masks(None, None)
