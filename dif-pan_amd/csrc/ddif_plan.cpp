@@ -198,6 +198,14 @@ Plan::~Plan() {
     for (auto st : side) (void)hipStreamDestroy(st);
     for (auto e : fork_ev) (void)hipEventDestroy(e);
     for (auto e : join_ev) (void)hipEventDestroy(e);
+    if (wg_stream) {
+        (void)hipStreamSynchronize(wg_stream);
+        (void)hipStreamDestroy(wg_stream);
+    }
+    if (wg_fork) (void)hipEventDestroy(wg_fork);
+    if (wg_join) (void)hipEventDestroy(wg_join);
+    for (auto e : a_free)
+        if (e) (void)hipEventDestroy(e);
 #endif
     for (void* p : allocs) (void)hipFree(p);
     for (auto e : ev0) (void)hipEventDestroy(e);

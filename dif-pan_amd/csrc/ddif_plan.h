@@ -217,6 +217,13 @@ struct Plan {
     std::vector<std::function<void(hipStream_t)>> bwd;  // reverse program, in FORWARD order (run back to front)
     struct TrainScratch;
     std::shared_ptr<TrainScratch> ts;
+    // reverse pass on two streams: the weight-gradient launches (large, compute-bound, leaves of the graph) go to `wg_stream` while the gradient
+    // chain (many small latency-bound launches) continues on the caller's stream; events order them (ddif_train.cpp).  Off in the emulator.
+    hipStream_t wg_stream = nullptr;
+    hipEvent_t wg_fork = nullptr, wg_join = nullptr, a_free[3] = {nullptr, nullptr, nullptr};
+    bool wg_async = false;
+    hipStream_t train_fork(hipStream_t main);  // the stream a weight-gradient launch goes to, ordered after everything issued on `main` so far
+    void train_join(hipStream_t main);         // `main` waits for everything issued on the side stream
     float* d_loss = nullptr;          // device scalar
     float* dtb = nullptr;             // [B][nslots] gradient of the time-bias rows
     float* taux = nullptr;            // [B][32 + 128 + 128 + 32] pe | pre-activation | hidden | temb of the time MLP (train forward)

@@ -25,6 +25,14 @@ static bool train_x3_() {  // DDIF_TRAIN_X3=0: exact-fp32 MFMA for the dgrad con
     static const bool v = [] { const char* e = getenv("DDIF_TRAIN_X3"); return !e || atoi(e) != 0; }();
     return v;
 }
+static inline void dd_wait_event(hipStream_t s, hipEvent_t e) {  // (the host emulator runs everything in order on one stream: never reached there)
+#ifndef DDIF_EMU
+    (void)hipStreamWaitEvent(s, e, 0);
+#else
+    (void)s;
+    (void)e;
+#endif
+}
 static inline dim3 tgrid(size_t n) {
     size_t g = (n + 255) / 256;
     if (g > 8192) g = 8192;
@@ -79,7 +87,7 @@ int linattn_prepare() {
 }  // namespace tk
 
 struct Plan::TrainScratch {
-    float *a = nullptr, *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *bpart = nullptr, *S = nullptr, *wpad = nullptr;
+    float *a = nullptr, *a_ring[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *bpart = nullptr, *wbpart = nullptr, *S = nullptr, *wpad = nullptr;
     double *spart = nullptr, *cpart = nullptr, *dwpart = nullptr;
     size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_wpad = 0, n_dwpart = 0;
     const float* stem_sc = nullptr;  // set by train_step: the self-conditioning source of THIS iteration (sc_in or x_in)
@@ -121,8 +129,26 @@ int Plan::build_backward() {
     auto need = [](size_t& cur, size_t n) { if (n > cur) cur = n; };
     auto numel = [&](const Tensor& t) { return (size_t)BB * t.H * t.W * t.C; };
     auto fbuf = [&](float** p, size_t n) -> int { return dalloc(p, n); };
+    int ring_ctr = 0;  // slots of T->a_ring handed to the GroupNorm-recompute / weight-gradient pairs in turn
     DDIF_TRY(tk::wgrad_prepare());
     DDIF_TRY(tk::linattn_prepare());
+#ifndef DDIF_EMU
+    {   // the side stream of the weight gradients (DDIF_TRAIN_STREAMS=0: everything on the caller's stream)
+        const char* env = getenv("DDIF_TRAIN_STREAMS");  // read per plan (a test builds one plan of each kind in one process)
+        const bool two = !env || atoi(env) != 0;
+        if (two && !wg_stream) {
+            // lowest priority: the gradient chain on the caller's stream is a sequence of small dependent launches -- it should never queue behind
+            // the weight gradients' workgroups, which only fill the compute units it leaves idle
+            int least = 0, greatest = 0;
+            DDIF_HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            DDIF_HIPCHK(hipStreamCreateWithPriority(&wg_stream, hipStreamNonBlocking, least));
+            DDIF_HIPCHK(hipEventCreateWithFlags(&wg_fork, hipEventDisableTiming));
+            DDIF_HIPCHK(hipEventCreateWithFlags(&wg_join, hipEventDisableTiming));
+            for (auto& e : a_free) DDIF_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        wg_async = two;
+    }
+#endif
 
     // ---- building blocks (each appends launches to a closure list `L` executed in order)
     using Launch = std::function<void(hipStream_t)>;
@@ -154,7 +180,7 @@ int Plan::build_backward() {
         if (g.rb < 1) return fail(DDIF_ERR_INVALID, "training: W=%d is too wide for the weight-gradient kernel", W_);
         need(T->n_partial, g.partial_floats);
         need(T->n_bpart, (size_t)g.nsplit * g.n_co * 32);
-        L.v.push_back([=](hipStream_t st) { tk::wgrad(st, x, dy, BB, H_, W_, Cin, Cout, g, ks == 1, T->partial, *dw, T->bpart, db ? *db : nullptr); });
+        L.v.push_back([=](hipStream_t st) { tk::wgrad(this->train_fork(st), x, dy, BB, H_, W_, Cin, Cout, g, ks == 1, T->partial, *dw, T->wbpart, db ? *db : nullptr); });
         return 0;
     };
     // backward of  [GroupNorm (+SiLU) (+mask)] -> conv  (one `Block` of the reference, :288-300, and the other normalised convs)
@@ -167,7 +193,7 @@ int Plan::build_backward() {
         const int nchunk = HW < 32 ? HW : 32;
         const float *gamma = nullptr, *beta = nullptr;
         const double* fst = nullptr;
-        int fnp = 0;
+        int fnp = 0, ring = 0;
         if (pro) {
             gamma = V(nkey + ".weight");
             beta = V(nkey + ".bias");
@@ -185,7 +211,12 @@ int Plan::build_backward() {
             if (!a_mat) {
                 const double* fs = fst;
                 const int fn = fnp;
-                L.v.push_back([=](hipStream_t st) { tk::gn_act(st, x.p, fs ? fs : T->spart, fn, gamma, beta, mask, BB, HW, C, pro == 2, T->a); });
+                ring = ring_ctr++ % 3;
+                const int rk = ring;
+                L.v.push_back([=](hipStream_t st) {
+                    if (this->wg_async) dd_wait_event(st, this->a_free[rk]);  // the weight gradient that read this slot three blocks ago is done
+                    tk::gn_act(st, x.p, fs ? fs : T->spart, fn, gamma, beta, mask, BB, HW, C, pro == 2, T->a_ring[rk]);
+                });
             }
         }
         float** dw = G(ckey + ".weight");
@@ -197,7 +228,12 @@ int Plan::build_backward() {
             need(T->n_partial, g.partial_floats);
             need(T->n_bpart, (size_t)g.nsplit * g.n_co * 32);
             const int Co = dy.C, H_ = x.H, W_ = x.W;
-            L.v.push_back([=](hipStream_t st) { tk::wgrad(st, T->a, dy.p, BB, H_, W_, C, Co, g, ks == 1, T->partial, *dw, T->bpart, db ? *db : nullptr); });
+            const int rk = ring;
+            L.v.push_back([=](hipStream_t st) {
+                hipStream_t ws = this->train_fork(st);
+                tk::wgrad(ws, T->a_ring[rk], dy.p, BB, H_, W_, C, Co, g, ks == 1, T->partial, *dw, T->wbpart, db ? *db : nullptr);
+                if (this->wg_async) (void)hipEventRecord(this->a_free[rk], ws);
+            });
         } else {
             DDIF_TRY(add_wgrad(L, a_mat ? a_mat : x.p, C, dy.p, dy.C, x.H, x.W, ks, dw, db));
         }
@@ -353,8 +389,8 @@ int Plan::build_backward() {
                     float** dwp = &T->wpad;
                     DDIF_TRY(add_wgrad(L, cpad.p, Cp, dhid, Co, hid.H, hid.W, 3, dwp, nullptr));
                     float** dw = G(ci + ".body.0.weight");
-                    L.v.push_back([=](hipStream_t st) {
-                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)Co * Cr * 9), dim3(256), 0, st, (const float*)T->wpad, Co, Cp, Cr, 9, *dw);
+                    L.v.push_back([=](hipStream_t st) {  // (in order behind its weight gradient, on that stream)
+                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)Co * Cr * 9), dim3(256), 0, this->wg_async ? this->wg_stream : st, (const float*)T->wpad, Co, Cp, Cr, 9, *dw);
                     });
                 }
                 break;
@@ -391,7 +427,10 @@ int Plan::build_backward() {
                     need(T->n_bpart, (size_t)gg.nsplit * gg.n_co * 32);
                     float** dw = G(m.key + ".weight");
                     float** db = G(m.key + ".bias");
-                    L.v.push_back([=](hipStream_t st) { tk::wgrad(st, T->tmp, dy, BB, 2 * H_, 2 * W_, C, Co, gg, false, T->partial, *dw, T->bpart, *db); });
+                    L.v.push_back([=](hipStream_t st) {
+                        tk::wgrad(this->train_fork(st), T->tmp, dy, BB, 2 * H_, 2 * W_, C, Co, gg, false, T->partial, *dw, T->wbpart, *db);
+                        this->train_join(st);  // T->tmp is scratch of the gradient chain: nothing may overwrite it before this launch has read it
+                    });
                 }
                 Tensor dxu;
                 DDIF_TRY(add_dgrad(L, m.key, dyT, &dxu));
@@ -422,8 +461,10 @@ int Plan::build_backward() {
                     float** dw = G(m.key + ".weight");
                     float** db = G(m.key + ".bias");
                     L.v.push_back([=](hipStream_t st) {
-                        tk::wgrad(st, T->a, dy, BB, H_, W_, Cp, Co, gg, false, T->partial, T->wpad, T->bpart, *db);
-                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)Co * Cin * 9), dim3(256), 0, st, (const float*)T->wpad, Co, Cp, Cin, 9, *dw);
+                        hipStream_t ws = this->train_fork(st);
+                        tk::wgrad(ws, T->a, dy, BB, H_, W_, Cp, Co, gg, false, T->partial, T->wpad, T->wbpart, *db);
+                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)Co * Cin * 9), dim3(256), 0, ws, (const float*)T->wpad, Co, Cp, Cin, 9, *dw);
+                        this->train_join(st);
                     });
                 }
                 dx = nullptr;
@@ -523,7 +564,7 @@ int Plan::build_backward() {
                     DDIF_TRY(add_wgrad(L, kdwp.p, Cp, dkv, 2 * fea, Hl, Wl, 1, dwp, G(ci + ".kv.1.bias")));
                     float** dw1 = G(ci + ".kv.1.weight");
                     L.v.push_back([=](hipStream_t st) {
-                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)2 * fea * cd), dim3(256), 0, st, (const float*)T->wpad, 2 * fea, Cp, cd, 1, *dw1);
+                        hipLaunchKernelGGL(unpad_weight_kernel, tgrid((size_t)2 * fea * cd), dim3(256), 0, this->wg_async ? this->wg_stream : st, (const float*)T->wpad, 2 * fea, Cp, cd, 1, *dw1);
                     });
                     Tensor dkvT = kv;
                     dkvT.p = dkv;
@@ -619,9 +660,11 @@ int Plan::build_backward() {
 
     // ---- scratch
     DDIF_TRY(fbuf(&T->a, T->n_a + 64));
+    for (int k = 0; k < 3; ++k) DDIF_TRY(fbuf(&T->a_ring[k], T->n_a + 64));
     DDIF_TRY(fbuf(&T->tmp, T->n_tmp + 64));
     DDIF_TRY(fbuf(&T->partial, T->n_partial + 64));
     DDIF_TRY(fbuf(&T->bpart, T->n_bpart + 64));
+    DDIF_TRY(fbuf(&T->wbpart, T->n_bpart + 64));
     DDIF_TRY(fbuf(&T->S, (size_t)BB * 2 + 64));
     DDIF_TRY(fbuf(&T->wpad, T->n_wpad + 64));
     DDIF_TRY(fbuf(&T->dctx, T->n_dctx + 64));
@@ -649,12 +692,25 @@ int Plan::train_backward(const float* target_nhwc, float upstream, float* loss_d
     }
     tk::l1_bwd(s, net_out.p, target_nhwc, n, upstream, d_net_out);
     for (auto& f : bwd) f(s);
+    train_join(s);  // every weight gradient is in place
     if (loss_dev) DDIF_HIPCHK(hipMemcpyAsync(loss_dev, d_loss, sizeof(float), hipMemcpyDeviceToDevice, s));
     DDIF_HIPCHK(hipGetLastError());
     return 0;
 }
 
 void Plan::train_set_stem_source(const float* sc_nhwc) { ts->stem_sc = sc_nhwc; }
+
+hipStream_t Plan::train_fork(hipStream_t main) {
+    if (!wg_async) return main;
+    (void)hipEventRecord(wg_fork, main);  // (one event serves every fork: a wait captures the record in front of it)
+    dd_wait_event(wg_stream, wg_fork);
+    return wg_stream;
+}
+void Plan::train_join(hipStream_t main) {
+    if (!wg_async) return;
+    (void)hipEventRecord(wg_join, wg_stream);
+    dd_wait_event(main, wg_join);
+}
 
 }  // namespace ddif
 

@@ -437,6 +437,46 @@ def test_native_step_equals_the_op_by_op_tape_at_the_benchmark_tile_size(backend
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
+def test_two_stream_reverse_pass_is_bit_identical_to_the_one_stream_one(backend, monkeypatch):
+    """The reverse pass issues the weight-gradient launches on a side stream, ordered against the gradient chain with events (csrc/ddif_train.cpp).
+    A plan built with `DDIF_TRAIN_STREAMS=0` runs the same launches on one stream: loss, prediction and all 702 gradients must be the same BITS,
+    three iterations in a row (a missing dependency shows up as a difference or a NaN, not as a tolerance question)."""
+    from ddif_testlib import make_net
+
+    dev = _dev(backend)
+    B, C, H = 4, 8, 64
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.rand(B, C, H, H, generator=gen).to(dev)
+    noise = torch.randn(B, C, H, H, generator=gen).to(dev)
+    sc = torch.randn(B, C, H, H, generator=gen).to(dev)
+    cond = gc.tiles_for("wv3", B, H, H, seed=4)["cond"].to(dev)
+    a, s, t = torch.full((B,), 0.8), torch.full((B,), 0.6), torch.tensor([3.0, 100.0, 250.0, 499.0])
+    results = []
+    for streams in ("1", "0"):
+        monkeypatch.setenv("DDIF_TRAIN_STREAMS", streams)
+        torch.manual_seed(11)
+        net = make_net("wv3", dev)  # same weights both times (make_net seeds its initialisation)
+        net.train()
+        plan = net.plan_for(B, H, H, dev, train=True)
+        named = [(n, torch.zeros_like(p)) for n, p in net.named_parameters()]
+        plan.train_bind(named)
+        net._net.refresh_from_device(net.named_parameters())
+        plan.set_cond(cond, force=True)
+        plan.random_train_masks(9, 0, 0.2, 0.2)
+        out = []
+        for _ in range(3):
+            loss, pred = plan.train_step(x0, noise, a, s, t, sc)
+            torch.cuda.synchronize()
+            out.append((float(loss), pred.clone(), [g.clone() for _, g in named]))
+        results.append(out)
+        net.eval()
+    for (l1, p1, g1), (l0, p0, g0) in zip(*results):
+        assert l1 == l0 and torch.equal(p1, p0)
+        for (n, _), u, v in zip(named, g1, g0):
+            assert torch.isfinite(u).all() and torch.equal(u, v), n
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_reference_optimizer_lines_run_unchanged_on_the_drop_in(backend):
     """diffusion_engine.py:205-241 verbatim in spirit: torch.optim.AdamW over `denoise_fn.parameters()`, `opt.zero_grad()`,
     `diff_loss.backward()`, `clip_grad_norm_(…, 0.003)`, `opt.step()` -- two iterations; the loss must be finite, the clipped gradient norm
