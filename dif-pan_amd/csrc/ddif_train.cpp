@@ -330,9 +330,10 @@ int Plan::build_backward() {
                     float* dst = dtb + slot;
                     const int nck = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
                     need(T->n_bpart, (size_t)BB * nck * C);
-                    L.v.push_back([=](hipStream_t st) {
-                        hipLaunchKernelGGL(plane_sum_partial_nhwc_kernel, dim3(nck, BB), dim3(256), 256 * sizeof(float), st, (const float*)dh1, HW, C, nck, T->bpart);
-                        hipLaunchKernelGGL(plane_sum_final_kernel, dim3((BB * C + 255) / 256), dim3(256), 0, st, (const float*)T->bpart, BB, C, nck, ld, dst);
+                    L.v.push_back([=](hipStream_t st) {  // a leaf (the time MLP's backward runs after the join): on the side stream; T->bpart is used there only
+                        hipStream_t ws = this->train_fork(st);
+                        hipLaunchKernelGGL(plane_sum_partial_nhwc_kernel, dim3(nck, BB), dim3(256), 256 * sizeof(float), ws, (const float*)dh1, HW, C, nck, T->bpart);
+                        hipLaunchKernelGGL(plane_sum_final_kernel, dim3((BB * C + 255) / 256), dim3(256), 0, ws, (const float*)T->bpart, BB, C, nck, ld, dst);
                     });
                 }
                 Tensor dh1T = h1;
@@ -551,9 +552,10 @@ int Plan::build_backward() {
                     L.v.push_back([=](hipStream_t st) {
                         tk::dw3x3_plain(st, ddwq, fea, BB, Hl, Wl, w9, T->tmp, true);  // d(xn) through the depthwise conv: the same kernel on mirrored taps
                         hipLaunchKernelGGL(add2_ld_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)T->tmp, fea, other, ld_other, fea, npix, dxn);
-                        hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((fea + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), st, (const float*)xn.p, fea,
+                        hipStream_t ws = this->train_fork(st);  // a leaf: beside the gradient chain, like the conv weight gradients
+                        hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((fea + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), ws, (const float*)xn.p, fea,
                                            (const float*)ddwq, fea, BB, fea, Hl, Wl, nsplit, T->dwpart);
-                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((fea * 9 + 7) / 8), dim3(256), 256 * sizeof(double), st, (const double*)T->dwpart, nsplit, fea, *dw0);
+                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((fea * 9 + 7) / 8), dim3(256), 256 * sizeof(double), ws, (const double*)T->dwpart, nsplit, fea, *dw0);
                     });
                 }
                 // kv = kv.1(kdw) + b;  kdw = depthwise3x3(cond; kv.0): weight gradients only (cond needs no gradient)
@@ -577,9 +579,10 @@ int Plan::build_backward() {
                     const Tensor cimg = cdec[m.lev];
                     const int ldk = dkdw.C;
                     L.v.push_back([=](hipStream_t st) {
-                        hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((cd + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), st, (const float*)cimg.p, cd,
+                        hipStream_t ws = this->train_fork(st);
+                        hipLaunchKernelGGL(dw_wgrad_partial_nhwc_kernel, dim3((cd + 31) / 32, nsplit), dim3(256), 8 * 32 * 9 * sizeof(double), ws, (const float*)cimg.p, cd,
                                            (const float*)dkdw.p, ldk, BB, cd, Hl, Wl, nsplit, T->dwpart);
-                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((cd * 9 + 7) / 8), dim3(256), 256 * sizeof(double), st, (const double*)T->dwpart, nsplit, cd, *dwk0);
+                        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((cd * 9 + 7) / 8), dim3(256), 256 * sizeof(double), ws, (const double*)T->dwpart, nsplit, cd, *dwk0);
                     });
                 }
                 // prenorm_x: xn = GroupNorm(cat[h, skip])  (no SiLU); then split the gradient of the cat
@@ -638,6 +641,7 @@ int Plan::build_backward() {
         const float *wall = net->wall, *w3 = net->w3, *w1 = net->w1;
         float* dtb_ = dtb;
         L.v.push_back([=](hipStream_t st) {
+            this->train_join(st);  // the time-bias row gradients (plane sums of every ResnetBlock) were written on the side stream
             hipLaunchKernelGGL(time_dte_kernel, dim3(BB), dim3(256), 256 * sizeof(float), st, (const float*)dtb_, wall, ns, inner, T->dte);
             tk::linear_bwd(st, te, wall, dtb_, BB, inner, ns, nullptr, T->dwall, T->dball);
             {   // the table is rebuilt only when the bound gradient tensors moved
