@@ -526,6 +526,9 @@ int Net::refresh_device(int n, const char* const* keys, const float* const* ptrs
         if (!keys[i] || !ptrs[i]) return fail(DDIF_ERR_INVALID, "ddif_net_refresh: NULL key / pointer at %d", i);
         by_key[keys[i]] = ptrs[i];
     }
+#ifndef DDIF_EMU
+    for (hipEvent_t e : reader_events) (void)hipStreamWaitEvent(stream, e, 0);  // (a never-recorded or completed event does not block)
+#endif
     std::vector<const float*> flat;
     flat.reserve(recipes.size() * 2);
     for (auto& r : recipes) {

@@ -94,6 +94,7 @@ struct Net {
     int n_recs = 0;
     long long refresh_blocks = 0;
     int refresh_device(int n, const char* const* keys, const float* const* ptrs, hipStream_t stream);
+    std::vector<hipEvent_t> reader_events;  // train-mode plans: 'my side stream has read the weights' -- a refresh waits for them before it rewrites the packs
 
     ~Net() {
         if (blob) (void)hipFree(blob);

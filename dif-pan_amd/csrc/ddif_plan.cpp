@@ -202,6 +202,11 @@ Plan::~Plan() {
         (void)hipStreamSynchronize(wg_stream);
         (void)hipStreamDestroy(wg_stream);
     }
+    if (side_read) {
+        auto& ev = net->reader_events;
+        ev.erase(std::remove(ev.begin(), ev.end(), side_read), ev.end());
+        (void)hipEventDestroy(side_read);
+    }
     if (wg_fork) (void)hipEventDestroy(wg_fork);
     if (wg_join) (void)hipEventDestroy(wg_join);
     for (auto e : a_free)
@@ -962,6 +967,12 @@ int Plan::build_impl() {
             cur = t2;
         }
     }
+    if (train_mode) {  // the decoder-only half of the cond-only program ran on the side stream (set_cond): it must be complete from here on
+        Op j;
+        j.name = "join cond-only side work";
+        j.run = [this](hipStream_t s, const StepCtx&) { this->train_join(s); };
+        step.push_back(std::move(j));
+    }
     for (auto& L : net->ups) {
         if (L.kind == L_UP) {
             ConvSpec s;
@@ -997,6 +1008,7 @@ int Plan::build_impl() {
         const int fea = L.cin, d = fea / 8, Hl = cur.H, Wl = cur.W, BB = B;
         const int cd = Cl + 3 * P;
         // ---- cond-only: kv -> softmax_W(k) -> context   (sr3_dwt.py:514-517,541,546,563)
+        const size_t pre_dec0 = pre.size();  // train: everything this block adds to the cond-only program is decoder-only -> the side stream
         float* ctx = nullptr;
         Tensor kdw, kv;
         {
@@ -1127,6 +1139,7 @@ int Plan::build_impl() {
                     pc.bytes = 8.0 * B * Hl * Wl * fea;
                     pc.run = [kk, BB, d, Hl, Wl, cx, pt](hipStream_t s, const StepCtx&) { tk::linattn_ctx(s, kk.p, BB, 8, d, Hl, Wl, cx, pt); };
                     pre.push_back(std::move(pc));
+                    for (size_t i = pre_dec0; i < pre.size(); ++i) pre[i].side = true;
                 }
                 op.run = [qq, oo, BB, d, Hl, Wl, fea, cx](hipStream_t s, const StepCtx&) { tk::linattn_apply(s, qq.p, cx, BB, 8, d, Hl, Wl, oo.p, fea); };
                 step.push_back(std::move(op));
@@ -1622,7 +1635,20 @@ int Plan::set_cond(const float* cond, hipStream_t s) {
     if (!cond) return fail(DDIF_ERR_INVALID, "ddif_plan_set_cond: cond is NULL");
     cond_nchw = const_cast<float*>(cond);
     StepCtx ctx;
-    run_prog(pre, s, ctx, false);
+    if (train_mode && wg_async) {
+        // encoder half (and everything shared) on the caller's stream, then the decoder-only half -- kv convs, contexts, padded copies for the weight
+        // gradients -- on the side stream: it overlaps the stem / encoder / middle of the forward pass that follows, which joins in front of its
+        // first decoder block.  (Encoder ops all precede decoder ops in `pre`; the side ops depend on the resized cond images only.)
+        train_join(s);  // a previous set_cond's side work may still be reading what the ops below rewrite
+        for (auto& op : pre)
+            if (!op.side) op.run(s, ctx);
+        hipStream_t ws = train_fork(s);
+        for (auto& op : pre)
+            if (op.side) op.run(ws, ctx);
+        (void)hipEventRecord(side_read, ws);  // ddif_net_refresh waits for this before it rewrites the weight packs these ops read
+    } else {
+        run_prog(pre, s, ctx, false);
+    }
     cond_set = true;
     DDIF_HIPCHK(hipGetLastError());
     return 0;

@@ -30,6 +30,7 @@ struct Op {
     double flop = 0, bytes = 0;
     bool timed = false;  // member of the dominant kernel class (3x3 implicit-GEMM convs at the high-resolution levels)
     bool win = false;    // the launch honours StepCtx's batch window (every op of the eval-mode step program does)
+    bool side = false;   // train-mode cond-only program: a decoder-only op -- issued on the plan's side stream, joined in front of the first decoder block
     int cls = 5;         // profiling class: 0 conv3x3 (> 256 px / sample), 1 conv1x1 (> 256 px), 2 low-resolution levels, 3 attention, 4 softmax statistics, 5 other
     const char* name = "";
     std::string label;   // layer + shape, for the DDIF_OP_TIMING dump
@@ -220,7 +221,7 @@ struct Plan {
     // reverse pass on two streams: the weight-gradient launches (large, compute-bound, leaves of the graph) go to `wg_stream` while the gradient
     // chain (many small latency-bound launches) continues on the caller's stream; events order them (ddif_train.cpp).  Off in the emulator.
     hipStream_t wg_stream = nullptr;
-    hipEvent_t wg_fork = nullptr, wg_join = nullptr, a_free[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t wg_fork = nullptr, wg_join = nullptr, side_read = nullptr, a_free[3] = {nullptr, nullptr, nullptr};
     bool wg_async = false;
     hipStream_t train_fork(hipStream_t main);  // the stream a weight-gradient launch goes to, ordered after everything issued on `main` so far
     void train_join(hipStream_t main);         // `main` waits for everything issued on the side stream

@@ -145,6 +145,8 @@ int Plan::build_backward() {
             DDIF_HIPCHK(hipEventCreateWithFlags(&wg_fork, hipEventDisableTiming));
             DDIF_HIPCHK(hipEventCreateWithFlags(&wg_join, hipEventDisableTiming));
             for (auto& e : a_free) DDIF_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            DDIF_HIPCHK(hipEventCreateWithFlags(&side_read, hipEventDisableTiming));
+            net->reader_events.push_back(side_read);
         }
         wg_async = two;
     }
@@ -282,6 +284,7 @@ int Plan::build_backward() {
             op.run = [src, dst, npix](hipStream_t st, const StepCtx&) {
                 hipLaunchKernelGGL(pad_channels_kernel, tgrid(npix * dst.C), dim3(256), 0, st, (const float*)src.p, src.C, dst.C, npix, dst.p);
             };
+            op.side = true;  // read by the reverse pass only; behind the decoder-only ops that produce their inputs
             pre.push_back(std::move(op));
         }
     }

@@ -58,6 +58,13 @@ def main():
     out["device weight refresh"] = timed(lambda: net._net.refresh_from_device(net.named_parameters()))
     pt.set_cond(cond, force=True)
     out["train step (fwd + bwd)"] = timed(lambda: pt.train_step(x0, noise, a, s, t, sc, want_pred=False))
+    # host side of the same call: how long the CPU needs to ISSUE one step's launches (the queue is drained first; no synchronisation inside)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        pt.train_step(x0, noise, a, s, t, sc, want_pred=False)
+    out["train step, host issue time"] = (time.perf_counter() - t0) / 5 * 1e3
+    torch.cuda.synchronize()
     for k, v in out.items():
         print(f"{k:28s} {v:8.3f} ms")
 
