@@ -249,19 +249,19 @@ __global__ __launch_bounds__(LA_THREADS) void la_kside_fwd_kernel(const float* k
 
 // out[b][o] = sum over the groups of part[b][g][o], in group order (eight loads in flight)
 __global__ void la_reduce_kernel(const float* part, int B, int groups, int n, float* out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * n) return;
-    const size_t b = i / n, o = i % n;
-    const float* p = part + b * groups * n + o;
-    float acc = 0.f;
-    for (int g0 = 0; g0 < groups; g0 += 8) {
-        float v[8];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * n; i += (size_t)gridDim.x * blockDim.x) {  // (the launch grid is capped)
+        const size_t b = i / n, o = i % n;
+        const float* p = part + b * groups * n + o;
+        float acc = 0.f;
+        for (int g0 = 0; g0 < groups; g0 += 8) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = g0 + u < groups ? p[(size_t)(g0 + u) * n] : 0.f;
+            for (int u = 0; u < 8; ++u) v[u] = g0 + u < groups ? p[(size_t)(g0 + u) * n] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        out[i] = acc;
     }
-    out[i] = acc;
 }
 
 // ---- q side, forward: o = sc * ctx^T q_sm for a group of columns.  grid = (column groups, B)
