@@ -970,7 +970,12 @@ int Plan::build_impl() {
     if (train_mode) {  // the decoder-only half of the cond-only program ran on the side stream (set_cond): it must be complete from here on
         Op j;
         j.name = "join cond-only side work";
-        j.run = [this](hipStream_t s, const StepCtx&) { this->train_join(s); };
+        j.run = [this](hipStream_t s, const StepCtx&) {  // (not under a stream capture: the samplers join before they start capturing)
+            if (this->side_pending) {
+                this->train_join(s);
+                this->side_pending = false;
+            }
+        };
         step.push_back(std::move(j));
     }
     for (auto& L : net->ups) {
@@ -1646,6 +1651,7 @@ int Plan::set_cond(const float* cond, hipStream_t s) {
         for (auto& op : pre)
             if (op.side) op.run(ws, ctx);
         (void)hipEventRecord(side_read, ws);  // ddif_net_refresh waits for this before it rewrites the weight packs these ops read
+        side_pending = true;
     } else {
         run_prog(pre, s, ctx, false);
     }
@@ -1684,6 +1690,10 @@ static int check_sampler_net(const Net* n) {
 int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int n_tabs, const float* t_model, const float* xT,
                       const float* noise, uint64_t seed, uint64_t tile0, float lo, float hi, int do_clamp, float* out, hipStream_t s) {
     if (int e = check_sampler_net(net)) return e;
+    if (side_pending) {  // a train-mode plan: the cond-only side work must not be waited for inside a captured step
+        train_join(s);
+        side_pending = false;
+    }
     const int HW = H * W;
     const size_t n = (size_t)B * HW * C;
     if (xT) hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
@@ -1879,6 +1889,10 @@ int Plan::sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, floa
     if (!t || t->n_evals < 1 || t->order < 1 || t->order > 3 || !t->t_model || !t->alpha || !t->sigma || !t->ord || !t->cx || !t->a_phi1 || !xT || !out)
         return fail(DDIF_ERR_INVALID, "ddif_plan_sample_dpmpp: bad tables");
     if (int e = check_sampler_net(net)) return e;
+    if (side_pending) {
+        train_join(s);
+        side_pending = false;
+    }
     const int HW = H * W;
     const size_t n = (size_t)B * HW * C;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);

@@ -59,6 +59,8 @@ void linattn_ctx(hipStream_t s, const float* kv, int B, int heads, int d, int H,
 void linattn_apply(hipStream_t s, const float* q, const float* ctx, int B, int heads, int d, int H, int W, float* out, int ld_o);
 void linattn_bwd(hipStream_t s, const float* q, const float* kv, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dkv,
                  float* dctx, float* part);
+void linattn_bwd_q(hipStream_t s, const float* q, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dctx, float* part);
+void linattn_bwd_k(hipStream_t s, const float* kv, const float* dctx, int B, int heads, int d, int H, int W, float* dkv);
 int linattn_prepare();
 // kernels_bwd.h  (ddif_bwd.cpp)
 void silu_fwd(hipStream_t s, const float* x, size_t n, float* y);
@@ -223,6 +225,7 @@ struct Plan {
     hipStream_t wg_stream = nullptr;
     hipEvent_t wg_fork = nullptr, wg_join = nullptr, side_read = nullptr, a_free[3] = {nullptr, nullptr, nullptr};
     bool wg_async = false;
+    bool side_pending = false;                 // set_cond issued side-stream work that no launch of the caller's stream has waited for yet
     hipStream_t train_fork(hipStream_t main);  // the stream a weight-gradient launch goes to, ordered after everything issued on `main` so far
     void train_join(hipStream_t main);         // `main` waits for everything issued on the side stream
     float* d_loss = nullptr;          // device scalar

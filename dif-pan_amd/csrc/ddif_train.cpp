@@ -69,13 +69,21 @@ void linattn_fwd(hipStream_t s, const float* q, const float* kv, int B, int head
     linattn_apply(s, q, ctx, B, heads, d, H, W, out, ld_o);
 }
 // reverse: q side (dq_pre + partial dctx per column group) -> reduce -> k side (dk_pre, dv)
-void linattn_bwd(hipStream_t s, const float* q, const float* kv, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dkv,
-                 float* dctx, float* part) {
-    const int C = heads * d, gk = la_groups(W, C, H), gq = la_groups(H, C, W);
+void linattn_bwd_q(hipStream_t s, const float* q, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dctx, float* part) {
+    const int C = heads * d, gq = la_groups(H, C, W);
     hipLaunchKernelGGL(la_qside_bwd_kernel, dim3(gq, B), dim3(LA_THREADS), la_qside_bwd_smem(H, W, C, d), s, q, dout, ld_g, ctx, H, W, C, d, 1.0f / std::sqrt((float)d), dq,
                        part);
     hipLaunchKernelGGL(la_reduce_kernel, tgrid((size_t)B * C * d), dim3(256), 0, s, (const float*)part, B, gq, C * d, dctx);
-    hipLaunchKernelGGL(la_kside_bwd_kernel, dim3(gk, B), dim3(LA_THREADS), la_kside_bwd_smem(H, W, C, d), s, kv, (const float*)dctx, H, W, C, d, dkv);
+}
+// the k side only feeds kv's own backward (cond needs no gradient): a leaf subtree of the reverse graph
+void linattn_bwd_k(hipStream_t s, const float* kv, const float* dctx, int B, int heads, int d, int H, int W, float* dkv) {
+    const int C = heads * d, gk = la_groups(W, C, H);
+    hipLaunchKernelGGL(la_kside_bwd_kernel, dim3(gk, B), dim3(LA_THREADS), la_kside_bwd_smem(H, W, C, d), s, kv, dctx, H, W, C, d, dkv);
+}
+void linattn_bwd(hipStream_t s, const float* q, const float* kv, const float* dout, int ld_g, const float* ctx, int B, int heads, int d, int H, int W, float* dq, float* dkv,
+                 float* dctx, float* part) {
+    linattn_bwd_q(s, q, dout, ld_g, ctx, B, heads, d, H, W, dq, dctx, part);
+    linattn_bwd_k(s, kv, dctx, B, heads, d, H, W, dkv);
 }
 int linattn_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(la_kside_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -92,8 +100,7 @@ struct Plan::TrainScratch {
     size_t n_a = 0, n_tmp = 0, n_partial = 0, n_bpart = 0, n_cpart = 0, n_wpad = 0, n_dwpart = 0;
     const float* stem_sc = nullptr;  // set by train_step: the self-conditioning source of THIS iteration (sc_in or x_in)
     // time MLP backward
-    float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr, *dctx = nullptr;
-    size_t n_dctx = 0;
+    float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr;
     SlotScatter* slot_tab = nullptr;
     std::vector<SlotScatter> slot_host;
 };
@@ -157,7 +164,8 @@ int Plan::build_backward() {
     struct Seq { std::vector<Launch> v; };
 
     // dgrad conv of forward conv `key`: dy [B,H,W,Cout_f] -> dx [B,H,W,(Cin_f padded to 4)]
-    auto add_dgrad = [&](Seq& L, const std::string& key, Tensor dy, Tensor* dx) -> int {
+    //   side: the conv belongs to a leaf subtree whose input was produced on the side stream -- it is issued there too (in order behind it)
+    auto add_dgrad = [&](Seq& L, const std::string& key, Tensor dy, Tensor* dx, bool side = false) -> int {
         auto it = net->dconv.find(key);
         if (it == net->dconv.end()) return fail(DDIF_ERR_MISSING, "training: no dgrad weights for %s", key.c_str());
         auto prog = std::make_shared<std::vector<Op>>();
@@ -169,9 +177,10 @@ int Plan::build_backward() {
         s.exact = !train_x3_();
         s.name = "dgrad";
         if (int e = add_conv(*prog, s, dx)) return e;
-        L.v.push_back([prog](hipStream_t st) {
+        L.v.push_back([this, prog, side](hipStream_t st) {
             StepCtx ctx;
-            for (auto& op : *prog) op.run(st, ctx);
+            hipStream_t rs = (side && this->wg_async) ? this->wg_stream : st;
+            for (auto& op : *prog) op.run(rs, ctx);
         });
         return 0;
     };
@@ -531,10 +540,14 @@ int Plan::build_backward() {
                 DDIF_TRY(fbuf(&dkv, numel(kv)));
                 {
                     if (!m.ctx || !m.la_part) return fail(DDIF_ERR_STATE, "training: %s has no saved attention context", ci.c_str());
-                    need(T->n_dctx, (size_t)BB * fea * d);
                     const float* ctx = m.ctx;
                     float* part = m.la_part;
-                    L.v.push_back([=](hipStream_t st) { tk::linattn_bwd(st, q.p, kv.p, dcat.p, ldc, ctx, BB, 8, d, Hl, Wl, dq, dkv, T->dctx, part); });
+                    float* dctx = nullptr;  // per block: the k side reads it from the side stream while the chain moves on
+                    DDIF_TRY(fbuf(&dctx, (size_t)BB * fea * d));
+                    L.v.push_back([=](hipStream_t st) {
+                        tk::linattn_bwd_q(st, q.p, dcat.p, ldc, ctx, BB, 8, d, Hl, Wl, dq, dctx, part);
+                        tk::linattn_bwd_k(this->train_fork(st), kv.p, dctx, BB, 8, d, Hl, Wl, dkv);  // kv's backward is a leaf subtree: side stream from here on
+                    });
                 }
                 // q = q.1(dwq) + b;  dwq = depthwise3x3(xn; q.0)
                 Tensor dqT = q;
@@ -575,7 +588,7 @@ int Plan::build_backward() {
                     dkvT.p = dkv;
                     dkvT.st = nullptr;
                     Tensor dkdw;  // padded to Cp channels
-                    DDIF_TRY(add_dgrad(L, ci + ".kv.1", dkvT, &dkdw));
+                    DDIF_TRY(add_dgrad(L, ci + ".kv.1", dkvT, &dkdw, true));
                     const int nsplit = std::min(512, BB * Hl);
                     need(T->n_dwpart, (size_t)nsplit * cd * 9);
                     float** dwk0 = G(ci + ".kv.0.weight");
@@ -674,7 +687,6 @@ int Plan::build_backward() {
     DDIF_TRY(fbuf(&T->wbpart, T->n_bpart + 64));
     DDIF_TRY(fbuf(&T->S, (size_t)BB * 2 + 64));
     DDIF_TRY(fbuf(&T->wpad, T->n_wpad + 64));
-    DDIF_TRY(fbuf(&T->dctx, T->n_dctx + 64));
     DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 512));
     DDIF_TRY(dalloc(&T->cpart, T->n_cpart + 64));
     DDIF_TRY(dalloc(&T->dwpart, T->n_dwpart + 64));

@@ -477,6 +477,35 @@ def test_two_stream_reverse_pass_is_bit_identical_to_the_one_stream_one(backend,
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
+def test_a_sampler_on_a_train_mode_plan_joins_the_side_stream_before_it_captures(backend):
+    """`set_cond` of a train-mode plan leaves its decoder-only half running on the plan's side stream; the step program waits for it in front
+    of the first decoder block.  The samplers replay captured step pairs -- an event wait inside a capture would be illegal -- so they join first.
+    A fresh train-mode plan (identity masks) must sample what the inference plan samples (other kernel fusions: tolerance, not bits)."""
+    from ddif_testlib import make_net
+
+    dev = _dev(backend)
+    B, C, H, T = 2, 8, 32, 6
+    net = make_net("wv3", dev)
+    cond = gc.tiles_for("wv3", B, H, H, seed=2)["cond"].to(dev)
+    gen = torch.Generator().manual_seed(1)
+    x_T = torch.randn(B, C, H, H, generator=gen).to(dev)
+    noise = torch.randn(T, B, C, H, H, generator=gen).to(dev)
+    t_model = [float(i) for i in reversed(range(T))]
+    c0, c1, cz = [0.6] * T, [0.4] * T, [0.05] * (T - 1) + [0.0]
+    outs = []
+    for train in (False, True):
+        (net.train() if train else net.eval())
+        plan = net.plan_for(B, H, H, dev, train=train)
+        plan.set_cond(cond, force=True)
+        outs.append(plan.sample_ddpm(t_model, c0, c1, cz, x_T, noise, 0, 0, (0.0, 1.0), dev))
+        plan.set_cond(cond, force=True)  # twice in a row: the second call waits for the first one's side work
+        outs.append(plan.sample_ddpm(t_model, c0, c1, cz, x_T, noise, 0, 0, (0.0, 1.0), dev))
+    net.eval()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
+    assert torch.isfinite(outs[2]).all() and float((outs[2] - outs[0]).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_reference_optimizer_lines_run_unchanged_on_the_drop_in(backend):
     """diffusion_engine.py:205-241 verbatim in spirit: torch.optim.AdamW over `denoise_fn.parameters()`, `opt.zero_grad()`,
     `diff_loss.backward()`, `clip_grad_norm_(…, 0.003)`, `opt.step()` -- two iterations; the loss must be finite, the clipped gradient norm
