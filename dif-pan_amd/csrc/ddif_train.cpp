@@ -615,6 +615,12 @@ int Plan::build_backward() {
                     DDIF_TRY(fbuf(&dx, numel(m.in)));
                     DDIF_TRY(fbuf(&dskip, numel(skip)));
                     const Tensor hin = m.in;
+                    if (hin.st && skip.st && Ca % 4 == 0 && Cb % 4 == 0 && !getenv("DDIF_TRAIN_GN_RESTAT")) {
+                        // the cat is never formed: both sources are read in place, with the statistics their producers left, and each gets its gradient directly
+                        L.v.push_back([=](hipStream_t st) {
+                            tk::gn_bwd_cat(st, hin.p, Ca, skip.p, Cb, hin.st, hin.np, skip.st, skip.np, dxn, gamma, beta, BB, HW, nchunk, T->cpart, T->S, *dg, *dbt, dx, dskip);
+                        });
+                    } else
                     L.v.push_back([=](hipStream_t st) {
                         hipLaunchKernelGGL(concat2_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)hin.p, Ca, (const float*)skip.p, Cb, npix, T->a);
                         tk::gn_stats(st, T->a, BB, (size_t)HW * fea, nchunk, T->spart);

@@ -431,14 +431,18 @@ __device__ __forceinline__ float gnb_dy(float xh, float g, float bt, float da, f
     return da * m * (s * (1.f + y * (1.f - s)));
 }
 // per (sample, pixel chunk, channel): {sum dy, sum dy x_hat}.  grid = (nchunk, B); thread = (pixel row r, channel quad q)
-__global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma,
-                                                              const float* beta, int HW, int C, int nchunk, int silu, double* cpart /* [B][nchunk][C][2] */) {
+// TWO = 1: x is the channel concatenation of two tensors (x: c0 channels, x1: C - c0; 4 | c0) that is never materialised -- FastAttnCondInjection's
+// prenorm_x over cat[h, skip] -- with the statistics from both producers' partials.
+template <int TWO>
+__global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, const float* x1, int c0, const float* da, const float* mask, const double* st, int np,
+                                                              const double* st1, int np1, const float* gamma, const float* beta, int HW, int C, int nchunk, int silu,
+                                                              double* cpart /* [B][nchunk][C][2] */) {
     DDIF_DYN_SMEM(smem_);
     double* red = reinterpret_cast<double*>(smem_);  // [256][8]
     const int b = blockIdx.y, tid = threadIdx.x;
     const int C4 = C / 4, rows = 256 / C4 > 0 ? 256 / C4 : 1;
     float mean, rstd;
-    gn_finalize_wave(st, np, nullptr, 0, b, (double)C * HW, &mean, &rstd);
+    gn_finalize_wave(st, np, TWO ? st1 : nullptr, TWO ? np1 : 0, b, (double)C * HW, &mean, &rstd);
     const int per = (HW + nchunk - 1) / nchunk;
     const int p0 = blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
     for (int q0 = 0; q0 < C4; q0 += 256) {  // C > 1024: several passes over channel quads
@@ -447,7 +451,8 @@ __global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, co
         if (q < C4 && r < rows) {
             for (int p = p0 + r; p < p1; p += rows) {
                 const size_t e = ((size_t)b * HW + p) * C + q * 4;
-                const float4 xv = *reinterpret_cast<const float4*>(x + e);
+                const size_t px = (size_t)b * HW + p;
+                const float4 xv = *reinterpret_cast<const float4*>(!TWO ? x + e : (q * 4 < c0 ? x + px * c0 + q * 4 : x1 + px * (C - c0) + (q * 4 - c0)));
                 const float4 dv = *reinterpret_cast<const float4*>(da + e);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -556,16 +561,21 @@ __global__ __launch_bounds__(GNB_RED_NT) void gnb_bwd_reduce_kernel(const double
 }
 // dx = rstd (gamma dy - m1 - x_hat m2)  (+ res: the gradient arriving over the residual path of a ResnetBlock / SelfAttention, added here instead
 // of by a launch of its own)
-__global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma,
-                                                         const float* beta, const float* S, const float* res, int HW, int C, int silu, float* dx) {
+// TWO = 1: the two sources as above, and the gradient goes straight to the two tensors' own gradients (dx: c0 channels, dx1: C - c0) -- no cat / split launches
+template <int TWO>
+__global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* x1, int c0, const float* da, const float* mask, const double* st, int np,
+                                                         const double* st1, int np1, const float* gamma, const float* beta, const float* S, const float* res, int HW, int C,
+                                                         int silu, float* dx, float* dx1) {
     const int b = blockIdx.y;
     float mean, rstd;
-    gn_finalize_wave(st, np, nullptr, 0, b, (double)C * HW, &mean, &rstd);
+    gn_finalize_wave(st, np, TWO ? st1 : nullptr, TWO ? np1 : 0, b, (double)C * HW, &mean, &rstd);
     const float m1 = S[b * 2] / (float)HW, m2 = S[b * 2 + 1] / (float)HW;
     const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        const float4 xv = *reinterpret_cast<const float4*>(x + base + i * 4);
+        const size_t pl = (i * 4) / C;  // pixel of the sample
+        const int c = (int)(i * 4 - pl * C);
+        const size_t px = (size_t)b * HW + pl;
+        const float4 xv = *reinterpret_cast<const float4*>(!TWO ? x + base + i * 4 : (c < c0 ? x + px * c0 + c : x1 + px * (C - c0) + (c - c0)));
         const float4 dv = *reinterpret_cast<const float4*>(da + base + i * 4);
         float o[4];
 #pragma unroll
@@ -581,7 +591,8 @@ __global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const f
             o[2] += rv.z;
             o[3] += rv.w;
         }
-        *reinterpret_cast<float4*>(dx + base + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        float* dst = !TWO ? dx + base + i * 4 : (c < c0 ? dx + px * c0 + c : dx1 + px * (C - c0) + (c - c0));
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 // out[b * C + c] = sum over pixels of in[b, c, :] (NCHW planes; fixed-order tree): the FeatureWiseAffine gradient d(noise_func output)
