@@ -14,6 +14,13 @@ static inline f32x16 ddif_mfma_bf16_emu(float4 a, float4 b, f32x16 c) {
     return hipemu_mfma_32x32x16_bf16(ua, ub, c);
 }
 #define DDIF_MFMA_32x32x16_BF16(a, b, c) ddif_mfma_bf16_emu((a), (b), (c))
+static inline f32x16 ddif_mfma_f16_emu(float4 a, float4 b, f32x16 c) {
+    hipemu_u32x4 ua, ub;
+    __builtin_memcpy(&ua, &a, 16);
+    __builtin_memcpy(&ub, &b, 16);
+    return hipemu_mfma_32x32x16_f16(ua, ub, c);
+}
+#define DDIF_MFMA_32x32x16_F16(a, b, c) ddif_mfma_f16_emu((a), (b), (c))
 #define DDIF_DYN_SMEM(name) char* name = hipemu::tctx().dyn_smem
 #define DDIF_SCHED_FENCE() ((void)0)
 #else
@@ -26,6 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 ddif_bf16x8 __attribute__((ext_vector_type(8)));
 #define DDIF_MFMA_32x32x16_BF16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ddif_bf16x8, (a)), __builtin_bit_cast(ddif_bf16x8, (b)), (c), 0, 0, 0)
+// v_mfma_f32_32x32x16_f16: the same operand layout with IEEE halves (the f16x2 split path below)
+typedef _Float16 ddif_f16x8 __attribute__((ext_vector_type(8)));
+#define DDIF_MFMA_32x32x16_F16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ddif_f16x8, (a)), __builtin_bit_cast(ddif_f16x8, (b)), (c), 0, 0, 0)
 #define DDIF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define DDIF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // instruction-scheduling fence (no code)
 #endif
@@ -105,6 +116,53 @@ __device__ __forceinline__ void dd_split3_pair(float a, float b, unsigned* hi, u
     *hi = H;
     *mid = M;
     *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2b));
+#endif
+}
+
+// ---- 2-way fp16 split ("f16x2"): x * S = hi + lo, hi = half(x S) (round to nearest even, 11 significant bits), lo =
+// half(x S - hi) (the remainder is exact in fp32): 22 significant bits, |x S - hi - lo| <= 2^-22 |x S|.  Three cross products
+// lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_f16 (each exact in fp32, fp32 accumulate; the dropped lo*lo term is 2^-22 relative)
+// reproduce the fp32 product as well as the exact-fp32 MFMA does (tools/probes/f16x2.cpp on MI355X, K = 288, error / sum|a b|:
+// 1.1e-7 max / 1.6e-8 rms against 1.0e-7 / 2.3e-8 for v_mfma_f32_32x32x2_f32 and 1.6e-7 / 2.0e-8 for bf16x3) at HALF the matrix
+// instructions of bf16x3 and two operand planes instead of three.  What fp16 does not have is bf16's exponent range, so both
+// operands are pre-scaled by fixed powers of two (exact) and the accumulator is scaled back in the epilogue's fma:
+//   activations x 2^4: finite for |x| < 4094 (a GroupNorm(1 group) output is bounded by sqrt(N) max|gamma| + max|beta|; the host
+//     checks that bound against 4094 per conv and keeps the conv on bf16x3 otherwise; a raw tensor beyond it gives inf -> NaN,
+//     never a silently wrong finite value); the lo part is a NORMAL half for |x| >= 2^-7, below that its quantum is the
+//     subnormal 2^-24 / 2^4, i.e. an absolute error <= 1.9e-9 per element (gfx950 keeps half subnormals in v_cvt_pk_f16_f32 and
+//     in the matrix core: probe);
+//   weights x 2^10: finite for |w| < 64 (checked by the host at commit), lo normal for |w| >= 2^-13, absolute error <= 3e-11 below.
+#define DDIF_F16_ASCALE 16.0f
+#define DDIF_F16_WSCALE 1024.0f
+#define DDIF_F16_OSCALE (1.0f / (DDIF_F16_ASCALE * DDIF_F16_WSCALE))
+#define DDIF_F16_AMAX 4094.0f
+#define DDIF_F16_WMAX 63.9f
+#ifdef DDIF_EMU
+static inline unsigned dd_f16_bits(float x) { return hipemu_f32_to_f16(x); }
+static inline float dd_f16_val(unsigned b) { return hipemu_f16_to_f32((unsigned short)b); }
+#endif
+// a, b are ALREADY scaled; results packed (a in the low half)
+__device__ __forceinline__ void dd_split2_pair(float a, float b, unsigned* hi, unsigned* lo) {
+#ifdef DDIF_EMU
+    const unsigned ha = dd_f16_bits(a), hb = dd_f16_bits(b);
+    *hi = ha | (hb << 16);
+    *lo = dd_f16_bits(a - dd_f16_val(ha)) | (dd_f16_bits(b - dd_f16_val(hb)) << 16);
+#else
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+    const v2f v = {a, b};
+    const v2h H = __builtin_convertvector(v, v2h);  // v_cvt_pk_f16_f32 (RNE)
+    const v2f r = {a - (float)H.x, b - (float)H.y};
+    *hi = __builtin_bit_cast(unsigned, H);
+    *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, v2h));
+#endif
+}
+// SiLU(x) * S with the scale folded into the sigmoid's denominator: x * rcp((1 + e) / S)
+__device__ __forceinline__ float dd_silu_scaled(float x, float inv_s) {
+#ifdef DDIF_EMU
+    return x * (1.0f / fmaf(exp2f(-1.4426950408889634f * x), inv_s, inv_s));
+#else
+    return x * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(-1.4426950408889634f * x), inv_s, inv_s));
 #endif
 }
 

@@ -7,39 +7,42 @@
 namespace ddif {
 
 namespace {
-template <int KS, int MB, int PRO, int EPI>
-ConvVariant lr_variant(const char* name) {
+template <int KS, int MB, int PRO, int EPI, bool F16 = false>
+ConvVariant lr_variant1(const char* name) {
     ConvVariant v;
-    v.fn = conv_lr_kernel<KS, MB, PRO, EPI>;
-    using G = LrGeom<KS, MB, PRO, (EPI & EPI_COLST) != 0>;
+    v.fn = conv_lr_kernel<KS, MB, PRO, EPI, 0, F16>;
+    using G = LrGeom<KS, MB, PRO, (EPI & EPI_COLST) != 0, F16>;
     v.smem = G::smem;
     v.th = G::TH;
     v.tw = G::TW;
     v.nt = 32;
     v.nthr = 256;
     v.x3 = true;
+    v.f16 = F16;
     v.lr = true;
     v.name = name;
     return v;
 }
 template <int MB>
-ConvVariant lr_for(int ks, int pro, int epi) {
+ConvVariant lr_for(int ks, int pro, int epi, bool f16) {
+#define LRV(KS, PRO, EPI, NAME) (f16 ? lr_variant1<KS, MB, PRO, EPI, true>(NAME) : lr_variant1<KS, MB, PRO, EPI, false>(NAME))
     if (ks == 3) {
-        if (pro == PRO_GN_SILU && epi == 0) return lr_variant<3, MB, PRO_GN_SILU, 0>("lr3x3_gn_silu");
-        if (pro == PRO_GN_SILU && epi == EPI_RES) return lr_variant<3, MB, PRO_GN_SILU, EPI_RES>("lr3x3_gn_silu_res");
-        if (pro == PRO_NONE && epi == EPI_SILU) return lr_variant<3, MB, PRO_NONE, EPI_SILU>("lr3x3_silu");
-        if (pro == PRO_NONE && epi == 0) return lr_variant<3, MB, PRO_NONE, 0>("lr3x3");
-        if (pro == PRO_NONE && epi == EPI_RES) return lr_variant<3, MB, PRO_NONE, EPI_RES>("lr3x3_res");  // merged ffn[3] o ffn[2] + residual
+        if (pro == PRO_GN_SILU && epi == 0) return LRV(3, PRO_GN_SILU, 0, "lr3x3_gn_silu");
+        if (pro == PRO_GN_SILU && epi == EPI_RES) return LRV(3, PRO_GN_SILU, EPI_RES, "lr3x3_gn_silu_res");
+        if (pro == PRO_NONE && epi == EPI_SILU) return LRV(3, PRO_NONE, EPI_SILU, "lr3x3_silu");
+        if (pro == PRO_NONE && epi == 0) return LRV(3, PRO_NONE, 0, "lr3x3");
+        if (pro == PRO_NONE && epi == EPI_RES) return LRV(3, PRO_NONE, EPI_RES, "lr3x3_res");  // merged ffn[3] o ffn[2] + residual
     } else if (ks == 1) {
-        if (pro == PRO_NONE && epi == EPI_FILM) return lr_variant<1, MB, PRO_NONE, EPI_FILM>("lr1x1_film");
-        if (pro == PRO_NONE && epi == EPI_RES) return lr_variant<1, MB, PRO_NONE, EPI_RES>("lr1x1_res");
-        if (pro == PRO_NONE && epi == 0) return lr_variant<1, MB, PRO_NONE, 0>("lr1x1");
-        if (pro == PRO_NONE && epi == EPI_COLST) return lr_variant<1, MB, PRO_NONE, EPI_COLST>("lr1x1_colstats");
-        if (pro == PRO_GN && epi == 0) return lr_variant<1, MB, PRO_GN, 0>("lr1x1_gn");
-        if (pro == PRO_GN_SILU && epi == 0) return lr_variant<1, MB, PRO_GN_SILU, 0>("lr1x1_gn_silu");
-        if (pro == PRO_COLSM && epi == 0) return lr_variant<1, MB, PRO_COLSM, 0>("lr1x1_colsoftmax");
+        if (pro == PRO_NONE && epi == EPI_FILM) return LRV(1, PRO_NONE, EPI_FILM, "lr1x1_film");
+        if (pro == PRO_NONE && epi == EPI_RES) return LRV(1, PRO_NONE, EPI_RES, "lr1x1_res");
+        if (pro == PRO_NONE && epi == 0) return LRV(1, PRO_NONE, 0, "lr1x1");
+        if (pro == PRO_NONE && epi == EPI_COLST) return LRV(1, PRO_NONE, EPI_COLST, "lr1x1_colstats");
+        if (pro == PRO_GN && epi == 0) return LRV(1, PRO_GN, 0, "lr1x1_gn");
+        if (pro == PRO_GN_SILU && epi == 0) return LRV(1, PRO_GN_SILU, 0, "lr1x1_gn_silu");
+        if (pro == PRO_COLSM && epi == 0) return lr_variant1<1, MB, PRO_COLSM, 0, false>("lr1x1_colsoftmax");  // bf16x3 only
     }
     return ConvVariant();
+#undef LRV
 }
 }  // namespace
 
@@ -55,9 +58,9 @@ void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
 
 // mb = 2: 8x8 pixel tiles, mb = 4: 8x16.  The per-sample time bias needs no variant of its own here (the epilogue reads
 // bias and time-bias rows straight from memory), so EPI_TBS is accepted and ignored.
-ConvVariant get_lr_variant(int ks, int mb, int pro, int epi) {
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, bool f16) {
     epi &= ~EPI_TBS;
-    return mb == 2 ? lr_for<2>(ks, pro, epi) : lr_for<4>(ks, pro, epi);
+    return mb == 2 ? lr_for<2>(ks, pro, epi, f16) : lr_for<4>(ks, pro, epi, f16);
 }
 
 }  // namespace ddif

@@ -220,11 +220,55 @@ size_t pack_conv_x3(Blob& b, const float* w, int cout, int cin, int ks, int ck) 
     return off;
 }
 
+// f16x2 order (kernels_conv.h MATH = 3, kernels_lr.h F16; inference plans only -- never refreshed on the device):
+//   [n-block of 32 couts][chunk][tap][16-channel slab k16][plane: hi, lo][half h][cout j][8 halves: cin = chunk*ck + 16*k16 + 8*h + t]
+// of w * 2^10 (ddif_dev.h DDIF_F16_WSCALE): hi = half(w S) round to nearest even, lo = half(w S - hi).  Returns (size_t)-1 without
+// packing when a weight is too large for the scaled half range (the conv then stays on bf16x3).
+inline uint16_t f16_bits_host(float x) {
+    const _Float16 hv = (_Float16)x;
+    uint16_t b;
+    std::memcpy(&b, &hv, 2);
+    return b;
+}
+inline float f16_val_host(uint16_t b) {
+    _Float16 hv;
+    std::memcpy(&hv, &b, 2);
+    return (float)hv;
+}
+size_t pack_conv_f16(Blob& b, const float* w, int cout, int cin, int ks, int ck) {
+    const int taps = ks * ks, K16 = ck / 16;
+    for (size_t i = 0; i < (size_t)cout * cin * taps; ++i)
+        if (!(std::fabs(w[i]) <= DDIF_F16_WMAX)) return (size_t)-1;
+    const int n_chunks = (cin + ck - 1) / ck, nb = (cout + 31) / 32, nb_pad = (nb + 3) & ~3;
+    const size_t per = (size_t)taps * K16 * 2 * 256;  // floats per (n-block, chunk)
+    const size_t off = b.add(nullptr, (size_t)nb_pad * n_chunks * per);
+    uint16_t* o = reinterpret_cast<uint16_t*>(b.v.data() + off);
+    for (int nbi = 0; nbi < nb; ++nbi)
+        for (int ch = 0; ch < n_chunks; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int k16 = 0; k16 < K16; ++k16)
+                    for (int h = 0; h < 2; ++h)
+                        for (int j = 0; j < 32; ++j)
+                            for (int t = 0; t < 8; ++t) {
+                                const int ci = ch * ck + 16 * k16 + 8 * h + t, co = nbi * 32 + j;
+                                float val = 0.f;
+                                if (co < cout && ci < cin) val = w[((size_t)co * cin + ci) * taps + tap] * DDIF_F16_WSCALE;
+                                uint16_t q[2];
+                                q[0] = f16_bits_host(val);
+                                q[1] = f16_bits_host(val - f16_val_host(q[0]));
+                                for (int pl = 0; pl < 2; ++pl) {
+                                    const size_t fl = (((((size_t)nbi * n_chunks + ch) * taps + tap) * K16 + k16) * 2 + pl) * 256 + (size_t)(h * 32 + j) * 4;
+                                    o[fl * 2 + t] = q[pl];
+                                }
+                            }
+    return off;
+}
+
 }  // namespace
 
 int Net::commit(hipStream_t stream) {
     Blob b;
-    struct PendConv { std::string name; size_t w_off; long bias_off; int cin, cout, ks, ck, n_chunks; long x3_off = -1; };
+    struct PendConv { std::string name; size_t w_off; long bias_off; int cin, cout, ks, ck, n_chunks; long x3_off = -1; long f16_off = -1; };
     std::vector<PendConv> pend;
     std::map<std::string, size_t> vec_off;
     std::string missing;
@@ -277,6 +321,7 @@ int Net::commit(hipStream_t stream) {
         if (p.ck % 16 == 0 && (p.ks == 3 || p.ck == 32)) {
             p.x3_off = (long)pack_conv_x3(b, w->v.data(), p.cout, p.cin, p.ks, p.ck);
             rec_pack(RF_PACK_X3, name + ".weight", "", (size_t)p.x3_off, p.cout, p.cin, 0, p.ks, p.ck, p.n_chunks);
+            p.f16_off = (long)pack_conv_f16(b, w->v.data(), p.cout, p.cin, p.ks, p.ck);  // inference only: no refresh recipe (merged_stale)
         }
         p.bias_off = bs ? (long)b.add(bs->v.data(), bs->v.size()) : -1;
         if (bs) rec_copy(RF_COPY, name + ".bias", "", (size_t)p.bias_off, bs->v.size());
@@ -438,6 +483,7 @@ int Net::commit(hipStream_t stream) {
                 p.ck = 16;
                 p.w_off = pack_conv(b, wm.data(), co, cin, 3, p.ck, &p.n_chunks);
                 p.x3_off = (long)pack_conv_x3(b, wm.data(), co, cin, 3, p.ck);
+                p.f16_off = (long)pack_conv_f16(b, wm.data(), co, cin, 3, p.ck);
                 p.bias_off = (long)b.add(b3->v.data(), b3->v.size());
                 pend.push_back(p);
             }
@@ -495,6 +541,7 @@ int Net::commit(hipStream_t stream) {
         PackedConv pc;
         pc.w = blob + p.w_off;
         pc.w_x3 = p.x3_off >= 0 ? blob + p.x3_off : nullptr;
+        pc.w_f16 = p.f16_off >= 0 ? blob + p.f16_off : nullptr;
         pc.bias = p.bias_off >= 0 ? blob + p.bias_off : nullptr;
         pc.cin = p.cin;
         pc.cout = p.cout;
@@ -503,7 +550,14 @@ int Net::commit(hipStream_t stream) {
         pc.n_chunks = p.n_chunks;
         conv[p.name] = pc;
     }
-    for (auto& kv : vec_off) vec[kv.first] = blob + kv.second;
+    vec_absmax.clear();
+    for (auto& kv : vec_off) {
+        vec[kv.first] = blob + kv.second;
+        float m = 0.f;
+        if (const HostTensor* t = get(kv.first))
+            for (float x : t->v) m = std::fabs(x) > m || std::isnan(x) ? (std::isnan(x) ? INFINITY : std::fabs(x)) : m;
+        vec_absmax[blob + kv.second] = m;
+    }
     freqs = blob + o_fr;
     w1 = blob + o_w1;
     b1 = blob + o_b1;

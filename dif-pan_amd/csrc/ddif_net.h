@@ -43,6 +43,8 @@ struct Layer {
 struct PackedConv {
     const float* w = nullptr;
     const float* w_x3 = nullptr;  // 3x3 convs: the same weights as three bf16 planes (kernels_conv.h MATH = 1)
+    const float* w_f16 = nullptr; // the same weights x 2^10 as two half planes (kernels_conv.h MATH = 3); inference plans only, null when a
+                                  // weight exceeds the scaled half range
     const float* bias = nullptr;
     int cin = 0, cout = 0, ks = 1, ck = 32, n_chunks = 0;
 };
@@ -65,6 +67,7 @@ struct Net {
     size_t blob_floats = 0;
     std::map<std::string, PackedConv> conv;       // key = conv weight key without ".weight"
     std::map<std::string, const float*> vec;      // GroupNorm gammas/betas and depthwise weights by full key
+    std::map<const float*, float> vec_absmax;     // max |v| of each of them (the f16x2 path bounds GroupNorm outputs with it)
     // time embedding
     const float *freqs = nullptr, *w1 = nullptr, *b1 = nullptr, *w3 = nullptr, *b3 = nullptr, *wall = nullptr,
                 *ball = nullptr;

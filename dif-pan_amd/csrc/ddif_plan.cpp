@@ -50,6 +50,17 @@ ConvVariant variant_for_cfg(int cfg) {
             default: break;
         }
     }
+    if constexpr (KS == 3 && S == 1 && VEC == 1 && (PRO == PRO_NONE || PRO == PRO_GN_SILU)) {
+        switch (cfg) {
+            // f16x2 (MATH = 3): the bf16x3 tilings 7 / 8 / 9 (+ 20).  (A 16x16 x 64-cout tiling on eight waves measured 0.5 % faster on the
+            // step at B = 64 -- 4.75 vs 4.775 ms -- but a cout tile that depends on the item count regroups the GroupNorm partials, and
+            // tiles of a batch are then no longer bit-equal to single-tile runs: not kept.)
+            case 27: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 3>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = true; break;
+            case 28: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 3>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.f16 = true; break;
+            case 29: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 3>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.f16 = true; break;
+            default: break;
+        }
+    }
     if constexpr (KS == 3 && S == 1 && U == 0 && VEC == 1) {
         switch (cfg) {
             case 5: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; break;
@@ -70,9 +81,9 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 // per-thread source select (stem: cat[x, x] of 8 + 8 or 4 + 4 channels inside one 16-channel chunk).
 // epi: EPI_* bits (kernels_conv.h) -- FiLM (CondInjection.x_conv), scalar output path (Cout % 4 != 0), residual add.
 // Only the combinations the network uses are instantiated.
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi) {
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, bool f16) {
     ConvVariant v;
-    if (cfg == 20 || cfg == 21) return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi) : v;
+    if (cfg == 20 || cfg == 21) return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi, f16 && pro != PRO_COLSM) : v;
     const bool plain = stride == 1 && !ups;
     if (epi == EPI_FILM) {
         if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
@@ -118,13 +129,17 @@ static int x3_enabled() {  // DDIF_X3=0: the exact-fp32 MFMA instantiation every
     static const int x3 = [] { const char* e = getenv("DDIF_X3"); return e ? atoi(e) : 1; }();
     return x3;
 }
+static int f16_enabled() {  // DDIF_F16=0: the split-operand convs stay on bf16x3 (six products) instead of f16x2 (three); tests/test_env_switches.py
+    static const int f16 = [] { const char* e = getenv("DDIF_F16"); return e ? atoi(e) : 1; }();
+    return f16;
+}
 static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) as well; covered by tests/test_env_switches.py
     static const int lr = [] { const char* e = getenv("DDIF_LR"); return e ? atoi(e) : 1; }();
     return lr;
 }
 // cfg 20 / 21: the low-resolution kernel (kernels_lr.h) with 8x8 / 8x16 pixel tiles -- samples of <= 256 pixels whose
 // channel counts fit its 16-channel slabs
-static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B, int cin, int c0, bool allow_lr = true, bool exact = false) {
+static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B, int cin, int c0, bool allow_lr = true, bool exact = false, bool f16ok = false) {
     const bool wide = (Wout >= 16) && stride == 1;
     (void)pro;
     const bool x3 = x3_enabled() && !exact;
@@ -139,9 +154,10 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
         return base;
     }
     if (ks == 3 && vec == 1 && stride == 1 && x3) {
-        if (wide && Hout >= 32 && Wout >= 32) return 7;
-        if (wide || Cout <= 32) return 8;
-        return 9;
+        const bool f16 = f16ok && (pro == PRO_NONE || pro == PRO_GN_SILU);
+        if (wide && Hout >= 32 && Wout >= 32) return f16 ? 27 : 7;
+        if (wide || Cout <= 32) return f16 ? 28 : 8;
+        return f16 ? 29 : 9;
     }
     if (ks == 3 && vec == 1 && wide && !ups_) {
         const long items32 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
@@ -440,13 +456,21 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int vec = (c0 % 4 != 0 || c1 % 4 != 0) ? 0 : ((c1 == 0 || c0 % pc.ck == 0) ? 1 : 2);
     if ((size_t)B * Hin * Win * (c0 > c1 ? c0 : c1) * 4 >= ((size_t)1 << 32) || (size_t)B * Hout * Wout * pc.cout * 8 >= ((size_t)1 << 32))
         return fail(DDIF_ERR_INVALID, "%s: a tensor of this batch reaches 4 GiB (32-bit offsets); split the batch", s.name);
-    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact);
+    // f16x2 (kernels_conv.h MATH = 3): inference plans only (the half packs are not refreshed on the device), shared weights inside the
+    // scaled half range (pc.w_f16), and for a GroupNorm prologue an output bound sqrt(N) max|gamma| + max|beta| inside the activation range
+    bool f16ok = f16_enabled() && !train_mode && pc.w_f16 && !s.w_override && !s.exact;
+    if (f16ok && (s.pro == PRO_GN || s.pro == PRO_GN_SILU)) {
+        auto ig = net->vec_absmax.find(s.gamma), ib = net->vec_absmax.find(s.beta);
+        const double n = (double)(c0 + c1) * Hin * Win;
+        f16ok = ig != net->vec_absmax.end() && ib != net->vec_absmax.end() && std::sqrt(n) * ig->second + ib->second < DDIF_F16_AMAX;
+    }
+    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact, f16ok);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0);
-    if (s.cso_mx && (cfg < 20 || Hout > (cfg == 20 ? 8 : 16)))
+    if (s.cso_mx && ((cfg != 20 && cfg != 21) || Hout > (cfg == 20 ? 8 : 16)))
         return fail(DDIF_ERR_INVALID, "%s: column statistics epilogue needs the low-resolution kernel and H <= 16", s.name);
-    ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
-    if (!var.fn && cfg >= 20) {  // prologue / epilogue combination the low-resolution kernel does not carry
-        cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false);
+    ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi, f16ok);
+    if (!var.fn && (cfg == 20 || cfg == 21)) {  // prologue / epilogue combination the low-resolution kernel does not carry
+        cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false, false, f16ok);
         var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     }
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
@@ -475,8 +499,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.Hout = Hout;
     a.Wout = Wout;
     a.Cout = pc.cout;
-    a.w = s.w_override ? s.w_override : (var.x3 ? pc.w_x3 : pc.w);
-    if (var.x3 && !s.w_override && !pc.w_x3) return fail(DDIF_ERR_STATE, "%s: bf16x3 variant without split weights", s.name);
+    a.w = s.w_override ? s.w_override : (var.f16 ? pc.w_f16 : (var.x3 ? pc.w_x3 : pc.w));
+    if (var.x3 && !s.w_override && !a.w) return fail(DDIF_ERR_STATE, "%s: split-operand variant without split weights", s.name);
     a.w_bstride = s.w_bstride;
     a.cs_mx = s.cs_mx;
     a.cs_sm = s.cs_sm;
@@ -524,7 +548,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     // q_sample_forward with one t per sample use the EPI_TBS instantiation (rows loaded per work item)
     ConvKernelFn fn_tbs = nullptr;
     if (s.tb_off >= 0) {
-        const ConvVariant vt = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi | EPI_TBS);
+        const ConvVariant vt = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi | EPI_TBS, f16ok);
         if (!vt.fn || vt.smem != var.smem) return fail(DDIF_ERR_INVALID, "%s: no per-sample time-bias kernel variant", s.name);
         fn_tbs = vt.fn;
         if (var.smem + 8192 > 64 * 1024)

@@ -42,12 +42,13 @@ struct ConvVariant {
     size_t smem = 0;
     int th = 0, tw = 0, nt = 0, nthr = 256;
     bool x3 = false;  // bf16x3 instantiation: wants PackedConv::w_x3
+    bool f16 = false; // f16x2 instantiation: wants PackedConv::w_f16 (x3 is set as well: split-operand path)
     int wg_cap = 2;   // persistent workgroups per CU (upper bound; LDS may allow fewer)
     bool lr = false;  // low-resolution kernel (kernels_lr.h): smem is the whole requirement, nothing is added per launch
     const char* name = "";
 };
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi);
-ConvVariant get_lr_variant(int ks, int mb, int pro, int epi);  // ddif_lr.cpp
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, bool f16 = false);
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, bool f16 = false);  // ddif_lr.cpp
 // launchers of kernels that live in other translation units (every non-template kernel header is compiled into exactly one object)
 namespace tk {
 // kernels_train.h  (ddif_train.cpp)

@@ -103,24 +103,35 @@ enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_
 // ddif_dev.h), six cross products per 16-channel slab on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  fp32-class
 // result (not bitwise the fmaf chain), 198 instead of 512 matrix cycles per slab, and the matrix core runs beside the
 // VALU instead of on it.  LDS holds three bf16 planes per operand (96 B per pixel and 16-channel chunk + 16 B pad).
+// 3 = "f16x2" (ddif_dev.h): operands pre-scaled by fixed powers of two and split two ways into IEEE halves (hi, lo), THREE cross
+// products per slab on v_mfma_f32_32x32x16_f16 -- the accuracy of the exact-fp32 MFMA (measured, tools/probes/f16x2.cpp) at half
+// the matrix instructions of bf16x3, two LDS planes per operand instead of three (64 B per pixel and chunk + 16 B pad, 2/3 of
+// the weight bytes) and a 3-op-per-value split instead of 5.5.  The accumulator is scaled back in the epilogue's fma.
 template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0, int MATH = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    constexpr bool X3 = MATH >= 1;
+    constexpr bool X3 = MATH >= 1;   // split-operand paths (bf16x3, f16x2): 16-bit planes in LDS
+    constexpr bool F16 = MATH == 3;
+    constexpr int NPL = F16 ? 2 : 3; // operand planes
     constexpr bool WSB = MATH == 2;  // ONE weight buffer (an extra barrier per stage): 69 KB of LDS -> two workgroups per CU, whose VALU
                                      // staging and bf16 MFMAs then overlap (different pipes)
     constexpr int NWB = WSB ? 1 : 2;
     constexpr int PS = CK / 2;                            // X3: floats per bf16 plane of one staged pixel (CK x 2 B)
-    constexpr int LDA = X3 ? 3 * PS + 4 : CK + 4;         // floats per staged pixel (X3: 3 planes + 16 B pad)
+    constexpr int LDA = X3 ? NPL * PS + 4 : CK + 4;       // floats per staged pixel (X3: NPL planes + 16 B pad)
     constexpr int LDH = CK + 4;                           // row of the fp32 scratch tile of the depthwise prologue
     constexpr int TAPS = KS * KS;
     constexpr int K8 = CK / 8;
     constexpr int K16 = CK / 16;
     constexpr int C4 = CK / 4;
     constexpr int NF = X3 ? TAPS * K16 : TAPS * K8;       // MFMA steps per chunk: (tap, k8), or (tap, 16-channel slab)
-    constexpr int ABUF = IH * IW * LDA;                   // floats per LDS buffer
+    // row pad of the staged tile (floats): lanes 0-15 / 16-31 of an A-fragment read own consecutive pixels of two ROWS of the tile;
+    // with a halo the row stride IW * LDA puts the second row on the banks of the first (2-way conflicts on every ds_read_b128 of
+    // the 16-wide tile, 3-way on the 8-wide one); these pads make the reads conflict-free (bank search: DESIGN section 3)
+    constexpr int RP = (X3 && KS == 3 && STRIDE == 1) ? (NPL == 2 ? 24 : 8) : 0;
+    constexpr int LDR = IW * LDA + RP;                    // floats per staged tile row
+    constexpr int ABUF = IH * LDR;                        // floats per LDS buffer
     // PRO_GN_DW (1x1 conv over depthwise3x3(GroupNorm(x))): the LOAD tile has a one-pixel halo and goes to a scratch
     // LDS region; the depthwise conv turns it into the A tile of the 1x1 contraction.
     constexpr bool DWM = (PRO == PRO_GN_DW);
@@ -134,16 +145,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int DWMAX = DWM ? 9 * 256 : 0;                       // depthwise weights of up to 256 channels
     constexpr int DITEMS = (TH * TW * C4 + NTHR - 1) / NTHR;
     constexpr int NITEMS = (LH * LW * C4 + NTHR - 1) / NTHR;  // float4 input-staging items per thread and chunk
-    constexpr int WCHUNK = X3 ? NF * 3 * 256 : NF * 256;  // floats per (32-cout block, chunk): X3 = 3 bf16 planes of 1 KiB per step
+    constexpr int WCHUNK = X3 ? NF * NPL * 256 : NF * 256;  // floats per (32-cout block, chunk): X3 = NPL 16-bit planes of 1 KiB per step
     constexpr int WBUF = NB * WN * WCHUNK;                // floats of one weight chunk (all n-blocks of the cout tile)
     constexpr int WITEMS = (WBUF / 4 + NTHR - 1) / NTHR;  // float4 weight-staging items per thread and chunk
-    constexpr int DUMMY = DWM ? CK : (X3 ? 3 * PS : CK);  // pad slot of pixel 0 of the buffer the staging items go to (Hs for the
+    constexpr int DUMMY = DWM ? CK : (X3 ? NPL * PS : CK);  // pad slot of pixel 0 of the buffer the staging items go to (Hs for the
                                                           // depthwise prologue, else the A buffer): items past the end write here
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per workgroup");
     static_assert(!X3 || (CK % 16 == 0 && VEC == 1), "bf16x3 path: 16-channel slabs, float4 staging");
     static_assert(TH * TW == 32 * MB * WM, "pixel tile must match the wave layout");
     static_assert(CK % 8 == 0 && NTHR % C4 == 0, "chunk size");
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
+    static_assert(!F16 || PRO != PRO_COLSM, "f16x2: the column-softmax prologue stays on bf16x3 / fp32 (probabilities far below 2^-7)");
+    static_assert(RP == 0 || !DWM, "row pad: 3x3 tiles only");
 
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = (wm * MB + mb) * 32 + j;
-        abase[mb] = ((m / TW) * STRIDE * IW + (m % TW) * STRIDE) * LDA + 4 * h;
+        abase[mb] = (m / TW) * STRIDE * LDR + (m % TW) * STRIDE * LDA + 4 * h;
         e_my[mb] = m / TW;  // the pixel this lane owns in the (transposed) accumulator block mb
         e_mx[mb] = m % TW;
         e_off[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * a.Cout + 4 * h) * 4);
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         const int pix = in ? pixr : LH * LW - 1;
         a_py[it] = pix / LW;
         a_px[it] = pix % LW;
-        a_lds[it] = in ? (DWM ? pix * LDH + c4 * 4 : (X3 ? pix * LDA + c4 * 2 : pix * LDA + c4 * 4)) : DUMMY;
+        a_lds[it] = in ? (DWM ? pix * LDH + c4 * 4 : (X3 ? a_py[it] * LDR + a_px[it] * LDA + c4 * 2 : pix * LDA + c4 * 4)) : DUMMY;
         a_in |= (in ? 1u : 0u) << it;
     }
     unsigned w_boff[WITEMS];
@@ -391,7 +404,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             float x = (&R.sv[it].x)[i];
             if (GNP) {
                 x = fmaf(x, fs_ga[i], fs_gb[i]);
-                if (PRO == PRO_GN_SILU) x = dd_silu(x);
+                if (PRO == PRO_GN_SILU) x = (F16 && !DWM) ? dd_silu_scaled(x, 1.0f / DDIF_F16_ASCALE) : dd_silu(x);
+                else if (F16 && !DWM) x *= DDIF_F16_ASCALE;
+            } else if (F16 && !DWM) {
+                x *= DDIF_F16_ASCALE;
             }
             if (PRO == PRO_COLSM) {
                 if (fs_colsm) x = dd_exp2_fast((x - (&R.mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&R.smv[it].x)[i]);
@@ -404,6 +420,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             if (a.out_xn && ok && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
                 *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cb + c4 * 4) =
                     make_float4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (F16) {
+            unsigned h01, l01, h23, l23;
+            dd_split2_pair(v[0], v[1], &h01, &l01);
+            dd_split2_pair(v[2], v[3], &h23, &l23);
+            const int ps = ((a_in >> it) & 1u) ? PS : 0;  // plane stride in floats (the dummy slot takes both)
+            *reinterpret_cast<uint2*>(&dst[a_lds[it]]) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(&dst[a_lds[it] + ps]) = make_uint2(l01, l23);
         } else if constexpr (X3) {
             unsigned h01, m01, l01, h23, m23, l23;
             dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
@@ -436,7 +459,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                         s2 = fmaf(hv.z, wk.z, s2);
                         s3 = fmaf(hv.w, wk.w, s3);
                     }
-                    if constexpr (X3) {
+                    if constexpr (F16) {
+                        unsigned h01, l01, h23, l23;
+                        dd_split2_pair(s0 * DDIF_F16_ASCALE, s1 * DDIF_F16_ASCALE, &h01, &l01);
+                        dd_split2_pair(s2 * DDIF_F16_ASCALE, s3 * DDIF_F16_ASCALE, &h23, &l23);
+                        *reinterpret_cast<uint2*>(&dst[p * LDA + c4 * 2]) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(&dst[p * LDA + PS + c4 * 2]) = make_uint2(l01, l23);
+                    } else if constexpr (X3) {
                         unsigned h01, m01, l01, h23, m23, l23;
                         dd_split3_pair(s0, s1, &h01, &m01, &l01);
                         dd_split3_pair(s2, s3, &h23, &m23, &l23);
@@ -579,18 +608,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             //     bf16x3: per tap one 16-channel slab; three planes per operand, six cross products, small terms first;
             //     the fragments of tap t+1 are read before the MFMAs of tap t (register double buffer)
             constexpr int FB = (MB * NB >= 2) ? 1 : 2;  // register double buffer only for the single-tile shapes (wide cout tiles would spill)
-            float4 xa[FB][MB][3], wb[FB][NB][3];
+            float4 xa[FB][MB][NPL], wb[FB][NB][NPL];
             auto load_frags3 = [&](int f, int slot) {  // step f = (tap, 16-channel slab)
                 const int tap = f / K16, k16 = f % K16;
-                const int aoff = ((tap / KS) * IW + (tap % KS)) * LDA + k16 * 8;
+                const int aoff = (tap / KS) * LDR + (tap % KS) * LDA + k16 * 8;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NPL; ++q) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
                         xa[slot][mb][q] = (ABL & 128) ? make_float4(1.f, 2.f, 3.f, (float)(f + q)) : *reinterpret_cast<const float4*>(&Ac[abase[mb] + aoff + q * PS]);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        wb[slot][nb][q] = (ABL & 128) ? make_float4(4.f, 3.f, 2.f, (float)(f - q)) : *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + (f * 3 + q) * 256]);
+                        wb[slot][nb][q] = (ABL & 128) ? make_float4(4.f, 3.f, 2.f, (float)(f - q)) : *reinterpret_cast<const float4*>(&Wc[nb * WCHUNK + (f * NPL + q) * 256]);
                 }
             };
             if (FB == 2) load_frags3(0, 0);
@@ -609,7 +638,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                     for (int nb = 0; nb < NB; ++nb) {
                         f32x16 c = acc[mb][nb];
                         if (ABL & 1) {  // no matrix work: keep the fragments alive
-                            c[0] += wb[sl][nb][0].x + xa[sl][mb][0].y + wb[sl][nb][1].z + xa[sl][mb][1].w + wb[sl][nb][2].x + xa[sl][mb][2].y;
+                            c[0] += wb[sl][nb][0].x + xa[sl][mb][0].y + wb[sl][nb][1].z + xa[sl][mb][1].w + wb[sl][nb][NPL - 1].x + xa[sl][mb][NPL - 1].y;
+                            acc[mb][nb] = c;
+                            continue;
+                        }
+                        if constexpr (F16) {
+                            c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][1], xa[sl][mb][0], c);  // lo * hi
+                            c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][0], xa[sl][mb][1], c);  // hi * lo
+                            c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][0], xa[sl][mb][0], c);  // hi * hi
                             acc[mb][nb] = c;
                             continue;
                         }
@@ -682,7 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                                 float v[4];
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    float x = acc[mb][nb][4 * g + i] + (&bt.x)[i];
+                                    float x = F16 ? fmaf(acc[mb][nb][4 * g + i], DDIF_F16_OSCALE, (&bt.x)[i]) : acc[mb][nb][4 * g + i] + (&bt.x)[i];
                                     if constexpr (TBS) x += (&e_t[nb][g].x)[i];
                                     if constexpr (FILM) x = x * (1.f + (&e_fs[mb][nb][g].x)[i]) + (&e_fh[mb][nb][g].x)[i];
                                     if constexpr (SILU) x = dd_silu(x);
@@ -712,7 +748,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                             const int co = (nbg0 + nb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                             if (e_pok[mb] && co < a.Cout) {
                                 const size_t pix = (size_t)((Cp.b * a.Hout + Cp.oy0 + e_my[mb]) * a.Wout + Cp.ox0 + e_mx[mb]);
-                                float x = acc[mb][nb][r] + BTs[co];
+                                float x = F16 ? fmaf(acc[mb][nb][r], DDIF_F16_OSCALE, BTs[co]) : acc[mb][nb][r] + BTs[co];
                                 if constexpr (TBS) x += tb[co];
                                 if constexpr (FILM) x = x * (1.f + a.film[pix * 2 * a.Cout + co]) + a.film[pix * 2 * a.Cout + a.Cout + co];
                                 if constexpr (SILU) x = dd_silu(x);
@@ -855,8 +891,10 @@ template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO 
 constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN; + conv_smem_extra() at launch
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
-    constexpr int lda = MATH >= 1 ? 3 * CK / 2 + 4 : CK + 4, wchunk = MATH >= 1 ? KS * KS * (CK / 16) * 3 * 256 : KS * KS * (CK / 8) * 256;
-    return (size_t)(2 * IH * IW * lda + (MATH == 2 ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
+    constexpr int npl = MATH == 3 ? 2 : 3;
+    constexpr int lda = MATH >= 1 ? npl * CK / 2 + 4 : CK + 4, wchunk = MATH >= 1 ? KS * KS * (CK / 16) * npl * 256 : KS * KS * (CK / 8) * 256;
+    constexpr int rp = (MATH >= 1 && KS == 3 && STRIDE == 1) ? (npl == 2 ? 24 : 8) : 0;
+    return (size_t)(2 * IH * (IW * lda + rp) + (MATH == 2 ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
 }
 // GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts
 inline size_t conv_smem_extra(int pro, int n_chunks, int ck, int cout_pad) {

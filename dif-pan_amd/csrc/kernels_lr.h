@@ -35,14 +35,15 @@ namespace ddif {
 
 // TALL: 16x8 instead of 8x16 pixels for MB = 4 -- whole image columns inside one tile, which is what the column-softmax
 // statistics epilogue (EPI_COLST) needs
-template <int KS, int MB, int PRO, bool TALL = false>
+template <int KS, int MB, int PRO, bool TALL = false, bool F16 = false>
 struct LrGeom {
+    static constexpr int NPL = F16 ? 2 : 3;                    // operand planes: f16x2 (hi, lo) or bf16x3 (hi, mid, lo)
     static constexpr int TH = (TALL && MB == 4) ? 16 : 8, TW = (MB == 2 || TALL) ? 8 : 16;
     static constexpr int PAD = KS / 2;
     static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD; // staged tile (halo of the 3x3 taps)
     static constexpr int PC = (MB == 4 && KS == 3) ? 64 : 128; // channels staged per phase
     static constexpr int SP = PC / 16;                         // 16-channel slabs per phase
-    static constexpr int APIX = SP * 24 + 4;                   // floats per staged pixel: SP x (3 planes x 32 B) + 16 B pad
+    static constexpr int APIX = SP * NPL * 8 + 4;              // floats per staged pixel: SP x (NPL planes x 32 B) + 16 B pad
     static constexpr int AFL = IH * IW * APIX;
     static constexpr int RFL = 4 * MB * 4 * 64 * 4;            // K-partials: [wave][mb][quad g][lane] float4
     static constexpr size_t smem = (size_t)((AFL > RFL ? AFL : RFL) + 16) * sizeof(float);
@@ -52,11 +53,16 @@ struct LrGeom {
 };
 
 // ABL (tools/mbench_lr.cpp only): 1 = no weight loads, 2 = no MFMAs, 4 = no activation loads, 8 = no output stores
-template <int KS, int MB, int PRO, int EPI, int ABL = 0>
+// F16: the f16x2 split (ddif_dev.h; kernels_conv.h MATH = 3) instead of bf16x3 -- operands pre-scaled by 2^4 / 2^10 and split into two
+// half planes, three products per slab and tap, 2/3 of the weight stream and of the staged tile; the accumulator is scaled back in the epilogue
+template <int KS, int MB, int PRO, int EPI, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     constexpr bool COLST = (EPI & EPI_COLST) != 0;
     static_assert(!COLST || KS == 1, "column statistics epilogue: 1x1 convs");
-    using G = LrGeom<KS, MB, PRO, COLST>;
+    static_assert(!F16 || PRO != PRO_COLSM, "f16x2: the column-softmax prologue stays on bf16x3");
+    using G = LrGeom<KS, MB, PRO, COLST, F16>;
+    constexpr int NPL = G::NPL, SLF = NPL * 8;  // floats of one 16-channel slab of a staged pixel
+    constexpr int WSTEP = NPL * 1024;           // bytes of one (slab, tap) step of the packed weights
     constexpr int TH = G::TH, TW = G::TW, LP = G::PAD, LH = G::IH, LW = G::IW, IW = G::IW, PC = G::PC, SP = G::SP;
     constexpr int APIX = G::APIX, TAPS = G::TAPS, U = G::U, SPW = G::SPW;
     constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU);
@@ -135,14 +141,14 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
         }
 
         // weight stream of this wave: slabs wave, wave+4, ... ; steps = (slab, tap) in order; ring slot = step within the phase
-        const char* wbase = reinterpret_cast<const char*>(a.w + (size_t)b * a.w_bstride) + ((size_t)ct * NSW * TAPS) * 3072 + (size_t)lane * 16;
+        const char* wbase = reinterpret_cast<const char*>(a.w + (size_t)b * a.w_bstride) + ((size_t)ct * NSW * TAPS) * WSTEP + (size_t)lane * 16;
         int pf_slab = wave, pf_tap = 0;  // prefetch cursor
-        float4 wr[U][3];
+        float4 wr[U][NPL];
         auto ring_load = [&](int slot) {
             const int s = pf_slab < NS ? pf_slab : 0;  // (the initial fill of a wave without slabs re-reads slab 0; never consumed)
-            const char* p = wbase + ((size_t)s * TAPS + pf_tap) * 3072;
+            const char* p = wbase + ((size_t)s * TAPS + pf_tap) * WSTEP;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NPL; ++q) {
                 if (ABL & 1) wr[slot][q] = make_float4(1e-3f * (float)q, 2e-3f, 3e-3f, 4e-3f);
                 else wr[slot][q] = *reinterpret_cast<const float4*>(p + q * 1024);
             }
@@ -200,6 +206,10 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     ga[i] = (&gq4.x)[i] * rstd;
                     gb[i] = (&bq4.x)[i] - mean * ga[i];
+                    if constexpr (F16 && PRO == PRO_GN) {  // no activation behind the normalisation: scale the affine map itself
+                        ga[i] *= DDIF_F16_ASCALE;
+                        gb[i] *= DDIF_F16_ASCALE;
+                    }
                 }
             }
 #pragma unroll
@@ -211,8 +221,10 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     float x = (&sv[it].x)[i];
                     if constexpr (GNP) {
-                        x = fmaf(x, ga[i], gb[i]);
-                        if constexpr (PRO == PRO_GN_SILU) x = dd_silu(x);
+                        x = fmaf(x, ga[i], gb[i]);  // (F16, PRO_GN: the activation scale is folded into ga / gb above)
+                        if constexpr (PRO == PRO_GN_SILU) x = F16 ? dd_silu_scaled(x, 1.0f / DDIF_F16_ASCALE) : dd_silu(x);
+                    } else if constexpr (F16) {
+                        x *= DDIF_F16_ASCALE;
                     }
                     if constexpr (PRO == PRO_COLSM) {
                         if (colsm) x = dd_exp2_fast((x - (&mxv[it].x)[i]) * 1.4426950408889634f) * dd_rcp_fast((&smv[it].x)[i]);
@@ -220,13 +232,21 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                     v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation (and channels past the end are zero)
                 }
                 if (pix < LH * LW) {
-                    unsigned h01, m01, l01, h23, m23, l23;
-                    dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
-                    dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
-                    float* d = &As[pix * APIX + slab_l * 24 + cin_slab / 2];
-                    *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
-                    *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
-                    *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
+                    float* d = &As[pix * APIX + slab_l * SLF + cin_slab / 2];
+                    if constexpr (F16) {
+                        unsigned h01, l01, h23, l23;
+                        dd_split2_pair(v[0], v[1], &h01, &l01);
+                        dd_split2_pair(v[2], v[3], &h23, &l23);
+                        *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(d + 8) = make_uint2(l01, l23);
+                    } else {
+                        unsigned h01, m01, l01, h23, m23, l23;
+                        dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
+                        dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
+                        *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
+                        *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
+                    }
                 }
             }
         };
@@ -258,17 +278,24 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                     for (int tap = 0; tap < TAPS; ++tap) {
                         constexpr int UU = U;
                         const int u = (k * TAPS + tap) % UU;
-                        const int aoff = ((tap / KS) * IW + (tap % KS)) * APIX + sl * 24;
-                        float4 xa[MB][3];
+                        const int aoff = ((tap / KS) * IW + (tap % KS)) * APIX + sl * SLF;
+                        float4 xa[MB][NPL];
 #pragma unroll
-                        for (int q = 0; q < 3; ++q)
+                        for (int q = 0; q < NPL; ++q)
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[abase[mb] + aoff + q * 8]);
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
                             f32x16 cacc = acc[mb];
                             if (ABL & 2) {
-                                cacc[0] += wr[u][0].x * xa[mb][0].x + wr[u][1].y * xa[mb][1].y + wr[u][2].z * xa[mb][2].z;
+                                cacc[0] += wr[u][0].x * xa[mb][0].x + wr[u][1].y * xa[mb][1].y + wr[u][NPL - 1].z * xa[mb][NPL - 1].z;
+                                acc[mb] = cacc;
+                                continue;
+                            }
+                            if constexpr (F16) {
+                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][1], xa[mb][0], cacc);  // lo * hi
+                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[mb][1], cacc);  // hi * lo
+                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[mb][0], cacc);  // hi * hi
                                 acc[mb] = cacc;
                                 continue;
                             }
@@ -308,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float x = ((&pp[0].x)[i] + (&pp[1].x)[i]) + ((&pp[2].x)[i] + (&pp[3].x)[i]);
-                x += (&bq.x)[i] + (&tq.x)[i];
+                x = F16 ? fmaf(x, DDIF_F16_OSCALE, (&bq.x)[i] + (&tq.x)[i]) : x + ((&bq.x)[i] + (&tq.x)[i]);
                 if constexpr (FILM) x = x * (1.f + (&e_fs[mb].x)[i]) + (&e_fh[mb].x)[i];
                 if constexpr (SILU) x = dd_silu(x);
                 if constexpr (RES) x += (&e_res[mb].x)[i];

@@ -211,24 +211,68 @@ class _Batches:
     """Mini-batches (pan, lms, hr) of raw-count tensors out of an in-memory set {"pan", "lms", "gt"} (the three arrays PanDataset / HISRDataSets
     read from their h5 files, dataset/pan_dataset.py:37-66, dataset/hisr.py:22-46), reshuffled every epoch like DataLoader(shuffle=True).
     With `world > 1` every epoch's permutation comes from a generator seeded by (seed, epoch) -- the SAME on every rank -- and rank r takes
-    order[r::world] (what DistributedSampler does): the ranks see disjoint samples whatever their own torch RNG state is."""
+    order[r::world] (what DistributedSampler does): the ranks see disjoint samples whatever their own torch RNG state is.
+
+    Position inside the epoch is part of the training state (`state()` / `load_state()`): a checkpoint written in the MIDDLE of an epoch
+    resumes with the same permutation at the next batch.  With one rank the permutation comes from the global torch generator (as DataLoader's
+    RandomSampler draws it), so the state keeps the generator state the permutation was drawn FROM; on resume it is re-drawn from that state
+    without disturbing the (restored) global stream."""
 
     def __init__(self, data: Dict[str, torch.Tensor], batch_size: int, shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0):
         self.pan, self.lms, self.gt = (torch.as_tensor(np.asarray(data[k]), dtype=torch.float32) for k in ("pan", "lms", "gt"))
         self.n, self.bs, self.shuffle = self.gt.shape[0], batch_size, shuffle
-        self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
+        self.rank, self.world, self.seed = rank, world, seed
+        if world > 1 and self.n < world:
+            raise DdifError("engine_google: %d training samples for %d ranks -- every rank needs at least one (the gradient all-reduce would "
+                            "otherwise wait for ranks that have no batch)" % (self.n, world))
+        self.epoch = 0        # epochs STARTED so far
+        self.offset = 0       # batches of the current epoch already handed out
+        self._perm_rng = None # world == 1: the global generator state the current epoch's permutation was drawn from
+        self._resume = None
 
-    def __iter__(self):
+    def _order(self, epoch_index: int, redraw_from=None):
         if self.world > 1:
-            g = torch.Generator().manual_seed(self.seed * 1_000_003 + self.epoch)
+            g = torch.Generator().manual_seed(self.seed * 1_000_003 + epoch_index)
             order = torch.randperm(self.n, generator=g) if self.shuffle else torch.arange(self.n)
             n_even = (self.n // self.world) * self.world  # every rank the same number of samples (the tail is dropped, as drop_last does)
-            order = order[:n_even][self.rank::self.world] if n_even else order[self.rank::self.world]
+            return order[:n_even][self.rank::self.world]
+        if not self.shuffle:
+            return torch.arange(self.n)
+        if redraw_from is not None:  # mid-epoch resume: the same permutation again, the global stream untouched
+            keep = torch.get_rng_state()
+            torch.set_rng_state(redraw_from)
+            order = torch.randperm(self.n)
+            torch.set_rng_state(keep)
+            self._perm_rng = redraw_from
+            return order
+        self._perm_rng = torch.get_rng_state()
+        return torch.randperm(self.n)
+
+    def state(self) -> dict:
+        return {"epoch": self.epoch, "offset": self.offset, "perm_rng": self._perm_rng}
+
+    def load_state(self, st: dict):
+        self.epoch, self._resume = int(st["epoch"]), dict(st)
+
+    def __iter__(self):
+        st, self._resume = self._resume, None
+        nb = lambda order: -(-len(order) // self.bs)
+        start = 0
+        if st is not None and int(st.get("offset", 0)) > 0 and self.epoch > 0:
+            order = self._order(self.epoch - 1, redraw_from=st.get("perm_rng"))  # the epoch that was in force when the state was taken
+            if int(st["offset"]) < nb(order):
+                start = int(st["offset"])
+            else:
+                order = None  # the checkpoint fell on the epoch's last batch: a fresh epoch starts, exactly as the uninterrupted run does
         else:
-            order = torch.randperm(self.n) if self.shuffle else torch.arange(self.n)
-        self.epoch += 1
-        for k in range(0, len(order), self.bs):
+            order = None
+        if order is None:
+            order = self._order(self.epoch)
+            self.epoch += 1
+        self.offset = start
+        for k in range(start * self.bs, len(order), self.bs):
             idx = order[k:k + self.bs]
+            self.offset += 1  # counted when handed out: a state taken while the consumer works on this batch resumes at the next one
             yield self.pan[idx], self.lms[idx], self.gt[idx]
 
 
@@ -327,7 +371,8 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
     `ema_updater.ema_model`, a deep copy, :277-329 -- the training schedule is never respaced) with SAM / ERGAS / PSNR / CC / SSIM from
     `ddif_metrics`.  Every `save_every` iterations (rank 0): `diffusion_{name}_iter_{N}.pth` and `ema_diffusion_{name}_iter_{N}.pth` as bare
     state_dicts like the reference (:333-340; `test_fn(weight_path=...)` loads either) plus `train_state_{name}_iter_{N}.pth` with the
-    optimizer moments, step, iteration and RNG states; `resume_state=<that file>` continues such a run bit-identically.
+    optimizer moments, step, iteration, RNG states and the data position (epoch, batch offset inside it, the generator state the epoch's
+    permutation was drawn from); `resume_state=<that file>` continues such a run bit-identically, also from the middle of an epoch.
     `log_every` (not in the reference, default 1 = its behaviour): read the losses back and log every k-th iteration only -- the iteration
     itself never synchronises with the host.  Plotting, tensorboard and .mat dumps of the reference are out of scope.  Returns a dict with the loss history, the validation records,
     the model, the diffusion wrapper and the EMA weights."""
@@ -395,7 +440,10 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
         net.mark_weights_dirty()
         opt.load_state_dict(st["optimizer"])
         iterations = int(st["iterations"])
-        train.epoch = int(st.get("epoch", 0))
+        if "data" in st:
+            train.load_state(st["data"])  # epoch in force, batch offset inside it, and the generator state its permutation came from
+        else:
+            train.epoch = int(st.get("epoch", 0))  # states written before the offset was recorded: exact only on an epoch boundary
         resume_tiles = int(st.get("tile_counter", 0))
         diffusion._mask_calls = int(st.get("mask_calls", 0))
         torch.set_rng_state(st["rng"]["torch"])
@@ -435,7 +483,7 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
         ema_sd = {n: e.detach().cpu().clone() for n, e in zip(names, ema)}
         torch.save(model_sd, os.path.join(save_dir, f"diffusion_{name}_iter_{it}.pth"))      # bare state_dicts, reference :333-340
         torch.save(ema_sd, os.path.join(save_dir, f"ema_diffusion_{name}_iter_{it}.pth"))
-        torch.save({"model": model_sd, "ema": ema_sd, "optimizer": opt.state_dict(), "iterations": it, "epoch": train.epoch,
+        torch.save({"model": model_sd, "ema": ema_sd, "optimizer": opt.state_dict(), "iterations": it, "epoch": train.epoch, "data": train.state(),
                     "tile_counter": tile_counter, "mask_calls": int(getattr(diffusion, "_mask_calls", 0)),
                     "rng": {"torch": torch.get_rng_state(), "python": _random.getstate(),
                             "cuda": torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None}},

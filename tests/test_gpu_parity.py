@@ -197,6 +197,29 @@ def test_ddpm_cave_T2000_truncated_matches_reference_golden(case):
     assert _maxerr(out, torch.from_numpy(g["out"])) <= 1e-4
 
 
+def test_ddpm_cave_128_T2000_first_steps_match_oracle():
+    """BASELINE configs[3] at ITS size: CAVE 128 x 128 patches (31 + 3 bands, 256 bottleneck tokens, scalar stem / scalar-output epilogue) on the
+    T = 2000 schedule -- the first 10 steps of the sampling LOOP (p_sample_loop, diffusion_ddpm_pan.py:445-507: self-conditioning on the current
+    image, clamp of x0 + lms, posterior mean, noise), not just the forward the 128 x 128 golden pins.  Expected values: the pinned CPU oracle on
+    the same x_T and per-step noise."""
+    ds, B, H, T, n, seed = "cave", 1, 128, 2000, 10, 41
+    C = gc.DATASETS[ds][0]
+    cond = gc.tiles_for(ds, B, H, H, seed=seed)["cond"]
+    xT, noise = reference_noise_stream(seed, (B, C, H, H), n)
+    order = list(reversed(range(T)))[:n]
+    tabs = O.schedule_tables(O.cosine_betas(T))
+    it = iter([xT] + [noise[k] for k in range(n)])
+    with torch.no_grad():
+        ref = O.ddpm_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, tabs, noise_fn=lambda s: next(it), timesteps=order)
+    d = make_diffusion(net_for(ds), C, T, H, DEV)
+    plan = d._plan(cond.to(DEV))
+    c1, c2 = d.posterior_mean_coef1.cpu(), d.posterior_mean_coef2.cpu()
+    cz = (0.5 * d.posterior_log_variance_clipped.cpu()).exp()
+    out = plan.sample_ddpm([float(i) for i in order], [float(c1[i]) for i in order], [float(c2[i]) for i in order],
+                           [float(cz[i]) for i in order], xT.to(DEV), noise.to(DEV).contiguous(), 0, 0, (0.0, 1.0), DEV)
+    assert _maxerr(out, ref) <= 1e-4
+
+
 @pytest.mark.parametrize("case", gc.FORWARD_BIG_CASES, ids=lambda c: c[0])
 def test_forward_cave_128_matches_reference_golden(case):
     """CAVE at its BASELINE size: multi-tile scalar-staged stem (31 + 31 channels), the C = 31 scalar-output epilogue at

@@ -437,6 +437,60 @@ def test_native_step_equals_the_op_by_op_tape_at_the_benchmark_tile_size(backend
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
+def test_native_training_step_at_the_benchmarked_batch_matches_the_oracle_and_autograd(backend):
+    """BASELINE configs[4] is timed at batch 32 of 64 x 64 tiles (`bench.py --config wv3_train_b32`); the reference golden pins the native step at
+    B = 2, 16 x 16.  At B = 32 the weight-gradient K splits, the GroupNorm-backward chunking and the linear-attention reduce grids take other
+    geometries, so the SAME shape is checked here against the oracle (pinned train-mode restatement, oracle/ddif_oracle.py unet_forward with explicit
+    masks = `UNetSR3.forward` under .train(), models/sr3_dwt.py:169-219) + torch autograd on the CPU (= `loss.backward()`,
+    diffusion_engine.py:230-233): prediction, loss and the gradient of every one of the 702 parameters.  The masks are the library's own Philox
+    draws read back through ddif_plan_train_get_dropout / _droppath and handed to the oracle."""
+    from ddif_testlib import make_net
+    from oracle import ddif_oracle as O
+
+    dev = _dev(backend)
+    ds, B, C, H = "wv3", 32, 8, 64
+    gen = torch.Generator().manual_seed(2024)
+    x = torch.randn(B, C, H, H, generator=gen)
+    sc = torch.randn(B, C, H, H, generator=gen)
+    target = torch.rand(B, C, H, H, generator=gen)
+    cond = gc.tiles_for(ds, B, H, H, seed=31)["cond"]
+    t = torch.randint(0, 3000, (B,), generator=gen)
+    net = make_net(ds, dev).train()
+    try:
+        plan = net.plan_for(B, H, H, dev, train=True)
+        net._net.refresh_from_device(net.named_parameters())
+        plan.set_cond(cond.to(dev), force=True)
+        plan.random_train_masks(4242, 0, 0.2, 0.2)
+        masks, paths = plan.train_masks()
+        grads = {n: torch.full_like(p, float("nan")) for n, p in net.named_parameters()}
+        plan.train_bind(list(grads.items()))
+        loss, y = plan.train_forward_backward(x.to(dev), t, sc.to(dev), target.to(dev))
+        torch.cuda.synchronize()
+        # the CPU side: oracle forward under the same masks, autograd backward (a few seconds on the host cores)
+        sd = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in gc.weights_for(ds).items()}
+        y_ref = O.unet_forward(sd, gc.cfg_for(ds), x, t, cond, sc, drop_masks=[m.cpu() for m in masks], path_scales=[p for p in paths.cpu()])
+        loss_ref = (y_ref - target).abs().mean()
+        loss_ref.backward()
+        assert float((y.cpu() - y_ref.detach()).abs().max()) <= 5e-5
+        assert abs(float(loss) - float(loss_ref.detach())) <= 1e-6
+        ref = {n: (sd[n].grad if sd[n].grad is not None else torch.zeros_like(sd[n])) for n in grads}
+        gmax = max(float(g.norm()) for g in ref.values())
+        worst, worst_n = 0.0, ""
+        for n, gr in ref.items():
+            got = grads[n].cpu()
+            assert got.shape == gr.shape and torch.isfinite(got).all(), n
+            diff, den = float((got - gr).norm()), float(gr.norm())
+            # (analytically-zero gradients -- biases in front of a whole-line softmax -- hold rounding noise on both sides: floor relative to the
+            # step's largest gradient, as in the native-vs-tape test below)
+            assert diff <= 2e-4 * den + 2e-6 * gmax, (n, diff, den, gmax)
+            if den > 1e-3 * gmax and diff / den > worst:
+                worst, worst_n = diff / den, n
+        print("native step at B=32, 64x64 vs oracle + autograd: worst relative gradient error %.2e (%s), loss %.6f" % (worst, worst_n, float(loss)))
+    finally:
+        net.eval()
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_two_stream_reverse_pass_is_bit_identical_to_the_one_stream_one(backend, monkeypatch):
     """The reverse pass issues the weight-gradient launches on a side stream, ordered against the gradient chain with events (csrc/ddif_train.cpp).
     A plan built with `DDIF_TRAIN_STREAMS=0` runs the same launches on one stream: loss, prediction and all 702 gradients must be the same BITS,

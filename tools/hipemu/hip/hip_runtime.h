@@ -141,6 +141,34 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_u32x4 a, hipemu_u32
     hipemu::wave_release();
     return d;
 }
+// v_mfma_f32_32x32x16_f16: the same lane layout with IEEE half operands (subnormals kept, as measured on gfx950:
+// tools/probes/f16x2.cpp).  Products of two halves (11 x 11 significant bits) are exact in fp32.
+static inline float hipemu_f16_to_f32(unsigned short b) { _Float16 hv; __builtin_memcpy(&hv, &b, 2); return (float)hv; }
+static inline unsigned short hipemu_f32_to_f16(float f) { _Float16 hv = (_Float16)f; unsigned short b; __builtin_memcpy(&b, &hv, 2); return b; }  // round to nearest even
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x16 c) {
+    float ab[16];
+    for (int t = 0; t < 8; ++t) {
+        const unsigned aw = a.v[t >> 1], bw = b.v[t >> 1];
+        ab[t] = hipemu_f16_to_f32((unsigned short)((t & 1) ? (aw >> 16) : (aw & 0xffffu)));
+        ab[8 + t] = hipemu_f16_to_f32((unsigned short)((t & 1) ? (bw >> 16) : (bw & 0xffffu)));
+    }
+    const float* g = (const float*)hipemu::wave_gather(ab, sizeof(ab));
+    int l = hipemu::tctx().lane;
+    int col = l & 31, hi = l >> 5;
+    hipemu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = d[r];
+        for (int half = 0; half < 2; ++half) {
+            const float* ar = g + (row + 32 * half) * 16;
+            const float* bc = g + (col + 32 * half) * 16 + 8;
+            for (int t = 0; t < 8; ++t) acc += ar[t] * bc[t];
+        }
+        d[r] = acc;
+    }
+    hipemu::wave_release();
+    return d;
+}
 // v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15]; D col=l&15, row=(l>>4)*4+r
 static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c) {
     float ab[2] = {a, b};
