@@ -18,10 +18,11 @@ every rank samples its own 64 tiles, noise keyed by global tile index).
 scaling: 64 / N tiles per GPU), DPM-Solver++ 2M 50 NFE, all-gather + stitch of the scene inside the timed region.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     : dominant kernel class (3x3 implicit-GEMM convolutions, bf16x3 split products on v_mfma_f32_32x32x16_bf16) timed
+  roofline     : dominant kernel class (3x3 implicit-GEMM convolutions, f16x2 split products on v_mfma_f32_32x32x16_f16) timed
                  with HIP events on the launch stream inside the timed region; `achieved` = algorithmic fp32 flops / duration,
-                 `peak` = the dense bf16 MFMA peak / 6 (six bf16 products are issued per fp32 product), so `frac` is the issued
-                 fraction of the matrix pipe the kernel actually runs on
+                 `peak` = the dense 16-bit MFMA peak / the products the class issues per fp32 product (3 on the f16x2 path, 6 on
+                 bf16x3, 16 on the exact fp32 MFMA; reported by the library per launch), so `frac` is the issued fraction of the
+                 matrix pipe the kernel actually runs on
   cpu_baseline : the CPU oracle (a port of the reference sampler, oracle/ddif_oracle.py) timed on this box's host cores
                  on a bounded sample of the same workload (N=1, rank 0 only).
 """
@@ -46,8 +47,7 @@ def log(msg):
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix (= vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_BF16_MFMA_TFLOPS = 2516.8  # dense bf16 MFMA (16 x the fp32 rate); the bf16x3 path issues 6 bf16 products per fp32 product
-PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0  # fp32-equivalent ceiling of the bf16x3 path: algorithmic TF / this = issued TF / bf16 peak
+PEAK_BF16_MFMA_TFLOPS = 2516.8  # dense bf16 / fp16 MFMA (16 x the fp32 rate); the f16x2 path issues 3 half products per fp32 product, bf16x3 issues 6
 PEAK_HBM_GBS = 8000.0
 PROF_STEPS_TARGET = 40  # denoising steps bracketed with events over the whole timed region (every launch of such a step has its own pair)
 
@@ -273,8 +273,11 @@ def main():
     step_flop_total = cost["step_flop"] * n_evals + cost["cond_flop"]
     # the committed PMC passes are of the default (wv3, B = 64) command: other configurations report no traffic
     traffic, traffic_info = committed_traffic() if (args.config == "wv3" and B == 64) else (None, {"traffic_from_committed_profile": False})
-    x3 = "bf16x3" in prof["kernel"]
-    peak = PEAK_X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    x3 = "split products" in prof["kernel"]
+    # products the dominant class issues on the matrix pipe per algorithmic fp32 product (flop-weighted over its launches: 3 = f16x2, 6 = bf16x3,
+    # 16 = exact fp32 MFMA in units of the 16-bit rate); its fp32-equivalent ceiling is the dense 16-bit MFMA peak over that
+    products = (prof["total_mfma_flop"] / prof["total_flop"]) if prof["total_flop"] > 0 else 16.0
+    peak = PEAK_BF16_MFMA_TFLOPS / products
     ms_step = dt / args.steps * 1e3 / n_evals
     # per-class breakdown of the profiled denoising steps (every launch of those steps sits between two HIP events)
     n_rec = prof["steps_recorded"]
@@ -283,7 +286,7 @@ def main():
         if not c["launches"] or not n_rec:
             continue
         ms = c["total_ms"] / n_rec
-        floor_ms = max(c["total_flop"] / (peak * 1e12), c["total_bytes"] / (PEAK_HBM_GBS * 1e9)) * 1e3 / n_rec
+        floor_ms = max(c["total_mfma_flop"] / (PEAK_BF16_MFMA_TFLOPS * 1e12), c["total_bytes"] / (PEAK_HBM_GBS * 1e9)) * 1e3 / n_rec
         cls_ms_total += ms
         classes.append({"class": c["name"], "launches_per_step": c["launches"] / n_rec, "ms_per_step": ms,
                         "tflops": c["total_flop"] / (c["total_ms"] * 1e-3) / 1e12, "algorithmic_gbytes_per_s": c["total_bytes"] / (c["total_ms"] * 1e-3) / 1e9,
@@ -316,20 +319,23 @@ def main():
                    "sampler": cf["sampler"], "parallelism": "tile-shard x%d" % world, "launches_per_denoising_step": n_launch["step"],
                    "plan_memory_mb": {"total": mem["total_bytes"] / 1e6, "step_activation_arena": mem["arena_bytes"] / 1e6,
                                       "same_activations_unaliased": mem["unaliased_bytes"] / 1e6},
-                   "conv_math": ("fp32 operands split into 3 bf16 planes, 6 exact products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (3x3 convs, "
-                                 "wide 1x1 convs, low-resolution levels); exact fp32 MFMA elsewhere") if x3 else "exact fp32 MFMA"},
+                   "conv_math": ("fp32 operands pre-scaled by powers of two and split into 2 fp16 planes, 3 exact products on v_mfma_f32_32x32x16_f16, fp32 accumulate "
+                                 "(3x3 convs, low-resolution levels, q.1 of the fused attention block); 3 bf16 planes / 6 products where the operand range is open "
+                                 "(per-sample folded attention weights, wide 1x1 convs); exact fp32 MFMA elsewhere") if x3 else "exact fp32 MFMA"},
         "roofline": {
             "bound": "mfma",
             "achieved": ach_tflops,
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": ach_tflops / peak,
-            "peak_note": ("`achieved` counts ALGORITHMIC fp32 flops (2*M*N*K, unpadded) of the dominant class; every fp32 product is issued as 6 bf16 MFMA products "
-                          "(3-way split of both operands), so the ceiling of this kernel is the dense bf16 MFMA peak %.1f / 6 = %.1f TF and `frac` = issued "
-                          "bf16 TFLOP/s / %.1f" % (PEAK_BF16_MFMA_TFLOPS, PEAK_X3_TFLOPS, PEAK_BF16_MFMA_TFLOPS)) if x3 else "dense fp32 matrix peak (guide); exact fp32 MFMA",
-            "mfma_issued_tflops": (6.0 * ach_tflops) if x3 else ach_tflops,
+            "peak_note": ("`achieved` counts ALGORITHMIC fp32 flops (2*M*N*K, unpadded) of the dominant class; every fp32 product is issued as %.2f 16-bit MFMA products "
+                          "(flop-weighted over the class: 3 = f16x2 two-way split, 6 = bf16x3 three-way split), so the ceiling of this class is the dense 16-bit MFMA "
+                          "peak %.1f / %.2f = %.1f TF and `frac` = issued 16-bit TFLOP/s / %.1f" % (products, PEAK_BF16_MFMA_TFLOPS, products, peak, PEAK_BF16_MFMA_TFLOPS))
+                          if x3 else "dense fp32 matrix peak (guide); exact fp32 MFMA",
+            "mfma_products_per_fp32_product": products,
+            "mfma_issued_tflops": products * ach_tflops if x3 else ach_tflops,
             "frac_of_f32_mfma_peak_algorithmic": ach_tflops / PEAK_F32_MFMA_TFLOPS,
-            "frac_of_f32_note": "secondary: algorithmic TFLOP/s over the 157.3 TF fp32-matrix peak -- NOT a bound of the bf16x3 path (it may exceed 1)",
+            "frac_of_f32_note": "secondary: algorithmic TFLOP/s over the 157.3 TF fp32-matrix peak -- NOT a bound of the split-operand paths (it may exceed 1)",
             "traffic": traffic,
             "traffic_unit": "bytes of HBM traffic per launch of the dominant class (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this command)",
             **traffic_info,
@@ -341,11 +347,11 @@ def main():
             "whole_step": {
                 "ms_per_denoising_step": ms_step,
                 "tflops": step_flop_total * args.steps / dt / 1e12,
-                "frac_of_x3_peak": step_flop_total * args.steps / dt / 1e12 / peak,
+                "frac_of_split_peak": step_flop_total * args.steps / dt / 1e12 / peak,
                 "frac_of_f32_mfma_peak_algorithmic": step_flop_total * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "hbm_frac": (cost["step_bytes"] * n_evals + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
                 "profiled_steps": n_rec,
-                "classes_note": "HIP events around every launch of %d whole denoising steps (one in %d); floor = max(flops / %.1f TF, algorithmic bytes / 8 TB/s)" % (n_rec, prof_every, peak),
+                "classes_note": "HIP events around every launch of %d whole denoising steps (one in %d); floor = max(issued 16-bit MFMA flops / %.1f TF, algorithmic bytes / 8 TB/s)" % (n_rec, prof_every, PEAK_BF16_MFMA_TFLOPS),
                 "classes_ms_per_step_sum": cls_ms_total if classes_ok else None,
                 "classes": classes if classes_ok else None,
                 **({} if classes_ok else {"classes_error": "class sum %.3f ms vs %.3f ms per step: table withheld" % (cls_ms_total, ms_step)}),

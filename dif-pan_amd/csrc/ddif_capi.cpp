@@ -276,6 +276,7 @@ int ddif_prof_begin(ddif_plan_t plan, int every_n_steps, int max_events) {
     }
     p.ev_flop.assign(p.ev0.size(), 0.0);
     p.ev_bytes.assign(p.ev0.size(), 0.0);
+    p.ev_mflop.assign(p.ev0.size(), 0.0);
     p.ev_cls.assign(p.ev0.size(), 5);
     p.ev_used = 0;
     p.prof_steps = 0;
@@ -301,13 +302,18 @@ int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
         p.cls_res[k].total_ms += ms;
         p.cls_res[k].total_flop += p.ev_flop[i];
         p.cls_res[k].total_bytes += p.ev_bytes[i];
+        p.cls_res[k].total_mfma_flop += p.ev_mflop[i];
         if (k != 0) continue;  // the aggregate result is the dominant class (3x3 convs of the high-resolution levels)
         out->launches += 1;
         out->total_ms += ms;
         out->total_flop += p.ev_flop[i];
         out->total_bytes += p.ev_bytes[i];
+        out->total_mfma_flop += p.ev_mflop[i];
     }
-    if (p.n_conv3_x3 > 0)
+    if (p.n_conv3_f16 > 0)
+        std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convs; f16x2 split products on %d of %d, bf16x3 on %d)", p.n_conv3_f16,
+                      p.n_conv3, p.n_conv3_x3 - p.n_conv3_f16);
+    else if (p.n_conv3_x3 > 0)
         std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions; bf16x3 split products on %d of %d)", p.n_conv3_x3, p.n_conv3);
     else
         std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convolutions; exact fp32 MFMA)");

@@ -1,0 +1,46 @@
+// Instantiations + launcher of the fused linear-attention kernel (kernels_lafuse.h) -- a translation unit of its own so that it
+// builds in parallel with the conv kernel families.
+#include "ddif_plan.h"
+#include "kernels_lafuse.h"
+
+namespace ddif {
+
+namespace {
+template <int TH, int TW, int NBQ, int NBA>
+int la_launch1(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only) {
+    using G = LaFuseGeom<TH, TW, NBQ, NBA>;
+    auto fn = linattn_fused_kernel<TH, TW, NBQ, NBA>;
+    if (prepare_only) {
+        DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));
+        return 0;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), G::smem, s, a);
+    return 0;
+}
+template <int TH, int TW>
+int la_launch_t(const LaFuseArgs& a, int nbq, int nba, int grid, hipStream_t s, bool prep) {
+    switch (nbq * 10 + nba) {
+        case 21: return la_launch1<TH, TW, 2, 1>(a, grid, s, prep);
+        case 31: return la_launch1<TH, TW, 3, 1>(a, grid, s, prep);
+        case 41: return la_launch1<TH, TW, 4, 1>(a, grid, s, prep);
+        case 22: return la_launch1<TH, TW, 2, 2>(a, grid, s, prep);
+        case 32: return la_launch1<TH, TW, 3, 2>(a, grid, s, prep);
+        case 42: return la_launch1<TH, TW, 4, 2>(a, grid, s, prep);
+        default: return fail(DDIF_ERR_INVALID, "linattn_fused: no instantiation for %d q blocks / %d output blocks", nbq, nba);
+    }
+}
+}  // namespace
+
+// shapes the fused kernel carries: whole columns of 64 or 32 rows, 64 / 96 / 128 feature channels, 32 / 64 output channels
+bool lafuse_supported(int H, int fea, int dout) {
+    return (H == 64 || H == 32) && fea % 32 == 0 && fea >= 64 && fea <= 128 && dout % 32 == 0 && dout >= 32 && dout <= 64;
+}
+int lafuse_strip(int H) { return 256 / H; }
+int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only) {
+    const int nbq = (a.c0 + a.c1) / 32, nba = a.dout / 32;
+    if (a.H == 64) return la_launch_t<64, 4>(a, nbq, nba, grid, s, prepare_only);
+    if (a.H == 32) return la_launch_t<32, 8>(a, nbq, nba, grid, s, prepare_only);
+    return fail(DDIF_ERR_INVALID, "linattn_fused: H = %d", a.H);
+}
+
+}  // namespace ddif

@@ -6,6 +6,7 @@
 #include "kernels_conv.h"
 #include "kernels_misc.h"
 #include "attn_args.h"
+#include "kernels_lafuse.h"
 
 namespace ddif {
 
@@ -132,6 +133,10 @@ static int x3_enabled() {  // DDIF_X3=0: the exact-fp32 MFMA instantiation every
 static int f16_enabled() {  // DDIF_F16=0: the split-operand convs stay on bf16x3 (six products) instead of f16x2 (three); tests/test_env_switches.py
     static const int f16 = [] { const char* e = getenv("DDIF_F16"); return e ? atoi(e) : 1; }();
     return f16;
+}
+static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention half as three launches (q conv, column statistics, attn_out conv)
+    static const int v = [] { const char* e = getenv("DDIF_LAFUSE"); return e ? atoi(e) : 1; }();
+    return v;
 }
 static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) as well; covered by tests/test_env_switches.py
     static const int lr = [] { const char* e = getenv("DDIF_LR"); return e ? atoi(e) : 1; }();
@@ -340,7 +345,7 @@ int Plan::build() {
     path_sites.clear();
     mask_recs = nullptr;
     n_mask_recs = 0;
-    n_conv3 = n_conv3_x3 = 0;
+    n_conv3 = n_conv3_x3 = n_conv3_f16 = 0;
     tb_rows = 0;
     tb = tvals = nullptr;
     arena_next = 0;
@@ -571,10 +576,12 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
     op.cls = (Hout * Wout <= 256) ? 2 : (pc.ks == 3 ? 0 : 1);
+    op.mfma_w = var.f16 ? 3 : (var.x3 ? 6 : 16);
     op.timed = op.cls == 0;
     if (pc.ks == 3 && &prog == &step) {
         ++n_conv3;
         if (var.x3) ++n_conv3_x3;
+        if (var.f16) ++n_conv3_f16;
     }
     op.win = true;
     op.run = [a, var, fn_tbs, grid, block, smem, dyn, self_c, tb_off, items_per_sample, cap](hipStream_t st, const StepCtx& ctx) {
@@ -1274,12 +1281,101 @@ int Plan::build_impl() {
         }
         // ---- per step
         Tensor xn, q, amix, f1, f2, f3;
-        DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl, true));
         const PackedConv* pq1 = PC(ci + ".q.1");
         if (!pq1) return fail(DDIF_ERR_MISSING, "%s.q.1 missing", ci.c_str());
         if (!cur.st || !skip.st) return fail(DDIF_ERR_STATE, "%s: prenorm without producer statistics", ci.c_str());
         const float *pn_g = V(ci + ".prenorm_x.weight"), *pn_b = V(ci + ".prenorm_x.bias"), *q0w = V(ci + ".q.0.weight");
         if (!pn_g || !pn_b || !q0w) return fail(DDIF_ERR_MISSING, "%s: prenorm/q.0 weights missing", ci.c_str());
+        // ---- the whole attention half in ONE launch where the level keeps whole image columns inside a workgroup (kernels_lafuse.h):
+        //      xn = GN(cat[h, skip]) -> q = q.1(q.0(xn)) -> softmax over H -> M_b p + W_res xn + bias; q and xn never reach memory
+        bool fused_attn = false;
+        {
+            const PackedConv* pm = PC(ci + ".attn_mix");
+            const float* wr = V(ci + ".attn_res.weight");
+            bool ok = lafuse_enabled() && f16_enabled() && x3_enabled() && lr_enabled() && pm && wr && pq1->w_f16 && pq1->bias && pm->bias && Hl * Wl > 256 &&
+                      pq1->cout == fea && pq1->ck == 32 && pm->ck == 32 && pm->cin == 2 * fea && cur.C % 16 == 0 && skip.C % 16 == 0 && lafuse_supported(Hl, fea, pm->cout);
+            if (ok) {  // f16x2 range of depthwise(GroupNorm(.)): (sqrt(N) max|gamma| + max|beta|) * 9 max|w_dw| inside the scaled half range
+                auto ig = net->vec_absmax.find(pn_g), ib = net->vec_absmax.find(pn_b), iw = net->vec_absmax.find(q0w);
+                ok = ig != net->vec_absmax.end() && ib != net->vec_absmax.end() && iw != net->vec_absmax.end() &&
+                     (std::sqrt((double)fea * Hl * Wl) * ig->second + ib->second) * 9.0 * iw->second < DDIF_F16_AMAX;
+            }
+            if (ok) {
+                const float* wo = V(ci + ".attn_out.weight");
+                if (!wo) return fail(DDIF_ERR_MISSING, "%s.attn_out.weight missing", ci.c_str());
+                const int nb_pad = (((pm->cout + 31) / 32) + 3) & ~3;
+                const size_t per = (size_t)nb_pad * pm->n_chunks * 2 * 3 * 256;  // bf16x3 planes, 32-channel chunks
+                float* wmix = nullptr;
+                DDIF_TRY(dalloc(&wmix, per * B));
+                {
+                    Op op;
+                    op.name = "pack_mix_weights";
+                    const float scale = 1.0f / std::sqrt((float)d);
+                    const int co_n = pm->cout, nch = pm->n_chunks;
+                    op.flop = 2.0 * B * co_n * (double)fea * d;
+                    op.run = [wo, wr, ctx, wmix, BB, co_n, fea, d, scale, nch, nb_pad, per](hipStream_t s, const StepCtx&) {
+                        hipLaunchKernelGGL(pack_mix_weights_x3_kernel, ew_grid(per * BB), dim3(256), 0, s, wo, wr, (const float*)ctx, BB, co_n, fea, d, scale, 32, nch, nb_pad, wmix);
+                    };
+                    pre.push_back(std::move(op));
+                }
+                use(cur.p);
+                use(skip.p);
+                DDIF_TRY(alloc_tensor(&amix, pm->cout, Hl, Wl, true));
+                LaFuseArgs a{};
+                a.in0 = cur.p;
+                a.c0 = cur.C;
+                a.in1 = skip.p;
+                a.c1 = skip.C;
+                a.B = B;
+                a.H = Hl;
+                a.W = Wl;
+                a.st0 = cur.st;
+                a.np0 = cur.np;
+                a.st1 = skip.st;
+                a.np1 = skip.np;
+                a.gamma = pn_g;
+                a.beta = pn_b;
+                a.dw_w = q0w;
+                a.wq = pq1->w_f16;
+                a.nchq = pq1->n_chunks;
+                a.bq = pq1->bias;
+                a.wmix = wmix;
+                a.wmix_bstride = (long long)per;
+                a.nch_mix = pm->n_chunks;
+                a.bias = pm->bias;
+                a.out = amix.p;
+                a.dout = pm->cout;
+                if (!dry) DDIF_TRY(lafuse_launch(a, 1, nullptr, true));
+                const int nstrips = (Wl + lafuse_strip(Hl) - 1) / lafuse_strip(Hl);
+                long cap = num_cus();
+                if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
+                Op op;
+                op.name = "linattn_fused";
+                {
+                    char lb[160];
+                    snprintf(lb, sizeof lb, "linattn_fused GN+dw3x3+q.1+softmax_H+attn_out+res %d+%d->%d @%dx%d", cur.C, skip.C, pm->cout, Hl, Wl);
+                    op.label = lb;
+                }
+                op.flop = 2.0 * B * Hl * Wl * ((double)fea * fea + 9.0 * fea + 2.0 * fea * pm->cout);
+                op.bytes = 4.0 * B * Hl * Wl * ((double)fea + pm->cout);
+                op.cls = 1;
+                // q.1 on f16x2 (x3), attn_out / attn_res on bf16x3 (x6): weight of the sum
+                op.mfma_w = (3.0 * fea * fea + 6.0 * 2.0 * fea * pm->cout) / ((double)fea * fea + 9.0 * fea + 2.0 * fea * pm->cout);
+                op.win = true;
+                op.run = [a, nstrips, cap](hipStream_t st, const StepCtx& sc) {
+                    LaFuseArgs aa = a;
+                    if (sc.bn) {
+                        aa.b0 = sc.b0;
+                        aa.B = sc.bn;
+                    }
+                    const long nw = (long)aa.B * nstrips;
+                    (void)lafuse_launch(aa, (int)(nw < cap ? nw : cap), st, false);
+                };
+                step.push_back(std::move(op));
+                fused_attn = true;
+            }
+        }
+        if (!fused_attn) {
+        DDIF_TRY(alloc_tensor(&xn, fea, Hl, Wl, true));
         if (pq1->ck != 32 || cur.C % 4 != 0 || skip.C % 4 != 0 || fea > 256)
             return fail(DDIF_ERR_INVALID, "%s: the fused q = 1x1(dw3x3(GN(cat))) kernel needs 4 | channels and <= 256 of them (got %d+%d)", ci.c_str(), cur.C, skip.C);
         float *qmx = nullptr, *qsm = nullptr;
@@ -1413,6 +1509,7 @@ int Plan::build_impl() {
             s.name = "softmax_H(q).ctx.attn_out+res";
             DDIF_TRY(add_conv(step, s, &amix));
         }
+        }  // !fused_attn
         {
             ConvSpec s;
             s.pc = PC(ci + ".ffn.0");
@@ -1652,6 +1749,7 @@ void Plan::run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bo
         if (t) {
             (void)hipEventRecord(ev1[ev_used], s);
             ev_flop[ev_used] = op.flop;
+            ev_mflop[ev_used] = op.flop * op.mfma_w;
             ev_bytes[ev_used] = op.bytes;
             ev_cls[ev_used] = op.cls;
             ++ev_used;

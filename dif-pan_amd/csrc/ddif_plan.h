@@ -28,6 +28,7 @@ struct StepCtx {
 struct Op {
     std::function<void(hipStream_t, const StepCtx&)> run;
     double flop = 0, bytes = 0;
+    double mfma_w = 16;  // matrix-pipe issue weight of the op's flops in units of the dense 16-bit MFMA rate: 3 = f16x2, 6 = bf16x3, 16 = exact fp32 MFMA / VALU
     bool timed = false;  // member of the dominant kernel class (3x3 implicit-GEMM convs at the high-resolution levels)
     bool win = false;    // the launch honours StepCtx's batch window (every op of the eval-mode step program does)
     bool side = false;   // train-mode cond-only program: a decoder-only op -- issued on the plan's side stream, joined in front of the first decoder block
@@ -49,6 +50,11 @@ struct ConvVariant {
 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, bool f16 = false);
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, bool f16 = false);  // ddif_lr.cpp
+// fused linear-attention block (kernels_lafuse.h, ddif_la.cpp)
+struct LaFuseArgs;
+bool lafuse_supported(int H, int fea, int dout);
+int lafuse_strip(int H);
+int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only);
 // launchers of kernels that live in other translation units (every non-template kernel header is compiled into exactly one object)
 namespace tk {
 // kernels_train.h  (ddif_train.cpp)
@@ -168,7 +174,7 @@ struct Plan {
     int prof_every = 0, prof_max = 0;
     bool prof_all = false;  // time every op of a profiled step (per-class breakdown), not only the dominant class
     std::vector<hipEvent_t> ev0, ev1;
-    std::vector<double> ev_flop, ev_bytes;
+    std::vector<double> ev_flop, ev_bytes, ev_mflop;
     std::vector<int> ev_cls;
     int ev_used = 0;
     long long prof_steps = 0;  // whole steps recorded since ddif_prof_begin (a step that does not fit the remaining events is not profiled)
@@ -197,6 +203,7 @@ struct Plan {
     int ensure_tb(int rows);
     int time_rows(const float* t_host, int rows, hipStream_t s);
     void run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof);
+    int n_conv3_f16 = 0;
     int n_conv3 = 0, n_conv3_x3 = 0;  // 3x3 conv ops of the step program / of them on the bf16x3 path (reported by prof_collect)
     bool op_timing_done = false;  // DDIF_OP_TIMING=<csv path>: one profiled step is timed op by op (development aid)
 

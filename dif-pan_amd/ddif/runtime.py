@@ -54,12 +54,12 @@ class DpmTables(C.Structure):
 class ProfResult(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flop", C.c_double),
                 ("total_bytes", C.c_double), ("kernel_name", C.c_char * 128), ("steps_recorded", C.c_int64),
-                ("launches_per_step", C.c_int64)]
+                ("launches_per_step", C.c_int64), ("total_mfma_flop", C.c_double)]
 
 
 class ProfClass(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flop", C.c_double), ("total_bytes", C.c_double),
-                ("name", C.c_char * 64)]
+                ("name", C.c_char * 64), ("total_mfma_flop", C.c_double)]
 
 
 class _Lib:
@@ -562,11 +562,11 @@ class PlanHandle:
         self.lib.check(self.lib.dll.ddif_prof_collect(self.h, C.byref(r)), "ddif_prof_collect")
         cls = (ProfClass * 6)()
         self.lib.check(self.lib.dll.ddif_prof_classes(self.h, cls), "ddif_prof_classes")
-        classes = [dict(name=c.name.decode(), launches=c.launches, total_ms=c.total_ms, total_flop=c.total_flop, total_bytes=c.total_bytes)
-                   for c in cls]
+        classes = [dict(name=c.name.decode(), launches=c.launches, total_ms=c.total_ms, total_flop=c.total_flop, total_bytes=c.total_bytes,
+                        total_mfma_flop=c.total_mfma_flop) for c in cls]
         return dict(launches=r.launches, total_ms=r.total_ms, total_flop=r.total_flop, total_bytes=r.total_bytes,
                     kernel=r.kernel_name.decode(), classes=classes, steps_recorded=int(r.steps_recorded),
-                    launches_per_step=int(r.launches_per_step))
+                    launches_per_step=int(r.launches_per_step), total_mfma_flop=r.total_mfma_flop)
 
     def num_launches(self) -> dict:
         a, b = C.c_int(), C.c_int()

@@ -341,6 +341,9 @@ typedef struct ddif_prof_result {
     char kernel_name[128];
     int64_t steps_recorded;  /* whole denoising steps the sums (and ddif_prof_classes) cover */
     int64_t launches_per_step; /* launches of the step program (event pairs one profiled step consumes) */
+    double total_mfma_flop;  /* the same flops weighted by what the kernel ISSUES on the matrix pipe, in units of the dense 16-bit MFMA rate:
+                              * x3 on the f16x2 path (three half products per fp32 product), x6 on bf16x3, x16 on the exact fp32 MFMA (which
+                              * runs at 1/16 of that rate): total_mfma_flop / time / 2516.8 TF = the fraction of the matrix pipe's peak in use */
 } ddif_prof_result;
 DDIF_API int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out);
 /* Per-class breakdown of the same profiled steps (EVERY launch of a profiled step is bracketed): six entries -- 3x3 convs and
@@ -350,6 +353,7 @@ typedef struct ddif_prof_class {
     int64_t launches;
     double total_ms, total_flop, total_bytes;
     char name[64];
+    double total_mfma_flop;  /* as in ddif_prof_result */
 } ddif_prof_class;
 DDIF_API int ddif_prof_classes(ddif_plan_t plan, ddif_prof_class* out6);
 /* launches of the step program (one denoising step = this many event pairs when profiled) and of the set_cond program */

@@ -129,6 +129,27 @@ def test_emulated_dpm_solver_matches_oracle():
     assert float((out - ref).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("ds", ["wv3", "gf2"])
+def test_emulated_forward_64x64_runs_the_fused_high_resolution_kernels(ds, monkeypatch):
+    """A whole 64 x 64 tile: the f16x2 3x3 convs on their 16 x 16 tiling and the fused linear-attention block (csrc/kernels_lafuse.h) with
+    64-row columns (a column spans a wave pair: statistics exchange through LDS), 32-row columns (one wave per column), 64- and 96-channel
+    inputs -- against the oracle, and against the three-launch form (`DDIF_LAFUSE=0`) it replaces."""
+    B, H = 1, 64
+    C = gc.DATASETS[ds][0]
+    g = torch.Generator().manual_seed(64)
+    x = torch.randn(B, C, H, H, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    cond = gc.tiles_for(ds, B, H, H, seed=65)["cond"]
+    with torch.no_grad():
+        ref = O.unet_forward(gc.weights_for(ds), gc.cfg_for(ds), x, t, cond, None)
+    net = net_for(ds)
+    net._net and net._net.plans.clear()
+    y = net(x, t, cond).clone()
+    assert float((y - ref).abs().max()) <= 2e-5
+    # 168 launches per step with the three-launch attention half; the 8 decoder blocks at 64 x 64 / 32 x 32 now take one launch each
+    assert net.plan_for(B, H, H, torch.device("cpu")).num_launches()["step"] == 152
+
+
 def test_emulated_grid_cap_hook_gives_identical_results():
     """ddif_debug_set_grid_cap (the hook the -m gpu multi-item tests rely on): one workgroup walking every work item
     of every conv launch, across the sample boundaries of a B=3 batch, reproduces the uncapped result bit for bit."""
