@@ -254,6 +254,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acca[nb][r] = 0.f;
         const float* wmix_b = a.wmix + (size_t)b * a.wmix_bstride;
+        if constexpr (!(ABL & 16)) load_mix(wmix_b, 0);  // block 0 of M_b: requested before the chunk loop, written to LDS behind it
 
 #pragma unroll 1
         for (int k = 0; k < NCH; ++k) {
@@ -388,7 +389,6 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
         //      ONE column.  Then a += M_b p through the wave's own LDS region (bf16x3 planes in A-operand order); the M_b fragments of the block
         //      come through LDS as well (fetched once per workgroup, double-buffered by block parity).
         float* Apw = Ap + (32 * wave) * APS;
-        if constexpr (!(ABL & 16)) load_mix(wmix_b, 0);
 #pragma unroll
         for (int nb = 0; nb < ((ABL & 16) ? 0 : NBQ); ++nb) {
             DDIF_SCHED_FENCE();

@@ -92,6 +92,21 @@ int main(int argc, char** argv) {
         RUNB(0); RUNB(1); RUNB(128); RUNB(129); RUNB(256); RUNB(14); RUNB(399);
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'f') {  // round 4: what an f16x2 (MATH = 3) 3x3 launch is made of, and the 4-wave 8x16 tiling with two workgroups per CU
+#define RUNF(ABLV) run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, ABLV, 0, 3>("3x3 gn_silu 32->32 @64^2 f16x2 8w 16x16", B, 64, 64, 32, 32, 1)
+        RUNF(0); RUNF(1); RUNF(128); RUNF(129); RUNF(256); RUNF(2); RUNF(4); RUNF(8); RUNF(14); RUNF(270); RUNF(399);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 3>("3x3 gn_silu 32->32 @64^2 f16x2 4w 8x16 2wg/cu", B, 64, 64, 32, 32, 2);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 3>("3x3 gn_silu 32->32 @64^2 f16x2 4w 8x16 1wg/cu", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, EPI_RES, 3>("3x3 gn_silu+res 32->32 @64^2 f16x2 8w", B, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 3>("3x3 gn_silu 64->64 @32^2 f16x2 8w 16x16", B, 32, 32, 64, 64, 1);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_GN_SILU, 0, 0, 3>("3x3 gn_silu 64->64 @32^2 f16x2 4w 8x16 2wg/cu", B, 32, 32, 64, 64, 2);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0, EPI_SILU, 3>("3x3 silu 32->64 @64^2 f16x2 8w (ffn.0)", B, 64, 64, 32, 64, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 2, PRO_NONE, 0, EPI_SILU, 3>("3x3 silu 32->64 @64^2 f16x2 8w NT64 (ffn.0)", B, 64, 64, 32, 64, 1);
+        run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0, EPI_SILU, 3>("3x3 silu 32->64 @64^2 f16x2 4w 8x16 2wg/cu (ffn.0)", B, 64, 64, 32, 64, 2);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0, EPI_RES, 3>("3x3 res 64->32 @64^2 f16x2 8w (ffn.23)", B, 64, 64, 64, 32, 1);
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 16, 0, 3>("3x3 gn_silu 32->32 @64^2 f16x2 8w stamps", B, 64, 64, 32, 32, 1);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'x') {  // bf16x3 (MATH = 1) against the exact-fp32 MFMA
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) f32", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
