@@ -65,7 +65,14 @@ int ddif_net_create(ddif_net_t* out, const ddif_net_cfg* cfg, int device) {
     DDIF_GUARD_END
 }
 
-void ddif_net_destroy(ddif_net_t net) { delete net; }
+void ddif_net_destroy(ddif_net_t net) {
+    if (!net) return;
+    if (net->n.live_plans > 0) {  // plans point into the net (weight blobs, reader events): the last of them frees it (ddif_plan_destroy)
+        net->n.orphaned = true;
+        return;
+    }
+    delete net;
+}
 
 int ddif_net_load(ddif_net_t net, const char* key, const float* data, const int64_t* shape, int ndim) {
     DDIF_GUARD_BEGIN
@@ -107,6 +114,7 @@ int ddif_plan_create(ddif_plan_t* out, ddif_net_t net, int B, int H, int W) {
     h->p.H = H;
     h->p.W = W;
     if (int e = h->p.build()) return e;
+    ++net->n.live_plans;
     *out = h.release();
     return DDIF_OK;
     DDIF_GUARD_END
@@ -129,6 +137,7 @@ int ddif_plan_create_train(ddif_plan_t* out, ddif_net_t net, int B, int H, int W
     if (int e = h->p.build()) return e;
     // identity masks until the caller provides some: a train-mode plan then computes the eval network
     if (int e = h->p.train_random_masks(0, 0, 0.f, 0.f, nullptr)) return e;
+    ++net->n.live_plans;
     *out = h.release();
     return DDIF_OK;
     DDIF_GUARD_END
@@ -151,6 +160,7 @@ int ddif_plan_train_step(ddif_plan_t plan, const float* x0, const float* noise, 
                          const float* self_cond, float* loss_dev, float* pred, void* stream) {
     DDIF_GUARD_BEGIN
     DDIF_PLAN_ENTER(plan, "ddif_plan_train_step");
+    if (!plan->p.net->dgrad_filled) return ddif::fail(DDIF_ERR_STATE, "ddif_plan_train_step: the gradient-conv weight packs are still empty -- call ddif_net_refresh after creating the train-mode plan (and after every re-commit)");
     return plan->p.train_step(x0, noise, sqrt_ac_host, sqrt_1mac_host, time_host, self_cond, loss_dev, pred, (hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -159,6 +169,7 @@ int ddif_plan_train_forward_backward(ddif_plan_t plan, const float* x, const flo
                                      float* pred, void* stream) {
     DDIF_GUARD_BEGIN
     DDIF_PLAN_ENTER(plan, "ddif_plan_train_forward_backward");
+    if (!plan->p.net->dgrad_filled) return ddif::fail(DDIF_ERR_STATE, "ddif_plan_train_forward_backward: the gradient-conv weight packs are still empty -- call ddif_net_refresh after creating the train-mode plan (and after every re-commit)");
     return plan->p.train_forward_backward(x, time_host, self_cond, target, loss_dev, pred, (hipStream_t)stream);
     DDIF_GUARD_END
 }
@@ -214,7 +225,12 @@ int ddif_plan_train_random_masks(ddif_plan_t plan, uint64_t seed, uint64_t tile0
     DDIF_GUARD_END
 }
 
-void ddif_plan_destroy(ddif_plan_t plan) { delete plan; }
+void ddif_plan_destroy(ddif_plan_t plan) {
+    if (!plan) return;
+    ddif::Net* n = plan->p.net;
+    delete plan;
+    if (n && --n->live_plans == 0 && n->orphaned) delete reinterpret_cast<ddif_net*>(n);  // (Net is the only member of ddif_net)
+}
 
 int ddif_plan_set_cond(ddif_plan_t plan, const float* cond, void* stream) {
     DDIF_GUARD_BEGIN

@@ -60,7 +60,6 @@ void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
 // bias and time-bias rows straight from memory), so EPI_TBS is accepted and ignored.
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, bool f16) {
     epi &= ~EPI_TBS;
-    if (mb == 1) return (epi & EPI_COLST) ? ConvVariant() : lr_for<1>(ks, pro, epi, f16);  // (column statistics need whole columns in a tile)
     return mb == 2 ? lr_for<2>(ks, pro, epi, f16) : lr_for<4>(ks, pro, epi, f16);
 }
 

@@ -521,6 +521,9 @@ int Net::commit(hipStream_t stream) {
     merged_stale = false;
     last_ptrs.clear();
     dconv.clear();  // re-derived on demand (build_dgrad_packs) from the recipes of THIS commit
+    dgrad_filled = false;
+    // plans of the previous generation may still have launches in flight on their own (side) streams that read the blobs freed below
+    if (blob || dgrad_blob) DDIF_HIPCHK(hipDeviceSynchronize());
     if (dgrad_blob) {
         DDIF_HIPCHK(hipFree(dgrad_blob));
         dgrad_blob = nullptr;
@@ -634,6 +637,7 @@ int Net::refresh_device(int n, const char* const* keys, const float* const* ptrs
     hipLaunchKernelGGL(refresh_blob_kernel, dim3((unsigned)refresh_blocks), dim3(256), 0, stream, (const RefreshRec*)d_recs, n_recs);
     DDIF_HIPCHK(hipGetLastError());
     merged_stale = true;
+    if (dgrad_blob) dgrad_filled = true;
     return 0;
 }
 
@@ -707,6 +711,7 @@ int Net::build_dgrad_packs() {
     dgrad_floats = off + 64;
     DDIF_HIPCHK(hipMalloc((void**)&dgrad_blob, dgrad_floats * sizeof(float)));
     DDIF_HIPCHK(hipMemset(dgrad_blob, 0, dgrad_floats * sizeof(float)));
+    dgrad_filled = false;
     for (auto& kv : dconv) {
         PackedConv& pc = kv.second;
         pc.w = dgrad_blob + (reinterpret_cast<size_t>(pc.w) - 1);

@@ -90,6 +90,10 @@ struct Net {
     std::map<std::string, PackedConv> dconv;
     float* dgrad_blob = nullptr;
     size_t dgrad_floats = 0;
+    bool dgrad_filled = false;        // a refresh_device() has run since the dgrad packs were allocated (they start zeroed: a backward pass before that
+                                      // would return zero input gradients upstream of the last layer without any error)
+    int live_plans = 0;               // plans built on this net (they hold raw pointers into it); ddif_net_destroy defers to the last plan's destruction
+    bool orphaned = false;
     int build_dgrad_packs();
     bool merged_stale = false;        // the eval-only merged ffn[3] o ffn[2] weights were NOT refreshed (train-mode plans do not use them)
     void* d_recs = nullptr;           // device RefreshRec table of the last refresh

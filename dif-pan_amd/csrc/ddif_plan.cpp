@@ -84,7 +84,7 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 // Only the combinations the network uses are instantiated.
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, bool f16) {
     ConvVariant v;
-    if (cfg >= 20 && cfg <= 22) return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 22 ? 1 : (cfg == 20 ? 2 : 4), pro, epi, f16 && pro != PRO_COLSM) : v;
+    if (cfg == 20 || cfg == 21) return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi, f16 && pro != PRO_COLSM) : v;
     const bool plain = stride == 1 && !ups;
     if (epi == EPI_FILM) {
         if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
@@ -150,13 +150,10 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
     const bool x3 = x3_enabled() && !exact;
     if (allow_lr && x3 && lr_enabled() && vec == 1 && stride == 1 && !ups_ && Hout * Wout <= 256 && Cout % 4 == 0 && cin % 16 == 0 && c0 % 16 == 0 &&
         ck == (ks == 3 ? 16 : 32))
-    {
-        // tile size of the low-resolution kernel (kernels_lr.h MB): DDIF_LR_TILES = "ab", a = 32-pixel blocks per tile at the <= 8 x 8 levels (1 | 2),
-        // b = at the 16 x 16 level (2 | 4).  Smaller tiles = more, shorter workgroups per launch (the kernel is a latency chain per work item).
-        static const int tiles = [] { const char* e = getenv("DDIF_LR_TILES"); return e ? atoi(e) : 12; }();
-        const int a8 = tiles / 10 == 1 ? 22 : 20, a16 = tiles % 10 == 2 ? 20 : 21;
-        return (Hout <= 8 && Wout <= 8) ? a8 : a16;
-    }
+        // (smaller tiles -- 4 x 8 pixels at the 8 x 8 level, 8 x 8 at 16 x 16: twice the workgroups, each with half the matrix work -- measured
+        //  SLOWER, 1.375 -> 1.42 / 1.49 / 1.54 ms for the class, profiles/r04_f_lr_tiles_ab.txt: the items are latency chains that also stream the
+        //  weights once per item; more of them only adds weight traffic)
+        return (Hout <= 8 && Wout <= 8) ? 20 : 21;
     if (ks == 1 && vec == 1) {
         const int base = wide ? (Cout > 64 ? 3 : (Cout > 32 ? 1 : 0)) : (Cout > 64 ? 4 : 2);
         // 32-cout tiles stay on the exact instruction: with 12 MFMAs per stage the split only adds staging work
@@ -477,12 +474,10 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     }
     int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact, f16ok);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0);
-    if (s.cso_mx && cfg == 22) cfg = 20;  // column statistics: whole columns inside one tile (8 x 8 tiles at the 8 x 8 level)
-    if (s.cso_mx && cfg == 20 && Hout > 8) cfg = 21;
     if (s.cso_mx && ((cfg != 20 && cfg != 21) || Hout > (cfg == 20 ? 8 : 16)))
         return fail(DDIF_ERR_INVALID, "%s: column statistics epilogue needs the low-resolution kernel and H <= 16", s.name);
     ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi, f16ok);
-    if (!var.fn && cfg >= 20 && cfg <= 22) {  // prologue / epilogue combination the low-resolution kernel does not carry
+    if (!var.fn && (cfg == 20 || cfg == 21)) {  // prologue / epilogue combination the low-resolution kernel does not carry
         cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false, false, f16ok);
         var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     }

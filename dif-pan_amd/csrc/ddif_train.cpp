@@ -645,11 +645,6 @@ int Plan::build_backward() {
         DDIF_TRY(fbuf(&T->ds, (size_t)BB * in4));
         DDIF_TRY(fbuf(&T->dwall, (size_t)ns * inner));
         DDIF_TRY(fbuf(&T->dball, (size_t)ns));
-        {
-            float* raw = nullptr;
-            DDIF_TRY(fbuf(&raw, 64 * sizeof(SlotScatter) / sizeof(float) + 16));
-            T->slot_tab = reinterpret_cast<SlotScatter*>(raw);
-        }
         float* pe = taux;                                   // [B][inner]
         float* spre = taux + (size_t)BB * inner;            // [B][4 inner] pre-activation
         float* hid = spre + (size_t)BB * in4;               // [B][4 inner] swish
@@ -659,6 +654,11 @@ int Plan::build_backward() {
         auto slots = std::make_shared<std::vector<SlotG>>();
         for (auto& m : tmods)
             if (m.kind == TrainMod::RES) slots->push_back(SlotG{G(m.key + ".noise_func.noise_func.0.weight"), G(m.key + ".noise_func.noise_func.0.bias"), m.slot, m.t[0].C});
+        {   // one scatter record per ResnetBlock: sized from the module list
+            float* raw = nullptr;
+            DDIF_TRY(fbuf(&raw, (slots->size() + 1) * sizeof(SlotScatter) / sizeof(float) + 16));
+            T->slot_tab = reinterpret_cast<SlotScatter*>(raw);
+        }
         Seq L;
         const float *wall = net->wall, *w3 = net->w3, *w1 = net->w1;
         float* dtb_ = dtb;

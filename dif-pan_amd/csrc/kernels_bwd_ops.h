@@ -411,7 +411,7 @@ __global__ void gn_bwd_affine_kernel(const double* ws, int B, int C, float* dgam
 }  // namespace ddif
 
 // ================================================================================================================
-// Forward counterparts used by the TRAINING graph (ddif/train.py): the inference plan fuses these into its conv prologues /
+// Forward counterparts used by the op-by-op training tape (tests/train_tape.py): the inference plan fuses these into its conv prologues /
 // epilogues and never materialises what the backward pass needs, so the training forward runs them un-fused, NCHW, saving
 // every intermediate.  Same arithmetic as the reference modules (models/sr3_dwt.py); correctness first.
 namespace ddif {

@@ -38,7 +38,7 @@ namespace ddif {
 template <int KS, int MB, int PRO, bool TALL = false, bool F16 = false>
 struct LrGeom {
     static constexpr int NPL = F16 ? 2 : 3;                    // operand planes: f16x2 (hi, lo) or bf16x3 (hi, mid, lo)
-    static constexpr int TH = (TALL && MB == 4) ? 16 : (MB == 1 ? 4 : 8), TW = (MB <= 2 || TALL) ? 8 : 16;  // MB = 1: 4 x 8 pixels (half an 8 x 8 sample)
+    static constexpr int TH = (TALL && MB == 4) ? 16 : 8, TW = (MB == 2 || TALL) ? 8 : 16;
     static constexpr int PAD = KS / 2;
     static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD; // staged tile (halo of the 3x3 taps)
     static constexpr int PC = (MB == 4 && KS == 3) ? 64 : 128; // channels staged per phase

@@ -318,7 +318,7 @@ class GaussianDiffusion(nn.Module):
         """Reference :692-766, forward half: q_sample + (optional self-conditioning pass) + prediction + loss value.
         With the model in .train() mode both passes run the train-mode launch program (Dropout in every ResnetBlock,
         DropPath on every decoder FFN; fresh masks per pass from the library's generator seeded by torch's RNG, or the
-        masks pinned with `model.set_train_masks`).  With autograd enabled the main pass goes through `_train_step` (ddif.train) and the
+        masks pinned with `model.set_train_masks`).  With autograd enabled the main pass goes through `_train_step` and the
         returned loss supports `.backward()`; under `torch.no_grad()` it is the fused train-mode plan and a plain value."""
         b = x_start.shape[0]
         t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
@@ -357,7 +357,7 @@ class GaussianDiffusion(nn.Module):
         kernels read are re-packed from the parameter tensors on the device when they changed (`ddif_net_refresh`), the Dropout / DropPath
         masks come from the library's counter-based generator keyed by (seed, site, GLOBAL tile index `self.train_tile0 + b`, element) --
         so a batch split over ranks draws the masks the unsplit batch would -- or are the ones pinned with `model.set_train_masks`.
-        `DDIF_TRAIN_TAPE=1` selects round 2's op-by-op Python tape (ddif/train.py) instead (kept as a cross-check of the native program)."""
+        `DDIF_TRAIN_TAPE=1` selects round 2's op-by-op Python tape (tests/train_tape.py, test scaffolding) instead (kept as a cross-check of the native program)."""
         import os
 
         if self.loss_type != "l1":
@@ -437,7 +437,11 @@ class GaussianDiffusion(nn.Module):
 
     def _train_step_tape(self, x_start, noise, a, s, t, cond, x_self_cond, named):
         from .. import functional as DF
-        from ..train import TrainGraph, TrainStepFn
+        try:  # round 2's op-by-op tape is test scaffolding (tests/train_tape.py): an independent cross-check of the native reverse program
+            from train_tape import TrainGraph, TrainStepFn
+        except ImportError as e:
+            raise DdifError("DDIF_TRAIN_TAPE=1 selects the op-by-op training tape, which lives in tests/train_tape.py (put tests/ on sys.path); "
+                            "the product path is the native step") from e
 
         model = self.model
         graph = TrainGraph(model.cfg, dropout=float(model.cfg["dropout"]), drop_path=model.DROP_PATH_PROB)  # one tape per call (gradient accumulation safe)

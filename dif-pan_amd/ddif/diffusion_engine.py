@@ -2,7 +2,7 @@
 (the reference runs a training and a test job at import, diffusion_engine.py:508-533).
 
     test_fn(...)        reference :352-505   inference over a test set: cond assembly -> sampler -> (sr + lms).clip(0,1)
-    engine_google(...)  reference :52-348    training loop: cond assembly -> p_losses -> loss.backward() (ddif.train) -> [DDP all-reduce]
+    engine_google(...)  reference :52-348    training loop: cond assembly -> p_losses -> loss.backward() (csrc/ddif_train.cpp) -> [DDP all-reduce]
                                              -> fused clip + AdamW + EMA step; periodic DDIM-25 validation with metrics
     norm / unorm / clamp_fn                  reference :33-49
 
@@ -528,7 +528,8 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
                 flush_losses()
                 rec = validate()
                 records.append((iterations, rec))
-                log(f"[iter {iterations}] validation: {rec}")
+                log(f"[iter {iterations}] validation: {rec}  (SSIM: PARITY-UNPINNED -- a restatement of skimage's defaults, skimage is not in this image; "
+                    f"SAM / ERGAS / PSNR / CC are pinned to the reference's analysis_accu)")
             if save_dir and save_every and iterations % save_every == 0 and rank == 0:
                 flush_losses()
                 save(iterations)

@@ -1,5 +1,5 @@
 """Op-by-op forward AND backward of the denoiser's building blocks on libddif (C ABI: include/ddif.h, "forward ops of the
-TRAINING graph" + the backward ops) -- what ddif/train.py strings together.  Signatures follow torch.nn.functional where the
+TRAINING graph" + the backward ops) -- what the op-by-op tape of the tests (tests/train_tape.py) strings together.  Signatures follow torch.nn.functional where the
 reference uses it (models/sr3_dwt.py); tensors are torch fp32 NCHW on the GPU (CPU tensors only with the emulated test build).
 No torch arithmetic in here: torch allocates, views (cat / chunk / pad are data movement) and nothing else."""
 import ctypes as C

@@ -73,8 +73,13 @@ def sample_scene_dpmpp(net, diffusion, cond_all: torch.Tensor, x_T_all: torch.Te
     """BASELINE configs[2]: ONE scene = `cond_all` (n_tiles, 2C+4P, h, w; the same on every rank) sampled with DPM-Solver++ multistep, the tiles
     split in contiguous blocks over the ranks of the default process group (strong scaling: n_tiles / world per GPU), one all-gather, then the
     stitch.  `x_T_all` (n_tiles, C, h, w) is the scene's initial noise (the same on every rank; each rank uses its block), so the fused scene does
-    not depend on the number of GPUs.  Returns the fused scene (C, ny h, nx w) on every rank.  The reference feeds the whole scene through
-    the network instead (diffusion_engine.py:373-377) -- tiles never mix inside it, so the tiled run is the same computation per tile."""
+    not depend on the number of GPUs.  Returns the fused scene (C, ny h, nx w) on every rank.
+
+    Tiling is a DESIGN DECISION of this build, not a property of the reference: the reference feeds the whole scene through the network
+    (diffusion_engine.py:373-377), where GroupNorm(1 group) statistics span the whole scene, the 3x3 convs see their neighbours across what
+    would be tile edges (here: zero padding at every tile edge) and the H/8 self-attention attends over the whole scene.  A tiled run is
+    therefore NOT the same function as the whole-scene run; each tile is the reference's computation ON THAT TILE
+    (what `test_fn` does with 64 x 64 training-size inputs), and whole scenes up to the 4 GiB tensor limit can still go through one plan."""
     from .solver.dpm_solver import DPM_Solver, ImageSpaceClamp, NoiseScheduleVP, model_wrapper
 
     world = dist.get_world_size() if dist.is_initialized() else 1

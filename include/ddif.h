@@ -198,7 +198,7 @@ DDIF_API void ddif_optim_destroy(ddif_optim_t h);
 DDIF_API int ddif_optim_step(ddif_optim_t h, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                              float max_grad_norm, int ema_mode, float ema_decay, float* grad_norm_host, void* stream);
 
-/* ---- training building blocks (the full train step is not built yet) ---------------------------------- */
+/* ---- training: train-mode plans, the native training step (ddif_plan_train_step below), building blocks ---- */
 
 /* Train-mode network (UNetSR3 under .train(): nn.Dropout(p) between SiLU and conv of every ResnetBlock Block,
  * models/sr3_dwt.py:295, and DropPath(0.2) on every decoder FFN, :534,576).  A train-mode plan runs the same entry points
@@ -294,10 +294,9 @@ DDIF_API int ddif_swish_bwd(const float* x, const float* dy, int64_t n, float* d
 DDIF_API int ddif_l1_loss_bwd(const float* pred, const float* target, int64_t n, float upstream, float* dpred, void* stream);
 
 /* ---- forward ops of the TRAINING graph (a15) --------------------------------------------------------------------------------
- * The inference plan fuses GroupNorm / SiLU / FiLM / softmax into conv prologues and epilogues and never materialises what the
- * backward pass needs; the training forward (ddif/train.py) therefore runs the reference's modules op by op on these entry
- * points, NCHW, keeping every intermediate.  Same arithmetic as models/sr3_dwt.py; the convs run on the bf16x3 split products of
- * the inference path (fp32-class; DDIF_TRAIN_X3=0: the exact-fp32 MFMA). */
+ * Stateless NCHW ops of round 2's op-by-op training tape (tests/train_tape.py, kept as an independent cross-check of the native
+ * step; the product trains through ddif_plan_train_step, csrc/ddif_train.cpp: a reverse launch program over NHWC activations).
+ * Same arithmetic as models/sr3_dwt.py; the convs run on the bf16x3 split products (fp32-class; DDIF_TRAIN_X3=0: the exact-fp32 MFMA). */
 typedef struct ddif_convfwd* ddif_convfwd_t;
 /* nn.Conv2d(Cin, Cout, ks, stride, padding = ks / 2) [+ nearest x2 upsampling in front: Upsample, models/sr3_dwt.py:266-273];
  * x (B,Cin,H,W), w (Cout,Cin,ks,ks), bias (Cout) or NULL, y (B,Cout,Ho,Wo) */

@@ -1,4 +1,4 @@
-"""One training forward + backward of the whole denoiser through ddif.train.TrainGraph against the REAL reference (SURVEY.md 8(a) a15,
+"""One training forward + backward of the whole denoiser through the op-by-op tape (tests/train_tape.py TrainGraph) and the native reverse program against the REAL reference (SURVEY.md 8(a) a15,
 golden G7: tests/golden/traingrad_wv3_16.npz = tools/make_golden.py traingrad: `UNetSR3` under .train() with the Dropout / DropPath
 masks it drew, F.l1_loss against a fixed target, loss.backward(); diffusion_engine.py:230-233).  Checked: the train-mode output, the
 norm of the gradient of EVERY parameter (702 tensors) and a handful of full gradients.  Emulator on the CPU, real library on MI355X."""
@@ -43,7 +43,7 @@ def _case_inputs(case):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_training_step_gradients_match_the_reference(backend):
     from ddif import runtime
-    from ddif.train import TrainGraph
+    from train_tape import TrainGraph
 
     dev = _dev(backend)
     g, ds, x, sc, target, cond, t, masks, paths = _case_inputs(gc.TRAIN_GRAD_CASES[0])

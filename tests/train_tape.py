@@ -20,9 +20,9 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as TF  # ONLY interpolate() on the constant cond image
 
-from . import functional as F
-from . import runtime as R
-from .layout import layer_plan
+from ddif import functional as F  # TEST SCAFFOLDING since round 4: the product trains through ddif_plan_train_step (csrc/ddif_train.cpp)
+from ddif import runtime as R
+from ddif.layout import layer_plan
 
 
 def _acc(grads: Dict[str, torch.Tensor], key: str, g: torch.Tensor):

@@ -1,4 +1,4 @@
-"""One training step (forward + backward of the whole denoiser, ddif.train.TrainGraph) of the config-5 shape on the GPU: wall time per
+"""One training step (forward + backward of the whole denoiser, tests/train_tape.py TrainGraph) of the config-5 shape on the GPU: wall time per
 phase; run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.   python3 tools/train_step_bench.py [batch] [iters]"""
 import os
 import sys
@@ -11,7 +11,8 @@ import torch  # noqa: E402
 from ddif import runtime  # noqa: E402
 from ddif.layout import engine_cfg  # noqa: E402
 from ddif.synth import synth_state_dict, synth_tiles  # noqa: E402
-from ddif.train import TrainGraph  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from train_tape import TrainGraph  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
