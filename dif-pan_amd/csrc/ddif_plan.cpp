@@ -98,6 +98,8 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
         else if (ks == 1 && ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1, EPI_RES>(cfg); v.name = "conv1x1_colsoftmax_res"; }
     } else if (epi == EPI_TBS) {
         if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_TBS>(cfg); v.name = "conv3x3_gn_silu_tbs"; }
+    } else if (epi == EPI_SAMP) {
+        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU && cfg >= 7 && cfg != 20 && cfg != 21) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_SAMP>(cfg); v.name = "conv3x3_gn_silu_sampler"; }
     } else if (epi == EPI_SILU) {
         if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_SILU>(cfg); v.name = "conv3x3_silu"; }
     } else if (epi != 0) {
@@ -562,6 +564,18 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         if (var.smem + 8192 > 64 * 1024)
             DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_tbs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(var.smem + 8192)));
     }
+    // the final conv: the same tiling with the DDPM / DDIM update in its epilogue (split-operand tilings, vector output path)
+    ConvKernelFn fn_samp = nullptr;
+    if (s.samp && !train_mode && epi == 0 && s.tb_off < 0 && &prog == &step) {
+        const ConvVariant vs = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, EPI_SAMP, f16ok);
+        if (vs.fn && vs.smem == var.smem) {
+            fn_samp = vs.fn;
+            if (var.smem + 8192 > 64 * 1024)
+                DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_samp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(var.smem + 8192)));
+            final_fused = true;
+        }
+    }
+    const float* lms_p = lms.p;
     const bool dyn = s.dyn_input;
     const bool self_c = net->cfg.self_condition != 0;
     const int tb_off = s.tb_off;
@@ -587,7 +601,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         if (var.f16) ++n_conv3_f16;
     }
     op.win = true;
-    op.run = [a, var, fn_tbs, grid, block, smem, dyn, self_c, tb_off, items_per_sample, cap](hipStream_t st, const StepCtx& ctx) {
+    op.run = [a, var, fn_tbs, fn_samp, lms_p, grid, block, smem, dyn, self_c, tb_off, items_per_sample, cap](hipStream_t st, const StepCtx& ctx) {
         ConvArgs aa = a;
         dim3 g = grid;
         if (ctx.bn) {  // batch window of a forked region
@@ -609,6 +623,17 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
             aa.tbias_stride = ctx.tb_stride;
             aa.step_ptr = ctx.step_ptr;
             aa.tb_rowstride = ctx.tb_rowstride;
+        }
+        if (fn_samp && ctx.samp_out) {  // DDPM / DDIM loop: x_{t-1} straight from the epilogue
+            aa.s_img = ctx.x;
+            aa.s_lms = lms_p;
+            aa.s_out = ctx.samp_out;
+            aa.s_run = reinterpret_cast<const SamplerRun*>(ctx.samp_run);
+            aa.s_step_next = ctx.step_next;
+            aa.s_kind = ctx.samp_kind;
+            aa.step_ptr = ctx.step_ptr;
+            hipLaunchKernelGGL(fn_samp, g, block, smem, st, aa);
+            return;
         }
         hipLaunchKernelGGL((tb_off >= 0 && ctx.tb_stride != 0) ? fn_tbs : var.fn, g, block, smem, st, aa);
     };
@@ -1594,6 +1619,7 @@ int Plan::build_impl() {
         s.gamma = V("final_conv.block.0.weight");
         s.beta = V("final_conv.block.0.bias");
         s.name = "final";
+        s.samp = true;
         DDIF_TRY(add_conv(step, s, &net_out));
         if (train_mode) {
             TrainMod m;
@@ -1848,7 +1874,7 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
         DDIF_HIPCHK(hipMemcpyAsync(d_tabs + (size_t)i * tabs_cap, tabs_host[i], (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, s));
     }
     DDIF_HIPCHK(hipMemcpyAsync(d_run, &run, sizeof(run), hipMemcpyHostToDevice, s));
-    DDIF_HIPCHK(hipMemsetAsync(d_step, 0, sizeof(int), s));
+    DDIF_HIPCHK(hipMemsetAsync(d_step, 0, 2 * sizeof(int), s));
     // the host copies above must have been consumed before `run` (stack) goes away: pageable H2D copies are staged
     // synchronously by the runtime, so returning after the enqueue is safe.
 
@@ -1858,7 +1884,11 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
         ctx.x = ctx.sc = img[parity];  // self-conditioning == current image (diffusion_ddpm_pan.py:491,502; sr3_dwt.py:173)
         ctx.tb = tb;
         ctx.tb_stride = 0;
-        ctx.step_ptr = d_step;
+        ctx.step_ptr = d_step + parity;
+        ctx.step_next = d_step + (parity ^ 1);
+        ctx.samp_run = d_run;
+        ctx.samp_kind = kind;
+        ctx.samp_out = final_fused ? img[parity ^ 1] : nullptr;
         ctx.tb_rowstride = net->nslots;
         run_step_prog(st, ctx, prof);
         StepArgs a{};
@@ -1870,10 +1900,11 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
         a.C = C;
         a.HW = HW;
         a.run = reinterpret_cast<const SamplerRun*>(d_run);
-        a.step = d_step;
+        if (final_fused) return;  // the update ran in the final conv's epilogue, which also wrote the next step's counter
+        a.step = d_step + parity;
         if (kind == 0) hipLaunchKernelGGL(ddpm_step_kernel, ew_grid(n), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(ddim_step_kernel, ew_grid(n), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, st, d_step);
+        hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, st, (const int*)(d_step + parity), d_step + (parity ^ 1));
     };
 
     bool graph_ok = false;

@@ -23,6 +23,11 @@ struct StepCtx {
     const int* step_ptr = nullptr;  // samplers: device step counter selecting the time-bias row (row stride tb_rowstride)
     int tb_rowstride = 0;
     int b0 = 0, bn = 0;         // batch window [b0, b0 + bn) of a forked region (bn = 0: the whole batch)
+    // DDPM / DDIM loops: the sampler update runs in the final conv's epilogue (kernels_conv.h EPI_SAMP) when the plan carries that variant
+    float* samp_out = nullptr;      // x_{t-1} (null: plain network output)
+    const void* samp_run = nullptr; // device SamplerRun
+    int* step_next = nullptr;       // the counter the NEXT step reads
+    int samp_kind = 0;
 };
 
 struct Op {
@@ -117,6 +122,7 @@ struct ConvSpec {
     bool silu = false;
     bool stats = false;
     bool exact = false;                 // force the exact-fp32 MFMA instantiation of kernels_conv.h (gradient convs; pc->w only)
+    bool samp = false;                  // the network's final conv: also look up the sampler-epilogue variant (EPI_SAMP)
     const char* name = "conv";
 };
 
@@ -152,7 +158,8 @@ struct Plan {
     int tb_rows = 0;
     float* small = nullptr;           // device scratch for per-sample coefficient arrays (2*B floats)
     // sampler run state (device) + hipGraph replay of a pair of denoising steps
-    int* d_step = nullptr;
+    int* d_step = nullptr;              // two counters: a step's kernels read d_step[parity], the sampler update writes d_step[parity ^ 1]
+    bool final_fused = false;           // the final conv carries the sampler epilogue: no separate update / counter launches in the DDPM / DDIM loops
     void* d_run = nullptr;            // SamplerRun
     float* d_tabs = nullptr;
     int tabs_cap = 0;

@@ -33,6 +33,7 @@
 //     epilogue store and before the prefetch, i.e. no overlap of HBM latency with the MFMAs at all.
 #pragma once
 #include "ddif_dev.h"
+#include "sampler_dev.h"
 
 namespace ddif {
 
@@ -71,6 +72,14 @@ struct ConvArgs {
     float* cso_sm;
     long long* dbg;          // microbenchmark instrumentation (ABL & 16) only
     int b0;                  // batch window: the launch covers samples [b0, b0 + B) of the tensors (sub-batches of a forked region run concurrently)
+    // EPI_SAMP (the network's final conv inside a DDPM / DDIM loop): the sampler update runs in the epilogue -- x0 = this conv's output,
+    // out = update(x0, x_t, lms, noise) goes to s_out; the step counter of the NEXT step is written by workgroup 0 (double-buffered counters)
+    const float* s_img;      // x_t, NHWC like the output
+    const float* s_lms;
+    float* s_out;            // x_{t-1}
+    const SamplerRun* s_run;
+    int* s_step_next;        // receives *step_ptr + 1
+    int s_kind;              // 0 = DDPM p_sample, 1 = DDIM
 };
 
 template <int F>
@@ -87,7 +96,8 @@ struct StageKind {
 // 4 = residual add,  8 = SiLU on the output (a runtime flag gets if-converted: exp + rcp computed for every conv),
 // 16 = per-SAMPLE time-bias rows (tbias_stride != 0: forward() / p_losses with one t per sample; in the samplers every
 // sample shares the step's row and bias + time bias sit in LDS for the whole launch).
-enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_COLST = 32 };
+// 64 = sampler update in the epilogue (ConvArgs::s_*; diffusion_ddpm_pan.py:418-442 p_sample / :594-621 ddim_sample on the final conv's output).
+enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_COLST = 32, EPI_SAMP = 64 };
 // VEC (input staging): 0 = scalar loads, any channel counts;  1 = float4 loads, every CK-channel chunk lies in ONE source
 // (c1 == 0 or c0 % CK == 0): the source base is wave-uniform (SGPR) and a load costs one VALU add;  2 = float4 loads with
 // a per-thread source select (the stem's cat[x, x] with 8 + 8 channels).
@@ -137,6 +147,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr bool DWM = (PRO == PRO_GN_DW);
     constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW);
     constexpr bool FILM = (EPI & EPI_FILM) != 0, SOUT = (EPI & EPI_SOUT) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0, TBS = (EPI & EPI_TBS) != 0;
+    constexpr bool SAMP = (EPI & EPI_SAMP) != 0;
+    static_assert(!SAMP || (!SOUT && !RES && !FILM), "sampler epilogue: the plain vector epilogue of the final conv");
     static_assert(!DWM || (KS == 1 && STRIDE == 1 && !UPS && VEC == 1), "depthwise staging is for plain 1x1 convs");
     static_assert(PRO != PRO_COLSM || VEC == 1, "column-softmax prologue needs uniform-source float4 staging");
     constexpr int LPAD = DWM ? 1 : PAD;
@@ -186,6 +198,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     const int GBN = a.n_chunks * CK;
     const int c4 = tid % C4;
     const float* tbrow = a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0);
+    // sampler epilogue: this step's coefficients (scalar loads, once per workgroup)
+    [[maybe_unused]] SamplerRun s_run{};
+    [[maybe_unused]] int s_k = 0;
+    [[maybe_unused]] float s_c0 = 0.f, s_c1 = 0.f, s_c2 = 0.f, s_c3 = 0.f, s_c4 = 0.f;
+    [[maybe_unused]] const float* s_noise = nullptr;
+    if constexpr (SAMP) {
+        s_run = *a.s_run;
+        s_k = *a.step_ptr;
+        s_c0 = s_run.tab[0][s_k];
+        s_c1 = s_run.tab[1][s_k];
+        s_c2 = s_run.tab[2][s_k];
+        if (a.s_kind == 1) {
+            s_c3 = s_run.tab[3][s_k];
+            s_c4 = s_run.tab[4][s_k];
+        }
+        s_noise = s_run.noise ? s_run.noise + (size_t)s_k * ((size_t)a.B * a.Cout * a.Hout * a.Wout) : nullptr;
+        if (blockIdx.x == 0 && tid == 0) *a.s_step_next = s_k + 1;  // the next step's kernels read the OTHER counter (nobody reads this one during this step)
+    }
 
     int abase[MB], e_my[MB], e_mx[MB];
     unsigned e_off[MB], e_foff[MB];  // byte offset of this lane's pixel (+ 4h couts) from the tile's first output / FiLM element
@@ -550,6 +580,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         float4 e_t[(LAST && TBS) ? NB : 1][4];
         float4 e_res[(LAST && RES) ? MB : 1][(LAST && RES) ? NB : 1][4];
         float4 e_fs[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4], e_fh[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4];
+        [[maybe_unused]] float4 e_xi[(LAST && SAMP) ? MB : 1][(LAST && SAMP) ? NB : 1][4], e_xl[(LAST && SAMP) ? MB : 1][(LAST && SAMP) ? NB : 1][4];  // x_t, lms
         bool full = true;
         unsigned e_po[MB], e_pf[MB];  // this item's byte offsets (clamped to the tile origin for pixels outside the image)
         bool e_pok[MB];
@@ -570,6 +601,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                 [[maybe_unused]] const char* tb = reinterpret_cast<const char*>(tbrow + (size_t)Cp.b * a.tbias_stride + nbl);
                 [[maybe_unused]] const char* rbase = reinterpret_cast<const char*>(a.res + tile_pix * a.Cout + nbl);
                 [[maybe_unused]] const char* fbase = reinterpret_cast<const char*>(a.film + tile_pix * 2 * a.Cout + nbl);
+                [[maybe_unused]] const char* xibase = reinterpret_cast<const char*>(a.s_img + tile_pix * a.Cout + nbl);
+                [[maybe_unused]] const char* xlbase = reinterpret_cast<const char*>(a.s_lms + tile_pix * a.Cout + nbl);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -580,6 +613,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
                             if constexpr (RES) e_res[mb][nb][g] = *reinterpret_cast<const float4*>(rbase + (e_po[mb] + cq));
+                            if constexpr (SAMP) {
+                                e_xi[mb][nb][g] = *reinterpret_cast<const float4*>(xibase + (e_po[mb] + cq));
+                                e_xl[mb][nb][g] = *reinterpret_cast<const float4*>(xlbase + (e_po[mb] + cq));
+                            }
                             if constexpr (FILM) {
                                 e_fs[mb][nb][g] = *reinterpret_cast<const float4*>(fbase + (e_pf[mb] + cq));
                                 e_fh[mb][nb][g] = *reinterpret_cast<const float4*>(fbase + (size_t)a.Cout * 4 + (e_pf[mb] + cq));
@@ -725,7 +762,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                                     if constexpr (RES) x += (&e_res[mb][nb][g].x)[i];
                                     v[i] = x;
                                 }
-                                if (!GUARD || (e_pok[mb] && co < a.Cout)) {
+                                if constexpr (SAMP) {
+                                    if (e_pok[mb] && co < a.Cout) {
+#pragma clang fp contract(off)
+                                        // the sampler update on x0 = v (same expressions, same order as ddpm_step_kernel / ddim_step_kernel: no contraction)
+                                        const size_t pix = (size_t)((Cp.b * a.Hout + Cp.oy0 + e_my[mb]) * a.Wout + Cp.ox0 + e_mx[mb]);
+                                        const size_t hw = (size_t)a.Hout * a.Wout, pin = pix - (size_t)Cp.b * hw;
+                                        float o4[4];
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) {
+                                            float x0 = v[i];
+                                            const float l = (&e_xl[mb][nb][g].x)[i], xi = (&e_xi[mb][nb][g].x)[i];
+                                            if (s_run.do_clamp) x0 = fminf(fmaxf(x0 + l, s_run.lo), s_run.hi) - l;
+                                            const size_t e = ((size_t)Cp.b * a.Cout + co + i) * hw + pin;  // NCHW element index: the noise layout / Philox key
+                                            if (a.s_kind == 0) {
+                                                const float z = s_noise ? s_noise[e] : philox_normal(s_run.seed, (unsigned)(s_k + 1), (s_run.tile0 * a.Cout * hw) + e);
+                                                const float mean = s_c0 * x0 + s_c1 * xi;
+                                                o4[i] = mean + s_c2 * z;
+                                            } else {
+                                                const float eps = (s_c0 * xi - x0) / s_c1;
+                                                float r = x0 * s_c2 + s_c3 * eps;
+                                                if (s_c4 != 0.f) {
+                                                    const float z = s_noise ? s_noise[e] : philox_normal(s_run.seed, (unsigned)(s_k + 1), (s_run.tile0 * a.Cout * hw) + e);
+                                                    r += s_c4 * z;
+                                                }
+                                                o4[i] = r;
+                                            }
+                                        }
+                                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.s_out + tile_el) + (e_po[mb] + (unsigned)((nb * 32 + 8 * g) * 4))) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                                    }
+                                } else if (!GUARD || (e_pok[mb] && co < a.Cout)) {
                                     // (streaming / nontemporal stores measured slower: 1x1 64->64 @64^2 63 vs 38 us)
                                     if (!(ABL & 4) || v[0] == 12345.678f)
                                         *reinterpret_cast<float4*>(obase + (e_po[mb] + (unsigned)((nb * 32 + 8 * g) * 4))) = make_float4(v[0], v[1], v[2], v[3]);

@@ -4,6 +4,7 @@
 // diffusion/diffusion_ddpm_pan.py.
 #pragma once
 #include "ddif_dev.h"
+#include "sampler_dev.h"
 
 namespace ddif {
 
@@ -534,7 +535,6 @@ __global__ __launch_bounds__(64) void self_attn_mfma_kernel(const float* qkv, in
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* o);
 // Train mode (models/sr3_dwt.py:288-300 Block with Dropout; :534,576 DropPath on the decoder FFN).  In a train-mode plan
 // the dropout sits between the GroupNorm + SiLU prologue and the conv, so the activation is materialised once:
 //   y = silu(GroupNorm(x)) * mask        gn_silu_drop_kernel   (mask holds 0 or 1/(1-p); y is also what wgrad will need)
@@ -745,29 +745,6 @@ __global__ void nhwc_to_nchw_kernel(const float* in, int B, int C, int HW, float
     }
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// counter-based normal generator (Philox4x32-10 + Box-Muller), keyed by (seed, draw index, global element index) so
-// results do not depend on the batch split across GPUs.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                              unsigned* o) {
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
-__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned draw, unsigned long long elem) {
-    unsigned o[4];
-    philox4x32_10((unsigned)elem, (unsigned)(elem >> 32), draw, 0x5DD1Fu, (unsigned)seed, (unsigned)(seed >> 32), o);
-    const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-}
-
 // x_T = randn (p_sample_loop :484) written in the kernels' NHWC layout; element index is the NCHW index.
 __global__ void randn_nhwc_kernel(float* out, int B, int C, int HW, unsigned long long seed, unsigned draw,
                                   unsigned long long tile0) {
@@ -786,13 +763,6 @@ __global__ void randn_nhwc_kernel(float* out, int B, int C, int HW, unsigned lon
 // Per-run sampler state lives in DEVICE memory (rewritten at the start of every sampling call) and the step index is a
 // device counter advanced by step_advance_kernel: the kernels of a denoising step therefore take the same arguments
 // at every step, which is what lets the whole step be replayed from a hipGraph.
-struct SamplerRun {
-    const float* noise;  // (n_steps, B, C, H, W) NCHW standard normals in execution order, or null -> Philox
-    unsigned long long seed, tile0;
-    float lo, hi;
-    int do_clamp, n_steps;
-    const float* tab[6];  // per-step coefficient tables (device), meaning depends on the sampler
-};
 struct StepArgs {
     const float* x0;   // network output
     const float* img;  // x_t
@@ -802,7 +772,7 @@ struct StepArgs {
     const SamplerRun* run;
     const int* step;
 };
-__global__ void step_advance_kernel(int* step) { *step += 1; }
+__global__ void step_advance_kernel(const int* cur, int* next) { *next = *cur + 1; }  // double-buffered counters: nobody reads `next` during this step
 
 // DDPM p_sample (:418-442, 346-415, 316-325): x0c = clamp(x0 + lms) - lms; out = c1*x0c + c2*img + c3*z
 // with c1/c2 = posterior_mean_coef1/2[t] (tab 0/1), c3 = [t != 0] * exp(0.5 * posterior_log_variance_clipped[t]) (tab 2).

@@ -150,6 +150,27 @@ def test_emulated_forward_64x64_runs_the_fused_high_resolution_kernels(ds, monke
     assert net.plan_for(B, H, H, torch.device("cpu")).num_launches()["step"] == 152
 
 
+def test_emulated_ddpm_32x32_runs_the_sampler_update_in_the_final_conv_epilogue():
+    """At >= 32 x 32 the final conv has a split-operand tiling that carries the DDPM / DDIM update in its epilogue (kernels_conv.h EPI_SAMP:
+    clamp(x0 + lms) - lms, posterior mean, + sigma z, the next step's counter) -- no separate update / counter launches.  Three steps (an odd
+    count: the double-buffered step counter ends on the other parity) with uploaded reference-order noise against the oracle."""
+    ds, B, H, T, steps = "wv3", 2, 32, 20, 3
+    C, cond, g = _tiny(ds, B, H, H, 3)
+    xT = torch.randn(B, C, H, H, generator=g)
+    noise = torch.randn(steps, B, C, H, H, generator=g)
+    d = make_diffusion(net_for(ds), C, T, H, "cpu")
+    plan = d._plan(cond)
+    c1, c2 = d.posterior_mean_coef1, d.posterior_mean_coef2
+    cz = (0.5 * d.posterior_log_variance_clipped).exp()
+    order = list(reversed(range(T)))[:steps]
+    out = plan.sample_ddpm([float(i) for i in order], [float(c1[i]) for i in order], [float(c2[i]) for i in order],
+                           [float(cz[i]) for i in order], xT, noise, 0, 0, (0.0, 1.0), "cpu")
+    it = iter([xT] + [noise[k] for k in range(steps)])
+    with torch.no_grad():
+        ref = O.ddpm_sample(gc.weights_for(ds), gc.cfg_for(ds), cond, O.schedule_tables(O.cosine_betas(T)), noise_fn=lambda s: next(it), timesteps=order)
+    assert float((out - ref).abs().max()) <= 2e-5
+
+
 def test_emulated_grid_cap_hook_gives_identical_results():
     """ddif_debug_set_grid_cap (the hook the -m gpu multi-item tests rely on): one workgroup walking every work item
     of every conv launch, across the sample boundaries of a B=3 batch, reproduces the uncapped result bit for bit."""
