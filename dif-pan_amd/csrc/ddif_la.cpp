@@ -33,13 +33,14 @@ int la_launch_t(const LaFuseArgs& a, int nbq, int nba, int grid, hipStream_t s, 
 
 // shapes the fused kernel carries: whole columns of 64 or 32 rows, 64 / 96 / 128 feature channels, 32 / 64 output channels
 bool lafuse_supported(int H, int fea, int dout) {
-    return (H == 64 || H == 32) && fea % 32 == 0 && fea >= 64 && fea <= 128 && dout % 32 == 0 && dout >= 32 && dout <= 64;
+    return (H == 64 || H == 32 || H == 16) && fea % 32 == 0 && fea >= 64 && fea <= 128 && dout % 32 == 0 && dout >= 32 && dout <= 64;
 }
 int lafuse_strip(int H) { return 256 / H; }
 int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only) {
     const int nbq = (a.c0 + a.c1) / 32, nba = a.dout / 32;
     if (a.H == 64) return la_launch_t<64, 4>(a, nbq, nba, grid, s, prepare_only);
     if (a.H == 32) return la_launch_t<32, 8>(a, nbq, nba, grid, s, prepare_only);
+    if (a.H == 16) return la_launch_t<16, 16>(a, nbq, nba, grid, s, prepare_only);  // a 16 x 16 sample = one workgroup
     return fail(DDIF_ERR_INVALID, "linattn_fused: H = %d", a.H);
 }
 

@@ -1320,7 +1320,7 @@ int Plan::build_impl() {
         {
             const PackedConv* pm = PC(ci + ".attn_mix");
             const float* wr = V(ci + ".attn_res.weight");
-            bool ok = lafuse_enabled() && f16_enabled() && x3_enabled() && lr_enabled() && pm && wr && pq1->w_f16 && pq1->bias && pm->bias && Hl * Wl > 256 &&
+            bool ok = lafuse_enabled() && f16_enabled() && x3_enabled() && lr_enabled() && pm && wr && pq1->w_f16 && pq1->bias && pm->bias && Hl * Wl >= 256 &&
                       pq1->cout == fea && pq1->ck == 32 && pm->ck == 32 && pm->cin == 2 * fea && cur.C % 16 == 0 && skip.C % 16 == 0 && lafuse_supported(Hl, fea, pm->cout);
             if (ok) {  // f16x2 range of depthwise(GroupNorm(.)): (sqrt(N) max|gamma| + max|beta|) * 9 max|w_dw| inside the scaled half range
                 auto ig = net->vec_absmax.find(pn_g), ib = net->vec_absmax.find(pn_b), iw = net->vec_absmax.find(q0w);
@@ -1385,7 +1385,7 @@ int Plan::build_impl() {
                 }
                 op.flop = 2.0 * B * Hl * Wl * ((double)fea * fea + 9.0 * fea + 2.0 * fea * pm->cout);
                 op.bytes = 4.0 * B * Hl * Wl * ((double)fea + pm->cout);
-                op.cls = 1;
+                op.cls = (Hl * Wl <= 256) ? 2 : 1;
                 // q.1 on f16x2 (x3), attn_out / attn_res on bf16x3 (x6): weight of the sum
                 op.mfma_w = (3.0 * fea * fea + 6.0 * 2.0 * fea * pm->cout) / ((double)fea * fea + 9.0 * fea + 2.0 * fea * pm->cout);
                 op.win = true;

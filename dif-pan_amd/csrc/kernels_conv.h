@@ -182,8 +182,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef DDIF_EMU
     const int wave = tid >> 6;
+    [[maybe_unused]] const long long t_entry = 0;
 #else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: everything derived from it is scalar math
+    [[maybe_unused]] const long long t_entry = (ABL & 16) ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #endif
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, j = lane & 31;
@@ -562,6 +564,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         if ((ABL & 16) && a.dbg && tid == 0 && dbg_n < 126) a.dbg[blockIdx.x * 128 + dbg_n++] = (long long)__builtin_amdgcn_s_memtime();
 #endif
     };
+#ifndef DDIF_EMU
+    if ((ABL & 16) && a.dbg && tid == 0) a.dbg[blockIdx.x * 128 + dbg_n++] = t_entry;  // kernel entry; the next stamp = per-thread geometry set up
+#endif
     f32x16 acc[MB][NB];
     const int nflat = (w1 - w0) * a.n_chunks;
 

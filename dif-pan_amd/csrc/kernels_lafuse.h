@@ -80,31 +80,35 @@ __device__ __forceinline__ void row_pair_swap(float* x, float* y) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(*x), "+v"(*y));
 #endif
 }
+template <bool PAIR = true>  // PAIR: over the 32 lanes of a wavefront half; else over the 16-lane rows (a 16-row image column per row)
 __device__ __forceinline__ float half_allmax(float v) {
 #ifdef DDIF_EMU
 #pragma unroll
-    for (int m = 1; m <= 16; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    for (int m = 1; m <= (PAIR ? 16 : 8); m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
     return v;
 #else
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));  // row_ror:4
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));  // row_ror:8
+    if constexpr (!PAIR) return v;
     float x = v, y = v;  // every lane holds its 16-lane row's maximum; swap: x = rows [0, 0, 2, 2], y = rows [1, 1, 3, 3]
     row_pair_swap(&x, &y);
     return fmaxf(x, y);
 #endif
 }
+template <bool PAIR = true>
 __device__ __forceinline__ float half_allsum(float v) {
 #ifdef DDIF_EMU
 #pragma unroll
-    for (int m = 1; m <= 16; m <<= 1) v += __shfl_xor(v, m);
+    for (int m = 1; m <= (PAIR ? 16 : 8); m <<= 1) v += __shfl_xor(v, m);
     return v;
 #else
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    if constexpr (!PAIR) return v;
     float x = v, y = v;
     row_pair_swap(&x, &y);
     return x + y;  // (lower row + upper row in every lane of the half)
@@ -123,7 +127,7 @@ __device__ __forceinline__ float half_allsum(float v) {
 template <int TH, int TW, int NBQ, int NBA, int ABL = 0>
 __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     using G = LaFuseGeom<TH, TW, NBQ, NBA>;
-    static_assert(TH * TW == 256 && (TH == 32 || TH == 64), "a workgroup owns 256 pixels = whole columns of the sample");
+    static_assert(TH * TW == 256 && (TH == 16 || TH == 32 || TH == 64), "a workgroup owns 256 pixels = whole columns of the sample");
     constexpr int HH = G::HH, HW = G::HW, LDH = G::LDH, LDQ = G::LDQ, LDX = G::LDX, APS = G::APS, FEA = G::FEA;
     constexpr int NCH = 2 * NBQ;                              // 16-channel chunks
     constexpr int NIT = (HH * HW * 4 + 511) / 512;            // raw float4 items per thread and chunk
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     e[4 * g + i] = fmaf(accq[nb][4 * g + i], DDIF_F16_OSCALE, (&bq4.x)[i]);
-                    fac[4 * g + i] = half_allmax(e[4 * g + i]);
+                    fac[4 * g + i] = half_allmax<(TH >= 32)>(e[4 * g + i]);
                 }
             }
             if constexpr (TH == 64) {  // a column spans the wave pair (2x, 2x + 1): the pair's maxima meet in LDS
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 e[r] = dd_exp2_fast((e[r] - fac[r]) * L2E);
-                fac[r] = half_allsum(e[r]);
+                fac[r] = half_allsum<(TH >= 32)>(e[r]);
             }
             if constexpr (TH == 64) {
                 float* Ss = Cs + 8 * 2 * 16;
