@@ -28,8 +28,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
          "or test_forward_matches_oracle_other_sizes and 8x8")
 
 
-@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0"])
+@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
