@@ -171,6 +171,70 @@ def test_emulated_ddpm_32x32_runs_the_sampler_update_in_the_final_conv_epilogue(
     assert float((out - ref).abs().max()) <= 2e-5
 
 
+def test_f16x2_range_guards_fall_back_to_bf16x3():
+    """The two-plane fp16 split pre-scales its operands by fixed powers of two (csrc/ddif_dev.h): a conv takes it only when its weights are inside the
+    scaled half range (|w| < 64, checked at commit) and, behind a GroupNorm, when sqrt(N) max|gamma| + max|beta| < 4094 (checked per conv at plan
+    build); otherwise the conv stays on bf16x3.  Both guards are driven here: the forward must stay at fp32-class accuracy against the oracle with
+    an absurd GroupNorm gain and with a 100x conv weight (outputs of O(100) magnitude: relative bar)."""
+    from ddif.models.sr3_dwt import UNetSR3
+    from ddif_testlib import CTOR_KEYS
+
+    ds, B, H = "wv3", 1, 16
+    C, cond, g = _tiny(ds, B, H, H, 21)
+    x = torch.randn(B, C, H, H, generator=g)
+    t = torch.tensor([123])
+    for key, factor in (("downs.1.res_block.block1.block.0.weight", 500.0), ("downs.1.res_block.block2.block.3.weight", 100.0)):
+        sd = {k: v.clone() for k, v in gc.weights_for(ds).items()}
+        sd[key] = sd[key] * factor
+        cfg = gc.cfg_for(ds)
+        net = UNetSR3(**{k: cfg[k] for k in CTOR_KEYS})
+        net.load_state_dict(sd)
+        net = net.eval()
+        y = net(x, t, cond)
+        with torch.no_grad():
+            ref = O.unet_forward(sd, cfg, x, t, cond, None)
+        assert torch.isfinite(y).all()
+        assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), key
+
+
+def test_train_entry_points_refuse_empty_gradient_packs_and_plans_keep_their_net_alive():
+    """(1) the dgrad weight packs of a train-mode plan start zeroed and are filled by `ddif_net_refresh`; a backward pass before that used to
+    return silently-zero input gradients -- now the train entry points fail with DDIF_ERR_STATE.  (2) a plan holds raw pointers into its net:
+    `ddif_net_destroy` before `ddif_plan_destroy` defers the free to the last plan."""
+    import ctypes as C
+
+    from ddif import DdifError
+
+    ds, B, H = "wv3", 1, 8
+    Cc, cond, g = _tiny(ds, B, H, H, 4)
+    net = make_net(ds, "cpu").train()
+    try:
+        plan = net.plan_for(B, H, H, torch.device("cpu"), train=True)
+        plan.set_cond(cond, force=True)
+        grads = [(n, torch.zeros_like(p)) for n, p in net.named_parameters()]
+        plan.train_bind(grads)
+        x = torch.randn(B, Cc, H, H, generator=g)
+        with pytest.raises(DdifError, match="ddif_net_refresh"):
+            plan.train_forward_backward(x, torch.tensor([5]), None, torch.zeros_like(x))
+        net._net.refresh_from_device(net.named_parameters())
+        loss, _ = plan.train_forward_backward(x, torch.tensor([5]), None, torch.zeros_like(x))
+        assert np.isfinite(float(loss))
+    finally:
+        net.eval()
+    # (2) raw C ABI: destroy the net first, then use and destroy its plan
+    net2 = make_net(ds, "cpu")
+    p2 = net2.plan_for(B, H, H, torch.device("cpu"))
+    lib = net2._net.lib
+    nh, ph = net2._net.h, p2.h
+    lib.dll.ddif_net_destroy(nh)          # deferred: the plan is alive
+    a, b = C.c_int(), C.c_int()
+    assert lib.dll.ddif_plan_num_launches(ph, C.byref(a), C.byref(b)) == 0 and a.value > 0
+    lib.dll.ddif_plan_destroy(ph)         # frees the plan, then the orphaned net
+    net2._net.h = None                    # the Python handles must not free them again
+    p2.h = None
+    net2._net.plans.clear()
+
+
 def test_emulated_grid_cap_hook_gives_identical_results():
     """ddif_debug_set_grid_cap (the hook the -m gpu multi-item tests rely on): one workgroup walking every work item
     of every conv launch, across the sample boundaries of a B=3 batch, reproduces the uncapped result bit for bit."""

@@ -43,6 +43,51 @@ def test_assemble_cond_matches_the_fixture_generator():
     assert torch.equal(E.assemble_cond(hs["lms"], hs["pan"], None, "cave"), hs["cond"])
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_training_batches_resume_from_the_middle_of_an_epoch(world):
+    """a checkpoint rarely falls on an epoch boundary (`save_every=5000` against a data-dependent epoch length).  The data position is
+    part of the training state: epoch in force, batch offset inside it and -- with one rank, where the permutation comes from the global torch
+    generator like DataLoader's RandomSampler -- the generator state it was drawn from.  An 11-iteration run (7 samples, batch 2: epochs of 4
+    batches, the last one short) resumed from EVERY iteration reproduces the rest of the uninterrupted run, for one rank and for rank 1 of 2."""
+    data = {k: np.arange(7 * 2, dtype=np.float32).reshape(7, 2) + i for i, k in enumerate(("pan", "lms", "gt"))}
+    rank = world - 1
+
+    def run(n_it, resume=None):
+        tr = E._Batches(data, 2, True, rank, world, 3)
+        seen, states = [], []
+        if resume is not None:
+            torch.set_rng_state(resume["rng"])
+            tr.load_state(resume["data"])
+            it = resume["it"]
+        else:
+            torch.manual_seed(5)
+            it = 0
+        while it < n_it:
+            for _pan, _lms, gt in tr:
+                torch.rand(3)  # the iteration's own draws (timesteps, noise) advance the same generator
+                seen.append(gt[:, 0].tolist())
+                it += 1
+                states.append({"rng": torch.get_rng_state(), "data": tr.state(), "it": it})
+                if it >= n_it:
+                    break
+        return seen, states
+
+    full, states = run(11)
+    assert len(full) == 11
+    for cut in range(1, 11):
+        torch.manual_seed(999)  # whatever the process state is at resume time
+        tail, _ = run(11, resume=states[cut - 1])
+        assert tail == full[cut:], (world, cut)
+
+
+def test_training_batches_refuse_fewer_samples_than_ranks():
+    from ddif import DdifError
+
+    data = {k: np.zeros((1, 2), np.float32) for k in ("pan", "lms", "gt")}
+    with pytest.raises(DdifError, match="ranks"):
+        E._Batches(data, 1, True, 0, 2, 0)
+
+
 def test_engine_google_needs_h5py_or_arrays():
     """The reference reads h5 files (diffusion_engine.py:142-143); h5py is not in this image, so a path must fail loudly and name the
     in-memory alternative."""
