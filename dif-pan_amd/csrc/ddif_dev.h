@@ -166,6 +166,16 @@ __device__ __forceinline__ float dd_silu_scaled(float x, float inv_s) {
 #endif
 }
 
+// Contiguous share of a persistent workgroup: [floor(b n / g), floor((b + 1) n / g)) for b = blockIdx.x, g = gridDim.x -- the same partition as the
+// 64-bit expression, from three 32-bit divisions (n = q g + r  =>  floor(b n / g) = b q + floor(b r / g), and b r < g^2 < 2^32): the two emulated
+// 64-bit divisions were several hundred instructions at the head of every conv launch's dependent prologue chain.
+__device__ __forceinline__ void wg_work_range(int nwork, int* w0, int* w1) {
+    const unsigned g = gridDim.x, b = blockIdx.x, n = (unsigned)nwork;
+    const unsigned q = n / g, r = n - q * g;
+    *w0 = (int)(b * q + (b * r) / g);
+    *w1 = (int)((b + 1) * q + ((b + 1) * r) / g);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     const int tiles = a.tiles_x * a.tiles_y;
     const int ntiles = a.B * tiles;
     const int nwork = ntiles * a.n_ct;
-    const int w0 = (int)((long long)blockIdx.x * nwork / gridDim.x);
-    const int w1 = (int)((long long)(blockIdx.x + 1) * nwork / gridDim.x);
+    int w0, w1;
+    wg_work_range(nwork, &w0, &w1);
     if (w0 >= w1) return;  // whole workgroup leaves together
     const int Hc = UPS ? a.Hin * 2 : a.Hin, Wc = UPS ? a.Win * 2 : a.Win;
     const int Ctot = a.c0 + a.c1;

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     };
     const int nstrips = (a.W + TW - 1) / TW;
     const int nwork = a.B * nstrips;
-    const int w0 = (int)((long long)blockIdx.x * nwork / gridDim.x);
-    const int w1 = (int)((long long)(blockIdx.x + 1) * nwork / gridDim.x);
+    int w0, w1;
+    wg_work_range(nwork, &w0, &w1);
     if (w0 >= w1) return;
 
     // tables (once per launch)
