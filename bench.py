@@ -55,6 +55,10 @@ CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on (default; what the driver runs)
     "wv3": dict(ds="wv3", C=8, P=1, batch=64, tile=64, T=1000, sampler="ddpm", scaling="weak",
                 metric="fused megapixels/sec at T=%d, WV3 64x64x8 tiles"),
+    # configs[1]'s "bf16": the THROUGHPUT variant -- conv operands rounded once to bf16, one MFMA product, fp32 accumulate (ddif_set_math_mode).  Never the
+    # headline and never a parity configuration: the line carries its measured drift against the fp32-class path on the same tiles, seeds and steps.
+    "wv3_bf16": dict(ds="wv3", C=8, P=1, batch=64, tile=64, T=1000, sampler="ddpm", scaling="weak", math="bf16",
+                     metric="fused megapixels/sec at T=%d, WV3 64x64x8 tiles, bf16 conv operands (throughput variant)"),
     # configs[2]: ONE GF2 512x512 scene = 64 tiles of 64x64 split over the ranks (strong scaling), DPM-Solver++ 2M, 50 model evaluations,
     # all-gather + stitch inside the timed region
     "gf2_dpm50": dict(ds="gf2", C=4, P=1, batch=64, tile=64, T=1000, sampler="dpmpp2m", nfe=50, scaling="strong",
@@ -161,6 +165,11 @@ def main():
     lib = ddif.get_lib()
     assert not lib.emulated
     cf = CONFIGS[args.config]
+    bf16 = cf.get("math") == "bf16"
+    if bf16:
+        from ddif import runtime as _rt
+
+        _rt.set_math_mode("bf16")
     if cf["sampler"] == "train":
         return bench_training(args, cf, rank, world, dev)
     strong = cf["scaling"] == "strong"
@@ -266,6 +275,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert out is not None and bool(torch.isfinite(out).all())
+    drift = None
+    if bf16:
+        # the same job (tiles, seed, T steps) once more on the fp32-class path: what the single bf16 product costs in the fused image
+        from ddif import runtime as _rt
+
+        seed_last = 2000 + args.steps - 1
+        _rt.set_math_mode("split")
+        plan_ref = diffusion._plan(cond)
+        plan_ref.set_cond(cond, force=True)
+        ref = (diffusion(cond, mode="ddpm_sample", seed=seed_last, tile0=tile0, device_rng=True) + lms).clip(0, 1)
+        torch.cuda.synchronize()
+        _rt.set_math_mode("bf16")
+        mine = out[tile0:tile0 + B] if world > 1 else out
+        d = (mine - ref).double()
+        mse_t = d.pow(2).mean(dim=(1, 2, 3))
+        drift = {"against": "the fp32-class (split-product) path of this library: same tiles, seed %d, T=%d steps, batch %d" % (seed_last, T, B),
+                 "max_abs": float(d.abs().max()), "rms": float(d.pow(2).mean().sqrt()), "rel_l2": float(d.norm() / ref.double().norm()),
+                 "psnr_db_min_over_tiles": float((10.0 * torch.log10(1.0 / mse_t.clamp_min(1e-30))).min()), "data_range": [0.0, 1.0]}
+        log("bf16 drift against the fp32-class path after %d steps: max %.3e, rms %.3e, worst-tile PSNR %.1f dB" % (T, drift["max_abs"], drift["rms"], drift["psnr_db_min_over_tiles"]))
 
     mp_per_step = total * H * H / 1e6
     value = mp_per_step * args.steps / dt
@@ -273,7 +301,7 @@ def main():
     step_flop_total = cost["step_flop"] * n_evals + cost["cond_flop"]
     # the committed PMC passes are of the default (wv3, B = 64) command: other configurations report no traffic
     traffic, traffic_info = committed_traffic() if (args.config == "wv3" and B == 64) else (None, {"traffic_from_committed_profile": False})
-    x3 = "split products" in prof["kernel"]
+    x3 = "split products" in prof["kernel"] and not bf16
     # products the dominant class issues on the matrix pipe per algorithmic fp32 product (flop-weighted over its launches: 3 = f16x2, 6 = bf16x3,
     # 16 = exact fp32 MFMA in units of the 16-bit rate); its fp32-equivalent ceiling is the dense 16-bit MFMA peak over that
     products = (prof["total_mfma_flop"] / prof["total_flop"]) if prof["total_flop"] > 0 else 16.0
@@ -295,13 +323,28 @@ def main():
     classes_ok = bool(classes) and abs(cls_ms_total - ms_step) / ms_step < 0.15 and all(c["frac_of_floor"] is None or c["frac_of_floor"] <= 1.0 for c in classes)
     if not classes_ok:
         log("per-class table INCONSISTENT with the step (sum %.3f ms vs %.3f ms per denoising step): not reported" % (cls_ms_total, ms_step))
+    # one product per fp32 product: the dominant class's MFMA floor (flops / 2516.8 TF) drops below its HBM floor (algorithmic bytes / 8 TB/s) -- the
+    # throughput variant is priced against HBM
+    hbm_roofline = None
+    if bf16 and prof["total_ms"] > 0 and prof["total_bytes"] / (PEAK_HBM_GBS * 1e9) > prof["total_mfma_flop"] / (PEAK_BF16_MFMA_TFLOPS * 1e12):
+        ach_gbs = prof["total_bytes"] / (prof["total_ms"] * 1e-3) / 1e9
+        hbm_roofline = {
+            "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
+            "peak_note": "dominant class (3x3 convs of the 64^2 / 32^2 levels) with ONE bf16 product per fp32 product: algorithmic bytes / 8 TB/s exceeds flops / %.1f TF" % PEAK_BF16_MFMA_TFLOPS,
+            "mfma_products_per_fp32_product": products, "mfma_tflops": ach_tflops, "mfma_frac_of_dense_bf16_peak": ach_tflops * products / PEAK_BF16_MFMA_TFLOPS,
+            "algorithmic_bytes_per_launch": (prof["total_bytes"] / prof["launches"]) if prof["launches"] else None,
+            "kernel": prof["kernel"], "launches_timed": prof["launches"], "avg_launch_us": (prof["total_ms"] * 1e3 / prof["launches"]) if prof["launches"] else None,
+            "whole_step": {"ms_per_denoising_step": ms_step, "hbm_frac": (cost["step_bytes"] * n_evals + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
+                           "profiled_steps": n_rec, "classes_ms_per_step_sum": cls_ms_total if classes_ok else None, "classes": classes if classes_ok else None},
+        }
     if cf["sampler"] == "dpmpp2m":
         metric = cf["metric"] % n_evals
         workload = "GF2 pansharpening, one %dx%d scene = %d tiles of %dx%dx%d split over %d GPU(s) (%d per GPU), DPM-Solver++ 2M %d NFE (T=%d schedule), all-gather + stitch, fp32" % (
             ny * H, nx * H, total, H, H, C, world, B, n_evals, T)
     else:
         metric = cf["metric"] % T
-        workload = "%s, batch %d of %dx%dx%d tiles per GPU, T=%d DDPM p_sample, fp32" % ("WV3 pansharpening" if cf["ds"] == "wv3" else "CAVE MHIF", B, H, H, C, T)
+        workload = "%s, batch %d of %dx%dx%d tiles per GPU, T=%d DDPM p_sample, %s" % ("WV3 pansharpening" if cf["ds"] == "wv3" else "CAVE MHIF", B, H, H, C, T,
+                                                                                        "bf16 conv operands / fp32 accumulate and tensors (throughput variant)" if bf16 else "fp32")
     result = {
         "metric": metric,
         "value": value,
@@ -313,16 +356,19 @@ def main():
         "higher_is_better": True,
         "scaling": cf["scaling"],
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16" if bf16 else "f32",
         "data": "synthetic",
+        **({"drift": drift, "parity_configuration": False} if bf16 else {}),
         "config": {"workload": workload, "name": args.config, "tiles_per_gpu": B, "tiles_total": total, "tile": [H, H, C], "T": T, "model_evaluations": n_evals,
                    "sampler": cf["sampler"], "parallelism": "tile-shard x%d" % world, "launches_per_denoising_step": n_launch["step"],
                    "plan_memory_mb": {"total": mem["total_bytes"] / 1e6, "step_activation_arena": mem["arena_bytes"] / 1e6,
                                       "same_activations_unaliased": mem["unaliased_bytes"] / 1e6},
                    "conv_math": ("fp32 operands pre-scaled by powers of two and split into 2 fp16 planes, 3 exact products on v_mfma_f32_32x32x16_f16, fp32 accumulate "
                                  "(3x3 convs, low-resolution levels, q.1 of the fused attention block); 3 bf16 planes / 6 products where the operand range is open "
-                                 "(per-sample folded attention weights, wide 1x1 convs); exact fp32 MFMA elsewhere") if x3 else "exact fp32 MFMA"},
-        "roofline": {
+                                 "(per-sample folded attention weights, wide 1x1 convs); exact fp32 MFMA elsewhere") if x3 else
+                                ("THROUGHPUT variant: conv operands rounded once to bf16, one product on v_mfma_f32_32x32x16_bf16, fp32 accumulate; tensors in HBM, GroupNorm "
+                                 "statistics, attention blocks, per-sample folded attention weights and the sampler update stay fp32 / split-product") if bf16 else "exact fp32 MFMA"},
+        "roofline": hbm_roofline if hbm_roofline else {
             "bound": "mfma",
             "achieved": ach_tflops,
             "peak": peak,

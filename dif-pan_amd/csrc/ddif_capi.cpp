@@ -326,7 +326,10 @@ int ddif_prof_collect(ddif_plan_t plan, ddif_prof_result* out) {
         out->total_bytes += p.ev_bytes[i];
         out->total_mfma_flop += p.ev_mflop[i];
     }
-    if (p.n_conv3_f16 > 0)
+    if (p.n_conv3_b1 > 0)
+        std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convs; THROUGHPUT variant: one bf16 product on %d of %d)", p.n_conv3_b1,
+                      p.n_conv3);
+    else if (p.n_conv3_f16 > 0)
         std::snprintf(out->kernel_name, sizeof(out->kernel_name), "ddif::conv_mfma_kernel<3,...> (3x3 implicit-GEMM convs; f16x2 split products on %d of %d, bf16x3 on %d)", p.n_conv3_f16,
                       p.n_conv3, p.n_conv3_x3 - p.n_conv3_f16);
     else if (p.n_conv3_x3 > 0)
@@ -385,6 +388,13 @@ int ddif_plan_memory(ddif_plan_t plan, int64_t* total_bytes, int64_t* arena_byte
     if (unaliased_bytes) *unaliased_bytes = (int64_t)plan->p.unaliased_bytes;
     return DDIF_OK;
 }
+
+int ddif_set_math_mode(int mode) {
+    if (mode != DDIF_MATH_SPLIT && mode != DDIF_MATH_BF16) return ddif::fail(DDIF_ERR_INVALID, "math mode %d (DDIF_MATH_SPLIT or DDIF_MATH_BF16)", mode);
+    ddif::g_math_mode = mode;
+    return DDIF_OK;
+}
+int ddif_get_math_mode(void) { return ddif::g_math_mode; }
 
 int ddif_debug_set_grid_cap(int max_workgroups) {
     ddif::g_debug_grid_cap = max_workgroups > 0 ? max_workgroups : 0;

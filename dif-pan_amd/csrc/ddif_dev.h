@@ -119,6 +119,18 @@ __device__ __forceinline__ void dd_split3_pair(float a, float b, unsigned* hi, u
 #endif
 }
 
+// one RNE rounding to bf16 of two values, packed (a in the low half): the throughput variant's only operand conversion (kernels_conv.h MATH = 4)
+__device__ __forceinline__ unsigned dd_bf16_pair(float a, float b) {
+#ifdef DDIF_EMU
+    return dd_bf16_bits(a) | (dd_bf16_bits(b) << 16);
+#else
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+    const v2f v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b));  // v_cvt_pk_bf16_f32
+#endif
+}
+
 // ---- 2-way fp16 split ("f16x2"): x * S = hi + lo, hi = half(x S) (round to nearest even, 11 significant bits), lo =
 // half(x S - hi) (the remainder is exact in fp32): 22 significant bits, |x S - hi - lo| <= 2^-22 |x S|.  Three cross products
 // lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_f16 (each exact in fp32, fp32 accumulate; the dropped lo*lo term is 2^-22 relative)

@@ -7,11 +7,11 @@
 namespace ddif {
 
 namespace {
-template <int KS, int MB, int PRO, int EPI, bool F16 = false>
+template <int KS, int MB, int PRO, int EPI, bool F16 = false, bool B1 = false>
 ConvVariant lr_variant1(const char* name) {
     ConvVariant v;
-    v.fn = conv_lr_kernel<KS, MB, PRO, EPI, 0, F16>;
-    using G = LrGeom<KS, MB, PRO, (EPI & EPI_COLST) != 0, F16>;
+    v.fn = conv_lr_kernel<KS, MB, PRO, EPI, 0, F16, B1>;
+    using G = LrGeom<KS, MB, PRO, (EPI & EPI_COLST) != 0, F16, B1>;
     v.smem = G::smem;
     v.th = G::TH;
     v.tw = G::TW;
@@ -19,13 +19,14 @@ ConvVariant lr_variant1(const char* name) {
     v.nthr = 256;
     v.x3 = true;
     v.f16 = F16;
+    v.b1 = B1;
     v.lr = true;
     v.name = name;
     return v;
 }
 template <int MB>
-ConvVariant lr_for(int ks, int pro, int epi, bool f16) {
-#define LRV(KS, PRO, EPI, NAME) (f16 ? lr_variant1<KS, MB, PRO, EPI, true>(NAME) : lr_variant1<KS, MB, PRO, EPI, false>(NAME))
+ConvVariant lr_for(int ks, int pro, int epi, int math) {
+#define LRV(KS, PRO, EPI, NAME) (math == MATH_F16X2 ? lr_variant1<KS, MB, PRO, EPI, true>(NAME) : (math == MATH_BF16X1 ? lr_variant1<KS, MB, PRO, EPI, false, true>(NAME) : lr_variant1<KS, MB, PRO, EPI, false>(NAME)))
     if (ks == 3) {
         if (pro == PRO_GN_SILU && epi == 0) return LRV(3, PRO_GN_SILU, 0, "lr3x3_gn_silu");
         if (pro == PRO_GN_SILU && epi == EPI_RES) return LRV(3, PRO_GN_SILU, EPI_RES, "lr3x3_gn_silu_res");
@@ -39,7 +40,8 @@ ConvVariant lr_for(int ks, int pro, int epi, bool f16) {
         if (pro == PRO_NONE && epi == EPI_COLST) return LRV(1, PRO_NONE, EPI_COLST, "lr1x1_colstats");
         if (pro == PRO_GN && epi == 0) return LRV(1, PRO_GN, 0, "lr1x1_gn");
         if (pro == PRO_GN_SILU && epi == 0) return LRV(1, PRO_GN_SILU, 0, "lr1x1_gn_silu");
-        if (pro == PRO_COLSM && epi == 0) return lr_variant1<1, MB, PRO_COLSM, 0, false>("lr1x1_colsoftmax");  // bf16x3 only
+        if (pro == PRO_COLSM && epi == 0)  // never f16x2 (probabilities far below the half range)
+            return math == MATH_BF16X1 ? lr_variant1<1, MB, PRO_COLSM, 0, false, true>("lr1x1_colsoftmax") : lr_variant1<1, MB, PRO_COLSM, 0, false>("lr1x1_colsoftmax");
     }
     return ConvVariant();
 #undef LRV
@@ -58,9 +60,9 @@ void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
 
 // mb = 2: 8x8 pixel tiles, mb = 4: 8x16.  The per-sample time bias needs no variant of its own here (the epilogue reads
 // bias and time-bias rows straight from memory), so EPI_TBS is accepted and ignored.
-ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, bool f16) {
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math) {
     epi &= ~EPI_TBS;
-    return mb == 2 ? lr_for<2>(ks, pro, epi, f16) : lr_for<4>(ks, pro, epi, f16);
+    return mb == 2 ? lr_for<2>(ks, pro, epi, math) : lr_for<4>(ks, pro, epi, math);
 }
 
 }  // namespace ddif

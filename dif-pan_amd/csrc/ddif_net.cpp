@@ -264,11 +264,20 @@ size_t pack_conv_f16(Blob& b, const float* w, int cout, int cin, int ks, int ck)
     return off;
 }
 
+// bf16x1 order (kernels_conv.h MATH = 4, kernels_lr.h; the throughput variant, inference plans only): the hi plane of the bf16x3 pack on its own --
+//   [n-block of 32 couts][chunk][tap][16-channel slab k16][half h][cout j][8 bf16]  = RNE bf16 of the weight.
+size_t pack_conv_b1(Blob& b, size_t x3_off, int cout, int cin, int ks, int ck) {
+    const size_t steps = (size_t)((((cout + 31) / 32 + 3) & ~3)) * ((cin + ck - 1) / ck) * (ks * ks) * (ck / 16);
+    const size_t off = b.add(nullptr, steps * 256);
+    for (size_t st = 0; st < steps; ++st) std::memcpy(b.v.data() + off + st * 256, b.v.data() + x3_off + st * 3 * 256, 256 * sizeof(float));
+    return off;
+}
+
 }  // namespace
 
 int Net::commit(hipStream_t stream) {
     Blob b;
-    struct PendConv { std::string name; size_t w_off; long bias_off; int cin, cout, ks, ck, n_chunks; long x3_off = -1; long f16_off = -1; };
+    struct PendConv { std::string name; size_t w_off; long bias_off; int cin, cout, ks, ck, n_chunks; long x3_off = -1; long f16_off = -1; long b1_off = -1; };
     std::vector<PendConv> pend;
     std::map<std::string, size_t> vec_off;
     std::string missing;
@@ -322,6 +331,7 @@ int Net::commit(hipStream_t stream) {
             p.x3_off = (long)pack_conv_x3(b, w->v.data(), p.cout, p.cin, p.ks, p.ck);
             rec_pack(RF_PACK_X3, name + ".weight", "", (size_t)p.x3_off, p.cout, p.cin, 0, p.ks, p.ck, p.n_chunks);
             p.f16_off = (long)pack_conv_f16(b, w->v.data(), p.cout, p.cin, p.ks, p.ck);  // inference only: no refresh recipe (merged_stale)
+            p.b1_off = (long)pack_conv_b1(b, (size_t)p.x3_off, p.cout, p.cin, p.ks, p.ck);  // likewise
         }
         p.bias_off = bs ? (long)b.add(bs->v.data(), bs->v.size()) : -1;
         if (bs) rec_copy(RF_COPY, name + ".bias", "", (size_t)p.bias_off, bs->v.size());
@@ -439,6 +449,7 @@ int Net::commit(hipStream_t stream) {
                 // (train-mode plans run this conv with the SHARED weights -- the per-sample folded copies belong to inference -- on the bf16x3 path)
                 p.x3_off = (long)pack_conv_x3(b, cat.data(), co, p.cin, 1, p.ck);
                 rec_pack(RF_PACK_X3, ci + ".attn_out.weight", ci + ".attn_res.weight", (size_t)p.x3_off, co, fea, fea, 1, p.ck, p.n_chunks);
+                p.b1_off = (long)pack_conv_b1(b, (size_t)p.x3_off, co, p.cin, 1, p.ck);
             } else {  // attn_res is Identity (fea == dim_out): xn is added as a residual
                 p.cin = fea;
                 p.ck = fea <= 16 ? 16 : 32;
@@ -447,6 +458,7 @@ int Net::commit(hipStream_t stream) {
                 if (p.ck == 32) {
                     p.x3_off = (long)pack_conv_x3(b, wo->v.data(), co, fea, 1, p.ck);
                     rec_pack(RF_PACK_X3, ci + ".attn_out.weight", "", (size_t)p.x3_off, co, fea, 0, 1, p.ck, p.n_chunks);
+                    p.b1_off = (long)pack_conv_b1(b, (size_t)p.x3_off, co, fea, 1, p.ck);
                 }
             }
             p.bias_off = (long)b.add(bsum.data(), bsum.size());
@@ -484,6 +496,7 @@ int Net::commit(hipStream_t stream) {
                 p.w_off = pack_conv(b, wm.data(), co, cin, 3, p.ck, &p.n_chunks);
                 p.x3_off = (long)pack_conv_x3(b, wm.data(), co, cin, 3, p.ck);
                 p.f16_off = (long)pack_conv_f16(b, wm.data(), co, cin, 3, p.ck);
+                p.b1_off = (long)pack_conv_b1(b, (size_t)p.x3_off, co, cin, 3, p.ck);
                 p.bias_off = (long)b.add(b3->v.data(), b3->v.size());
                 pend.push_back(p);
             }
@@ -545,6 +558,7 @@ int Net::commit(hipStream_t stream) {
         pc.w = blob + p.w_off;
         pc.w_x3 = p.x3_off >= 0 ? blob + p.x3_off : nullptr;
         pc.w_f16 = p.f16_off >= 0 ? blob + p.f16_off : nullptr;
+        pc.w_b1 = p.b1_off >= 0 ? blob + p.b1_off : nullptr;
         pc.bias = p.bias_off >= 0 ? blob + p.bias_off : nullptr;
         pc.cin = p.cin;
         pc.cout = p.cout;

@@ -45,6 +45,7 @@ struct PackedConv {
     const float* w_x3 = nullptr;  // 3x3 convs: the same weights as three bf16 planes (kernels_conv.h MATH = 1)
     const float* w_f16 = nullptr; // the same weights x 2^10 as two half planes (kernels_conv.h MATH = 3); inference plans only, null when a
                                   // weight exceeds the scaled half range
+    const float* w_b1 = nullptr;  // the hi bf16 plane alone (kernels_conv.h MATH = 4: the throughput variant); inference plans only
     const float* bias = nullptr;
     int cin = 0, cout = 0, ks = 1, ck = 32, n_chunks = 0;
 };

@@ -38,6 +38,12 @@ ConvVariant variant_for_cfg(int cfg) {
                 case 15: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 4, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 4, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 128; v.x3 = true; break;
                 case 14: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = true; break;
                 case 16: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 128; v.x3 = true; break;
+                // bf16x1 (MATH = 4, the throughput variant): the same five tilings (cfg + 52); the 32-cout tile too (no split to pay for)
+                case 52: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.b1 = true; break;
+                case 53: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 64; v.x3 = v.b1 = true; break;
+                case 55: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 4, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 4, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 128; v.x3 = v.b1 = true; break;
+                case 54: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 4>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.b1 = true; break;
+                case 56: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO, 4, 4>(); v.th = 8; v.tw = 8; v.nt = 128; v.x3 = v.b1 = true; break;
                 default: break;
             }
         }
@@ -48,6 +54,10 @@ ConvVariant variant_for_cfg(int cfg) {
             case 7: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 1>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = true; break;
             case 8: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
             case 9: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = true; break;
+            // bf16x1 (MATH = 4, the throughput variant): the same three tilings (+ 40)
+            case 47: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 4>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.b1 = true; break;
+            case 48: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.b1 = true; break;
+            case 49: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 4>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.b1 = true; break;
             default: break;
         }
     }
@@ -82,9 +92,10 @@ ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not
 // per-thread source select (stem: cat[x, x] of 8 + 8 or 4 + 4 channels inside one 16-channel chunk).
 // epi: EPI_* bits (kernels_conv.h) -- FiLM (CondInjection.x_conv), scalar output path (Cout % 4 != 0), residual add.
 // Only the combinations the network uses are instantiated.
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, bool f16) {
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, int math) {
     ConvVariant v;
-    if (cfg == 20 || cfg == 21) return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi, f16 && pro != PRO_COLSM) : v;
+    if (cfg == 20 || cfg == 21)
+        return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi, (math == MATH_F16X2 && pro == PRO_COLSM) ? MATH_BF16X3 : math) : v;
     const bool plain = stride == 1 && !ups;
     if (epi == EPI_FILM) {
         if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
@@ -136,6 +147,7 @@ static int f16_enabled() {  // DDIF_F16=0: the split-operand convs stay on bf16x
     static const int f16 = [] { const char* e = getenv("DDIF_F16"); return e ? atoi(e) : 1; }();
     return f16;
 }
+int g_math_mode = [] { const char* e = getenv("DDIF_MATH"); return (e && std::strcmp(e, "bf16") == 0) ? 1 : 0; }();
 static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention half as three launches (q conv, column statistics, attn_out conv)
     static const int v = [] { const char* e = getenv("DDIF_LAFUSE"); return e ? atoi(e) : 1; }();
     return v;
@@ -146,7 +158,7 @@ static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general c
 }
 // cfg 20 / 21: the low-resolution kernel (kernels_lr.h) with 8x8 / 8x16 pixel tiles -- samples of <= 256 pixels whose
 // channel counts fit its 16-channel slabs
-static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B, int cin, int c0, bool allow_lr = true, bool exact = false, bool f16ok = false) {
+static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int Hout, int Wout, int Cout, int B, int cin, int c0, bool allow_lr = true, bool exact = false, bool f16ok = false, bool b1 = false) {
     const bool wide = (Wout >= 16) && stride == 1;
     (void)pro;
     const bool x3 = x3_enabled() && !exact;
@@ -160,14 +172,15 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
         const int base = wide ? (Cout > 64 ? 3 : (Cout > 32 ? 1 : 0)) : (Cout > 64 ? 4 : 2);
         // 32-cout tiles stay on the exact instruction: with 12 MFMAs per stage the split only adds staging work
         // (measured: softmax_H(q).ctx.attn_out 64+64->32 @64^2 72 vs 58 us)
+        if (x3 && ck == 32 && b1) return base + 52;  // 0,1,3,2,4 -> 52,53,55,54,56
         if (x3 && ck == 32 && base != 0) return base + 12;  // 1,3,2,4 -> 13,15,14,16
         return base;
     }
     if (ks == 3 && vec == 1 && stride == 1 && x3) {
         const bool f16 = f16ok && (pro == PRO_NONE || pro == PRO_GN_SILU);
-        if (wide && Hout >= 32 && Wout >= 32) return f16 ? 27 : 7;
-        if (wide || Cout <= 32) return f16 ? 28 : 8;
-        return f16 ? 29 : 9;
+        if (wide && Hout >= 32 && Wout >= 32) return b1 ? 47 : (f16 ? 27 : 7);
+        if (wide || Cout <= 32) return b1 ? 48 : (f16 ? 28 : 8);
+        return b1 ? 49 : (f16 ? 29 : 9);
     }
     if (ks == 3 && vec == 1 && wide && !ups_) {
         const long items32 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
@@ -350,7 +363,7 @@ int Plan::build() {
     path_sites.clear();
     mask_recs = nullptr;
     n_mask_recs = 0;
-    n_conv3 = n_conv3_x3 = n_conv3_f16 = 0;
+    n_conv3 = n_conv3_x3 = n_conv3_f16 = n_conv3_b1 = 0;
     tb_rows = 0;
     tb = tvals = nullptr;
     arena_next = 0;
@@ -474,14 +487,29 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         const double n = (double)(c0 + c1) * Hin * Win;
         f16ok = ig != net->vec_absmax.end() && ib != net->vec_absmax.end() && std::sqrt(n) * ig->second + ib->second < DDIF_F16_AMAX;
     }
-    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact, f16ok);
+    // bf16x1 (MATH = 4): the throughput variant, only under ddif_set_math_mode(DDIF_MATH_BF16); inference plans, shared weights
+    const bool b1ok = g_math_mode == 1 && !train_mode && pc.w_b1 && !s.w_override && !s.exact;
+    const bool f16ok0 = f16ok;
+    if (b1ok) f16ok = false;
+    int math = b1ok ? MATH_BF16X1 : (f16ok ? MATH_F16X2 : MATH_BF16X3);
+    int cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact, f16ok, b1ok);
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0);
     if (s.cso_mx && ((cfg != 20 && cfg != 21) || Hout > (cfg == 20 ? 8 : 16)))
         return fail(DDIF_ERR_INVALID, "%s: column statistics epilogue needs the low-resolution kernel and H <= 16", s.name);
-    ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi, f16ok);
+    ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi, math);
     if (!var.fn && (cfg == 20 || cfg == 21)) {  // prologue / epilogue combination the low-resolution kernel does not carry
-        cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false, false, f16ok);
+        cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false, false, f16ok, b1ok);
         var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    }
+    if (!var.fn && b1ok) {  // a combination the throughput variant does not instantiate: the default path of this conv
+        f16ok = f16ok0;
+        math = f16ok ? MATH_F16X2 : MATH_BF16X3;
+        cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, true, s.exact, f16ok, false);
+        var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi, math);
+        if (!var.fn && (cfg == 20 || cfg == 21)) {
+            cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false, false, f16ok, false);
+            var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+        }
     }
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
     if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
@@ -509,7 +537,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.Hout = Hout;
     a.Wout = Wout;
     a.Cout = pc.cout;
-    a.w = s.w_override ? s.w_override : (var.f16 ? pc.w_f16 : (var.x3 ? pc.w_x3 : pc.w));
+    a.w = s.w_override ? s.w_override : (var.b1 ? pc.w_b1 : (var.f16 ? pc.w_f16 : (var.x3 ? pc.w_x3 : pc.w)));
     if (var.x3 && !s.w_override && !a.w) return fail(DDIF_ERR_STATE, "%s: split-operand variant without split weights", s.name);
     a.w_bstride = s.w_bstride;
     a.cs_mx = s.cs_mx;
@@ -558,7 +586,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     // q_sample_forward with one t per sample use the EPI_TBS instantiation (rows loaded per work item)
     ConvKernelFn fn_tbs = nullptr;
     if (s.tb_off >= 0) {
-        const ConvVariant vt = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi | EPI_TBS, f16ok);
+        const ConvVariant vt = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi | EPI_TBS, math);
         if (!vt.fn || vt.smem != var.smem) return fail(DDIF_ERR_INVALID, "%s: no per-sample time-bias kernel variant", s.name);
         fn_tbs = vt.fn;
         if (var.smem + 8192 > 64 * 1024)
@@ -567,7 +595,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     // the final conv: the same tiling with the DDPM / DDIM update in its epilogue (split-operand tilings, vector output path)
     ConvKernelFn fn_samp = nullptr;
     if (s.samp && !train_mode && epi == 0 && s.tb_off < 0 && &prog == &step) {
-        const ConvVariant vs = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, EPI_SAMP, f16ok);
+        const ConvVariant vs = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, EPI_SAMP, math);
         if (vs.fn && vs.smem == var.smem) {
             fn_samp = vs.fn;
             if (var.smem + 8192 > 64 * 1024)
@@ -593,12 +621,13 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
     op.cls = (Hout * Wout <= 256) ? 2 : (pc.ks == 3 ? 0 : 1);
-    op.mfma_w = var.f16 ? 3 : (var.x3 ? 6 : 16);
+    op.mfma_w = var.b1 ? 1 : (var.f16 ? 3 : (var.x3 ? 6 : 16));
     op.timed = op.cls == 0;
     if (pc.ks == 3 && &prog == &step) {
         ++n_conv3;
         if (var.x3) ++n_conv3_x3;
         if (var.f16) ++n_conv3_f16;
+        if (var.b1) ++n_conv3_b1;
     }
     op.win = true;
     op.run = [a, var, fn_tbs, fn_samp, lms_p, grid, block, smem, dyn, self_c, tb_off, items_per_sample, cap](hipStream_t st, const StepCtx& ctx) {

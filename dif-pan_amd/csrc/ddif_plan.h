@@ -49,12 +49,17 @@ struct ConvVariant {
     int th = 0, tw = 0, nt = 0, nthr = 256;
     bool x3 = false;  // bf16x3 instantiation: wants PackedConv::w_x3
     bool f16 = false; // f16x2 instantiation: wants PackedConv::w_f16 (x3 is set as well: split-operand path)
+    bool b1 = false;  // bf16x1 instantiation (the throughput variant): wants PackedConv::w_b1 (x3 is set as well)
     int wg_cap = 2;   // persistent workgroups per CU (upper bound; LDS may allow fewer)
     bool lr = false;  // low-resolution kernel (kernels_lr.h): smem is the whole requirement, nothing is added per launch
     const char* name = "";
 };
-ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, bool f16 = false);
-ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, bool f16 = false);  // ddif_lr.cpp
+// operand format of a split-operand conv: what get_conv_variant / get_lr_variant instantiate and which weight pack the launch reads
+enum { MATH_BF16X3 = 0, MATH_F16X2 = 1, MATH_BF16X1 = 2 };
+ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, int math = MATH_BF16X3);
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3);  // ddif_lr.cpp
+// ddif_set_math_mode (include/ddif.h): 0 = fp32-class split products (default), 1 = the bf16 throughput variant, for plans built afterwards
+extern int g_math_mode;
 // fused linear-attention block (kernels_lafuse.h, ddif_la.cpp)
 struct LaFuseArgs;
 bool lafuse_supported(int H, int fea, int dout);
@@ -211,6 +216,7 @@ struct Plan {
     int time_rows(const float* t_host, int rows, hipStream_t s);
     void run_prog(std::vector<Op>& prog, hipStream_t s, const StepCtx& ctx, bool prof);
     int n_conv3_f16 = 0;
+    int n_conv3_b1 = 0;  // ... on the bf16x1 throughput variant
     int n_conv3 = 0, n_conv3_x3 = 0;  // 3x3 conv ops of the step program / of them on the bf16x3 path (reported by prof_collect)
     bool op_timing_done = false;  // DDIF_OP_TIMING=<csv path>: one profiled step is timed op by op (development aid)
 

@@ -117,6 +117,9 @@ enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_
 // products per slab on v_mfma_f32_32x32x16_f16 -- the accuracy of the exact-fp32 MFMA (measured, tools/probes/f16x2.cpp) at half
 // the matrix instructions of bf16x3, two LDS planes per operand instead of three (64 B per pixel and chunk + 16 B pad, 2/3 of
 // the weight bytes) and a 3-op-per-value split instead of 5.5.  The accumulator is scaled back in the epilogue's fma.
+// 4 = "bf16x1", the THROUGHPUT variant (BASELINE configs[1] "bf16"; never the default, never a parity configuration): both operands rounded once to
+// bf16, ONE product per slab on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 tensors / GroupNorm statistics / epilogue as everywhere else.
+// One LDS plane per operand (32 B per pixel and chunk + 16 B pad).  Selected only by ddif_set_math_mode(DDIF_MATH_BF16) / DDIF_MATH=bf16.
 template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0, int MATH = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
@@ -124,7 +127,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr bool X3 = MATH >= 1;   // split-operand paths (bf16x3, f16x2): 16-bit planes in LDS
     constexpr bool F16 = MATH == 3;
-    constexpr int NPL = F16 ? 2 : 3; // operand planes
+    constexpr bool B1 = MATH == 4;
+    constexpr int NPL = F16 ? 2 : (B1 ? 1 : 3); // operand planes
     constexpr bool WSB = MATH == 2;  // ONE weight buffer (an extra barrier per stage): 69 KB of LDS -> two workgroups per CU, whose VALU
                                      // staging and bf16 MFMAs then overlap (different pipes)
     constexpr int NWB = WSB ? 1 : 2;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     // row pad of the staged tile (floats): lanes 0-15 / 16-31 of an A-fragment read own consecutive pixels of two ROWS of the tile;
     // with a halo the row stride IW * LDA puts the second row on the banks of the first (2-way conflicts on every ds_read_b128 of
     // the 16-wide tile, 3-way on the 8-wide one); these pads make the reads conflict-free (bank search: DESIGN section 3)
-    constexpr int RP = (X3 && KS == 3 && STRIDE == 1) ? (NPL == 2 ? 24 : 8) : 0;
+    constexpr int RP = (X3 && KS == 3 && STRIDE == 1) ? (NPL == 2 ? 24 : (NPL == 1 ? 40 : 8)) : 0;
     constexpr int LDR = IW * LDA + RP;                    // floats per staged tile row
     constexpr int ABUF = IH * LDR;                        // floats per LDS buffer
     // PRO_GN_DW (1x1 conv over depthwise3x3(GroupNorm(x))): the LOAD tile has a one-pixel halo and goes to a scratch
@@ -452,6 +456,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             if (a.out_xn && ok && a_py[it] >= 1 && a_py[it] <= TH && a_px[it] >= 1 && a_px[it] <= TW)
                 *reinterpret_cast<float4*>(a.out_xn + ((size_t)((R.pos.b * a.Hin + R.pos.oy0 + a_py[it] - 1) * a.Win + R.pos.ox0 + a_px[it] - 1)) * Ctot + R.cb + c4 * 4) =
                     make_float4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (B1) {
+            *reinterpret_cast<uint2*>(&dst[a_lds[it]]) = make_uint2(dd_bf16_pair(v[0], v[1]), dd_bf16_pair(v[2], v[3]));
         } else if constexpr (F16) {
             unsigned h01, l01, h23, l23;
             dd_split2_pair(v[0], v[1], &h01, &l01);
@@ -491,7 +497,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                         s2 = fmaf(hv.z, wk.z, s2);
                         s3 = fmaf(hv.w, wk.w, s3);
                     }
-                    if constexpr (F16) {
+                    if constexpr (B1) {
+                        *reinterpret_cast<uint2*>(&dst[p * LDA + c4 * 2]) = make_uint2(dd_bf16_pair(s0, s1), dd_bf16_pair(s2, s3));
+                    } else if constexpr (F16) {
                         unsigned h01, l01, h23, l23;
                         dd_split2_pair(s0 * DDIF_F16_ASCALE, s1 * DDIF_F16_ASCALE, &h01, &l01);
                         dd_split2_pair(s2 * DDIF_F16_ASCALE, s3 * DDIF_F16_ASCALE, &h23, &l23);
@@ -680,23 +688,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                     for (int nb = 0; nb < NB; ++nb) {
                         f32x16 c = acc[mb][nb];
                         if (ABL & 1) {  // no matrix work: keep the fragments alive
-                            c[0] += wb[sl][nb][0].x + xa[sl][mb][0].y + wb[sl][nb][1].z + xa[sl][mb][1].w + wb[sl][nb][NPL - 1].x + xa[sl][mb][NPL - 1].y;
+                            c[0] += wb[sl][nb][0].x + xa[sl][mb][0].y + wb[sl][nb][NPL / 2].z + xa[sl][mb][NPL / 2].w + wb[sl][nb][NPL - 1].x + xa[sl][mb][NPL - 1].y;
                             acc[mb][nb] = c;
                             continue;
                         }
+                        if constexpr (B1) {
+                            acc[mb][nb] = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][0], c);
+                            continue;
+                        }
                         if constexpr (F16) {
-                            c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][1], xa[sl][mb][0], c);  // lo * hi
-                            c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][0], xa[sl][mb][1], c);  // hi * lo
+                            c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][NPL - 1], xa[sl][mb][0], c);  // lo * hi
+                            c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][0], xa[sl][mb][NPL - 1], c);  // hi * lo
                             c = DDIF_MFMA_32x32x16_F16(wb[sl][nb][0], xa[sl][mb][0], c);  // hi * hi
                             acc[mb][nb] = c;
                             continue;
                         }
-                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][2], xa[sl][mb][0], c);  // lo * hi
-                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][2], c);  // hi * lo
-                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][1], xa[sl][mb][1], c);  // mid * mid
-                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][1], xa[sl][mb][0], c);  // mid * hi
-                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][1], c);  // hi * mid
-                        c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][0], c);  // hi * hi
+                        if constexpr (NPL == 3) {
+                            c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][2], xa[sl][mb][0], c);  // lo * hi
+                            c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][2], c);  // hi * lo
+                            c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][1], xa[sl][mb][1], c);  // mid * mid
+                            c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][1], xa[sl][mb][0], c);  // mid * hi
+                            c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][1], c);  // hi * mid
+                            c = DDIF_MFMA_32x32x16_BF16(wb[sl][nb][0], xa[sl][mb][0], c);  // hi * hi
+                        }
                         acc[mb][nb] = c;
                     }
                 DDIF_SCHED_FENCE();
@@ -962,9 +976,9 @@ template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO 
 constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN; + conv_smem_extra() at launch
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
-    constexpr int npl = MATH == 3 ? 2 : 3;
+    constexpr int npl = MATH == 3 ? 2 : (MATH == 4 ? 1 : 3);
     constexpr int lda = MATH >= 1 ? npl * CK / 2 + 4 : CK + 4, wchunk = MATH >= 1 ? KS * KS * (CK / 16) * npl * 256 : KS * KS * (CK / 8) * 256;
-    constexpr int rp = (MATH >= 1 && KS == 3 && STRIDE == 1) ? (npl == 2 ? 24 : 8) : 0;
+    constexpr int rp = (MATH >= 1 && KS == 3 && STRIDE == 1) ? (npl == 2 ? 24 : (npl == 1 ? 40 : 8)) : 0;
     return (size_t)(2 * IH * (IW * lda + rp) + (MATH == 2 ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
 }
 // GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts

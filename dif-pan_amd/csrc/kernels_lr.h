@@ -35,9 +35,9 @@ namespace ddif {
 
 // TALL: 16x8 instead of 8x16 pixels for MB = 4 -- whole image columns inside one tile, which is what the column-softmax
 // statistics epilogue (EPI_COLST) needs
-template <int KS, int MB, int PRO, bool TALL = false, bool F16 = false>
+template <int KS, int MB, int PRO, bool TALL = false, bool F16 = false, bool B1 = false>
 struct LrGeom {
-    static constexpr int NPL = F16 ? 2 : 3;                    // operand planes: f16x2 (hi, lo) or bf16x3 (hi, mid, lo)
+    static constexpr int NPL = F16 ? 2 : (B1 ? 1 : 3);         // operand planes: f16x2 (hi, lo), bf16x3 (hi, mid, lo) or bf16x1 (the throughput variant)
     static constexpr int TH = (TALL && MB == 4) ? 16 : 8, TW = (MB == 2 || TALL) ? 8 : 16;
     static constexpr int PAD = KS / 2;
     static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD; // staged tile (halo of the 3x3 taps)
@@ -55,12 +55,14 @@ struct LrGeom {
 // ABL (tools/mbench_lr.cpp only): 1 = no weight loads, 2 = no MFMAs, 4 = no activation loads, 8 = no output stores
 // F16: the f16x2 split (ddif_dev.h; kernels_conv.h MATH = 3) instead of bf16x3 -- operands pre-scaled by 2^4 / 2^10 and split into two
 // half planes, three products per slab and tap, 2/3 of the weight stream and of the staged tile; the accumulator is scaled back in the epilogue
-template <int KS, int MB, int PRO, int EPI, int ABL = 0, bool F16 = false>
+// B1: the throughput variant (kernels_conv.h MATH = 4): one bf16 plane per operand, one product
+template <int KS, int MB, int PRO, int EPI, int ABL = 0, bool F16 = false, bool B1 = false>
 __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     constexpr bool COLST = (EPI & EPI_COLST) != 0;
     static_assert(!COLST || KS == 1, "column statistics epilogue: 1x1 convs");
     static_assert(!F16 || PRO != PRO_COLSM, "f16x2: the column-softmax prologue stays on bf16x3");
-    using G = LrGeom<KS, MB, PRO, COLST, F16>;
+    static_assert(!(F16 && B1), "one operand format");
+    using G = LrGeom<KS, MB, PRO, COLST, F16, B1>;
     constexpr int NPL = G::NPL, SLF = NPL * 8;  // floats of one 16-channel slab of a staged pixel
     constexpr int WSTEP = NPL * 1024;           // bytes of one (slab, tap) step of the packed weights
     constexpr int TH = G::TH, TW = G::TW, LP = G::PAD, LH = G::IH, LW = G::IW, IW = G::IW, PC = G::PC, SP = G::SP;
@@ -233,7 +235,9 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                 }
                 if (pix < LH * LW) {
                     float* d = &As[pix * APIX + slab_l * SLF + cin_slab / 2];
-                    if constexpr (F16) {
+                    if constexpr (B1) {
+                        *reinterpret_cast<uint2*>(d) = make_uint2(dd_bf16_pair(v[0], v[1]), dd_bf16_pair(v[2], v[3]));
+                    } else if constexpr (F16) {
                         unsigned h01, l01, h23, l23;
                         dd_split2_pair(v[0], v[1], &h01, &l01);
                         dd_split2_pair(v[2], v[3], &h23, &l23);
@@ -288,23 +292,29 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                         for (int mb = 0; mb < MB; ++mb) {
                             f32x16 cacc = acc[mb];
                             if (ABL & 2) {
-                                cacc[0] += wr[u][0].x * xa[mb][0].x + wr[u][1].y * xa[mb][1].y + wr[u][NPL - 1].z * xa[mb][NPL - 1].z;
+                                cacc[0] += wr[u][0].x * xa[mb][0].x + wr[u][NPL / 2].y * xa[mb][NPL / 2].y + wr[u][NPL - 1].z * xa[mb][NPL - 1].z;
                                 acc[mb] = cacc;
                                 continue;
                             }
+                            if constexpr (B1) {
+                                acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][0], cacc);
+                                continue;
+                            }
                             if constexpr (F16) {
-                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][1], xa[mb][0], cacc);  // lo * hi
-                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[mb][1], cacc);  // hi * lo
+                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][NPL - 1], xa[mb][0], cacc);  // lo * hi
+                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[mb][NPL - 1], cacc);  // hi * lo
                                 cacc = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[mb][0], cacc);  // hi * hi
                                 acc[mb] = cacc;
                                 continue;
                             }
-                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][2], xa[mb][0], cacc);  // lo * hi
-                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][2], cacc);  // hi * lo
-                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][1], cacc);  // mid * mid
-                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][0], cacc);  // mid * hi
-                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][1], cacc);  // hi * mid
-                            cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][0], cacc);  // hi * hi
+                            if constexpr (NPL == 3) {
+                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][2], xa[mb][0], cacc);  // lo * hi
+                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][2], cacc);  // hi * lo
+                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][1], cacc);  // mid * mid
+                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][0], cacc);  // mid * hi
+                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][1], cacc);  // hi * mid
+                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][0], cacc);  // hi * hi
+                            }
                             acc[mb] = cacc;
                         }
                         if (pf_slab < NS) ring_load(u);  // the step U ahead of this one (wave-uniform branch)

@@ -111,6 +111,8 @@ class _Lib:
         d.ddif_plan_cost.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
         d.ddif_plan_num_launches.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
         d.ddif_debug_set_grid_cap.argtypes = [i32]
+        d.ddif_set_math_mode.argtypes = [i32]
+        d.ddif_get_math_mode.argtypes = []
         d.ddif_plan_memory.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         d.ddif_cond_assemble.argtypes = [vp, vp, f32, i32, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_metrics.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
@@ -220,6 +222,23 @@ def set_debug_grid_cap(max_workgroups: int):
     lib.check(lib.dll.ddif_debug_set_grid_cap(int(max_workgroups)), "ddif_debug_set_grid_cap")
 
 
+MATH_MODES = {"split": 0, "bf16": 1}
+
+
+def set_math_mode(mode: str):
+    """Arithmetic of the convs of inference plans created AFTERWARDS (include/ddif.h ddif_set_math_mode): "split" = the fp32-class default
+    (the parity configuration), "bf16" = the throughput variant (one bf16 MFMA product, fp32 accumulate; BASELINE configs[1] "bf16")."""
+    if mode not in MATH_MODES:
+        raise DdifError(f"math mode {mode!r}: expected one of {sorted(MATH_MODES)}")
+    lib = get_lib()
+    lib.check(lib.dll.ddif_set_math_mode(MATH_MODES[mode]), "ddif_set_math_mode")
+
+
+def get_math_mode() -> str:
+    m = get_lib().dll.ddif_get_math_mode()
+    return {v: k for k, v in MATH_MODES.items()}[int(m)]
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -307,7 +326,8 @@ class NetHandle:
         self.epoch = getattr(self, "epoch", 0) + 1  # the plans' cond-only caches (FiLM bodies, kv contexts, folded attn_out weights) are stale
 
     def plan(self, B: int, H: int, W: int, train: bool = False) -> "PlanHandle":
-        key = (int(B), int(H), int(W)) + (("train",) if train else ())
+        # (an inference plan carries the conv arithmetic it was built under: set_math_mode("bf16") afterwards builds another one)
+        key = (int(B), int(H), int(W)) + (("train",) if train else (get_math_mode(),))
         p = self.plans.get(key)
         if p is None:
             p = PlanHandle(self, int(B), int(H), int(W), train=train)

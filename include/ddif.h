@@ -366,6 +366,18 @@ DDIF_API int ddif_plan_cost(ddif_plan_t plan, double* step_flop, double* step_by
  * is what the same activations would take with one buffer per tensor. */
 DDIF_API int ddif_plan_memory(ddif_plan_t plan, int64_t* total_bytes, int64_t* arena_bytes, int64_t* unaliased_bytes);
 
+/* Arithmetic of the convolutions of INFERENCE plans created afterwards (process-wide; also DDIF_MATH=bf16 in the environment):
+ *   DDIF_MATH_SPLIT (default): fp32-class results -- f16x2 / bf16x3 split products or the exact fp32 MFMA; the parity configuration.
+ *   DDIF_MATH_BF16: the THROUGHPUT variant BASELINE configs[1] names ("bf16"; the reference would get it from torch.autocast around
+ *     models/sr3_dwt.py's nn.Conv2d calls): conv operands rounded once to bf16, one v_mfma_f32_32x32x16_bf16 product, fp32 accumulation;
+ *     tensors in memory, GroupNorm statistics, attention and the sampler update stay fp32.  Not a parity configuration: bench.py reports
+ *     its drift against the split path next to its rate.  Training plans ignore it.
+ * Returns DDIF_ERR_INVALID for another value. */
+#define DDIF_MATH_SPLIT 0
+#define DDIF_MATH_BF16 1
+DDIF_API int ddif_set_math_mode(int mode);
+DDIF_API int ddif_get_math_mode(void);
+
 /* TEST HOOK: cap the persistent grid (workgroups per conv launch) of plans created afterwards; 0 removes the cap.
  * Results do not depend on the cap (work items are walked in a fixed order per workgroup and every reduction has a
  * fixed order); tests use it to make small cases walk many work items per workgroup, across sample boundaries,
