@@ -334,7 +334,7 @@ def main():
             "mfma_products_per_fp32_product": products, "mfma_tflops": ach_tflops, "mfma_frac_of_dense_bf16_peak": ach_tflops * products / PEAK_BF16_MFMA_TFLOPS,
             "algorithmic_bytes_per_launch": (prof["total_bytes"] / prof["launches"]) if prof["launches"] else None,
             "kernel": prof["kernel"], "launches_timed": prof["launches"], "avg_launch_us": (prof["total_ms"] * 1e3 / prof["launches"]) if prof["launches"] else None,
-            "whole_step": {"ms_per_denoising_step": ms_step, "hbm_frac": (cost["step_bytes"] * n_evals + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
+            "whole_step": {"ms_per_denoising_step": ms_step, "tflops": step_flop_total * args.steps / dt / 1e12, "hbm_frac": (cost["step_bytes"] * n_evals + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
                            "profiled_steps": n_rec, "classes_ms_per_step_sum": cls_ms_total if classes_ok else None, "classes": classes if classes_ok else None},
         }
     if cf["sampler"] == "dpmpp2m":

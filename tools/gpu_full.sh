@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/gpu_full.sh <tag> [skip-tests]  -- everything a round's profiles/ needs, in one gpurun call:
 #   gpu tests, rocprofv3 kernel stats (T=20), PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy; T=4), op-by-op timing (T=40),
-#   the default bench (T=1000, with cpu_baseline) and the two other BASELINE configurations
+#   the default bench (T=1000, with cpu_baseline), its bf16 throughput variant and the other BASELINE configurations
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -34,6 +34,7 @@ DDIF_OP_TIMING=$R/gpurun_out/${tag}_op_timing_T40_B64.csv python3 bench.py --ste
 cp gpurun_out/${tag}_hbm_traffic.json profiles/ 2>/dev/null   # so that the bench line below can tie its traffic to this build
 python3 bench.py > gpurun_out/${tag}_bench_T1000_B64.json 2> gpurun_out/${tag}_bench_T1000_B64.log
 cat gpurun_out/${tag}_bench_T1000_B64.json
+python3 bench.py --config wv3_bf16 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_wv3_bf16.json 2> gpurun_out/${tag}_bench_wv3_bf16.log
 python3 bench.py --config gf2_dpm50 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_gf2_dpm50.json 2> gpurun_out/${tag}_bench_gf2_dpm50.log
 # what one rank of an N-GPU strong-scaling run of the same scene holds: 32 / 16 / 8 tiles (N = 2 / 4 / 8), measured on this one GPU
 for b in 32 16 8; do
@@ -53,7 +54,7 @@ try:
     print("wv3_train_b32", r["value"], r["unit"], "ms/iteration", r["ms_per_step"])
 except Exception as e:
     print("wv3_train_b32 failed", e)
-for n in ("gf2_dpm50", "gf2_dpm50_tiles32", "gf2_dpm50_tiles16", "gf2_dpm50_tiles8", "cave128_t2000"):
+for n in ("wv3_bf16", "gf2_dpm50", "gf2_dpm50_tiles32", "gf2_dpm50_tiles16", "gf2_dpm50_tiles8", "cave128_t2000"):
     try:
         r = json.load(open("gpurun_out/${tag}_bench_%s.json" % n))
         print(n, r["value"], r["unit"], "ms/job", r["ms_per_step"], "job TF", r["roofline"]["whole_step"]["tflops"])
