@@ -300,12 +300,12 @@ int ddif_blockbwd_run(ddif_blockbwd_t h, const float* x, const float* gamma, con
     if (gn) {
         // GroupNorm (+ SiLU + dropout) backward
         hipLaunchKernelGGL(ddif::gnb_bwd_partial_kernel<0>, dim3(k.nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, (const float*)k.x_nhwc, (const float*)nullptr, 0, da, m,
-                           (const double*)k.spart, k.nchunk, (const double*)nullptr, 0, gamma, beta, HW, Ci, k.nchunk, silu, k.cpart);
+                           (const double*)k.spart, k.nchunk, (const double*)nullptr, 0, gamma, beta, HW, Ci, k.nchunk, silu, k.cpart, (double*)nullptr);
         hipLaunchKernelGGL(ddif::gnb_bwd_reduce_kernel, dim3((Ci + 31) / 32 + B), dim3(ddif::GNB_RED_NT), 2 * ddif::GNB_RED_NT * sizeof(double), s, (const double*)k.cpart, gamma, B, k.nchunk, Ci, dgamma, dbeta,
                            k.S);
         if (dx) {
             hipLaunchKernelGGL(ddif::gnb_bwd_dx_kernel<0>, ew, dim3(256), 0, s, (const float*)k.x_nhwc, (const float*)nullptr, 0, da, m, (const double*)k.spart, k.nchunk,
-                               (const double*)nullptr, 0, gamma, beta, (const float*)k.S, (const float*)nullptr, HW, Ci, silu, k.dx_nhwc, (float*)nullptr);
+                               (const double*)nullptr, 0, gamma, beta, (const float*)k.S, (const float*)nullptr, HW, Ci, silu, k.dx_nhwc, (float*)nullptr, (const double*)nullptr, 0);
             hipLaunchKernelGGL(ddif::bwd_nhwc_to_nchw_kernel, ddif::grid_for(n), dim3(256), ddif::TR_SMEM, s, (const float*)k.dx_nhwc, B, Ci, HW, dx);
         }
     } else if (dx) {
@@ -536,27 +536,34 @@ static inline dim3 ew_grid2(int B, int HW, int C) {
 void gn_act(hipStream_t s, const float* x, const double* st, int np, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out) {
     hipLaunchKernelGGL(gnb_act_kernel, ew_grid2(B, HW, C), dim3(256), 0, s, x, st, np, gamma, beta, mask, HW, C, silu, out);
 }
+// gpart != nullptr (the training step): two launches -- the partials (with their gamma-weighted chunk sums) and dx, which forms the per-sample sums from those; the
+// dgamma / dbeta reduction of `cpart` is the caller's (one launch for all GroupNorms of the iteration, gn_bwd_reduce_all); dgamma / dbeta / S are not touched here
 void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma, const float* beta, int B, int HW, int C,
-            int nchunk, int silu, double* cpart, float* S, float* dgamma, float* dbeta, const float* res, float* dx) {
+            int nchunk, int silu, double* cpart, float* S, float* dgamma, float* dbeta, const float* res, float* dx, double* gpart) {
     hipLaunchKernelGGL(gnb_bwd_partial_kernel<0>, dim3(nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, x, (const float*)nullptr, 0, da, mask, st, np, (const double*)nullptr, 0,
-                       gamma, beta, HW, C, nchunk, silu, cpart);
+                       gamma, beta, HW, C, nchunk, silu, cpart, gpart);
     // (plane sums + finalize as ONE single-workgroup launch measured 46 us against 10 + 15 us for the pair; as (C / 32 + B) workgroups of 1024 threads it is one launch)
-    hipLaunchKernelGGL(gnb_bwd_reduce_kernel, dim3((C + 31) / 32 + B), dim3(GNB_RED_NT), 2 * GNB_RED_NT * sizeof(double), s, (const double*)cpart, gamma, B, nchunk, C, dgamma, dbeta, S);
+    if (!gpart)
+        hipLaunchKernelGGL(gnb_bwd_reduce_kernel, dim3((C + 31) / 32 + B), dim3(GNB_RED_NT), 2 * GNB_RED_NT * sizeof(double), s, (const double*)cpart, gamma, B, nchunk, C, dgamma, dbeta, S);
     if (dx)
         hipLaunchKernelGGL(gnb_bwd_dx_kernel<0>, ew_grid2(B, HW, C), dim3(256), 0, s, x, (const float*)nullptr, 0, da, mask, st, np, (const double*)nullptr, 0, gamma, beta,
-                           (const float*)S, res, HW, C, silu, dx, (float*)nullptr);
+                           (const float*)S, res, HW, C, silu, dx, (float*)nullptr, (const double*)gpart, nchunk);
+}
+void gn_bwd_reduce_all(hipStream_t s, const GnRedRec* recs_dev, int nrec, int nblocks, int B) {
+    hipLaunchKernelGGL(gnb_bwd_reduce_all_kernel, dim3(nblocks), dim3(1024), 2 * 1024 * sizeof(double), s, recs_dev, nrec, B);
 }
 // GroupNorm (no SiLU, no mask) over the never-materialised concatenation cat[x0 (c0 channels), x1 (c1)]: statistics from both producers' partials, the gradient
 // written to the two tensors' own gradients
 void gn_bwd_cat(hipStream_t s, const float* x0, int c0, const float* x1, int c1, const double* st0, int np0, const double* st1, int np1, const float* da, const float* gamma,
-                const float* beta, int B, int HW, int nchunk, double* cpart, float* S, float* dgamma, float* dbeta, float* dx0, float* dx1) {
+                const float* beta, int B, int HW, int nchunk, double* cpart, float* S, float* dgamma, float* dbeta, float* dx0, float* dx1, double* gpart) {
     const int C = c0 + c1;
     hipLaunchKernelGGL(gnb_bwd_partial_kernel<1>, dim3(nchunk, B), dim3(256), 256 * 8 * sizeof(double), s, x0, x1, c0, da, (const float*)nullptr, st0, np0, st1, np1, gamma, beta, HW,
-                       C, nchunk, 0, cpart);
-    hipLaunchKernelGGL(gnb_bwd_reduce_kernel, dim3((C + 31) / 32 + B), dim3(GNB_RED_NT), 2 * GNB_RED_NT * sizeof(double), s, (const double*)cpart, gamma, B, nchunk, C, dgamma, dbeta,
-                       S);
+                       C, nchunk, 0, cpart, gpart);
+    if (!gpart)
+        hipLaunchKernelGGL(gnb_bwd_reduce_kernel, dim3((C + 31) / 32 + B), dim3(GNB_RED_NT), 2 * GNB_RED_NT * sizeof(double), s, (const double*)cpart, gamma, B, nchunk, C, dgamma,
+                           dbeta, S);
     hipLaunchKernelGGL(gnb_bwd_dx_kernel<1>, ew_grid2(B, HW, C), dim3(256), 0, s, x0, x1, c0, da, (const float*)nullptr, st0, np0, st1, np1, gamma, beta, (const float*)S,
-                       (const float*)nullptr, HW, C, 0, dx0, dx1);
+                       (const float*)nullptr, HW, C, 0, dx0, dx1, (const double*)gpart, nchunk);
 }
 }  // namespace tk
 }  // namespace ddif

@@ -253,6 +253,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // tensors.  Deterministic (fixed summation order), fp64 combine.  Split in two so that a kernel prologue can put the
 // loads (gn_load_partials: up to 4 pairs per lane and tensor in registers, no arithmetic on them) in flight together
 // with its other prologue loads and pay ONE memory latency before gn_reduce_partials.
+// one GroupNorm backward of a training iteration, for the batched dgamma / dbeta launch at the end of the reverse program (kernels_bwd.h gnb_bwd_reduce_all_kernel)
+struct GnRedRec { const double* cpart; float* dgamma; float* dbeta; int C, nchunk, blk0, pad; };
 struct GnPartials {
     double v[2][4][2];  // [tensor][k: partial lane + 64 k][sum | sum of squares]
 };

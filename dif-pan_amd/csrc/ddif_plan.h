@@ -91,9 +91,10 @@ void bias_grad(hipStream_t s, const float* dy, size_t npix, int Cout, int nbchun
 void gn_stats(hipStream_t s, const float* x, int B, size_t per_sample, int nchunk, double* spart);
 void gn_act(hipStream_t s, const float* x, const double* st, int np, const float* gamma, const float* beta, const float* mask, int B, int HW, int C, int silu, float* out);
 void gn_bwd(hipStream_t s, const float* x, const float* da, const float* mask, const double* st, int np, const float* gamma, const float* beta, int B, int HW, int C,
-            int nchunk, int silu, double* cpart, float* S, float* dgamma, float* dbeta, const float* res, float* dx);
+            int nchunk, int silu, double* cpart, float* S, float* dgamma, float* dbeta, const float* res, float* dx, double* gpart = nullptr);
+void gn_bwd_reduce_all(hipStream_t s, const GnRedRec* recs_dev, int nrec, int nblocks, int B);
 void gn_bwd_cat(hipStream_t s, const float* x0, int c0, const float* x1, int c1, const double* st0, int np0, const double* st1, int np1, const float* da, const float* gamma,
-                const float* beta, int B, int HW, int nchunk, double* cpart, float* S, float* dgamma, float* dbeta, float* dx0, float* dx1);
+                const float* beta, int B, int HW, int nchunk, double* cpart, float* S, float* dgamma, float* dbeta, float* dx0, float* dx1, double* gpart = nullptr);
 // kernels_bwd_ops.h  (ddif_bwd_ops.cpp)
 void linear_bwd(hipStream_t s, const float* x, const float* w, const float* dy, int B, int nin, int nout, float* dx, float* dw, float* db);
 void l1_fwd(hipStream_t s, const float* pred, const float* target, size_t n, float* out);

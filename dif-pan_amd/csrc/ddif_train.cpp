@@ -103,6 +103,11 @@ struct Plan::TrainScratch {
     float *dte = nullptr, *dh1 = nullptr, *ds = nullptr, *dwall = nullptr, *dball = nullptr;
     SlotScatter* slot_tab = nullptr;
     std::vector<SlotScatter> slot_host;
+    // GroupNorm backward: every pass keeps its per-chunk partials in a buffer of its own; ONE launch at the end of the reverse program turns all of them into dgamma / dbeta
+    struct GnSite { double* cpart; double* gpart; float** dg; float** dbt; int C, nchunk; };
+    std::vector<GnSite> gn_sites;
+    std::vector<GnRedRec> gnred_host;
+    GnRedRec* gnred_dev = nullptr;
 };
 
 int Plan::train_bind(int n, const char* const* keys, float* const* grads) {
@@ -137,6 +142,13 @@ int Plan::build_backward() {
     auto numel = [&](const Tensor& t) { return (size_t)BB * t.H * t.W * t.C; };
     auto fbuf = [&](float** p, size_t n) -> int { return dalloc(p, n); };
     int ring_ctr = 0;  // slots of T->a_ring handed to the GroupNorm-recompute / weight-gradient pairs in turn
+    // a GroupNorm backward site: its own partial buffers (the chip has 288 GB; all of them together are a few hundred MB at B = 32), reduced at the end of the program
+    auto gn_site = [&](int C, int nchunk, float** dg, float** dbt, double** cpart, double** gpart) -> int {
+        DDIF_TRY(dalloc(cpart, (size_t)BB * nchunk * C * 2 + 64));
+        DDIF_TRY(dalloc(gpart, (size_t)BB * nchunk * 2 + 64));
+        T->gn_sites.push_back({*cpart, *gpart, dg, dbt, C, nchunk});
+        return 0;
+    };
     DDIF_TRY(tk::wgrad_prepare());
     DDIF_TRY(tk::linattn_prepare());
 #ifndef DDIF_EMU
@@ -261,8 +273,10 @@ int Plan::build_backward() {
         if (need_dx) DDIF_TRY(fbuf(&dx, n));
         float** dg = G(nkey + ".weight");
         float** dbt = G(nkey + ".bias");
+        double *cp = nullptr, *gp = nullptr;
+        DDIF_TRY(gn_site(C, nchunk, dg, dbt, &cp, &gp));
         L.v.push_back([=](hipStream_t st) {
-            tk::gn_bwd(st, x.p, da.p, mask, fst ? fst : T->spart, fnp, gamma, beta, BB, HW, C, nchunk, pro == 2, T->cpart, T->S, *dg, *dbt, res, dx);
+            tk::gn_bwd(st, x.p, da.p, mask, fst ? fst : T->spart, fnp, gamma, beta, BB, HW, C, nchunk, pro == 2, cp, nullptr, nullptr, nullptr, res, dx, gp);
         });
         *dx_out = dx;
         return 0;
@@ -611,6 +625,8 @@ int Plan::build_backward() {
                     need(T->n_cpart, (size_t)BB * nchunk * fea * 2);
                     float** dg = G(ci + ".prenorm_x.weight");
                     float** dbt = G(ci + ".prenorm_x.bias");
+                    double *cp = nullptr, *gp = nullptr;
+                    DDIF_TRY(gn_site(fea, nchunk, dg, dbt, &cp, &gp));
                     float* dskip = nullptr;
                     DDIF_TRY(fbuf(&dx, numel(m.in)));
                     DDIF_TRY(fbuf(&dskip, numel(skip)));
@@ -618,13 +634,13 @@ int Plan::build_backward() {
                     if (hin.st && skip.st && Ca % 4 == 0 && Cb % 4 == 0 && !getenv("DDIF_TRAIN_GN_RESTAT")) {
                         // the cat is never formed: both sources are read in place, with the statistics their producers left, and each gets its gradient directly
                         L.v.push_back([=](hipStream_t st) {
-                            tk::gn_bwd_cat(st, hin.p, Ca, skip.p, Cb, hin.st, hin.np, skip.st, skip.np, dxn, gamma, beta, BB, HW, nchunk, T->cpart, T->S, *dg, *dbt, dx, dskip);
+                            tk::gn_bwd_cat(st, hin.p, Ca, skip.p, Cb, hin.st, hin.np, skip.st, skip.np, dxn, gamma, beta, BB, HW, nchunk, cp, nullptr, nullptr, nullptr, dx, dskip, gp);
                         });
                     } else
                     L.v.push_back([=](hipStream_t st) {
                         hipLaunchKernelGGL(concat2_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)hin.p, Ca, (const float*)skip.p, Cb, npix, T->a);
                         tk::gn_stats(st, T->a, BB, (size_t)HW * fea, nchunk, T->spart);
-                        tk::gn_bwd(st, T->a, dxn, nullptr, T->spart, nchunk, gamma, beta, BB, HW, fea, nchunk, 0, T->cpart, T->S, *dg, *dbt, nullptr, T->tmp);
+                        tk::gn_bwd(st, T->a, dxn, nullptr, T->spart, nchunk, gamma, beta, BB, HW, fea, nchunk, 0, cp, nullptr, nullptr, nullptr, nullptr, T->tmp, gp);
                         hipLaunchKernelGGL(split2_kernel, tgrid(npix * fea), dim3(256), 0, st, (const float*)T->tmp, Ca, Cb, npix, (const float*)nullptr, (const float*)nullptr, dx, dskip);
                     });
                     if (m.skip_from < 0) return fail(DDIF_ERR_STATE, "training: decoder block without a skip source");
@@ -680,6 +696,20 @@ int Plan::build_backward() {
             tk::linear_bwd(st, hid, w3, T->dte, BB, in4, inner, T->dh1, *gw3, *gb3);
             tk::silu_bwd(st, spre, T->dh1, (size_t)BB * in4, T->ds);
             tk::linear_bwd(st, pe, w1, T->ds, BB, inner, in4, nullptr, *gw1, *gb1);
+            if (!T->gn_sites.empty()) {  // dgamma / dbeta of every GroupNorm of the iteration: one launch (the table follows the bound gradient tensors, like the slot table)
+                std::vector<GnRedRec> tab;
+                int nblk = 0;
+                for (auto& g : T->gn_sites) {
+                    tab.push_back(GnRedRec{g.cpart, *g.dg, *g.dbt, g.C, g.nchunk, nblk, 0});
+                    nblk += (g.C + 31) / 32;
+                }
+                if (T->gnred_host.size() != tab.size() || memcmp(T->gnred_host.data(), tab.data(), tab.size() * sizeof(GnRedRec)) != 0) {
+                    (void)hipMemcpyAsync(T->gnred_dev, tab.data(), tab.size() * sizeof(GnRedRec), hipMemcpyHostToDevice, st);
+                    (void)hipStreamSynchronize(st);  // `tab` is a local (rare: first step / re-bind)
+                    T->gnred_host = tab;
+                }
+                tk::gn_bwd_reduce_all(st, T->gnred_dev, (int)tab.size(), nblk, BB);
+            }
         });
         seqs.push_back(std::move(L));
     }
@@ -696,6 +726,11 @@ int Plan::build_backward() {
     DDIF_TRY(dalloc(&T->spart, (size_t)BB * 32 * 2 + 512));
     DDIF_TRY(dalloc(&T->cpart, T->n_cpart + 64));
     DDIF_TRY(dalloc(&T->dwpart, T->n_dwpart + 64));
+    {
+        double* raw = nullptr;
+        DDIF_TRY(dalloc(&raw, (T->gn_sites.size() + 1) * sizeof(GnRedRec) / sizeof(double) + 8));
+        T->gnred_dev = reinterpret_cast<GnRedRec*>(raw);
+    }
 
     for (auto& L : seqs) {
         auto sp = std::make_shared<Seq>(std::move(L));

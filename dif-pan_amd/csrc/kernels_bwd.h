@@ -436,10 +436,13 @@ __device__ __forceinline__ float gnb_dy(float xh, float g, float bt, float da, f
 template <int TWO>
 __global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, const float* x1, int c0, const float* da, const float* mask, const double* st, int np,
                                                               const double* st1, int np1, const float* gamma, const float* beta, int HW, int C, int nchunk, int silu,
-                                                              double* cpart /* [B][nchunk][C][2] */) {
+                                                              double* cpart /* [B][nchunk][C][2] */, double* gpart /* nullable: [B][nchunk][2] */) {
+    // gpart (the training step, round 4): this chunk's gamma-weighted channel sums {sum_c gamma_c sum dy, sum_c gamma_c sum dy x_hat} -- what the dx launch needs
+    // of the partials (nchunk pairs per sample instead of nchunk x C): it then forms S_b itself and the reduce launch leaves the gradient chain
     DDIF_DYN_SMEM(smem_);
     double* red = reinterpret_cast<double*>(smem_);  // [256][8]
     const int b = blockIdx.y, tid = threadIdx.x;
+    double g0 = 0.0, g1 = 0.0;  // thread 0: accumulated over the channel passes
     const int C4 = C / 4, rows = 256 / C4 > 0 ? 256 / C4 : 1;
     float mean, rstd;
     gn_finalize_wave(st, np, TWO ? st1 : nullptr, TWO ? np1 : 0, b, (double)C * HW, &mean, &rstd);
@@ -466,15 +469,86 @@ __global__ __launch_bounds__(256) void gnb_bwd_partial_kernel(const float* x, co
 #pragma unroll
         for (int k = 0; k < 8; ++k) red[tid * 8 + k] = acc[k];
         __syncthreads();
+        double t0 = 0.0, t1 = 0.0;
         if (q < C4 && r == 0) {  // fixed order over the pixel rows
             const int stride = C4 < 256 ? C4 : 256;
             for (int k = 0; k < 8; ++k) {
                 double s = 0.0;
                 for (int rr = 0; rr < rows; ++rr) s += red[(rr * stride + tid) * 8 + k];
                 cpart[(((size_t)b * nchunk + blockIdx.x) * C + q * 4 + k / 2) * 2 + (k & 1)] = s;
+                if (k & 1) t1 += (double)gamma[q * 4 + k / 2] * s;
+                else t0 += (double)gamma[q * 4 + k / 2] * s;
             }
         }
         __syncthreads();
+        if (gpart) {  // workgroup-uniform: fixed-order tree over the channel-quad threads (threads past them hold zeros)
+            red[tid] = t0;
+            red[256 + tid] = t1;
+            __syncthreads();
+            for (int stp = 128; stp >= 1; stp >>= 1) {
+                if (tid < stp) {
+                    red[tid] += red[tid + stp];
+                    red[256 + tid] += red[256 + tid + stp];
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                g0 += red[0];
+                g1 += red[256];
+            }
+            __syncthreads();
+        }
+    }
+    if (gpart && tid == 0) {
+        gpart[((size_t)b * nchunk + blockIdx.x) * 2 + 0] = g0;
+        gpart[((size_t)b * nchunk + blockIdx.x) * 2 + 1] = g1;
+    }
+}
+// dgamma / dbeta of MANY GroupNorms in one launch (the training step, round 4): every GroupNorm backward of the iteration leaves its per-chunk partials in a
+// buffer of its own and this launch, at the end of the reverse program, turns all of them into parameter gradients -- one launch instead of one per GroupNorm
+// on the gradient chain.  Workgroup -> (record, 32 channels) through the records' first-block prefix; the body is gnb_bwd_reduce_kernel's channel branch.
+// (GnRedRec: ddif_dev.h -- {partials, dgamma, dbeta, C, nchunk, first workgroup})
+__global__ __launch_bounds__(1024) void gnb_bwd_reduce_all_kernel(const GnRedRec* recs, int nrec, int B) {
+    DDIF_DYN_SMEM(smem_);
+    double(*red)[1024] = reinterpret_cast<double(*)[1024]>(smem_);  // [2][1024]
+    const int tid = threadIdx.x;
+    int ri = 0;
+    for (int k = 1; k < nrec; ++k)
+        if ((int)blockIdx.x >= recs[k].blk0) ri = k;
+    const GnRedRec rc = recs[ri];
+    const int C = rc.C, nchunk = rc.nchunk;
+    const int c = ((int)blockIdx.x - rc.blk0) * 32 + (tid & 31), sl = tid >> 5;  // slice sl takes the pairs (b, k) = sl, sl + 32, ...
+    const int npair = B * nchunk;
+    const int cc = c < C ? c : C - 1;
+    double s0 = 0.0, s1 = 0.0;
+    for (int p0 = sl; p0 < npair; p0 += 32 * 8) {
+        double v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int pr = p0 + 32 * u < npair ? p0 + 32 * u : sl;
+            v0[u] = rc.cpart[((size_t)pr * C + cc) * 2 + 0];
+            v1[u] = rc.cpart[((size_t)pr * C + cc) * 2 + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p0 + 32 * u < npair) {
+                s0 += v0[u];
+                s1 += v1[u];
+            }
+    }
+    red[0][tid] = s0;
+    red[1][tid] = s1;
+    __syncthreads();
+    for (int st = 16; st >= 1; st >>= 1) {
+        if (sl < st) {
+            red[0][tid] += red[0][tid + st * 32];
+            red[1][tid] += red[1][tid + st * 32];
+        }
+        __syncthreads();
+    }
+    if (sl == 0 && c < C) {
+        if (rc.dbeta) rc.dbeta[c] = (float)red[0][tid];
+        if (rc.dgamma) rc.dgamma[c] = (float)red[1][tid];
     }
 }
 // Everything that follows the per-chunk partials, in ONE launch of 1024-thread workgroups (it replaces a plane-sum launch and a finalize launch):
@@ -562,14 +636,30 @@ __global__ __launch_bounds__(GNB_RED_NT) void gnb_bwd_reduce_kernel(const double
 // dx = rstd (gamma dy - m1 - x_hat m2)  (+ res: the gradient arriving over the residual path of a ResnetBlock / SelfAttention, added here instead
 // of by a launch of its own)
 // TWO = 1: the two sources as above, and the gradient goes straight to the two tensors' own gradients (dx: c0 channels, dx1: C - c0) -- no cat / split launches
+// gpart != nullptr: S_b from the partial launch's gamma-weighted chunk sums (nchunk <= 32 pairs, summed in chunk order by every thread) instead of `S`
 template <int TWO>
 __global__ __launch_bounds__(256) void gnb_bwd_dx_kernel(const float* x, const float* x1, int c0, const float* da, const float* mask, const double* st, int np,
                                                          const double* st1, int np1, const float* gamma, const float* beta, const float* S, const float* res, int HW, int C,
-                                                         int silu, float* dx, float* dx1) {
+                                                         int silu, float* dx, float* dx1, const double* gpart, int nchunk) {
     const int b = blockIdx.y;
     float mean, rstd;
     gn_finalize_wave(st, np, TWO ? st1 : nullptr, TWO ? np1 : 0, b, (double)C * HW, &mean, &rstd);
-    const float m1 = S[b * 2] / (float)HW, m2 = S[b * 2 + 1] / (float)HW;
+    float S0, S1;
+    if (gpart) {
+        const double* gp = gpart + (size_t)b * nchunk * 2;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < nchunk; ++k) {
+            s0 += gp[2 * k];
+            s1 += gp[2 * k + 1];
+        }
+        S0 = (float)(s0 / (double)C);
+        S1 = (float)(s1 / (double)C);
+    } else {
+        S0 = S[b * 2];
+        S1 = S[b * 2 + 1];
+    }
+    const float m1 = S0 / (float)HW, m2 = S1 / (float)HW;
     const size_t n4 = (size_t)HW * C / 4, base = (size_t)b * HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const size_t pl = (i * 4) / C;  // pixel of the sample
