@@ -89,8 +89,7 @@ def test_ddpm_short_matches_reference(case):
     assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-5
 
 
-@pytest.mark.slow
-@pytest.mark.skipif(not os.environ.get("DDIF_RUN_SLOW"), reason="2-minute CPU run; set DDIF_RUN_SLOW=1 (the GPU suite covers T=1000)")
+# (the full T = 1000 chain of the oracle against the reference's golden: ~40 s of CPU on 8 cores -- run by default since round 4)
 @pytest.mark.parametrize("case", [c for c in gc.DDPM_CASES if c[0] == "ddpm_wv3_16_T1000"], ids=lambda c: c[0])
 def test_ddpm_T1000_matches_reference(case):
     g = _load(case[0])
