@@ -7,6 +7,7 @@
 #include "kernels_misc.h"
 #include "attn_args.h"
 #include "kernels_lafuse.h"
+#include "kernels_ffn.h"
 
 namespace ddif {
 
@@ -148,6 +149,12 @@ static int f16_enabled() {  // DDIF_F16=0: the split-operand convs stay on bf16x
     return f16;
 }
 int g_math_mode = [] { const char* e = getenv("DDIF_MATH"); return (e && std::strcmp(e, "bf16") == 0) ? 1 : 0; }();
+// DDIF_FFNFUSE=1: the decoder's feed-forward half at the top level as ONE launch with the 2C-channel intermediate on chip (kernels_ffn.h) instead of two conv
+// launches.  OFF by default: parity-green and bit-stable, but measured 98-106 us against 94 us for the pair at B = 64 (profiles/r04_t_*).
+static int ffnfuse_enabled() {
+    static const int v = [] { const char* e = getenv("DDIF_FFNFUSE"); return e ? atoi(e) : 0; }();
+    return v;
+}
 static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention half as three launches (q conv, column statistics, attn_out conv)
     static const int v = [] { const char* e = getenv("DDIF_LAFUSE"); return e ? atoi(e) : 1; }();
     return v;
@@ -1567,7 +1574,59 @@ int Plan::build_impl() {
             DDIF_TRY(add_conv(step, s, &amix));
         }
         }  // !fused_attn
-        {
+        bool fused_ffn = false;
+        {   // the whole feed-forward half in one launch, the 2C-channel intermediate on chip (kernels_ffn.h): inference plans, the f16x2 path, supported shapes
+            const PackedConv *p0 = PC(ci + ".ffn.0"), *pm = train_mode ? nullptr : PC(ci + ".ffn.23");
+            if (p0 && pm && !train_mode && g_math_mode == 0 && ffnfuse_enabled() && f16_enabled() && x3_enabled() && p0->w_f16 && pm->w_f16 && pm->bias && p0->ks == 3 &&
+                pm->ks == 3 && p0->ck == 16 && pm->ck == 16 && p0->cin == amix.C && pm->cin == p0->cout && pm->cout == amix.C && ffnfuse_supported(amix.C, p0->cout) &&
+                amix.H * amix.W > 256 && (size_t)B * amix.H * amix.W * p0->cout * 4 < ((size_t)1 << 32)) {
+                use(amix.p);
+                DDIF_TRY(alloc_tensor(&f3, amix.C, amix.H, amix.W, true));
+                FfnFuseArgs a{};
+                a.x = amix.p;
+                a.w0 = p0->w_f16;
+                a.w1 = pm->w_f16;
+                a.bias = pm->bias;
+                a.out = f3.p;
+                a.B = B;
+                a.H = amix.H;
+                a.W = amix.W;
+                a.tiles_x = (amix.W + 15) / 16;
+                a.tiles_y = (amix.H + 15) / 16;
+                f3.np = a.tiles_x * a.tiles_y;
+                if (int e = dalloc(&f3.st, (size_t)B * f3.np * 2)) return e;
+                a.st_out = f3.st;
+                if (!dry) DDIF_TRY(ffnfuse_launch(a, 1, nullptr, true));
+                long cap = num_cus();
+                if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
+                const int tiles = a.tiles_x * a.tiles_y;
+                Op op;
+                op.name = "ffn_fused";
+                {
+                    char lb[160];
+                    snprintf(lb, sizeof lb, "ffn_fused ffn.0+SiLU+ffn.3(ffn.2)+res %d->%d->%d @%dx%d", amix.C, p0->cout, pm->cout, amix.H, amix.W);
+                    op.label = lb;
+                }
+                op.flop = 2.0 * B * amix.H * amix.W * 9.0 * 2.0 * (double)amix.C * p0->cout;
+                op.bytes = 4.0 * B * amix.H * amix.W * 2.0 * amix.C;
+                op.cls = 0;
+                op.mfma_w = 3;
+                op.timed = true;
+                op.win = true;
+                op.run = [a, tiles, cap](hipStream_t st, const StepCtx& sc) {
+                    FfnFuseArgs aa = a;
+                    if (sc.bn) {
+                        aa.b0 = sc.b0;
+                        aa.B = sc.bn;
+                    }
+                    const long nw = (long)aa.B * tiles;
+                    (void)ffnfuse_launch(aa, (int)(nw < cap ? nw : cap), st, false);
+                };
+                step.push_back(std::move(op));
+                fused_ffn = true;
+            }
+        }
+        if (!fused_ffn) {
             ConvSpec s;
             s.pc = PC(ci + ".ffn.0");
             if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.0 missing", ci.c_str());

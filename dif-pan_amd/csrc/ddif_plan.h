@@ -60,6 +60,10 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3);  // ddif_lr.cpp
 // ddif_set_math_mode (include/ddif.h): 0 = fp32-class split products (default), 1 = the bf16 throughput variant, for plans built afterwards
 extern int g_math_mode;
+// fused feed-forward half of a decoder block (kernels_ffn.h, ddif_ffn.cpp)
+struct FfnFuseArgs;
+bool ffnfuse_supported(int C, int CM);
+int ffnfuse_launch(const FfnFuseArgs& a, int grid, hipStream_t s, bool prepare_only);
 // fused linear-attention block (kernels_lafuse.h, ddif_la.cpp)
 struct LaFuseArgs;
 bool lafuse_supported(int H, int fea, int dout);
