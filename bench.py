@@ -33,6 +33,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between the ranks of a node needs it on this driver
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (also set by the ddif package; here for the self-launched ranks: profiles/r05_a_kernarg_ab.txt)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "dif-pan_amd"), ROOT, os.path.join(ROOT, "tests")):
@@ -321,6 +322,10 @@ def main():
                         "floor_ms_per_step": floor_ms, "frac_of_floor": floor_ms / ms if ms > 0 else None})
     # the table is only printed when it adds up: sum of the classes within 15 % of the measured denoising step, no class above its floor
     classes_ok = bool(classes) and abs(cls_ms_total - ms_step) / ms_step < 0.15 and all(c["frac_of_floor"] is None or c["frac_of_floor"] <= 1.0 for c in classes)
+    # ONE scale that does not move with the arithmetic: the step's floor = sum over the classes of max(issued 16-bit MFMA flops / dense peak,
+    # algorithmic bytes / 8 TB/s) -- a property of the launch program, not of the timing -- over the measured denoising step
+    step_floor_ms = sum(c["floor_ms_per_step"] for c in classes) if classes else None
+    step_frac = (step_floor_ms / ms_step) if step_floor_ms else None
     if not classes_ok:
         log("per-class table INCONSISTENT with the step (sum %.3f ms vs %.3f ms per denoising step): not reported" % (cls_ms_total, ms_step))
     # one product per fp32 product: the dominant class's MFMA floor (flops / 2516.8 TF) drops below its HBM floor (algorithmic bytes / 8 TB/s) -- the
@@ -334,6 +339,7 @@ def main():
             "mfma_products_per_fp32_product": products, "mfma_tflops": ach_tflops, "mfma_frac_of_dense_bf16_peak": ach_tflops * products / PEAK_BF16_MFMA_TFLOPS,
             "algorithmic_bytes_per_launch": (prof["total_bytes"] / prof["launches"]) if prof["launches"] else None,
             "kernel": prof["kernel"], "launches_timed": prof["launches"], "avg_launch_us": (prof["total_ms"] * 1e3 / prof["launches"]) if prof["launches"] else None,
+            "step_floor_ms": step_floor_ms, "step_frac": step_frac,
             "whole_step": {"ms_per_denoising_step": ms_step, "tflops": step_flop_total * args.steps / dt / 1e12, "hbm_frac": (cost["step_bytes"] * n_evals + cost["cond_bytes"]) * args.steps / dt / 1e9 / PEAK_HBM_GBS,
                            "profiled_steps": n_rec, "classes_ms_per_step_sum": cls_ms_total if classes_ok else None, "classes": classes if classes_ok else None},
         }
@@ -356,7 +362,7 @@ def main():
         "higher_is_better": True,
         "scaling": cf["scaling"],
         "vs_baseline": None,
-        "dtype": "bf16" if bf16 else "f32",
+        "dtype": "bf16" if bf16 else ("f32-class (f16x2 split)" if x3 else "f32"),
         "data": "synthetic",
         **({"drift": drift, "parity_configuration": False} if bf16 else {}),
         "config": {"workload": workload, "name": args.config, "tiles_per_gpu": B, "tiles_total": total, "tile": [H, H, C], "T": T, "model_evaluations": n_evals,
@@ -390,6 +396,9 @@ def main():
             "launches_timed": prof["launches"],
             "avg_launch_us": (prof["total_ms"] * 1e3 / prof["launches"]) if prof["launches"] else None,
             "algorithmic_gflop_per_launch": (prof["total_flop"] / prof["launches"] / 1e9) if prof["launches"] else None,
+            "step_floor_ms": step_floor_ms,
+            "step_frac": step_frac,
+            "step_frac_note": "step_floor_ms = sum over the step's kernel classes of max(issued 16-bit MFMA flops / %.1f TF, algorithmic bytes / 8 TB/s); step_frac = step_floor_ms / ms_per_denoising_step -- the round-over-round scale" % PEAK_BF16_MFMA_TFLOPS,
             "whole_step": {
                 "ms_per_denoising_step": ms_step,
                 "tflops": step_flop_total * args.steps / dt / 1e12,

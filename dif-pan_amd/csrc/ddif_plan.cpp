@@ -7,7 +7,6 @@
 #include "kernels_misc.h"
 #include "attn_args.h"
 #include "kernels_lafuse.h"
-#include "kernels_ffn.h"
 
 namespace ddif {
 
@@ -149,12 +148,6 @@ static int f16_enabled() {  // DDIF_F16=0: the split-operand convs stay on bf16x
     return f16;
 }
 int g_math_mode = [] { const char* e = getenv("DDIF_MATH"); return (e && std::strcmp(e, "bf16") == 0) ? 1 : 0; }();
-// DDIF_FFNFUSE=1: the decoder's feed-forward half at the top level as ONE launch with the 2C-channel intermediate on chip (kernels_ffn.h) instead of two conv
-// launches.  OFF by default: parity-green and bit-stable, but measured 98-106 us against 94 us for the pair at B = 64 (profiles/r04_t_*).
-static int ffnfuse_enabled() {
-    static const int v = [] { const char* e = getenv("DDIF_FFNFUSE"); return e ? atoi(e) : 0; }();
-    return v;
-}
 static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention half as three launches (q conv, column statistics, attn_out conv)
     static const int v = [] { const char* e = getenv("DDIF_LAFUSE"); return e ? atoi(e) : 1; }();
     return v;
@@ -241,9 +234,6 @@ Plan::~Plan() {
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
 #endif
 #ifndef DDIF_EMU
-    for (auto st : side) (void)hipStreamDestroy(st);
-    for (auto e : fork_ev) (void)hipEventDestroy(e);
-    for (auto e : join_ev) (void)hipEventDestroy(e);
     if (wg_stream) {
         (void)hipStreamSynchronize(wg_stream);
         (void)hipStreamDestroy(wg_stream);
@@ -316,7 +306,6 @@ int Plan::build() {
         tmods.clear();
         if (int e = net->build_dgrad_packs()) return e;
         if (int e = build_impl()) return e;
-        compute_regions();
         return build_backward();
     }
     dry = true;
@@ -326,15 +315,6 @@ int Plan::build() {
         auto it = fake2id.find(net_out.p);
         if (it != fake2id.end()) lives[it->second].last = 1 << 30;
     }
-    // inside a forked region the sub-batches run out of program order relative to each other (one may be several launches ahead):
-    // a tensor that is live anywhere inside a region must not share memory with another one that is -- extend both to the whole region
-    compute_regions();
-    for (auto& rg : regions)
-        for (auto& l : lives)
-            if (l.last >= rg.first && l.first < rg.second) {
-                if (l.first > rg.first) l.first = rg.first;
-                if (l.last < rg.second) l.last = rg.second;
-            }
     // first-fit interval colouring in order of first use
     std::vector<int> order(lives.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
@@ -383,96 +363,7 @@ int Plan::build() {
     }
     if (int e = build_impl()) return e;
     if (arena_next != (int)lives.size()) return fail(DDIF_ERR_STATE, "plan arena: the two build passes disagree");
-    compute_regions();
     return 0;
-}
-
-// forked regions (DDIF_SPLIT=k; default 1 = OFF): maximal runs of window-capable ops of the low-resolution levels and the bottleneck
-// attention (classes 2, 3); DDIF_SPLIT_ALL=1 makes the whole step one region.  MEASURED NEGATIVE on MI355X / ROCm 7.2 (profiles/
-// r03_b_split_ab.txt, B = 64, same box): 5.44 ms per denoising step unsplit, 5.51 / 5.78 / 6.93 / 9.37 ms with 2 / 4 / 8 / 16 sub-batches
-// of the low-resolution region, 5.63 / 5.66 ms with the whole step in 2 / 4 -- parallel branches of a captured graph do not overlap
-// enough to pay for their fork / join dependencies.  Kept as a tested switch (tests/test_env_switches.py), not a default.
-void Plan::compute_regions() {
-    static const int split_env = [] { const char* e = getenv("DDIF_SPLIT"); return e ? atoi(e) : 1; }();
-    static const bool split_all = [] { const char* e = getenv("DDIF_SPLIT_ALL"); return e && atoi(e) != 0; }();
-    split_k = 1;
-    regions.clear();
-    int k = split_env;
-    while (k > 1 && B % k != 0) --k;
-    if (k <= 1 || train_mode) return;
-    int i = 0;
-    const int n = (int)step.size();
-    auto in_region = [&](const Op& op) { return op.win && (split_all || op.cls == 2 || op.cls == 3); };
-    while (i < n) {
-        if (!in_region(step[i])) {
-            ++i;
-            continue;
-        }
-        int j = i;
-        while (j < n && in_region(step[j])) ++j;
-        if (j - i >= 4) regions.emplace_back(i, j);
-        i = j;
-    }
-    if (!regions.empty()) split_k = k;
-}
-
-int Plan::ensure_fork_resources() {
-#ifndef DDIF_EMU
-    while ((int)side.size() < split_k - 1) {
-        hipStream_t st = nullptr;
-        DDIF_HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        side.push_back(st);
-    }
-    while ((int)fork_ev.size() < (int)regions.size()) {
-        hipEvent_t e;
-        DDIF_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        fork_ev.push_back(e);
-    }
-    while ((int)join_ev.size() < (int)regions.size() * (split_k - 1)) {
-        hipEvent_t e;
-        DDIF_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        join_ev.push_back(e);
-    }
-#endif
-    return 0;
-}
-
-// The step program with its forked regions: outside a region ops run on `s` over the whole batch; a region runs as split_k batch
-// windows, window 0 on `s` and the others on side streams forked from / joined to `s` with events (under stream capture these become
-// parallel branches of the graph).  Profiled steps (an event pair around every launch) and the emulator run everything on `s`.
-void Plan::run_step_prog(hipStream_t s, const StepCtx& ctx, bool prof) {
-#ifdef DDIF_EMU
-    run_prog(step, s, ctx, prof);
-#else
-    static const char* op_timing = getenv("DDIF_OP_TIMING");
-    if (prof || split_k <= 1 || regions.empty() || (int)side.size() < split_k - 1 || (op_timing && !op_timing_done)) {
-        run_prog(step, s, ctx, prof);
-        return;
-    }
-    const int per = B / split_k;
-    int pos = 0;
-    for (size_t r = 0; r < regions.size(); ++r) {
-        const int r0 = regions[r].first, r1 = regions[r].second;
-        for (int i = pos; i < r0; ++i) step[i].run(s, ctx);
-        (void)hipEventRecord(fork_ev[r], s);
-        for (int w = 1; w < split_k; ++w) (void)hipStreamWaitEvent(side[w - 1], fork_ev[r], 0);
-        // launch order: op by op across the windows, so that the branches advance together
-        for (int i = r0; i < r1; ++i)
-            for (int w = 0; w < split_k; ++w) {
-                StepCtx c = ctx;
-                c.b0 = w * per;
-                c.bn = per;
-                step[i].run(w == 0 ? s : side[w - 1], c);
-            }
-        for (int w = 1; w < split_k; ++w) {
-            hipEvent_t e = join_ev[r * (split_k - 1) + (w - 1)];
-            (void)hipEventRecord(e, side[w - 1]);
-            (void)hipStreamWaitEvent(s, e, 0);
-        }
-        pos = r1;
-    }
-    for (int i = pos; i < (int)step.size(); ++i) step[i].run(s, ctx);
-#endif
 }
 
 int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
@@ -636,16 +527,9 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         if (var.f16) ++n_conv3_f16;
         if (var.b1) ++n_conv3_b1;
     }
-    op.win = true;
-    op.run = [a, var, fn_tbs, fn_samp, lms_p, grid, block, smem, dyn, self_c, tb_off, items_per_sample, cap](hipStream_t st, const StepCtx& ctx) {
+    op.run = [a, var, fn_tbs, fn_samp, lms_p, grid, block, smem, dyn, self_c, tb_off](hipStream_t st, const StepCtx& ctx) {
         ConvArgs aa = a;
-        dim3 g = grid;
-        if (ctx.bn) {  // batch window of a forked region
-            aa.b0 = ctx.b0;
-            aa.B = ctx.bn;
-            const long nw = (long)ctx.bn * items_per_sample;
-            g = dim3((unsigned)(nw < cap ? nw : cap), 1u);
-        }
+        const dim3 g = grid;
         if (dyn) {
             if (self_c) {
                 aa.in0 = ctx.sc;
@@ -861,15 +745,7 @@ int Plan::build_impl() {
             op.flop = 2.0 * B * 64 * 128.0 * (384 + 128) + 4.0 * B * 8 * 64.0 * 64 * 16;
             op.bytes = 8.0 * B * 64 * 128;
             const int ncu = num_cus();
-            op.win = true;
-            op.run = [a, ncu](hipStream_t s, const StepCtx& ctx) {
-                AttnBlockArgs aa = a;
-                if (ctx.bn) {
-                    aa.b0 = ctx.b0;
-                    aa.B = ctx.bn;
-                }
-                attn_block_launch(aa, aa.B < ncu ? aa.B : ncu, s);
-            };
+            op.run = [a, ncu](hipStream_t s, const StepCtx&) { attn_block_launch(a, a.B < ncu ? a.B : ncu, s); };
             step.push_back(std::move(op));
             return 0;
         }
@@ -893,11 +769,8 @@ int Plan::build_impl() {
             const float scale = 1.0f / std::sqrt((float)Cc);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)
             op.flop = 4.0 * B * 8 * (double)n * n * 16;
             op.bytes = 4.0 * B * n * 4.0 * Cc;
-            op.win = true;
-            op.run = [qkv, o, n, Cc, BB, scale](hipStream_t s, const StepCtx& ctx) {
-                const int b0 = ctx.bn ? ctx.b0 : 0, bn = ctx.bn ? ctx.bn : BB;
-                hipLaunchKernelGGL(self_attn_mfma_kernel, dim3((n + 63) / 64, 8, bn), dim3(64), 0, s, (const float*)qkv.p + (size_t)b0 * n * 3 * Cc, n, Cc, scale,
-                                   o.p + (size_t)b0 * n * Cc);
+            op.run = [qkv, o, n, Cc, BB, scale](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL(self_attn_mfma_kernel, dim3((n + 63) / 64, 8, BB), dim3(64), 0, s, (const float*)qkv.p, n, Cc, scale, o.p);
             };
             step.push_back(std::move(op));
         }
@@ -1424,15 +1297,9 @@ int Plan::build_impl() {
                 op.cls = (Hl * Wl <= 256) ? 2 : 1;
                 // q.1 on f16x2 (x3), attn_out / attn_res on bf16x3 (x6): weight of the sum
                 op.mfma_w = (3.0 * fea * fea + 6.0 * 2.0 * fea * pm->cout) / ((double)fea * fea + 9.0 * fea + 2.0 * fea * pm->cout);
-                op.win = true;
-                op.run = [a, nstrips, cap](hipStream_t st, const StepCtx& sc) {
-                    LaFuseArgs aa = a;
-                    if (sc.bn) {
-                        aa.b0 = sc.b0;
-                        aa.B = sc.bn;
-                    }
-                    const long nw = (long)aa.B * nstrips;
-                    (void)lafuse_launch(aa, (int)(nw < cap ? nw : cap), st, false);
+                op.run = [a, nstrips, cap](hipStream_t st, const StepCtx&) {
+                    const long nw = (long)a.B * nstrips;
+                    (void)lafuse_launch(a, (int)(nw < cap ? nw : cap), st, false);
                 };
                 step.push_back(std::move(op));
                 fused_attn = true;
@@ -1482,12 +1349,7 @@ int Plan::build_impl() {
             op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
             const size_t sm = (size_t)(Hl + 2) * (Wl + 2) * 36 * sizeof(float);
             if (sm > 64 * 1024) DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_dw3x3_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-            op.win = true;
-            op.run = [a, BB, fea, sm](hipStream_t s, const StepCtx& ctx) {
-                DwArgs aa = a;
-                aa.b0 = ctx.bn ? ctx.b0 : 0;
-                hipLaunchKernelGGL(gn_dw3x3_small_kernel, dim3((fea + 31) / 32, ctx.bn ? ctx.bn : BB), dim3(256), sm, s, aa);
-            };
+            op.run = [a, BB, fea, sm](hipStream_t s, const StepCtx&) { hipLaunchKernelGGL(gn_dw3x3_small_kernel, dim3((fea + 31) / 32, BB), dim3(256), sm, s, a); };
             step.push_back(std::move(op));
             ConvSpec s;
             s.pc = pq1;
@@ -1523,11 +1385,8 @@ int Plan::build_impl() {
             op.name = "q.softmax_stats";
             op.cls = 4;
             op.bytes = 8.0 * B * Hl * Wl * fea;
-            op.win = true;
-            op.run = [q, qmx, qsm, fea, BB, Hl, Wl](hipStream_t s, const StepCtx& ctx) {
-                const int b0 = ctx.bn ? ctx.b0 : 0, bn = ctx.bn ? ctx.bn : BB;
-                hipLaunchKernelGGL(softmax_stats_kernel, ew_grid((size_t)bn * Wl * fea), dim3(256), 0, s, (const float*)q.p + (size_t)b0 * Hl * Wl * fea, fea, 0, fea, bn, Hl, Wl,
-                                   0, qmx + (size_t)b0 * Wl * fea, qsm + (size_t)b0 * Wl * fea);
+            op.run = [q, qmx, qsm, fea, BB, Hl, Wl](hipStream_t s, const StepCtx&) {
+                hipLaunchKernelGGL(softmax_stats_kernel, ew_grid((size_t)BB * Wl * fea), dim3(256), 0, s, (const float*)q.p, fea, 0, fea, BB, Hl, Wl, 0, qmx, qsm);
             };
             step.push_back(std::move(op));
         }
@@ -1574,59 +1433,7 @@ int Plan::build_impl() {
             DDIF_TRY(add_conv(step, s, &amix));
         }
         }  // !fused_attn
-        bool fused_ffn = false;
-        {   // the whole feed-forward half in one launch, the 2C-channel intermediate on chip (kernels_ffn.h): inference plans, the f16x2 path, supported shapes
-            const PackedConv *p0 = PC(ci + ".ffn.0"), *pm = train_mode ? nullptr : PC(ci + ".ffn.23");
-            if (p0 && pm && !train_mode && g_math_mode == 0 && ffnfuse_enabled() && f16_enabled() && x3_enabled() && p0->w_f16 && pm->w_f16 && pm->bias && p0->ks == 3 &&
-                pm->ks == 3 && p0->ck == 16 && pm->ck == 16 && p0->cin == amix.C && pm->cin == p0->cout && pm->cout == amix.C && ffnfuse_supported(amix.C, p0->cout) &&
-                amix.H * amix.W > 256 && (size_t)B * amix.H * amix.W * p0->cout * 4 < ((size_t)1 << 32)) {
-                use(amix.p);
-                DDIF_TRY(alloc_tensor(&f3, amix.C, amix.H, amix.W, true));
-                FfnFuseArgs a{};
-                a.x = amix.p;
-                a.w0 = p0->w_f16;
-                a.w1 = pm->w_f16;
-                a.bias = pm->bias;
-                a.out = f3.p;
-                a.B = B;
-                a.H = amix.H;
-                a.W = amix.W;
-                a.tiles_x = (amix.W + 15) / 16;
-                a.tiles_y = (amix.H + 15) / 16;
-                f3.np = a.tiles_x * a.tiles_y;
-                if (int e = dalloc(&f3.st, (size_t)B * f3.np * 2)) return e;
-                a.st_out = f3.st;
-                if (!dry) DDIF_TRY(ffnfuse_launch(a, 1, nullptr, true));
-                long cap = num_cus();
-                if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
-                const int tiles = a.tiles_x * a.tiles_y;
-                Op op;
-                op.name = "ffn_fused";
-                {
-                    char lb[160];
-                    snprintf(lb, sizeof lb, "ffn_fused ffn.0+SiLU+ffn.3(ffn.2)+res %d->%d->%d @%dx%d", amix.C, p0->cout, pm->cout, amix.H, amix.W);
-                    op.label = lb;
-                }
-                op.flop = 2.0 * B * amix.H * amix.W * 9.0 * 2.0 * (double)amix.C * p0->cout;
-                op.bytes = 4.0 * B * amix.H * amix.W * 2.0 * amix.C;
-                op.cls = 0;
-                op.mfma_w = 3;
-                op.timed = true;
-                op.win = true;
-                op.run = [a, tiles, cap](hipStream_t st, const StepCtx& sc) {
-                    FfnFuseArgs aa = a;
-                    if (sc.bn) {
-                        aa.b0 = sc.b0;
-                        aa.B = sc.bn;
-                    }
-                    const long nw = (long)aa.B * tiles;
-                    (void)ffnfuse_launch(aa, (int)(nw < cap ? nw : cap), st, false);
-                };
-                step.push_back(std::move(op));
-                fused_ffn = true;
-            }
-        }
-        if (!fused_ffn) {
+        {
             ConvSpec s;
             s.pc = PC(ci + ".ffn.0");
             if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.ffn.0 missing", ci.c_str());
@@ -1966,7 +1773,6 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
     // the host copies above must have been consumed before `run` (stack) goes away: pageable H2D copies are staged
     // synchronously by the runtime, so returning after the enqueue is safe.
 
-    if (int e = ensure_fork_resources()) return e;
     auto one_step = [&](int parity, hipStream_t st, bool prof) {
         StepCtx ctx;
         ctx.x = ctx.sc = img[parity];  // self-conditioning == current image (diffusion_ddpm_pan.py:491,502; sr3_dwt.py:173)
@@ -1978,7 +1784,7 @@ int Plan::run_sampler(int kind, int n_steps, const float* const* tabs_host, int 
         ctx.samp_kind = kind;
         ctx.samp_out = final_fused ? img[parity ^ 1] : nullptr;
         ctx.tb_rowstride = net->nslots;
-        run_step_prog(st, ctx, prof);
+        run_prog(step, st, ctx, prof);
         StepArgs a{};
         a.x0 = net_out.p;
         a.img = img[parity];
@@ -2141,7 +1947,6 @@ int Plan::sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, floa
     const size_t n = (size_t)B * HW * C;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, ew_grid(n), dim3(256), 0, s, xT, B, C, HW, 0, C, img[0]);
     if (int e = time_rows(t->t_model, t->n_evals, s)) return e;
-    if (int e = ensure_fork_resources()) return e;
     int cur = 0;
     float* hist[3] = {nullptr, nullptr, nullptr};  // newest first
     int nhist = 0, slot = 0;
@@ -2150,7 +1955,7 @@ int Plan::sample_dpmpp(const ddif_dpm_tables* t, const float* xT, float lo, floa
         ctx.x = ctx.sc = img[cur];  // model_wrapper never passes self_cond (dpm_solver.py:295) -> x
         ctx.tb = tb + (size_t)k * net->nslots;
         const bool prof = prof_every > 0 && (k % prof_every) == 0;
-        run_step_prog(s, ctx, prof);
+        run_prog(step, s, ctx, prof);
         float* mnew = mbuf[slot];
         slot = (slot + 1) % 3;
         hipLaunchKernelGGL(dpm_x0_kernel, ew_grid(n), dim3(256), 0, s, (const float*)net_out.p, (const float*)img[cur], (const float*)lms.p,

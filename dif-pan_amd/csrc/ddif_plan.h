@@ -22,7 +22,6 @@ struct StepCtx {
     int tb_stride = 0;          // floats between the rows of consecutive samples (0: one row for the batch)
     const int* step_ptr = nullptr;  // samplers: device step counter selecting the time-bias row (row stride tb_rowstride)
     int tb_rowstride = 0;
-    int b0 = 0, bn = 0;         // batch window [b0, b0 + bn) of a forked region (bn = 0: the whole batch)
     // DDPM / DDIM loops: the sampler update runs in the final conv's epilogue (kernels_conv.h EPI_SAMP) when the plan carries that variant
     float* samp_out = nullptr;      // x_{t-1} (null: plain network output)
     const void* samp_run = nullptr; // device SamplerRun
@@ -35,7 +34,6 @@ struct Op {
     double flop = 0, bytes = 0;
     double mfma_w = 16;  // matrix-pipe issue weight of the op's flops in units of the dense 16-bit MFMA rate: 3 = f16x2, 6 = bf16x3, 16 = exact fp32 MFMA / VALU
     bool timed = false;  // member of the dominant kernel class (3x3 implicit-GEMM convs at the high-resolution levels)
-    bool win = false;    // the launch honours StepCtx's batch window (every op of the eval-mode step program does)
     bool side = false;   // train-mode cond-only program: a decoder-only op -- issued on the plan's side stream, joined in front of the first decoder block
     int cls = 5;         // profiling class: 0 conv3x3 (> 256 px / sample), 1 conv1x1 (> 256 px), 2 low-resolution levels, 3 attention, 4 softmax statistics, 5 other
     const char* name = "";
@@ -60,10 +58,6 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3);  // ddif_lr.cpp
 // ddif_set_math_mode (include/ddif.h): 0 = fp32-class split products (default), 1 = the bf16 throughput variant, for plans built afterwards
 extern int g_math_mode;
-// fused feed-forward half of a decoder block (kernels_ffn.h, ddif_ffn.cpp)
-struct FfnFuseArgs;
-bool ffnfuse_supported(int C, int CM);
-int ffnfuse_launch(const FfnFuseArgs& a, int grid, hipStream_t s, bool prepare_only);
 // fused linear-attention block (kernels_lafuse.h, ddif_la.cpp)
 struct LaFuseArgs;
 bool lafuse_supported(int H, int fea, int dout);
@@ -176,16 +170,6 @@ struct Plan {
     hipStream_t cap_stream = nullptr;
     void* graph_exec[2] = {nullptr, nullptr};  // [0] DDPM pair, [1] DDIM pair
     bool use_graph = true;
-    // forked regions: runs of launch-latency-bound ops (the 8x8 / 16x16 levels) are executed as `split_k` independent sub-batches on
-    // concurrent streams (branches of the captured graph): tiles never mix, so any op runs on any batch window; while one sub-batch
-    // waits out a launch's latency chain the others compute
-    int split_k = 1;
-    std::vector<std::pair<int, int>> regions;  // [first, last) op index ranges of the step program that fork
-    std::vector<hipStream_t> side;              // split_k - 1 side streams
-    std::vector<hipEvent_t> fork_ev, join_ev;
-    void compute_regions();
-    int ensure_fork_resources();
-    void run_step_prog(hipStream_t s, const StepCtx& ctx, bool prof);  // the step program, forking where `regions` say so (unless profiled)
 
     // profiling
     int prof_every = 0, prof_max = 0;

@@ -120,18 +120,24 @@ enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_
 // 4 = "bf16x1", the THROUGHPUT variant (BASELINE configs[1] "bf16"; never the default, never a parity configuration): both operands rounded once to
 // bf16, ONE product per slab on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 tensors / GroupNorm statistics / epilogue as everywhere else.
 // One LDS plane per operand (32 B per pixel and chunk + 16 B pad).  Selected only by ddif_set_math_mode(DDIF_MATH_BF16) / DDIF_MATH=bf16.
+// 5 = f16x2 with RESIDENT weights (round 5; 3x3 convs whose whole input is ONE CK = 32 channel stage and whose couts are one tile: 32 -> 32 at the
+// 64 x 64 level): the cout tile's weights (36 KB) are copied into LDS once per workgroup and stay there for all of its work items, a stage is a whole
+// item (18 MFMA steps, one barrier, no weight re-staging: half the staged bytes, half the barriers, twice the tile bytes in flight per prefetch).
+// The weights are the MATH = 3 pack for 16-channel chunks read slab-major (step f = slab * 9 + tap), i.e. the products are accumulated in exactly
+// the order of MATH = 3 with CK = 16: bit-identical results.
 template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int WM, int WN, int MB, int NB, int PRO, int VEC, int EPI = 0, int ABL = 0, int MATH = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PAD = KS / 2;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr bool X3 = MATH >= 1;   // split-operand paths (bf16x3, f16x2): 16-bit planes in LDS
-    constexpr bool F16 = MATH == 3;
+    constexpr bool F16 = MATH == 3 || MATH == 5;
+    constexpr bool WR = MATH == 5;   // weights resident in LDS for the whole launch (host: n_chunks == 1, n_ct == 1, shared weights)
     constexpr bool B1 = MATH == 4;
     constexpr int NPL = F16 ? 2 : (B1 ? 1 : 3); // operand planes
     constexpr bool WSB = MATH == 2;  // ONE weight buffer (an extra barrier per stage): 69 KB of LDS -> two workgroups per CU, whose VALU
                                      // staging and bf16 MFMAs then overlap (different pipes)
-    constexpr int NWB = WSB ? 1 : 2;
+    constexpr int NWB = (WSB || WR) ? 1 : 2;
     constexpr int PS = CK / 2;                            // X3: floats per bf16 plane of one staged pixel (CK x 2 B)
     constexpr int LDA = X3 ? NPL * PS + 4 : CK + 4;       // floats per staged pixel (X3: NPL planes + 16 B pad)
     constexpr int LDH = CK + 4;                           // row of the fp32 scratch tile of the depthwise prologue
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     // row pad of the staged tile (floats): lanes 0-15 / 16-31 of an A-fragment read own consecutive pixels of two ROWS of the tile;
     // with a halo the row stride IW * LDA puts the second row on the banks of the first (2-way conflicts on every ds_read_b128 of
     // the 16-wide tile, 3-way on the 8-wide one); these pads make the reads conflict-free (bank search: DESIGN section 3)
-    constexpr int RP = (X3 && KS == 3 && STRIDE == 1) ? (NPL == 2 ? 24 : (NPL == 1 ? 40 : 8)) : 0;
+    constexpr int RP = (X3 && KS == 3 && STRIDE == 1) ? (WR ? (64 - (IW * LDA) % 64) % 64 : (NPL == 2 ? 24 : (NPL == 1 ? 40 : 8))) : 0;  // WR (CK = 32, 16-wide tiles): row stride = 0 mod 64 banks
     constexpr int LDR = IW * LDA + RP;                    // floats per staged tile row
     constexpr int ABUF = IH * LDR;                        // floats per LDS buffer
     // PRO_GN_DW (1x1 conv over depthwise3x3(GroupNorm(x))): the LOAD tile has a one-pixel halo and goes to a scratch
@@ -163,7 +169,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NITEMS = (LH * LW * C4 + NTHR - 1) / NTHR;  // float4 input-staging items per thread and chunk
     constexpr int WCHUNK = X3 ? NF * NPL * 256 : NF * 256;  // floats per (32-cout block, chunk): X3 = NPL 16-bit planes of 1 KiB per step
     constexpr int WBUF = NB * WN * WCHUNK;                // floats of one weight chunk (all n-blocks of the cout tile)
-    constexpr int WITEMS = (WBUF / 4 + NTHR - 1) / NTHR;  // float4 weight-staging items per thread and chunk
+    constexpr int WITEMS = WR ? 0 : (WBUF / 4 + NTHR - 1) / NTHR;  // float4 weight-staging items per thread and chunk (WR: none, the prologue copies them once)
+    constexpr int WITEMS_A = WITEMS ? WITEMS : 1;
+    constexpr int WRI = WR ? (WBUF / 4 + NTHR - 1) / NTHR : 1;  // WR: float4 items per thread of the one-time weight copy
     constexpr int DUMMY = DWM ? CK : (X3 ? NPL * PS : CK);  // pad slot of pixel 0 of the buffer the staging items go to (Hs for the
                                                           // depthwise prologue, else the A buffer): items past the end write here
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per workgroup");
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     static_assert(NITEMS <= 32, "valid mask is 32 bits");
     static_assert(!F16 || PRO != PRO_COLSM, "f16x2: the column-softmax prologue stays on bf16x3 / fp32 (probabilities far below 2^-7)");
     static_assert(RP == 0 || !DWM, "row pad: 3x3 tiles only");
+    static_assert(!WR || (KS == 3 && STRIDE == 1 && !UPS && CK == 32 && TW == 16 && !DWM), "resident weights: plain 3x3 convs with one 32-channel stage");
 
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
@@ -248,8 +257,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         a_lds[it] = in ? (DWM ? pix * LDH + c4 * 4 : (X3 ? a_py[it] * LDR + a_px[it] * LDA + c4 * 2 : pix * LDA + c4 * 4)) : DUMMY;
         a_in |= (in ? 1u : 0u) << it;
     }
-    unsigned w_boff[WITEMS];
-    int w_lds[WITEMS];  // relative to Ws[buf]; items past the end go to the A buffer's dummy slot (negative)
+    unsigned w_boff[WITEMS_A];
+    int w_lds[WITEMS_A];  // relative to Ws[buf]; items past the end go to the A buffer's dummy slot (negative)
 #pragma unroll
     for (int it = 0; it < WITEMS; ++it) {
         const int qr = tid + it * NTHR;
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     };
 
     struct StageRegs {
-        float4 sv[NITEMS], wv[WITEMS];
+        float4 sv[NITEMS], wv[WITEMS_A];
         float4 mxv[PRO == PRO_COLSM ? NITEMS : 1], smv[PRO == PRO_COLSM ? NITEMS : 1];
         unsigned ok;
         int cb, ch;  // first channel of the chunk, chunk index
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     };
     auto fs_witem = [&](StageRegs& R, int buf, int it) {
         float* dst = As + buf * ABUF;
-        float* wdst = Ws + (WSB ? 0 : buf) * WBUF;
+        float* wdst = Ws + ((WSB || WR) ? 0 : buf) * WBUF;
         float* wp = w_lds[it] >= 0 ? wdst + w_lds[it] : dst + DUMMY;
         *reinterpret_cast<float4*>(wp) = R.wv[it];
     };
@@ -653,14 +662,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         if constexpr (ILV && !TAIL) fs_begin(Rn);
         // (3) contraction over taps x chunk channels: both fragments from LDS, no global load in here.  Weights are
         //     the MFMA's FIRST operand: D[cout][pixel] (see the header comment).
-        const float* Wc = Ws + (WSB ? 0 : cur) * WBUF + (wn * NB) * WCHUNK + h * 128 + j * 4;
+        const float* Wc = Ws + ((WSB || WR) ? 0 : cur) * WBUF + (wn * NB) * WCHUNK + h * 128 + j * 4;
         if constexpr (X3) {
             //     bf16x3: per tap one 16-channel slab; three planes per operand, six cross products, small terms first;
             //     the fragments of tap t+1 are read before the MFMAs of tap t (register double buffer)
             constexpr int FB = (MB * NB >= 2) ? 1 : 2;  // register double buffer only for the single-tile shapes (wide cout tiles would spill)
             float4 xa[FB][MB][NPL], wb[FB][NB][NPL];
             auto load_frags3 = [&](int f, int slot) {  // step f = (tap, 16-channel slab)
-                const int tap = f / K16, k16 = f % K16;
+                // WR: the pack is [16-channel chunk][tap] (the MATH = 3, CK = 16 pack), so step f walks slab-major -- the accumulation order of MATH = 3
+                const int tap = WR ? f % TAPS : f / K16, k16 = WR ? f / TAPS : f % K16;
                 const int aoff = (tap / KS) * LDR + (tap % KS) * LDA + k16 * 8;
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
@@ -905,8 +915,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             t_dw[k] = a.dw_w[i < 9 * Ctot ? i : 9 * Ctot - 1];
         }
     }
+    // WR: the cout tile's weights, once per workgroup (L2 hits for all but the first workgroups of an XCD); five named registers, not an array
+    // (hipcc leaves a float4 array that is live across the branches below in scratch)
+    [[maybe_unused]] float4 t_w0, t_w1, t_w2, t_w3, t_w4;
+    static_assert(WRI <= 5, "resident weights: at most five float4 per thread");
+    if constexpr (WR) {
+        const float4* wsrc = reinterpret_cast<const float4*>(a.w);
+        auto wld = [&](int k) { const int i = tid + k * NTHR; return wsrc[i < WBUF / 4 ? i : WBUF / 4 - 1]; };
+        t_w0 = wld(0);
+        if (WRI > 1) t_w1 = wld(1);
+        if (WRI > 2) t_w2 = wld(2);
+        if (WRI > 3) t_w3 = wld(3);
+        if (WRI > 4) t_w4 = wld(4);
+    }
     if (GNP) gn_load_partials(a.st0, a.np0, a.st1, a.np1, R0.pos.b, &gp);
     // ... and now the uses
+    if constexpr (WR) {
+        auto wst = [&](int k, const float4& v) { const int i = tid + k * NTHR; *reinterpret_cast<float4*>(i < WBUF / 4 ? &Ws[i * 4] : As + DUMMY) = v; };  // past the end: the A buffer's pad slot
+        wst(0, t_w0);
+        if (WRI > 1) wst(1, t_w1);
+        if (WRI > 2) wst(2, t_w2);
+        if (WRI > 3) wst(3, t_w3);
+        if (WRI > 4) wst(4, t_w4);
+    }
     if (GNP) {
 #pragma unroll
         for (int k = 0; k < TBL; ++k) {
@@ -958,10 +989,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 #endif
     const int npairs = nflat >> 1;
     for (int pr = 0; pr < npairs; ++pr) {
-        if (bufch[0] == a.n_chunks - 1) stage(StageKind<1>{}, 0, R1, R0);
+        if (WR || bufch[0] == a.n_chunks - 1) stage(StageKind<1>{}, 0, R1, R0);   // WR: every stage is a whole item
         else stage(StageKind<0>{}, 0, R1, R0);
         __syncthreads();
-        if (bufch[1] == a.n_chunks - 1) stage(StageKind<1>{}, 1, R0, R1);
+        if (WR || bufch[1] == a.n_chunks - 1) stage(StageKind<1>{}, 1, R0, R1);
         else stage(StageKind<0>{}, 1, R0, R1);
         __syncthreads();
     }
@@ -976,10 +1007,10 @@ template <int KS, int STRIDE, int UPS, int TH, int TW, int CK, int NBT, int PRO 
 constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgroup = NB * WN; + conv_smem_extra() at launch
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr size_t dw = PRO == PRO_GN_DW ? (size_t)((TH + 2) * (TW + 2) * (CK + 4) + 9 * 256) : 0;
-    constexpr int npl = MATH == 3 ? 2 : (MATH == 4 ? 1 : 3);
+    constexpr int npl = (MATH == 3 || MATH == 5) ? 2 : (MATH == 4 ? 1 : 3);
     constexpr int lda = MATH >= 1 ? npl * CK / 2 + 4 : CK + 4, wchunk = MATH >= 1 ? KS * KS * (CK / 16) * npl * 256 : KS * KS * (CK / 8) * 256;
-    constexpr int rp = (MATH >= 1 && KS == 3 && STRIDE == 1) ? (npl == 2 ? 24 : (npl == 1 ? 40 : 8)) : 0;
-    return (size_t)(2 * IH * (IW * lda + rp) + (MATH == 2 ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
+    constexpr int rp = (MATH >= 1 && KS == 3 && STRIDE == 1) ? (MATH == 5 ? (64 - (IW * lda) % 64) % 64 : (npl == 2 ? 24 : (npl == 1 ? 40 : 8))) : 0;
+    return (size_t)(2 * IH * (IW * lda + rp) + ((MATH == 2 || MATH == 5) ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
 }
 // GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts
 inline size_t conv_smem_extra(int pro, int n_chunks, int ck, int cout_pad) {

@@ -357,17 +357,13 @@ class GaussianDiffusion(nn.Module):
         kernels read are re-packed from the parameter tensors on the device when they changed (`ddif_net_refresh`), the Dropout / DropPath
         masks come from the library's counter-based generator keyed by (seed, site, GLOBAL tile index `self.train_tile0 + b`, element) --
         so a batch split over ranks draws the masks the unsplit batch would -- or are the ones pinned with `model.set_train_masks`.
-        `DDIF_TRAIN_TAPE=1` selects round 2's op-by-op Python tape (tests/train_tape.py, test scaffolding) instead (kept as a cross-check of the native program)."""
-        import os
-
+        (Round 2's op-by-op Python tape is test scaffolding: tests/train_tape.py `tape_train_step`, which the cross-check test patches in for `_train_step`.)"""
         if self.loss_type != "l1":
             raise DdifError("training: only loss_type='l1' (the engine configuration) has a backward pass")
         if float(getattr(self, "p2_loss_weight_gamma", 0.0)) != 0.0:
             raise DdifError("training: p2 loss weighting is not implemented by the backward pass")
         model = self.model
         named = [(n, p) for n, p in model.named_parameters()]
-        if os.environ.get("DDIF_TRAIN_TAPE", "0") == "1":
-            return self._train_step_tape(x_start, noise, a, s, t, cond, x_self_cond, named)
         plan = self._native_plan(x_start, cond, named)
         gb = getattr(plan, "_grad_bufs", None)
         if gb is None:
@@ -434,26 +430,6 @@ class GaussianDiffusion(nn.Module):
         plan = self._native_plan(x_start, cond, named)
         self._bind(plan, named, grads)
         return plan.train_step(x_start, noise, a, s, t, x_self_cond)
-
-    def _train_step_tape(self, x_start, noise, a, s, t, cond, x_self_cond, named):
-        from .. import functional as DF
-        try:  # round 2's op-by-op tape is test scaffolding (tests/train_tape.py): an independent cross-check of the native reverse program
-            from train_tape import TrainGraph, TrainStepFn
-        except ImportError as e:
-            raise DdifError("DDIF_TRAIN_TAPE=1 selects the op-by-op training tape, which lives in tests/train_tape.py (put tests/ on sys.path); "
-                            "the product path is the native step") from e
-
-        model = self.model
-        graph = TrainGraph(model.cfg, dropout=float(model.cfg["dropout"]), drop_path=model.DROP_PATH_PROB)  # one tape per call (gradient accumulation safe)
-        names = tuple(n for n, _ in named)
-        x_noisy = DF.q_sample(x_start, noise, a, s)
-        pinned = getattr(model, "_train_masks", None)
-        drop_masks, path_scales = (None, None)
-        if pinned is not None:
-            drop_masks, paths = pinned
-            path_scales = None if paths is None else [paths[k] for k in range(paths.shape[0])]
-        loss, pred = TrainStepFn.apply(graph, names, x_noisy, t, cond, x_self_cond, x_start, drop_masks, path_scales, *[p for _, p in named])
-        return loss, pred
 
     def forward(self, x, mode="train", *args, **kwargs):
         if mode == "train":

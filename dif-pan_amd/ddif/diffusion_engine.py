@@ -490,7 +490,6 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
                    os.path.join(save_dir, f"train_state_{name}_iter_{it}.pth"))
 
     net.train()
-    native = os.environ.get("DDIF_TRAIN_TAPE", "0") != "1"
     tile_counter = resume_tiles
     if world > 1:
         diffusion.train_mask_seed = (int(data_seed) + 1) * 1_000_003  # same mask stream on every rank, keyed by GLOBAL tile index below
@@ -502,13 +501,7 @@ def engine_google(train_dataset_path, valid_dataset_path, dataset_name=None, ima
             res = (hr / div - lms_n).contiguous()
             diffusion.train_tile0 = tile_counter * world + rank * res.shape[0]  # global index of this rank's first sample: masks do not depend on the split
             tile_counter += res.shape[0]
-            if native:
-                diff_loss, recon_x = diffusion.train_step_into(res, cond, grads)  # gradients written straight into `grads` (no zeroing needed)
-            else:
-                for g in grads:
-                    g.zero_()
-                diff_loss, recon_x = diffusion(res, cond=cond)
-                diff_loss.backward()
+            diff_loss, recon_x = diffusion.train_step_into(res, cond, grads)  # gradients written straight into `grads` (no zeroing needed)
             if world > 1:
                 average_gradients(grads, world)
             opt.lr = lr_at(iterations, lr_d)

@@ -8,15 +8,12 @@
                 split-K kernel (kernels_lr.h) -- the golden cases at 16x16 / 32x32 otherwise run almost entirely on the
                 latter, so this is what keeps the general kernel's small-tile instantiations covered.
 
-  DDIF_FFNFUSE=1 the decoder's feed-forward half at the top level as ONE launch with the 2C-channel intermediate in LDS (csrc/kernels_ffn.h) -- opt-in: correct but
-                not faster than the two conv launches (profiles/r04_t_ffn_fused_ab.txt); it must stay correct and bit-stable across batch sizes.
+  DDIF_F16=0    the split-operand convs on bf16x3 (six products) instead of f16x2 (three);
+  DDIF_LAFUSE=0 the decoder's linear-attention half as three launches instead of the fused block (csrc/kernels_lafuse.h).
 
-  DDIF_SPLIT=4  the low-resolution region of every denoising step as 4 concurrent sub-batches (batch windows of every launch, forked
-                branches of the captured graph; csrc/ddif_plan.cpp run_step_prog) -- measured slower on MI355X and OFF by default, but it
-                must stay correct: device-RNG DDPM at B = 64 bit-equal to per-tile runs, and the T = 20 batch-64 job against the oracle.
-
-All other A/B switches of round 1 (wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides) were
-deleted together with their code."""
+All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
+kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04_t_*, r03_b_*) were deleted together with
+their code."""
 import os
 import subprocess
 import sys
@@ -31,9 +28,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
          "or test_forward_matches_oracle_other_sizes and 8x8")
 
 
-@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"},
-                                 {"DDIF_FFNFUSE": "1"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "FFNFUSE=1"])
+@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
@@ -66,30 +62,3 @@ def test_training_gradients_on_the_exact_fp32_convs():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout, tail
-
-
-
-def test_fused_feed_forward_kernel_is_bit_stable_across_batch_sizes():
-    """DDIF_FFNFUSE=1 (opt-in, kernels_ffn.h: the decoder's feed-forward half at the top level as one launch, the intermediate on chip): the halo of the
-    intermediate is recomputed per tile from the input alone, so the B = 64 results must still be bit-equal to single-tile runs and match the oracle."""
-    e = dict(os.environ)
-    e["DDIF_FFNFUSE"] = "1"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_batch64.py"), "-m", "gpu", "-x", "-q",
-                        "-k", "device_rng_batch64 or reference_noise_vs_single_tiles or forward_batch64 or capped_grid", "-p", "no:cacheprovider"], env=e, cwd=ROOT,
-                       capture_output=True, text=True, timeout=1500)
-    tail = (r.stdout + r.stderr)[-3000:]
-    assert r.returncode == 0, tail
-    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
-
-
-def test_forked_low_resolution_region_is_bit_exact():
-    """DDIF_SPLIT=4: batch windows + forked graph branches.  Tiles never mix, so the B = 64 results must still be bit-equal to single-tile
-    runs (which never fork) and match the oracle."""
-    e = dict(os.environ)
-    e["DDIF_SPLIT"] = "4"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_batch64.py"), "-m", "gpu", "-x", "-q",
-                        "-k", "device_rng_batch64 or reference_noise_vs_single_tiles or forward_batch64", "-p", "no:cacheprovider"], env=e, cwd=ROOT,
-                       capture_output=True, text=True, timeout=1500)
-    tail = (r.stdout + r.stderr)[-3000:]
-    assert r.returncode == 0, tail
-    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail

@@ -383,7 +383,7 @@ def test_engine_google_trains_on_after_validation_checkpoints_and_resumes(backen
 def test_native_step_equals_the_op_by_op_tape_at_the_benchmark_tile_size(backend, monkeypatch):
     """The reference golden pins the native step at 16 x 16 tiles.  At the benchmark's 64 x 64 (other band / line-group geometries of the
     weight-gradient, linear-attention and depthwise kernels, all four resolution levels at their real sizes) the native forward + reverse
-    program is compared with round 2's op-by-op tape (`DDIF_TRAIN_TAPE=1`: the stateless NCHW ops of csrc/kernels_bwd_ops.h, each pinned
+    program is compared with round 2's op-by-op tape (tests/train_tape.py `tape_train_step`: the stateless NCHW ops of csrc/kernels_bwd_ops.h, each pinned
     against autograd in tests/test_backward_ops.py) on the same inputs, timesteps and pinned masks: loss, prediction and the gradient of every
     one of the 702 parameters."""
     from ddif_testlib import make_diffusion, make_net
@@ -408,10 +408,11 @@ def test_native_step_equals_the_op_by_op_tape_at_the_benchmark_tile_size(backend
         net.set_train_masks([m.clone() for m in masks], paths.clone())
 
         def run(tape):
-            monkeypatch.setenv("DDIF_TRAIN_TAPE", "1" if tape else "0")
+            from train_tape import tape_train_step
+
             for p in net.parameters():
                 p.grad = None
-            loss, pred = d._train_step(x0, noise, a, s, t, cond, sc)
+            loss, pred = tape_train_step(d, x0, noise, a, s, t, cond, sc) if tape else d._train_step(x0, noise, a, s, t, cond, sc)
             loss.backward()
             return float(loss.detach()), pred.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
 

@@ -367,3 +367,20 @@ class TrainStepFn(torch.autograd.Function):
         dy = R.l1_loss_backward(ctx.y, ctx.target, upstream=float(gloss))
         G = ctx.graph.backward(dy)
         return (None,) * 9 + tuple(G.get(n) for n in ctx.names)
+
+
+def tape_train_step(diffusion, x_start, noise, a, s, t, cond, x_self_cond):
+    """`GaussianDiffusion._train_step` on the op-by-op tape instead of the native step (same signature, same (loss, pred) result with an autograd
+    node behind `loss`): the cross-check test patches this in; the product package never imports it."""
+    model = diffusion.model
+    named = [(n, p) for n, p in model.named_parameters()]
+    graph = TrainGraph(model.cfg, dropout=float(model.cfg["dropout"]), drop_path=model.DROP_PATH_PROB)  # one tape per call (gradient accumulation safe)
+    names = tuple(n for n, _ in named)
+    x_noisy = F.q_sample(x_start, noise, a, s)
+    pinned = getattr(model, "_train_masks", None)
+    drop_masks, path_scales = (None, None)
+    if pinned is not None:
+        drop_masks, paths = pinned
+        path_scales = None if paths is None else [paths[k] for k in range(paths.shape[0])]
+    loss, pred = TrainStepFn.apply(graph, names, x_noisy, t, cond, x_self_cond, x_start, drop_masks, path_scales, *[p for _, p in named])
+    return loss, pred

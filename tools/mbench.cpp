@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
 #include "ddif_net.h"
 #include "kernels_conv.h"
 using namespace ddif;
@@ -12,6 +15,8 @@ namespace ddif { thread_local std::string g_err; int fail(int c, const char*, ..
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
+static std::vector<float> g_last_out;  // output of the previous run (mode r compares two instantiations bit for bit)
+static bool g_keep_out = false;
 template <int KS, int S, int U, int TH, int TW, int CKc, int WM, int WN, int MB, int NB, int PRO, int ABL, int EPI = 0, int MATH = 0>
 void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu) {
     const int Hout = S == 2 ? (H - 1) / 2 + 1 : (U ? 2 * H : H), Wout = S == 2 ? (W - 1) / 2 + 1 : (U ? 2 * W : W);
@@ -23,6 +28,11 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
     CK_(hipMalloc(&gamma, Cin * 4)); CK_(hipMalloc(&beta, Cin * 4)); CK_(hipMalloc(&bias, Cout * 4));
     std::vector<float> h(std::max(std::max(nin, nw), nout)); for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-3f;
     CK_(hipMemcpy(in, h.data(), nin * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(w, h.data(), nw * 4, hipMemcpyHostToDevice));
+    std::vector<_Float16> hw;
+    if (MATH == 3 || MATH == 5) {  // valid halves (the float bit patterns above contain half NaNs): hi / lo planes of small numbers
+        hw.resize(nw * 2); for (auto& v : hw) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
+        CK_(hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    }
     CK_(hipMemcpy(res, h.data(), nout * 4, hipMemcpyHostToDevice));
     CK_(hipMemcpy(gamma, h.data(), Cin * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(beta, h.data(), Cin * 4, hipMemcpyHostToDevice));
     CK_(hipMemcpy(bias, h.data(), Cout * 4, hipMemcpyHostToDevice));
@@ -60,6 +70,46 @@ void run(const char* name, int B, int H, int W, int Cin, int Cout, int wg_per_cu
             for (int i = 0; i < 126 && hd[blk * 128 + i]; ++i) printf(" %lld%s", hd[blk * 128 + i] - t0, (i % 5 == 3) ? " |" : ""); printf("\n"); }
     }
     printf("%-46s abl=%2d wg/cu=%d grid=%5u smem=%6zu  %8.1f us  %6.1f TF\n", name, ABL, wg_per_cu, grid.x, smem, us, flop / us / 1e6);
+    if (g_keep_out) {
+        std::vector<float> ho(nout); CK_(hipMemcpy(ho.data(), out, nout * 4, hipMemcpyDeviceToHost));
+        if (g_last_out.size() == nout) {
+            size_t nd = 0; double mx = 0; for (size_t i = 0; i < nout; ++i) { if (memcmp(&ho[i], &g_last_out[i], 4)) { ++nd; mx = std::max(mx, (double)fabsf(ho[i] - g_last_out[i])); } }
+            std::vector<double> hst((size_t)B * np * 2); CK_(hipMemcpy(hst.data(), sto, hst.size() * 8, hipMemcpyDeviceToHost));
+            double ss = 0; for (double v : hst) ss += v;
+            printf("    vs previous run: %zu of %zu outputs differ (max |d| %.3g); out[1000] = %.6f, sum of partials %.6f\n", nd, nout, mx, ho[1000], ss);
+        }
+        if ((MATH == 3 || MATH == 5) && KS == 3 && S == 1 && !U && (PRO == PRO_GN_SILU || PRO == PRO_NONE)) {
+            // host check of 256 outputs in double: weights = (hi + lo) / 2^10 of the packed halves ([n-block][16-channel chunk][tap][plane][half h][cout j][8 cin]),
+            // activations rounded as the kernel stages them (x16, hi + lo halves)
+            const int nch16 = (Cin + 15) / 16; double emax = 0, vmax = 0;
+            const double N = (double)Cin * H * W, mean = 64 * 10.0 / N, var = 64 * 5000.0 / N - mean * mean, rstd = 1.0 / sqrt(var + 1e-5);
+            for (int t = 0; t < 256; ++t) {
+                const int b = (t * 7) % B, y = (t * 13 + (t >> 4)) % H, x = (t * 29 + 3) % W, co = (t * 5) % Cout;
+                double acc = 0;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        double v = h[((size_t)(b * H + iy) * W + ix) * Cin + ci];
+                        if (PRO == PRO_GN_SILU) { const float g = h[ci] * (float)rstd, bb = h[ci] - (float)mean * g; float xn = fmaf((float)v, g, bb); v = xn / (1.0 + exp(-(double)xn)); }
+                        const float vs = (float)v * 16.0f; const _Float16 ah = (_Float16)vs; const _Float16 al = (_Float16)(vs - (float)ah);
+                        const int ch = ci / 16, hh = (ci % 16) / 8, tt = ci % 8, nbi = co / 32, j = co % 32;
+                        const size_t fl = ((((size_t)nbi * nch16 + ch) * 9 + tap) * 2) * 256 + (size_t)(hh * 32 + j) * 4;
+                        const double wh = (double)(float)hw[fl * 2 + tt], wl = (double)(float)hw[(fl + 256) * 2 + tt];
+                        acc += (wh * ((double)(float)ah + (double)(float)al) + wl * (double)(float)ah) ;  // hi*hi + hi*lo + lo*hi (lo*lo dropped, as the kernel does)
+                    }
+                }
+                double ref = acc / 16384.0 + h[co];
+                if (EPI & EPI_RES) ref += h[((size_t)(b * Hout + y) * Wout + x) * Cout + co];
+                if (EPI & EPI_SILU) ref = ref / (1.0 + exp(-ref));
+                const double got = g_last_out.size() ? 0 : 0; (void)got;
+                const double e = fabs(ref - ho[((size_t)(b * Hout + y) * Wout + x) * Cout + co]);
+                emax = std::max(emax, e); vmax = std::max(vmax, fabs(ref));
+            }
+            printf("    host check (256 outputs, fp64): max |err| %.3g, max |ref| %.3g\n", emax, vmax);
+        }
+        g_last_out.swap(ho);
+    }
     hipFree(in); hipFree(w); hipFree(out); hipFree(res); hipFree(gamma); hipFree(beta); hipFree(bias); hipFree(st); hipFree(sto);
 }
 
@@ -105,6 +155,23 @@ int main(int argc, char** argv) {
         run<3, 1, 0, 8, 16, 16, 4, 1, 1, 1, PRO_NONE, 0, EPI_SILU, 3>("3x3 silu 32->64 @64^2 f16x2 4w 8x16 2wg/cu (ffn.0)", B, 64, 64, 32, 64, 2);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0, EPI_RES, 3>("3x3 res 64->32 @64^2 f16x2 8w (ffn.23)", B, 64, 64, 64, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 16, 0, 3>("3x3 gn_silu 32->32 @64^2 f16x2 8w stamps", B, 64, 64, 32, 32, 1);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'r') {  // round 5: resident weights + one 32-channel stage per item (MATH = 5) against MATH = 3 with 16-channel stages
+        g_keep_out = true;
+        srand(7); run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 3>("3x3 gn_silu 32->32 @64^2 f16x2 CK16", B, 64, 64, 32, 32, 1);
+        srand(7); run<3, 1, 0, 16, 16, 32, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 5>("3x3 gn_silu 32->32 @64^2 f16x2 CK32 resident", B, 64, 64, 32, 32, 1);
+        srand(9); run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, EPI_RES, 3>("3x3 gn_silu+res 32->32 @64^2 f16x2 CK16", B, 64, 64, 32, 32, 1);
+        srand(9); run<3, 1, 0, 16, 16, 32, 8, 1, 1, 1, PRO_GN_SILU, 0, EPI_RES, 5>("3x3 gn_silu+res 32->32 @64^2 f16x2 CK32 resident", B, 64, 64, 32, 32, 1);
+        srand(11); run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 0, 0, 3>("3x3 32->32 @64^2 f16x2 CK16 (no prologue)", B, 64, 64, 32, 32, 1);
+        srand(11); run<3, 1, 0, 16, 16, 32, 8, 1, 1, 1, PRO_NONE, 0, 0, 5>("3x3 32->32 @64^2 f16x2 CK32 resident (no prologue)", B, 64, 64, 32, 32, 1);
+        g_keep_out = false;
+        // B = 8 (the GF2 strong-scaling share): latency floor of one launch
+        run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 3>("B=8 3x3 gn_silu 32->32 @64^2 f16x2 CK16", 8, 64, 64, 32, 32, 1);
+        run<3, 1, 0, 16, 16, 32, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 5>("B=8 3x3 gn_silu 32->32 @64^2 f16x2 CK32 resident", 8, 64, 64, 32, 32, 1);
+#define RUNR(ABLV) run<3, 1, 0, 16, 16, 32, 8, 1, 1, 1, PRO_GN_SILU, ABLV, 0, 5>("3x3 gn_silu 32->32 @64^2 f16x2 CK32 resident", B, 64, 64, 32, 32, 1)
+        RUNR(1); RUNR(128); RUNR(129); RUNR(256); RUNR(2); RUNR(4); RUNR(14); RUNR(270); RUNR(399);
+        run<3, 1, 0, 16, 16, 32, 8, 1, 1, 1, PRO_GN_SILU, 16, 0, 5>("3x3 gn_silu 32->32 @64^2 f16x2 CK32 resident stamps", B, 64, 64, 32, 32, 1);
         return 0;
     }
     if (argc > 1 && argv[1][0] == 'x') {  // bf16x3 (MATH = 1) against the exact-fp32 MFMA
