@@ -155,7 +155,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the ddif hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under a launcher (WORLD_SIZE in the environment) the process group is RCCL even at world size 1, and every collective of the multi-GPU path
+    # runs (an all-gather / all-reduce over one rank): `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` is the RCCL smoke of the
+    # 1-GPU lease (tests/test_rccl_world1.py).  `python bench.py` (the driver's N = 1 line) has no process group and no collectives.
+    if "WORLD_SIZE" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -207,7 +210,7 @@ def main():
     log("network built (%d params), %d synthetic tiles on this rank" % (sum(p.numel() for p in net.parameters()), B))
     cond = tiles["cond"].to(dev)
     lms = cond[:, :C].contiguous()
-    gathered = torch.empty((total, C, H, H), device=dev) if (world > 1 or strong) else None
+    gathered = torch.empty((total, C, H, H), device=dev) if (dist.is_initialized() or strong) else None
     plan = diffusion._plan(cond)  # builds workspaces + runs set_cond once (not timed)
     cost = plan.cost()
     mem = plan.memory()
@@ -238,7 +241,7 @@ def main():
         else:
             res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=tile0, device_rng=True)
         sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
-        if world > 1:
+        if dist.is_initialized():
             dist.all_gather_into_tensor(gathered, sr)  # the only exchange: every rank ends with all tiles
             sr = gathered
         if strong:
@@ -251,7 +254,7 @@ def main():
         torch.cuda.synchronize()
         log("warmup step %d: %.3f s" % (w, time.perf_counter() - tw))
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     # profiled denoising steps: about PROF_STEPS_TARGET over the whole timed region, at most one step in 10 (a profiled step is launched
     # kernel by kernel with an event pair around each); the event buffer is sized for exactly those steps, and the library reports how
@@ -266,12 +269,12 @@ def main():
     for k in range(args.steps):
         out = one_step(2000 + k)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = plan.prof_collect()
     log("timed region: %.3f s for %d step(s); %d of %d planned denoising steps profiled" % (dt, args.steps, prof["steps_recorded"], n_prof_planned))
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -288,7 +291,7 @@ def main():
         ref = (diffusion(cond, mode="ddpm_sample", seed=seed_last, tile0=tile0, device_rng=True) + lms).clip(0, 1)
         torch.cuda.synchronize()
         _rt.set_math_mode("bf16")
-        mine = out[tile0:tile0 + B] if world > 1 else out
+        mine = out[tile0:tile0 + B] if dist.is_initialized() else out
         d = (mine - ref).double()
         mse_t = d.pow(2).mean(dim=(1, 2, 3))
         drift = {"against": "the fp32-class (split-product) path of this library: same tiles, seed %d, T=%d steps, batch %d" % (seed_last, T, B),
@@ -423,7 +426,7 @@ def main():
         result["vs_cpu_baseline_b1"] = value / cb["by_batch"]["1"]["value"]
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -461,14 +464,14 @@ def bench_training(args, cf, rank, world, dev):
     for p, g in zip(params, grads):
         p.grad = g
     ema = [p.detach().clone() for p in params]
-    if world > 1:
+    if dist.is_initialized():
         broadcast_parameters(params + ema)
     opt = runtime.FusedAdamW(params, grads, ema, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
     torch.manual_seed(7 + rank)
     random.seed(7 + rank)
     n_param = sum(p.numel() for p in params)
     comm_ms = [0.0]
-    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if world > 1 else None
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if dist.is_initialized() else None
     sc_passes = [0]
     qsf = runtime.PlanHandle.q_sample_forward
 
@@ -480,7 +483,7 @@ def bench_training(args, cf, rank, world, dev):
 
     def one_step(timed=False):
         loss, _ = d.train_step_into(res, cond, grads)  # q_sample + self-conditioning draw + forward + backward: gradients written into `grads`
-        if world > 1:
+        if dist.is_initialized():
             if timed:
                 ev[0].record()
             average_gradients(grads, world)
@@ -495,7 +498,7 @@ def bench_training(args, cf, rank, world, dev):
     for w in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     sc_passes[0] = 0
     t0 = time.perf_counter()
@@ -503,10 +506,10 @@ def bench_training(args, cf, rank, world, dev):
     for k in range(args.steps):
         loss = one_step(timed=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -529,7 +532,7 @@ def bench_training(args, cf, rank, world, dev):
                                           "matrix peak; the weight-gradient kernels run the exact fp32 MFMA, forward / dgrad convs the bf16x3 path",
                              "path": "native reverse launch program (csrc/ddif_train.cpp, ddif_plan_train_step): NHWC end to end, device-side weight refresh"},
                 "build_id": build_id()}
-        if world > 1:
+        if dist.is_initialized():
             line["allreduce"] = {"bytes": 4 * n_param, "ms_per_iteration": comm_ms[0] / args.steps,
                                  "algorithmic_gbytes_per_s": 4 * n_param / (comm_ms[0] / args.steps * 1e-3) / 1e9 if comm_ms[0] > 0 else None,
                                  "bus_gbytes_per_s": 2.0 * (world - 1) / world * 4 * n_param / (comm_ms[0] / args.steps * 1e-3) / 1e9 if comm_ms[0] > 0 else None,
@@ -538,7 +541,7 @@ def bench_training(args, cf, rank, world, dev):
             line["cpu_baseline"] = cpu_baseline_training(sd, cfg, tiles, T, args.cpu_seconds, args.cpu_threads)
             line["vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -60,6 +60,7 @@ int ddif_net_create(ddif_net_t* out, const ddif_net_cfg* cfg, int device) {
     h->n.cfg = *cfg;
     h->n.device = device;
     if (int e = h->n.build_layers()) return e;
+    h->n.owner = h.get();
     *out = h.release();
     return DDIF_OK;
     DDIF_GUARD_END
@@ -67,9 +68,12 @@ int ddif_net_create(ddif_net_t* out, const ddif_net_cfg* cfg, int device) {
 
 void ddif_net_destroy(ddif_net_t net) {
     if (!net) return;
-    if (net->n.live_plans > 0) {  // plans point into the net (weight blobs, reader events): the last of them frees it (ddif_plan_destroy)
-        net->n.orphaned = true;
-        return;
+    {
+        std::lock_guard<std::mutex> lk(net->n.life_mu);
+        if (net->n.live_plans > 0) {  // plans point into the net (weight blobs, reader events): the last of them frees it (ddif_plan_destroy)
+            net->n.orphaned = true;
+            return;
+        }
     }
     delete net;
 }
@@ -114,7 +118,10 @@ int ddif_plan_create(ddif_plan_t* out, ddif_net_t net, int B, int H, int W) {
     h->p.H = H;
     h->p.W = W;
     if (int e = h->p.build()) return e;
-    ++net->n.live_plans;
+    {
+        std::lock_guard<std::mutex> lk(net->n.life_mu);
+        ++net->n.live_plans;
+    }
     *out = h.release();
     return DDIF_OK;
     DDIF_GUARD_END
@@ -137,7 +144,10 @@ int ddif_plan_create_train(ddif_plan_t* out, ddif_net_t net, int B, int H, int W
     if (int e = h->p.build()) return e;
     // identity masks until the caller provides some: a train-mode plan then computes the eval network
     if (int e = h->p.train_random_masks(0, 0, 0.f, 0.f, nullptr)) return e;
-    ++net->n.live_plans;
+    {
+        std::lock_guard<std::mutex> lk(net->n.life_mu);
+        ++net->n.live_plans;
+    }
     *out = h.release();
     return DDIF_OK;
     DDIF_GUARD_END
@@ -229,7 +239,12 @@ void ddif_plan_destroy(ddif_plan_t plan) {
     if (!plan) return;
     ddif::Net* n = plan->p.net;
     delete plan;
-    if (n && --n->live_plans == 0 && n->orphaned) delete reinterpret_cast<ddif_net*>(n);  // (Net is the only member of ddif_net)
+    ddif_net* last = nullptr;
+    if (n) {
+        std::lock_guard<std::mutex> lk(n->life_mu);
+        if (--n->live_plans == 0 && n->orphaned) last = static_cast<ddif_net*>(n->owner);
+    }
+    delete last;  // outside the lock it lives in
 }
 
 int ddif_plan_set_cond(ddif_plan_t plan, const float* cond, void* stream) {
@@ -395,6 +410,20 @@ int ddif_set_math_mode(int mode) {
     return DDIF_OK;
 }
 int ddif_get_math_mode(void) { return ddif::g_math_mode; }
+
+int ddif_set_f16_raw(int on) {
+    ddif::g_f16_raw = on ? 1 : 0;
+    return DDIF_OK;
+}
+int ddif_get_f16_raw(void) { return ddif::g_f16_raw; }
+int ddif_plan_range_status(ddif_plan_t plan, void* stream, int* overflow) {
+    DDIF_GUARD_BEGIN
+    if (!plan || !overflow) return ddif::fail(DDIF_ERR_INVALID, "ddif_plan_range_status: NULL argument");
+    DeviceScope ds(plan->p.net->device);
+    if (!ds.ok) return ddif::fail(DDIF_ERR_HIP, "ddif_plan_range_status: hipSetDevice failed");
+    return plan->p.range_status(reinterpret_cast<hipStream_t>(stream), overflow);
+    DDIF_GUARD_END
+}
 
 int ddif_debug_set_grid_cap(int max_workgroups) {
     ddif::g_debug_grid_cap = max_workgroups > 0 ? max_workgroups : 0;

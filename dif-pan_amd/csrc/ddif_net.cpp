@@ -536,7 +536,12 @@ int Net::commit(hipStream_t stream) {
     dconv.clear();  // re-derived on demand (build_dgrad_packs) from the recipes of THIS commit
     dgrad_filled = false;
     // plans of the previous generation may still have launches in flight on their own (side) streams that read the blobs freed below
-    if (blob || dgrad_blob) DDIF_HIPCHK(hipDeviceSynchronize());
+    // (their own streams and events only -- not hipDeviceSynchronize, which fails while ANY stream of the process is being captured; the hipFree
+    //  calls below wait for whatever else still uses the allocations)
+    if (blob || dgrad_blob) {
+        for (hipEvent_t e : reader_events) DDIF_HIPCHK(hipEventSynchronize(e));
+        DDIF_HIPCHK(hipStreamSynchronize(stream));
+    }
     if (dgrad_blob) {
         DDIF_HIPCHK(hipFree(dgrad_blob));
         dgrad_blob = nullptr;

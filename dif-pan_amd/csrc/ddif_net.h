@@ -1,5 +1,6 @@
 // Host-side structures of libddif: the network (weights repacked for the kernels) and helpers.
 #pragma once
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -93,8 +94,12 @@ struct Net {
     size_t dgrad_floats = 0;
     bool dgrad_filled = false;        // a refresh_device() has run since the dgrad packs were allocated (they start zeroed: a backward pass before that
                                       // would return zero input gradients upstream of the last layer without any error)
-    int live_plans = 0;               // plans built on this net (they hold raw pointers into it); ddif_net_destroy defers to the last plan's destruction
+    // plans built on this net hold raw pointers into it: ddif_net_destroy defers to the last plan's destruction.  Both fields under `life_mu` (plans and
+    // nets are destroyed from Python finalizers, possibly on different threads); `owner` = the C-ABI handle that contains this Net.
+    std::mutex life_mu;
+    int live_plans = 0;
     bool orphaned = false;
+    void* owner = nullptr;
     int build_dgrad_packs();
     bool merged_stale = false;        // the eval-only merged ffn[3] o ffn[2] weights were NOT refreshed (train-mode plans do not use them)
     void* d_recs = nullptr;           // device RefreshRec table of the last refresh

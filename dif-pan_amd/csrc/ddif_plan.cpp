@@ -71,6 +71,12 @@ ConvVariant variant_for_cfg(int cfg) {
             case 29: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 3>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.f16 = true; break;
             default: break;
         }
+        if constexpr (U == 0) {
+            // 37 = tiling 27 with RESIDENT weights (MATH = 5, round 5): 32 input channels as ONE stage per work item, the cout tile's weights copied into
+            // LDS once per workgroup.  Same pack, same accumulation order, same partials as 27 -- bit-identical results, 3-6 % faster in isolation
+            // (profiles/r05_a_mbench_resident.txt).  Chosen by add_conv for 32 -> <= 32 channel convs.
+            if (cfg == 37) { v.fn = conv_mfma_kernel<KS, S, U, 16, 16, 32, 8, 1, 1, 1, PRO, VEC, EPI, 0, 5>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, 32, 1, PRO, 8, 5>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = v.wr = true; }
+        }
     }
     if constexpr (KS == 3 && S == 1 && U == 0 && VEC == 1) {
         switch (cfg) {
@@ -148,6 +154,7 @@ static int f16_enabled() {  // DDIF_F16=0: the split-operand convs stay on bf16x
     return f16;
 }
 int g_math_mode = [] { const char* e = getenv("DDIF_MATH"); return (e && std::strcmp(e, "bf16") == 0) ? 1 : 0; }();
+int g_f16_raw = [] { const char* e = getenv("DDIF_F16_RAW"); return e ? (atoi(e) != 0) : 1; }();
 static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention half as three launches (q conv, column statistics, attn_out conv)
     static const int v = [] { const char* e = getenv("DDIF_LAFUSE"); return e ? atoi(e) : 1; }();
     return v;
@@ -301,6 +308,18 @@ void Plan::use(const void* p) {
 
 // Two passes over the same builder: the dry pass only records shapes and liveness, the real pass allocates.
 int Plan::build() {
+    math_mode = g_math_mode;
+    f16_raw = g_f16_raw;
+    final_fused = false;
+    n_range_convs = 0;
+    if (!d_range) {
+        void* q = nullptr;
+        DDIF_HIPCHK(hipMalloc(&q, 64));
+        DDIF_HIPCHK(hipMemset(q, 0, 64));
+        allocs.push_back(q);
+        bytes_allocated += 64;
+        d_range = reinterpret_cast<int*>(q);
+    }
     if (train_mode) {  // no activation arena: the reverse pass reads the forward's tensors
         dry = false;
         tmods.clear();
@@ -351,6 +370,8 @@ int Plan::build() {
     mask_recs = nullptr;
     n_mask_recs = 0;
     n_conv3 = n_conv3_x3 = n_conv3_f16 = n_conv3_b1 = 0;
+    n_range_convs = 0;
+    final_fused = false;
     tb_rows = 0;
     tb = tvals = nullptr;
     arena_next = 0;
@@ -380,13 +401,15 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     // f16x2 (kernels_conv.h MATH = 3): inference plans only (the half packs are not refreshed on the device), shared weights inside the
     // scaled half range (pc.w_f16), and for a GroupNorm prologue an output bound sqrt(N) max|gamma| + max|beta| inside the activation range
     bool f16ok = f16_enabled() && !train_mode && pc.w_f16 && !s.w_override && !s.exact;
+    const bool raw_in = !(s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW);  // nothing bounds the staged values: f16x2 only under the plan's range watch
+    if (raw_in && !f16_raw) f16ok = false;
     if (f16ok && (s.pro == PRO_GN || s.pro == PRO_GN_SILU)) {
         auto ig = net->vec_absmax.find(s.gamma), ib = net->vec_absmax.find(s.beta);
         const double n = (double)(c0 + c1) * Hin * Win;
         f16ok = ig != net->vec_absmax.end() && ib != net->vec_absmax.end() && std::sqrt(n) * ig->second + ib->second < DDIF_F16_AMAX;
     }
     // bf16x1 (MATH = 4): the throughput variant, only under ddif_set_math_mode(DDIF_MATH_BF16); inference plans, shared weights
-    const bool b1ok = g_math_mode == 1 && !train_mode && pc.w_b1 && !s.w_override && !s.exact;
+    const bool b1ok = math_mode == 1 && !train_mode && pc.w_b1 && !s.w_override && !s.exact;
     const bool f16ok0 = f16ok;
     if (b1ok) f16ok = false;
     int math = b1ok ? MATH_BF16X1 : (f16ok ? MATH_F16X2 : MATH_BF16X3);
@@ -394,6 +417,10 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int epi = (s.film ? EPI_FILM : 0) | (s.res ? EPI_RES : 0) | (pc.cout % 4 != 0 ? EPI_SOUT : 0) | (s.silu ? EPI_SILU : 0) | (s.cso_mx ? EPI_COLST : 0);
     if (s.cso_mx && ((cfg != 20 && cfg != 21) || Hout > (cfg == 20 ? 8 : 16)))
         return fail(DDIF_ERR_INVALID, "%s: column statistics epilogue needs the low-resolution kernel and H <= 16", s.name);
+    static const bool wres_env = [] { const char* e = getenv("DDIF_WRES"); return !e || atoi(e) != 0; }();  // DDIF_WRES=0: tiling 27 everywhere (tests/test_env_switches.py)
+    if (cfg == 27 && wres_env && c0 == 32 && c1 == 0 && pc.cout <= 32 && pc.ck == 16 && pc.n_chunks == 2 && !s.w_override && s.w_bstride == 0 &&
+        get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, 37, vec, epi, math).fn)
+        cfg = 37;
     ConvVariant var = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi, math);
     if (!var.fn && (cfg == 20 || cfg == 21)) {  // prologue / epilogue combination the low-resolution kernel does not carry
         cfg = pick_cfg(pc.ks, pc.ck, s.pro, vec, s.stride, s.ups, Hout, Wout, pc.cout, B, c0 + c1, c1 ? c0 : c0 + c1, false, false, f16ok, b1ok);
@@ -446,7 +473,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.cso_sm = s.cso_sm;
     if (s.pro == PRO_GN_DW && (!s.dw_w || c0 + c1 > 256)) return fail(DDIF_ERR_INVALID, "%s: depthwise staging needs weights and <= 256 channels", s.name);
     if (s.pro == PRO_COLSM && (!s.cs_mx || !s.cs_sm || c0 % pc.ck != 0)) return fail(DDIF_ERR_INVALID, "%s: column-softmax prologue needs statistics and c0 %% %d == 0", s.name, pc.ck);
-    a.n_chunks = pc.n_chunks;
+    a.n_chunks = var.wr ? 1 : pc.n_chunks;  // (resident weights: the whole input is one 32-channel stage)
     a.bias = (s.use_bias && pc.bias) ? pc.bias : zeros;
     a.tbias = zeros;  // strides 0: a row of zeros for every sample and step
     a.st0 = s.in0.st;
@@ -467,11 +494,15 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         a.st_out = out->st;
     }
     a.n_ct = gy;
+    if (var.f16 && raw_in) {  // (the kernels only look at it in their raw-input f16x2 instantiations)
+        a.range_flag = d_range;
+        ++n_range_convs;
+    }
     // persistent launch: a few workgroups per CU, each walking a contiguous range of (cout tile, pixel tile) items
     const long items_per_sample = (long)a.tiles_x * a.tiles_y * gy;
     const long nwork = (long)B * items_per_sample;
     const int gy0 = (pc.cout + var.nt - 1) / var.nt;
-    const size_t smem = var.lr ? var.smem : var.smem + conv_smem_extra(s.pro, pc.n_chunks, pc.ck, gy0 * var.nt);
+    const size_t smem = var.lr ? var.smem : var.smem + conv_smem_extra(s.pro, var.wr ? 1 : pc.n_chunks, var.wr ? 32 : pc.ck, gy0 * var.nt);
     long cap = (long)num_cus() * wg_per_cu(smem, var.wg_cap);
     if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
     const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
@@ -1721,6 +1752,18 @@ int Plan::forward(const float* x, const float* t_host, const float* sc, float* o
     run_prog(step, s, ctx, false);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, ew_grid((size_t)B * HW * C), dim3(256), 0, s, (const float*)net_out.p, B, C, HW, out);
     DDIF_HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The sticky range flag of the plan's raw-input f16x2 convs: read (and cleared) once per sampler / forward call by the caller, never inside a loop.
+int Plan::range_status(hipStream_t s, int* overflow) {
+    int v = 0;
+    if (d_range && n_range_convs > 0) {
+        DDIF_HIPCHK(hipMemcpyAsync(&v, d_range, sizeof(int), hipMemcpyDeviceToHost, s));
+        DDIF_HIPCHK(hipStreamSynchronize(s));
+        if (v) DDIF_HIPCHK(hipMemsetAsync(d_range, 0, sizeof(int), s));
+    }
+    if (overflow) *overflow = v ? 1 : 0;
     return 0;
 }
 

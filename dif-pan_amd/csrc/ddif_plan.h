@@ -50,6 +50,7 @@ struct ConvVariant {
     bool b1 = false;  // bf16x1 instantiation (the throughput variant): wants PackedConv::w_b1 (x3 is set as well)
     int wg_cap = 2;   // persistent workgroups per CU (upper bound; LDS may allow fewer)
     bool lr = false;  // low-resolution kernel (kernels_lr.h): smem is the whole requirement, nothing is added per launch
+    bool wr = false;  // resident-weights instantiation (kernels_conv.h MATH = 5): ONE 32-channel stage per work item -- the launch passes n_chunks = 1, CK = 32; reads w_f16
     const char* name = "";
 };
 // operand format of a split-operand conv: what get_conv_variant / get_lr_variant instantiate and which weight pack the launch reads
@@ -58,6 +59,9 @@ ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int c
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3);  // ddif_lr.cpp
 // ddif_set_math_mode (include/ddif.h): 0 = fp32-class split products (default), 1 = the bf16 throughput variant, for plans built afterwards
 extern int g_math_mode;
+// ddif_set_f16_raw (include/ddif.h): 1 (default) = convs without a GroupNorm prologue may run f16x2 on their raw input, watched by the plan's range flag;
+// 0 = they stay on bf16x3 (full fp32 range).  Snapshotted, like the math mode, when a plan is created.
+extern int g_f16_raw;
 // fused linear-attention block (kernels_lafuse.h, ddif_la.cpp)
 struct LaFuseArgs;
 bool lafuse_supported(int H, int fea, int dout);
@@ -164,6 +168,11 @@ struct Plan {
     // sampler run state (device) + hipGraph replay of a pair of denoising steps
     int* d_step = nullptr;              // two counters: a step's kernels read d_step[parity], the sampler update writes d_step[parity ^ 1]
     bool final_fused = false;           // the final conv carries the sampler epilogue: no separate update / counter launches in the DDPM / DDIM loops
+    int math_mode = 0;                  // g_math_mode / g_f16_raw at creation: one plan is built under ONE arithmetic even when the process-wide switches change while it builds
+    int f16_raw = 1;
+    int* d_range = nullptr;             // sticky device flag: an f16x2 conv on a raw input staged a value beyond the scaled half range (ConvArgs::range_flag)
+    int n_range_convs = 0;              // launches of the step / cond-only programs that watch it
+    int range_status(hipStream_t s, int* overflow);  // synchronises `s`, reads and clears the flag
     void* d_run = nullptr;            // SamplerRun
     float* d_tabs = nullptr;
     int tabs_cap = 0;

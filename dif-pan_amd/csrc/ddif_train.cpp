@@ -108,6 +108,7 @@ struct Plan::TrainScratch {
     std::vector<GnSite> gn_sites;
     std::vector<GnRedRec> gnred_host;
     GnRedRec* gnred_dev = nullptr;
+    hipError_t upload_err = hipSuccess;  // a table upload inside the reverse program failed: the step reports it (train_backward) and the host mirror stays stale, so the next step retries
 };
 
 int Plan::train_bind(int n, const char* const* keys, float* const* grads) {
@@ -686,9 +687,10 @@ int Plan::build_backward() {
                 std::vector<SlotScatter> tab;
                 for (auto& sg : *slots) tab.push_back(SlotScatter{*sg.w, *sg.b, sg.off, sg.n});
                 if (T->slot_host.size() != tab.size() || memcmp(T->slot_host.data(), tab.data(), tab.size() * sizeof(SlotScatter)) != 0) {
-                    (void)hipMemcpyAsync(T->slot_tab, tab.data(), tab.size() * sizeof(SlotScatter), hipMemcpyHostToDevice, st);
-                    (void)hipStreamSynchronize(st);  // `tab` is a local: the copy must have read it (rare: first step / re-bind)
-                    T->slot_host = tab;
+                    hipError_t e = hipMemcpyAsync(T->slot_tab, tab.data(), tab.size() * sizeof(SlotScatter), hipMemcpyHostToDevice, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);  // `tab` is a local: the copy must have read it (rare: first step / re-bind)
+                    if (e == hipSuccess) T->slot_host = tab;          // the mirror follows the device table only when the upload succeeded
+                    else T->upload_err = e;
                 }
                 hipLaunchKernelGGL(slot_scatter_kernel, dim3((unsigned)tab.size()), dim3(256), 0, st, (const SlotScatter*)T->slot_tab, (int)tab.size(), (const float*)T->dwall,
                                    (const float*)T->dball, inner);
@@ -704,9 +706,10 @@ int Plan::build_backward() {
                     nblk += (g.C + 31) / 32;
                 }
                 if (T->gnred_host.size() != tab.size() || memcmp(T->gnred_host.data(), tab.data(), tab.size() * sizeof(GnRedRec)) != 0) {
-                    (void)hipMemcpyAsync(T->gnred_dev, tab.data(), tab.size() * sizeof(GnRedRec), hipMemcpyHostToDevice, st);
-                    (void)hipStreamSynchronize(st);  // `tab` is a local (rare: first step / re-bind)
-                    T->gnred_host = tab;
+                    hipError_t e = hipMemcpyAsync(T->gnred_dev, tab.data(), tab.size() * sizeof(GnRedRec), hipMemcpyHostToDevice, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);  // `tab` is a local (rare: first step / re-bind)
+                    if (e == hipSuccess) T->gnred_host = tab;
+                    else T->upload_err = e;
                 }
                 tk::gn_bwd_reduce_all(st, T->gnred_dev, (int)tab.size(), nblk, BB);
             }
@@ -754,6 +757,11 @@ int Plan::train_backward(const float* target_nhwc, float upstream, float* loss_d
     for (auto& f : bwd) f(s);
     train_join(s);  // every weight gradient is in place
     if (loss_dev) DDIF_HIPCHK(hipMemcpyAsync(loss_dev, d_loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (ts->upload_err != hipSuccess) {  // a gradient-routing table did not reach the device: this step's dgamma / dbeta / time-MLP gradients are not valid
+        const hipError_t e = ts->upload_err;
+        ts->upload_err = hipSuccess;
+        return fail(DDIF_ERR_HIP, "training step: table upload failed (%s)", hipGetErrorString(e));
+    }
     DDIF_HIPCHK(hipGetLastError());
     return 0;
 }

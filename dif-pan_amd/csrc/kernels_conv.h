@@ -80,6 +80,10 @@ struct ConvArgs {
     const SamplerRun* s_run;
     int* s_step_next;        // receives *step_ptr + 1
     int s_kind;              // 0 = DDPM p_sample, 1 = DDIM
+    // f16x2 on a RAW input (no GroupNorm prologue to bound it): a value whose scaled half would overflow (|x| * 2^4 >= 65520 -> inf -> NaN in the output)
+    // sets this sticky per-plan flag; the host reads it once per sampler call (ddif_plan_range_status) and rebuilds the plan with these convs on
+    // bf16x3 (full fp32 range).  Null: not checked.  (A plain store of 1 by any number of threads: no atomics needed.)
+    int* range_flag;
 };
 
 template <int F>
@@ -422,6 +426,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     // by < 15 % and is not slowed itself), and the six dependent MFMAs of a tap leave ~40 idle issue slots per wave.
     float fs_ga[4] = {0.f, 0.f, 0.f, 0.f}, fs_gb[4] = {0.f, 0.f, 0.f, 0.f};
     bool fs_colsm = false;
+    constexpr bool RANGE = F16 && !GNP && !DWM;  // raw activations x 2^4 into halves: watch the range (ConvArgs::range_flag)
+    [[maybe_unused]] float r_max = 0.f;         // largest |scaled value| this thread staged
     auto fs_begin = [&](StageRegs& R) {
         if (GNP) {
             if (R.pos.b != gn_b) {  // workgroup-uniform; every wavefront reduces the partials itself (no barrier)
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             }
             v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation
         }
+        if constexpr (RANGE) r_max = fmaxf(fmaxf(r_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         if (DWM) {
             *reinterpret_cast<float4*>(&Hs[a_lds[it]]) = make_float4(v[0], v[1], v[2], v[3]);
             // centre pixels inside the image: this IS xn = GroupNorm(cat[h, skip]) (attn_res input)
@@ -1000,6 +1007,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     __syncthreads();
     flush_stats();
     stamp();
+    if constexpr (RANGE) {
+        if (a.range_flag && !(r_max < 65520.f)) *a.range_flag = 1;  // a scaled half of this launch overflowed (or was NaN): the output is not to be trusted
+    }
 }
 
 

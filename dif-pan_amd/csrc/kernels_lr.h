@@ -35,6 +35,9 @@ namespace ddif {
 
 // TALL: 16x8 instead of 8x16 pixels for MB = 4 -- whole image columns inside one tile, which is what the column-softmax
 // statistics epilogue (EPI_COLST) needs
+#ifndef LR_ROWPAD
+#define LR_ROWPAD 1
+#endif
 template <int KS, int MB, int PRO, bool TALL = false, bool F16 = false, bool B1 = false>
 struct LrGeom {
     static constexpr int NPL = F16 ? 2 : (B1 ? 1 : 3);         // operand planes: f16x2 (hi, lo), bf16x3 (hi, mid, lo) or bf16x1 (the throughput variant)
@@ -44,7 +47,13 @@ struct LrGeom {
     static constexpr int PC = (MB == 4 && KS == 3) ? 64 : 128; // channels staged per phase
     static constexpr int SP = PC / 16;                         // 16-channel slabs per phase
     static constexpr int APIX = SP * NPL * 8 + 4;              // floats per staged pixel: SP x (NPL planes x 32 B) + 16 B pad
-    static constexpr int AFL = IH * IW * APIX;
+    // row pad (round 5): the A-fragment ds_read_b128 of a 32-pixel block is conflict-free when the pixel stride is odd in 16-byte slots (APIX / 4 is: 17, 25, 33,
+    // 49) AND the row stride is 8 mod 16 slots for the 8-wide tiles (lanes 0-7 / 8-15 / ... are rows) or 0 mod 16 for the 16-wide ones (bank enumeration
+    // over the documented lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}: DESIGN section 3); without it the rows collide two ways
+    static constexpr int RSL = (IW * APIX / 4) % 16;
+    static constexpr int RPAD = LR_ROWPAD ? (((TW == 8 ? 8 : 0) - RSL + 16) % 16) * 4 : 0;
+    static constexpr int AROW = IW * APIX + RPAD;              // floats per staged row
+    static constexpr int AFL = IH * AROW;
     static constexpr int RFL = 4 * MB * 4 * 64 * 4;            // K-partials: [wave][mb][quad g][lane] float4
     static constexpr size_t smem = (size_t)((AFL > RFL ? AFL : RFL) + 16) * sizeof(float);
     static constexpr int SPW = SP / 4;                         // slabs per wave and phase
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     constexpr int NPL = G::NPL, SLF = NPL * 8;  // floats of one 16-channel slab of a staged pixel
     constexpr int WSTEP = NPL * 1024;           // bytes of one (slab, tap) step of the packed weights
     constexpr int TH = G::TH, TW = G::TW, LP = G::PAD, LH = G::IH, LW = G::IW, IW = G::IW, PC = G::PC, SP = G::SP;
-    constexpr int APIX = G::APIX, TAPS = G::TAPS, U = G::U, SPW = G::SPW;
+    constexpr int APIX = G::APIX, AROW = G::AROW, TAPS = G::TAPS, U = G::U, SPW = G::SPW;
     constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU);
     static_assert(PRO == PRO_NONE || PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_COLSM, "prologues of the low-resolution kernel");
     constexpr bool FILM = (EPI & EPI_FILM) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0;
@@ -103,11 +112,13 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = mb * 32 + j;
-        abase[mb] = ((m / TW) * IW + (m % TW)) * APIX + 4 * h;
+        abase[mb] = (m / TW) * AROW + (m % TW) * APIX + 4 * h;
     }
 
     int gn_b = -1;
     float mean = 0.f, rstd = 1.f;
+    constexpr bool RANGE = F16 && !GNP && PRO != PRO_COLSM;  // raw activations x 2^4 into halves: watch the range (ConvArgs::range_flag, kernels_conv.h)
+    [[maybe_unused]] float r_max = 0.f;
 
     for (int work = w0; work < w1; ++work) {
         const int pt = work / a.n_ct, ct = work - pt * a.n_ct;  // cout tile fastest: neighbours re-read the same input from L2
@@ -233,8 +244,9 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                     }
                     v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation (and channels past the end are zero)
                 }
+                if constexpr (RANGE) r_max = fmaxf(fmaxf(r_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 if (pix < LH * LW) {
-                    float* d = &As[pix * APIX + slab_l * SLF + cin_slab / 2];
+                    float* d = &As[(pix / LW) * AROW + (pix % LW) * APIX + slab_l * SLF + cin_slab / 2];
                     if constexpr (B1) {
                         *reinterpret_cast<uint2*>(d) = make_uint2(dd_bf16_pair(v[0], v[1]), dd_bf16_pair(v[2], v[3]));
                     } else if constexpr (F16) {
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                     for (int tap = 0; tap < TAPS; ++tap) {
                         constexpr int UU = U;
                         const int u = (k * TAPS + tap) % UU;
-                        const int aoff = ((tap / KS) * IW + (tap % KS)) * APIX + sl * SLF;
+                        const int aoff = (tap / KS) * AROW + (tap % KS) * APIX + sl * SLF;
                         float4 xa[MB][NPL];
 #pragma unroll
                         for (int q = 0; q < NPL; ++q)
@@ -401,6 +413,9 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             a.st_out[pi + 0] = ((double)Sst[0] + (double)Sst[2]) + ((double)Sst[4] + (double)Sst[6]);
             a.st_out[pi + 1] = ((double)Sst[1] + (double)Sst[3]) + ((double)Sst[5] + (double)Sst[7]);
         }
+    }
+    if constexpr (RANGE) {
+        if (a.range_flag && !(r_max < 65520.f)) *a.range_flag = 1;
     }
 }
 

@@ -113,6 +113,9 @@ class _Lib:
         d.ddif_debug_set_grid_cap.argtypes = [i32]
         d.ddif_set_math_mode.argtypes = [i32]
         d.ddif_get_math_mode.argtypes = []
+        d.ddif_plan_range_status.argtypes = [vp, vp, C.POINTER(i32)]
+        d.ddif_set_f16_raw.argtypes = [i32]
+        d.ddif_get_f16_raw.argtypes = []
         d.ddif_plan_memory.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         d.ddif_cond_assemble.argtypes = [vp, vp, f32, i32, i32, i32, i32, i32, i32, vp, vp]
         d.ddif_metrics.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
@@ -239,6 +242,17 @@ def get_math_mode() -> str:
     return {v: k for k, v in MATH_MODES.items()}[int(m)]
 
 
+def set_f16_raw(on: bool):
+    """Inference plans created AFTERWARDS run convs WITHOUT a GroupNorm prologue on f16x2 under the plan's range watch (True, default) or on bf16x3 (False:
+    full fp32 exponent range, six matrix products instead of three) -- include/ddif.h ddif_set_f16_raw.  PlanHandle switches a plan over by itself when
+    the watch fires; this is the process-wide override."""
+    get_lib().dll.ddif_set_f16_raw(1 if on else 0)
+
+
+def get_f16_raw() -> bool:
+    return bool(get_lib().dll.ddif_get_f16_raw())
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -360,15 +374,61 @@ class PlanHandle:
         self.net, self.lib = net, net.lib
         self.B, self.H, self.W = B, H, W
         self.train = train
-        h = C.c_void_p()
-        if train:
-            self.lib.check(self.lib.dll.ddif_plan_create_train(C.byref(h), net.h, B, H, W), "ddif_plan_create_train")
-        else:
-            self.lib.check(self.lib.dll.ddif_plan_create(C.byref(h), net.h, B, H, W), "ddif_plan_create")
-        self.h = h
+        self.h = None
+        self.f16_raw = get_f16_raw()  # this plan's convs on raw inputs: f16x2 under the range watch, or (after the watch fired once) bf16x3
+        self.range_fallbacks = 0
+        self._create()
         self._cond_ref = None
         self._cond_ver = None
         self.net_out_channels = net.out_channel
+
+    def _create(self):
+        h = C.c_void_p()
+        if self.train:
+            self.lib.check(self.lib.dll.ddif_plan_create_train(C.byref(h), self.net.h, self.B, self.H, self.W), "ddif_plan_create_train")
+        else:
+            prev = get_f16_raw()
+            try:
+                set_f16_raw(self.f16_raw)
+                self.lib.check(self.lib.dll.ddif_plan_create(C.byref(h), self.net.h, self.B, self.H, self.W), "ddif_plan_create")
+            finally:
+                set_f16_raw(prev)
+        self.h = h
+
+    def _range_overflow(self, device) -> bool:
+        """ONE synchronisation + 4-byte read per sampler / forward call (never inside a loop): did a conv of this plan stage a value outside the scaled
+        half range of the f16x2 split (include/ddif.h ddif_plan_range_status)?"""
+        v = C.c_int(0)
+        self.lib.check(self.lib.dll.ddif_plan_range_status(self.h, _stream(self.lib, torch.device(device)), C.byref(v)), "ddif_plan_range_status")
+        return bool(v.value)
+
+    def _guarded(self, enqueue, device):
+        """Run `enqueue` (one library call of an inference plan); when the plan's range watch fired -- a trained checkpoint with residual-stream
+        activations beyond 4094 in front of a conv without GroupNorm -- rebuild the plan with those convs on bf16x3 (full fp32 range), restore its
+        cond caches and repeat the call: any checkpoint runs (reference utils/misc.py:89-122), never a NaN image."""
+        out = enqueue()
+        if self.train or not self._range_overflow(device):
+            return out
+        if not self.f16_raw:
+            raise DdifError("activations outside the fp16 range although this plan keeps raw-input convs on bf16x3 (status -5, DDIF_ERR_RANGE): non-finite input?")
+        import warnings
+
+        warnings.warn("ddif: an activation in front of a conv without GroupNorm left the f16x2 range (|x| >= 4094); this plan is rebuilt with those "
+                      "convs on bf16x3 (full fp32 range) and the call is repeated", RuntimeWarning, stacklevel=3)
+        cond = getattr(self, "_keep", None)
+        self.lib.dll.ddif_plan_destroy(self.h)
+        self.h = None
+        self.f16_raw = False
+        self.range_fallbacks += 1
+        self._create()
+        self._cond_ref = None
+        if cond is not None:
+            self.lib.check(self.lib.dll.ddif_plan_set_cond(self.h, _ptr(cond), _stream(self.lib, cond.device)), "ddif_plan_set_cond")
+            self._cond_ref = None  # (the next set_cond of the caller re-validates its own tensor)
+        out = enqueue()
+        if self._range_overflow(device):
+            raise DdifError("activations outside the fp16 range after the bf16x3 fallback (status -5, DDIF_ERR_RANGE)")
+        return out
 
     def __del__(self):
         try:
@@ -501,9 +561,12 @@ class PlanHandle:
         if t.numel() != self.B:
             t = t.reshape(-1).expand(self.B).contiguous()
         out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=x.device)
-        self.lib.check(self.lib.dll.ddif_plan_forward(self.h, _ptr(x), C.c_void_p(t.data_ptr()), _ptr(sc), _ptr(out),
-                                                      _stream(self.lib, x.device)), "ddif_plan_forward")
-        return out
+        def run():
+            self.lib.check(self.lib.dll.ddif_plan_forward(self.h, _ptr(x), C.c_void_p(t.data_ptr()), _ptr(sc), _ptr(out),
+                                                          _stream(self.lib, x.device)), "ddif_plan_forward")
+            return out
+
+        return self._guarded(run, x.device)
 
     def _check_sampler_inputs(self, x_T, noise, n_steps):
         img = (self.B, self.net.out_channel, self.H, self.W)
@@ -525,10 +588,13 @@ class PlanHandle:
         noise = None if noise is None else noise.contiguous()
         out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=device)
         lo, hi, do = (clamp[0], clamp[1], 1) if clamp is not None else (0.0, 0.0, 0)
-        self.lib.check(self.lib.dll.ddif_plan_sample_ddpm(self.h, C.byref(tabs), _ptr(x_T), _ptr(noise), int(seed),
-                                                          int(tile0), lo, hi, do, _ptr(out),
-                                                          _stream(self.lib, torch.device(device))), "ddif_plan_sample_ddpm")
-        return out
+        def run():
+            self.lib.check(self.lib.dll.ddif_plan_sample_ddpm(self.h, C.byref(tabs), _ptr(x_T), _ptr(noise), int(seed),
+                                                              int(tile0), lo, hi, do, _ptr(out),
+                                                              _stream(self.lib, torch.device(device))), "ddif_plan_sample_ddpm")
+            return out
+
+        return self._guarded(run, device)
 
     def sample_ddim(self, t_model, sqrt_recip, sqrt_recipm1, sqrt_ap, dir_coef, sigma, x_T, noise, seed, tile0, clamp,
                     device) -> torch.Tensor:
@@ -540,10 +606,13 @@ class PlanHandle:
         noise = None if noise is None else noise.contiguous()
         out = torch.empty((self.B, self.net_out_channels, self.H, self.W), dtype=torch.float32, device=device)
         lo, hi, do = (clamp[0], clamp[1], 1) if clamp is not None else (0.0, 0.0, 0)
-        self.lib.check(self.lib.dll.ddif_plan_sample_ddim(self.h, C.byref(tabs), _ptr(x_T), _ptr(noise), int(seed),
-                                                          int(tile0), lo, hi, do, _ptr(out),
-                                                          _stream(self.lib, torch.device(device))), "ddif_plan_sample_ddim")
-        return out
+        def run():
+            self.lib.check(self.lib.dll.ddif_plan_sample_ddim(self.h, C.byref(tabs), _ptr(x_T), _ptr(noise), int(seed),
+                                                              int(tile0), lo, hi, do, _ptr(out),
+                                                              _stream(self.lib, torch.device(device))), "ddif_plan_sample_ddim")
+            return out
+
+        return self._guarded(run, device)
 
     def sample_dpmpp(self, tabs: dict, x_T: torch.Tensor, clamp) -> torch.Tensor:
         self._check_sampler_inputs(x_T, None, 0)
@@ -555,9 +624,12 @@ class PlanHandle:
             setattr(t, k, C.cast(arr, _IP if k == "ord" else _FP))
         out = torch.empty_like(x_T)
         lo, hi, do = (clamp[0], clamp[1], 1) if clamp is not None else (0.0, 0.0, 0)
-        self.lib.check(self.lib.dll.ddif_plan_sample_dpmpp(self.h, C.byref(t), _ptr(x_T), lo, hi, do, _ptr(out),
-                                                           _stream(self.lib, x_T.device)), "ddif_plan_sample_dpmpp")
-        return out
+        def run():
+            self.lib.check(self.lib.dll.ddif_plan_sample_dpmpp(self.h, C.byref(t), _ptr(x_T), lo, hi, do, _ptr(out),
+                                                               _stream(self.lib, x_T.device)), "ddif_plan_sample_dpmpp")
+            return out
+
+        return self._guarded(run, x_T.device)
 
     def q_sample_forward(self, x0, noise, a, s, time, self_cond) -> torch.Tensor:
         img = (self.B, self.net.out_channel, self.H, self.W)
@@ -568,10 +640,13 @@ class PlanHandle:
         sc = None if self_cond is None else self_cond.contiguous()
         a, s, t = _row(a, x0.device), _row(s, x0.device), _row(time, x0.device)
         out = torch.empty_like(x0)
-        self.lib.check(self.lib.dll.ddif_plan_q_sample_forward(
-            self.h, _ptr(x0), _ptr(noise), C.c_void_p(a.data_ptr()), C.c_void_p(s.data_ptr()), C.c_void_p(t.data_ptr()),
-            _ptr(sc), _ptr(out), _stream(self.lib, x0.device)), "ddif_plan_q_sample_forward")
-        return out
+        def run():
+            self.lib.check(self.lib.dll.ddif_plan_q_sample_forward(
+                self.h, _ptr(x0), _ptr(noise), C.c_void_p(a.data_ptr()), C.c_void_p(s.data_ptr()), C.c_void_p(t.data_ptr()),
+                _ptr(sc), _ptr(out), _stream(self.lib, x0.device)), "ddif_plan_q_sample_forward")
+            return out
+
+        return self._guarded(run, x0.device)
 
     # -- measurement --------------------------------------------------------------------------------------------
     def prof_begin(self, every_n_steps: int, max_events: int):

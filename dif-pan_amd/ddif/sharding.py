@@ -54,8 +54,9 @@ def sample_sharded(diffusion, cond_all: torch.Tensor, mode: str = "ddpm_sample",
         kw = dict(kw, x_T=x_T[lo:hi].contiguous())
     res = diffusion(cond, mode=mode, seed=seed, tile0=tile_base + lo, device_rng=x_T is None, **kw)
     sr = (res + cond[:, :C]).clip(0, 1)  # diffusion_engine.py:446-447
-    if world == 1:
+    if not dist.is_initialized():
         return sr
+    # (with a process group the collective runs even at world size 1 -- a copy -- so that a 1-GPU run under a launcher exercises RCCL: tests/test_rccl_world1.py)
     out = torch.empty((cond_all.shape[0],) + tuple(sr.shape[1:]), dtype=sr.dtype, device=sr.device)
     dist.all_gather_into_tensor(out, sr.contiguous())
     return out
@@ -95,7 +96,7 @@ def sample_scene_dpmpp(net, diffusion, cond_all: torch.Tensor, x_T_all: torch.Te
     solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(lms, 0.0, 1.0))
     res = solver.sample(x_T_all[lo:hi].contiguous(), steps=steps, order=order, skip_type="time_uniform", method="multistep")
     sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
-    if world > 1:
+    if dist.is_initialized():
         out = torch.empty((n,) + tuple(sr.shape[1:]), dtype=sr.dtype, device=sr.device)
         dist.all_gather_into_tensor(out, sr.contiguous())
         sr = out

@@ -36,7 +36,8 @@ typedef enum ddif_status {
     DDIF_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
     DDIF_ERR_HIP = -2,         /* a HIP runtime call failed */
     DDIF_ERR_MISSING = -3,     /* a required weight was never loaded */
-    DDIF_ERR_STATE = -4        /* call order violated (e.g. sample before set_cond) */
+    DDIF_ERR_STATE = -4,       /* call order violated (e.g. sample before set_cond) */
+    DDIF_ERR_RANGE = -5        /* an activation left the range of the plan's arithmetic (ddif_plan_range_status): the result of that call is not valid */
 } ddif_status;
 
 typedef struct ddif_net* ddif_net_t;   /* weights (repacked for the kernels) of one UNetSR3 */
@@ -377,6 +378,20 @@ DDIF_API int ddif_plan_memory(ddif_plan_t plan, int64_t* total_bytes, int64_t* a
 #define DDIF_MATH_BF16 1
 DDIF_API int ddif_set_math_mode(int mode);
 DDIF_API int ddif_get_math_mode(void);
+
+/* Range guard of the f16x2 split (the default arithmetic of inference plans).  An IEEE half carries 2^4 x the activation, so the path is exact
+ * only for |x| < 4094.  Behind a GroupNorm that bound is proven on the host from gamma / beta; a conv WITHOUT a GroupNorm in front (the decoder's
+ * feed-forward pair, up-sampling convs, CondInjection.x_conv: models/sr3_dwt.py:528-533, 266-273, 380-396) stages its RAW input, which a trained
+ * checkpoint (utils/misc.py:89-122 loads any) may push past it -- the half becomes inf and the output NaN.  Those launches therefore watch what
+ * they stage and set a sticky per-plan flag.
+ *   ddif_plan_range_status: synchronises `stream`, writes 1 to *overflow if a launch of this plan staged a value outside the range since the
+ *     last call (and clears the flag), else 0, and returns DDIF_OK; called once per sampler / forward call by the Python layer, which then
+ *     rebuilds the plan under ddif_set_f16_raw(0) and repeats the call.  A caller that does not want to fall back treats 1 as DDIF_ERR_RANGE.
+ *   ddif_set_f16_raw(0): plans created afterwards keep convs on raw inputs on bf16x3 (full fp32 exponent range, six products instead of three);
+ *     1 (default; DDIF_F16_RAW=0 in the environment for 0) = f16x2 with the watch.  GroupNorm-prologue convs are unaffected. */
+DDIF_API int ddif_plan_range_status(ddif_plan_t plan, void* stream, int* overflow);
+DDIF_API int ddif_set_f16_raw(int on);
+DDIF_API int ddif_get_f16_raw(void);
 
 /* TEST HOOK: cap the persistent grid (workgroups per conv launch) of plans created afterwards; 0 removes the cap.
  * Results do not depend on the cap (work items are walked in a fixed order per workgroup and every reduction has a

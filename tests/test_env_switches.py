@@ -62,3 +62,45 @@ def test_training_gradients_on_the_exact_fp32_convs():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout, tail
+
+
+def test_resident_weights_tiling_is_bit_identical_to_the_tiling_it_replaces(tmp_path):
+    """DDIF_WRES=0 keeps tiling 27 (16-channel stages, weights re-staged per stage) where the default takes the resident-weights tiling 37 (kernels_conv.h
+    MATH = 5: one 32-channel stage per work item, weights in LDS for the whole launch) -- same pack, same accumulation order, same GroupNorm partials:
+    a 64 x 64 forward and a 4-step DDPM chain of two tiles must agree BIT FOR BIT between the two, and the default plan must really contain the tiling."""
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r, %r]
+import torch
+import golden_cases as gc
+from ddif_testlib import make_diffusion, make_net, use_gpu_library
+use_gpu_library()
+dev = torch.device("cuda:0")
+ds, B, H = "wv3", 2, 64
+C = gc.DATASETS[ds][0]
+g = torch.Generator().manual_seed(77)
+x = torch.randn(B, C, H, H, generator=g).to(dev)
+t = torch.tensor([900, 12]).to(dev)
+cond = gc.tiles_for(ds, B, H, H, seed=78)["cond"].to(dev)
+net = make_net(ds, dev)
+y = net(x, t, cond)
+d = make_diffusion(net, C, 4, H, dev)
+out = d(cond, mode="ddpm_sample", seed=3, tile0=0, device_rng=True)
+torch.save({"y": y.cpu(), "out": out.cpu()}, sys.argv[1])
+"""
+    import torch
+
+    res = {}
+    for flag in ("0", "1"):
+        e = dict(os.environ)
+        e["DDIF_WRES"] = flag
+        e["DDIF_DUMP_PLAN"] = "1"
+        f = str(tmp_path / ("wres%s.pt" % flag))
+        r = subprocess.run([sys.executable, "-c", code % (os.path.join(ROOT, "dif-pan_amd"), ROOT, os.path.join(ROOT, "tests")), f], env=e, cwd=ROOT, capture_output=True,
+                           text=True, timeout=1500)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        res[flag] = (torch.load(f), r.stderr.count("cfg=37"))
+    assert res["0"][1] == 0 and res["1"][1] >= 15, (res["0"][1], res["1"][1])  # 14 ResnetBlock convs + the final conv at the 64 x 64 level
+    assert torch.equal(res["0"][0]["y"], res["1"][0]["y"])
+    assert torch.equal(res["0"][0]["out"], res["1"][0]["out"])
+    assert bool(torch.isfinite(res["1"][0]["out"]).all())
