@@ -174,6 +174,43 @@ int main(int argc, char** argv) {
         run<3, 1, 0, 16, 16, 32, 8, 1, 1, 1, PRO_GN_SILU, 16, 0, 5>("3x3 gn_silu 32->32 @64^2 f16x2 CK32 resident stamps", B, 64, 64, 32, 32, 1);
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'i') {  // round 5: instruction-cache effect of ALTERNATING kernels (the step never runs the same instantiation twice in a row)
+        const int H = 64, W = 64, Cin = 32, Cout = 32;
+        const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * H * W * Cout, nw = 4 * 2 * 9 * 3 * 256;
+        float *in, *w, *out, *gamma, *beta, *bias, *res, *zeros; double *st, *sto;
+        CK_(hipMalloc(&in, nin * 4)); CK_(hipMalloc(&w, nw * 4)); CK_(hipMalloc(&out, nout * 4)); CK_(hipMalloc(&res, nout * 4)); CK_(hipMalloc(&gamma, 4096)); CK_(hipMalloc(&beta, 4096));
+        CK_(hipMalloc(&bias, 4096)); CK_(hipMalloc(&zeros, 4096)); CK_(hipMemset(zeros, 0, 4096)); CK_(hipMalloc(&st, (size_t)B * 64 * 16)); CK_(hipMalloc(&sto, (size_t)B * 64 * 16));
+        std::vector<float> hh(nin); for (auto& v : hh) v = (rand() % 2001 - 1000) * 1e-3f;
+        CK_(hipMemcpy(in, hh.data(), nin * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(res, hh.data(), nout * 4, hipMemcpyHostToDevice));
+        CK_(hipMemcpy(gamma, hh.data(), 4096, hipMemcpyHostToDevice)); CK_(hipMemcpy(beta, hh.data(), 4096, hipMemcpyHostToDevice)); CK_(hipMemcpy(bias, hh.data(), 4096, hipMemcpyHostToDevice));
+        std::vector<_Float16> hw(nw * 2); for (auto& v : hw) v = (_Float16)((rand() % 2001 - 1000) * 1e-3f);
+        CK_(hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice));
+        std::vector<double> hs((size_t)B * 64 * 2); for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 10.0; hs[i + 1] = 5000.0; }
+        CK_(hipMemcpy(st, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
+        ConvArgs a{}; a.in0 = in; a.c0 = Cin; a.B = B; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W; a.Cout = Cout; a.w = w; a.n_chunks = 2; a.bias = bias; a.gamma = gamma; a.beta = beta;
+        a.out = out; a.tiles_x = 4; a.tiles_y = 4; a.res = res; a.tbias = zeros; a.n_ct = 1; a.st0 = st; a.np0 = 64; a.st_out = sto;
+        ConvKernelFnT ks[4] = {conv_mfma_kernel<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 1, 0, 0, 3>, conv_mfma_kernel<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 1, EPI_RES, 0, 3>,
+                               conv_mfma_kernel<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 1, EPI_SILU, 0, 3>, conv_mfma_kernel<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_NONE, 1, EPI_RES, 0, 3>};
+        size_t sm[4] = {conv_smem_bytes<3, 1, 0, 16, 16, 16, 1, PRO_GN_SILU, 8, 3>() + conv_smem_extra(PRO_GN_SILU, 2, 16, 32), 0, conv_smem_bytes<3, 1, 0, 16, 16, 16, 1, PRO_NONE, 8, 3>() + conv_smem_extra(PRO_NONE, 2, 16, 32), 0};
+        sm[1] = sm[0]; sm[3] = sm[2];
+        for (int k = 0; k < 4; ++k) CK_(hipFuncSetAttribute((const void*)ks[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm[k]));
+        hipEvent_t e0, e1; CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
+        auto timeseq = [&](const char* name, std::vector<int> seq) {
+            for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(ks[seq[i % seq.size()]], dim3(256), dim3(512), sm[seq[i % seq.size()]], 0, a);
+            CK_(hipDeviceSynchronize());
+            const int iters = 120;
+            CK_(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(ks[seq[i % seq.size()]], dim3(256), dim3(512), sm[seq[i % seq.size()]], 0, a);
+            CK_(hipEventRecord(e1, 0)); CK_(hipEventSynchronize(e1));
+            float ms; CK_(hipEventElapsedTime(&ms, e0, e1));
+            printf("%-40s %7.2f us per launch\n", name, ms * 1e3 / iters);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            timeseq("A only (gn_silu)", {0}); timeseq("B only (gn_silu + res)", {1}); timeseq("C only (silu epilogue)", {2}); timeseq("D only (res, no prologue)", {3});
+            timeseq("A B alternating", {0, 1}); timeseq("A B C D round robin", {0, 1, 2, 3}); timeseq("A A B B C C D D", {0, 0, 1, 1, 2, 2, 3, 3});
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'x') {  // bf16x3 (MATH = 1) against the exact-fp32 MFMA
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) f32", B, 64, 64, 32, 32, 1);
         run<3, 1, 0, 16, 16, 16, 8, 1, 1, 1, PRO_GN_SILU, 0, 0, 1>("3x3 gn_silu 32->32 @64^2 (16x16,NT32,8w) bf16x3", B, 64, 64, 32, 32, 1);
