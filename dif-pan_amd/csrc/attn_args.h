@@ -16,7 +16,8 @@ struct AttnBlockArgs {
     float* out;           // [B, 64, 128]
     double* st_out;       // [B][1][2] or null
     int B;
-    int b0;               // batch window [b0, b0 + B)
+    int b0;               // first sample
+    int xcd;              // samples of one XCD contiguous (workgroup w runs on XCD w % 8; ddif_dev.h wg_work_range)
 };
 
 }  // namespace ddif

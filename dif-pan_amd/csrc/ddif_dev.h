@@ -181,8 +181,12 @@ __device__ __forceinline__ float dd_silu_scaled(float x, float inv_s) {
 // Contiguous share of a persistent workgroup: [floor(b n / g), floor((b + 1) n / g)) for b = blockIdx.x, g = gridDim.x -- the same partition as the
 // 64-bit expression, from three 32-bit divisions (n = q g + r  =>  floor(b n / g) = b q + floor(b r / g), and b r < g^2 < 2^32): the two emulated
 // 64-bit divisions were several hundred instructions at the head of every conv launch's dependent prologue chain.
-__device__ __forceinline__ void wg_work_range(int nwork, int* w0, int* w1) {
-    const unsigned g = gridDim.x, b = blockIdx.x, n = (unsigned)nwork;
+// xcd (round 5): the dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH: never relied on for correctness).  With xcd != 0 and 8 | grid the
+// workgroups of ONE XCD take a contiguous eighth of the work items, so that neighbouring tiles (shared halos), the cout tiles of one pixel tile and -- the
+// producer having used the same map -- the consumer's input all meet in that XCD's private L2 instead of in HBM / Infinity Cache.
+__device__ __forceinline__ void wg_work_range(int nwork, int* w0, int* w1, int xcd = 0) {
+    const unsigned g = gridDim.x, n = (unsigned)nwork;
+    const unsigned b = (xcd && (g & 7u) == 0u) ? (blockIdx.x & 7u) * (g >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const unsigned q = n / g, r = n - q * g;
     *w0 = (int)(b * q + (b * r) / g);
     *w1 = (int)((b + 1) * q + ((b + 1) * r) / g);

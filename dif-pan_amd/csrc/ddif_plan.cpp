@@ -159,6 +159,15 @@ static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention 
     static const int v = [] { const char* e = getenv("DDIF_LAFUSE"); return e ? atoi(e) : 1; }();
     return v;
 }
+// DDIF_XCD (bit mask, default 15 = all): XCD-contiguous work partition (ddif_dev.h wg_work_range) of 1 = the general conv kernel, 2 = the low-resolution kernel,
+// 4 = the fused linear-attention block, 8 = the per-sample kernels (bottleneck attention block, gn_dw3x3 of the low levels).  The dispatcher puts workgroup b on
+// XCD b % 8; with the map every kernel of the step gives XCD k the same eighth of the samples (tiles 8 k .. 8 k + 7 at B = 64), so halos, the cout tiles of a pixel
+// tile and a consumer's input (written by the same XCD one launch earlier) meet in that XCD's private L2: 3.90 -> 3.76 ms per denoising step, same box
+// (profiles/r05_k_xcd_ab.txt).  Results do not depend on it -- the partition only decides WHICH workgroup computes an item (tests/test_env_switches.py).
+static int xcd_mask() {
+    static const int v = [] { const char* e = getenv("DDIF_XCD"); return e ? atoi(e) : 15; }();
+    return v;
+}
 static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) as well; covered by tests/test_env_switches.py
     static const int lr = [] { const char* e = getenv("DDIF_LR"); return e ? atoi(e) : 1; }();
     return lr;
@@ -494,6 +503,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         a.st_out = out->st;
     }
     a.n_ct = gy;
+    a.xcd = (xcd_mask() & (var.lr ? 2 : 1)) ? 1 : 0;
     if (var.f16 && raw_in) {  // (the kernels only look at it in their raw-input f16x2 instantiations)
         a.range_flag = d_range;
         ++n_range_convs;
@@ -768,6 +778,7 @@ int Plan::build_impl() {
             a.out = out->p;
             a.st_out = out->st;
             a.B = B;
+            a.xcd = (xcd_mask() & 8) ? 1 : 0;
             if (!a.gamma || !a.beta) return fail(DDIF_ERR_MISSING, "%s: norm weights missing", ap.c_str());
             Op op;
             op.name = "attn_block";
@@ -1289,6 +1300,7 @@ int Plan::build_impl() {
                 use(skip.p);
                 DDIF_TRY(alloc_tensor(&amix, pm->cout, Hl, Wl, true));
                 LaFuseArgs a{};
+                a.xcd = (xcd_mask() & 4) ? 1 : 0;
                 a.in0 = cur.p;
                 a.c0 = cur.C;
                 a.in1 = skip.p;
@@ -1380,7 +1392,9 @@ int Plan::build_impl() {
             op.bytes = 4.0 * B * Hl * Wl * 3.0 * fea;
             const size_t sm = (size_t)(Hl + 2) * (Wl + 2) * 36 * sizeof(float);
             if (sm > 64 * 1024) DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_dw3x3_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-            op.run = [a, BB, fea, sm](hipStream_t s, const StepCtx&) { hipLaunchKernelGGL(gn_dw3x3_small_kernel, dim3((fea + 31) / 32, BB), dim3(256), sm, s, a); };
+            a.xcd = (xcd_mask() & 8) ? 1 : 0;
+            const dim3 gdw = a.xcd ? dim3(BB, (fea + 31) / 32) : dim3((fea + 31) / 32, BB);
+            op.run = [a, gdw, sm](hipStream_t s, const StepCtx&) { hipLaunchKernelGGL(gn_dw3x3_small_kernel, gdw, dim3(256), sm, s, a); };
             step.push_back(std::move(op));
             ConvSpec s;
             s.pc = pq1;

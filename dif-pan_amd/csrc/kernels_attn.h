@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
     const int h = lane >> 5, j = lane & 31;
     const int c4 = tid & 31, p0 = tid >> 5;  // staging: 32 float4 channel groups x 8 tokens per pass
 
-    for (int b = a.b0 + blockIdx.x; b < a.b0 + a.B; b += gridDim.x) {
+    const unsigned ga = gridDim.x;
+    const int bw = (a.xcd && (ga & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (ga >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;  // XCD-contiguous sample order
+    for (int b = a.b0 + bw; b < a.b0 + a.B; b += gridDim.x) {
         // ---- (1) loads in one burst: GroupNorm partials, the sample, affine parameters, first weight slab
         GnPartials gp;
         gn_load_partials(a.st, a.np, nullptr, 0, b, &gp);

@@ -84,6 +84,7 @@ struct ConvArgs {
     // sets this sticky per-plan flag; the host reads it once per sampler call (ddif_plan_range_status) and rebuilds the plan with these convs on
     // bf16x3 (full fp32 range).  Null: not checked.  (A plain store of 1 by any number of threads: no atomics needed.)
     int* range_flag;
+    int xcd;                 // wg_work_range: XCD-contiguous work partition (ddif_dev.h)
 };
 
 template <int F>
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     const int ntiles = a.B * tiles;
     const int nwork = ntiles * a.n_ct;
     int w0, w1;
-    wg_work_range(nwork, &w0, &w1);
+    wg_work_range(nwork, &w0, &w1, a.xcd);
     if (w0 >= w1) return;  // whole workgroup leaves together
     const int Hc = UPS ? a.Hin * 2 : a.Hin, Wc = UPS ? a.Win * 2 : a.Win;
     const int Ctot = a.c0 + a.c1;

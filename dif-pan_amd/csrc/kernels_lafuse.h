@@ -47,6 +47,7 @@ struct LaFuseArgs {
     float* out;              // [B, H, W, dout]
     int dout;
     long long* dbg;          // microbenchmark instrumentation (ABL & 64) only
+    int xcd;                 // wg_work_range: XCD-contiguous work partition (ddif_dev.h)
 };
 
 template <int TH, int TW, int NBQ, int NBA>
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     const int nstrips = (a.W + TW - 1) / TW;
     const int nwork = a.B * nstrips;
     int w0, w1;
-    wg_work_range(nwork, &w0, &w1);
+    wg_work_range(nwork, &w0, &w1, a.xcd);
     if (w0 >= w1) return;
 
     // tables (once per launch)

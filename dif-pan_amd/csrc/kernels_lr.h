@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     const int tiles = a.tiles_x * a.tiles_y;
     const int nwork = a.B * tiles * a.n_ct;
     int w0, w1;
-    wg_work_range(nwork, &w0, &w1);
+    wg_work_range(nwork, &w0, &w1, a.xcd);
     const int Ctot = a.c0 + a.c1;
     const int NS = (Ctot + 15) / 16;                 // 16-channel slabs (channels past the end of the last one stage zeros)
     const int NSW = a.n_chunks * (KS == 3 ? 1 : 2);  // slabs in the packed weights (>= NS)

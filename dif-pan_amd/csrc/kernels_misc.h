@@ -27,7 +27,8 @@ struct DwArgs {
     float* out_xn;       // [B,H,W,C] or null
     int tiles_x, tiles_y;
     int use_gn;
-    int b0;              // gn_dw3x3_small_kernel: batch window (blockIdx.y counts from b0)
+    int b0;              // gn_dw3x3_small_kernel: first sample (blockIdx.y counts from b0)
+    int xcd;             // gn_dw3x3_small_kernel: grid = (samples, chunks) with the samples XCD-contiguous (ddif_dev.h wg_work_range) instead of (chunks, samples)
     int flip;            // dw3x3(_q4)_kernel: taps mirrored (w[8 - k]): the input gradient of the same depthwise conv
 };
 
@@ -193,7 +194,10 @@ __global__ __launch_bounds__(256) void gn_dw3x3_small_kernel(DwArgs a) {
     DDIF_DYN_SMEM(smem);
     float* Hs = reinterpret_cast<float*>(smem);  // [(H+2)*(W+2)][HP]
     const int tid = threadIdx.x;
-    const int b = a.b0 + blockIdx.y, cb = blockIdx.x * CK;
+    // xcd: blockIdx.x = sample slot (workgroup s runs on XCD s % 8: the samples of one XCD are made contiguous, as the conv kernels' work partition does), blockIdx.y = chunk
+    const unsigned gs = gridDim.x;
+    const int bs = (a.xcd && (gs & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (gs >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int b = a.b0 + (a.xcd ? bs : (int)blockIdx.y), cb = (a.xcd ? (int)blockIdx.y : (int)blockIdx.x) * CK;
     const int C = a.c0 + a.c1, IW = a.W + 2, n = a.H * a.W, nh = (a.H + 2) * IW;
     const int c4 = tid & 7, c = cb + c4 * 4;
     const bool cok = c < C;

@@ -9,7 +9,9 @@
                 latter, so this is what keeps the general kernel's small-tile instantiations covered.
 
   DDIF_F16=0    the split-operand convs on bf16x3 (six products) instead of f16x2 (three);
-  DDIF_LAFUSE=0 the decoder's linear-attention half as three launches instead of the fused block (csrc/kernels_lafuse.h).
+  DDIF_LAFUSE=0 the decoder's linear-attention half as three launches instead of the fused block (csrc/kernels_lafuse.h);
+  DDIF_WRES=0 / DDIF_XCD=0  the 16-channel-stage tiling of the 32 -> 32 convs / the dispatcher's round-robin work partition instead of the resident-weights
+                tiling / the XCD-contiguous partition (round 5): bit-identical results either way.
 
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
 kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04_t_*, r03_b_*) were deleted together with
@@ -64,7 +66,7 @@ def test_training_gradients_on_the_exact_fp32_convs():
     assert " passed" in r.stdout, tail
 
 
-def test_resident_weights_tiling_is_bit_identical_to_the_tiling_it_replaces(tmp_path):
+def test_resident_weights_tiling_and_xcd_partition_are_bit_identical_to_what_they_replace(tmp_path):
     """DDIF_WRES=0 keeps tiling 27 (16-channel stages, weights re-staged per stage) where the default takes the resident-weights tiling 37 (kernels_conv.h
     MATH = 5: one 32-channel stage per work item, weights in LDS for the whole launch) -- same pack, same accumulation order, same GroupNorm partials:
     a 64 x 64 forward and a 4-step DDPM chain of two tiles must agree BIT FOR BIT between the two, and the default plan must really contain the tiling."""
@@ -94,6 +96,7 @@ torch.save({"y": y.cpu(), "out": out.cpu()}, sys.argv[1])
     for flag in ("0", "1"):
         e = dict(os.environ)
         e["DDIF_WRES"] = flag
+        e["DDIF_XCD"] = "0" if flag == "0" else "15"  # ... and the XCD-contiguous work partition (ddif_dev.h wg_work_range): which workgroup computes an item, never what
         e["DDIF_DUMP_PLAN"] = "1"
         f = str(tmp_path / ("wres%s.pt" % flag))
         r = subprocess.run([sys.executable, "-c", code % (os.path.join(ROOT, "dif-pan_amd"), ROOT, os.path.join(ROOT, "tests")), f], env=e, cwd=ROOT, capture_output=True,
