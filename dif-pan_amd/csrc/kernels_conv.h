@@ -914,7 +914,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     for (int k = 0; k < TBL; ++k) {
         const int i = tid + k * NTHR, c = i < a.Cout ? i : a.Cout - 1;
         t_bias[k] = a.bias[c];
-        t_tb[k] = TBS ? 0.f : tbrow[c];
     }
     if (DWM) {
 #pragma unroll
@@ -937,6 +936,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         if (WRI > 4) t_w4 = wld(4);
     }
     if (GNP) gn_load_partials(a.st0, a.np0, a.st1, a.np1, R0.pos.b, &gp);
+    // the step's time-bias row LAST: its address waits for the step counter (a dependent scalar load); issued earlier, every load behind it in program order waits too
+#pragma unroll
+    for (int k = 0; k < TBL; ++k) {
+        const int i = tid + k * NTHR, c = i < a.Cout ? i : a.Cout - 1;
+        t_tb[k] = TBS ? 0.f : tbrow[c];
+    }
     // ... and now the uses
     if constexpr (WR) {
         auto wst = [&](int k, const float4& v) { const int i = tid + k * NTHR; *reinterpret_cast<float4*>(i < WBUF / 4 ? &Ws[i * 4] : As + DUMMY) = v; };  // past the end: the A buffer's pad slot

@@ -136,7 +136,6 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
         const bool cok_o = co < a.Cout;  // Cout is a multiple of 4
         const int coc = cok_o ? co : 0;
         const float4 bq = *reinterpret_cast<const float4*>(a.bias + coc);
-        const float4 tq = *reinterpret_cast<const float4*>(tbrow + (size_t)b * a.tbias_stride + coc);
         [[maybe_unused]] float4 e_res[RES ? MB : 1], e_fs[FILM ? MB : 1], e_fh[FILM ? MB : 1];
         bool pok[MB];
         size_t opix[MB];
@@ -267,6 +266,9 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             }
         };
         stage_load(0);
+        // the time-bias row LAST: its address waits for the step counter (a dependent scalar load); issued earlier, every load behind it in program order
+        // would wait for that round trip too
+        const float4 tq = *reinterpret_cast<const float4*>(tbrow + (size_t)b * a.tbias_stride + coc);
 
         // ================= (2) first uses =================
         if (new_b) {  // every wavefront reduces the producer's partials itself (no barrier)
