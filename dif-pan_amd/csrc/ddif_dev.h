@@ -178,6 +178,30 @@ __device__ __forceinline__ float dd_silu_scaled(float x, float inv_s) {
 #endif
 }
 
+// Kernel-argument lines touched at kernel entry (round 5).  The argument block of the big kernels is 300-400 bytes = 5-7 scalar-cache lines, the L2s (and the scalar
+// caches) start COLD at every kernel boundary on this part, and hipcc loads the fields of a by-value struct lazily, where they are first used: every first touch of another
+// line deep inside the prologue was one more Infinity-Cache round trip in the dependent chain in front of the first MFMA.  One s_load per 64-byte line, waited for inside the
+// same statement (the results are dummies: nothing may still be in flight when the compiler reuses their registers), puts all lines into the scalar cache in ONE round trip.
+template <int BYTES>
+__device__ __forceinline__ void dd_touch_kernargs() {
+#if !defined(DDIF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();  // (constant address space: as a 64-bit SGPR pair)
+    static_assert(BYTES >= 4 && BYTES <= 448, "kernarg touch: up to eight loads");
+    // offsets 0, 64, 128, ... and the block's last dword (the segment need not start on a line boundary): NL loads in ONE statement
+    constexpr int NL = (BYTES + 63) / 64 + 1;
+#define DD_KA_OFF(i) ((i) * 64 < BYTES - 4 ? (i) * 64 : BYTES - 4)
+    [[maybe_unused]] unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+    if constexpr (NL == 2) asm volatile("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1) : "s"(ka), "n"(DD_KA_OFF(0)), "n"(DD_KA_OFF(1)) : "memory");
+    else if constexpr (NL == 3) asm volatile("s_load_dword %0, %3, %4\n\ts_load_dword %1, %3, %5\n\ts_load_dword %2, %3, %6\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2) : "s"(ka), "n"(DD_KA_OFF(0)), "n"(DD_KA_OFF(1)), "n"(DD_KA_OFF(2)) : "memory");
+    else if constexpr (NL == 4) asm volatile("s_load_dword %0, %4, %5\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %4, %7\n\ts_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka), "n"(DD_KA_OFF(0)), "n"(DD_KA_OFF(1)), "n"(DD_KA_OFF(2)), "n"(DD_KA_OFF(3)) : "memory");
+    else if constexpr (NL == 5) asm volatile("s_load_dword %0, %5, %6\n\ts_load_dword %1, %5, %7\n\ts_load_dword %2, %5, %8\n\ts_load_dword %3, %5, %9\n\ts_load_dword %4, %5, %10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(ka), "n"(DD_KA_OFF(0)), "n"(DD_KA_OFF(1)), "n"(DD_KA_OFF(2)), "n"(DD_KA_OFF(3)), "n"(DD_KA_OFF(4)) : "memory");
+    else if constexpr (NL == 6) asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\ts_load_dword %3, %6, %10\n\ts_load_dword %4, %6, %11\n\ts_load_dword %5, %6, %12\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5) : "s"(ka), "n"(DD_KA_OFF(0)), "n"(DD_KA_OFF(1)), "n"(DD_KA_OFF(2)), "n"(DD_KA_OFF(3)), "n"(DD_KA_OFF(4)), "n"(DD_KA_OFF(5)) : "memory");
+    else if constexpr (NL == 7) asm volatile("s_load_dword %0, %7, %8\n\ts_load_dword %1, %7, %9\n\ts_load_dword %2, %7, %10\n\ts_load_dword %3, %7, %11\n\ts_load_dword %4, %7, %12\n\ts_load_dword %5, %7, %13\n\ts_load_dword %6, %7, %14\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) : "s"(ka), "n"(DD_KA_OFF(0)), "n"(DD_KA_OFF(1)), "n"(DD_KA_OFF(2)), "n"(DD_KA_OFF(3)), "n"(DD_KA_OFF(4)), "n"(DD_KA_OFF(5)), "n"(DD_KA_OFF(6)) : "memory");
+    else if constexpr (NL == 8) asm volatile("s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\ts_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7) : "s"(ka), "n"(DD_KA_OFF(0)), "n"(DD_KA_OFF(1)), "n"(DD_KA_OFF(2)), "n"(DD_KA_OFF(3)), "n"(DD_KA_OFF(4)), "n"(DD_KA_OFF(5)), "n"(DD_KA_OFF(6)), "n"(DD_KA_OFF(7)) : "memory");
+#undef DD_KA_OFF
+#endif
+}
+
 // Contiguous share of a persistent workgroup: [floor(b n / g), floor((b + 1) n / g)) for b = blockIdx.x, g = gridDim.x -- the same partition as the
 // 64-bit expression, from three 32-bit divisions (n = q g + r  =>  floor(b n / g) = b q + floor(b r / g), and b r < g^2 < 2^32): the two emulated
 // 64-bit divisions were several hundred instructions at the head of every conv launch's dependent prologue chain.

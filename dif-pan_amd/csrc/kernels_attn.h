@@ -34,6 +34,7 @@ struct AttnBlockGeom {
 __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
     using G = AttnBlockGeom;
     constexpr int N = G::N, C = G::C, NSLAB = G::NSLAB, APIX = G::APIX, QROW = G::QROW, D = 16;
+    dd_touch_kernargs<sizeof(AttnBlockArgs)>();  // every line of the argument block in ONE round trip (ddif_dev.h)
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);  // bf16 planes: xn, later o
     float* Qs = As + G::AFL;                     // fp32 qkv [token][384]

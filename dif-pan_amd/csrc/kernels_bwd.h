@@ -59,6 +59,7 @@ struct WgradArgs {
 constexpr int WG_PF = 9, WG_PF_CENTRE = 13;  // prefetch registers (float4 per thread): 3x3 keeps 144 accumulators and must stay at 2 waves / SIMD
 template <int PF, int CENTRE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
+    dd_touch_kernargs<sizeof(WgradArgs)>();  // (ddif_dev.h: the argument block in one round trip)
     DDIF_DYN_SMEM(smem);
     constexpr int HALO = CENTRE ? 0 : 1;
     constexpr int NPF = CENTRE ? WG_PF_CENTRE : WG_PF;

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     static_assert(RP == 0 || !DWM, "row pad: 3x3 tiles only");
     static_assert(!WR || (KS == 3 && STRIDE == 1 && !UPS && CK == 32 && TW == 16 && !DWM), "resident weights: plain 3x3 convs with one 32-channel stage");
 
+    dd_touch_kernargs<sizeof(ConvArgs)>();  // every line of the argument block in ONE round trip (ddif_dev.h)
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);   // [2][ABUF]  input halo tile of one channel chunk
     float* Ws = As + 2 * ABUF;                    // [NWB][WBUF]  weight chunk in B-fragment order
@@ -966,18 +967,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             GBs[GBN + i] = a.beta[c];
         }
     }
-    {
-        const int nbt = a.n_ct * (32 * NB * WN);
-#pragma unroll
-        for (int k = 0; k < TBL; ++k) {
-            const int i = tid + k * NTHR;
-            if (i < nbt) BTs[i] = t_bias[k] + t_tb[k];
-        }
-        for (int i = tid + TBL * NTHR; i < nbt; i += NTHR) {
-            const int c = i < a.Cout ? i : a.Cout - 1;
-            BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
-        }
-    }
     if (DWM) {
 #pragma unroll
         for (int k = 0; k < DWI; ++k) {
@@ -992,6 +981,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     __syncthreads();
     stamp();
     finish_stage(R0, 0);
+    {   // bias + the step's time-bias row: needed by the first EPILOGUE only, so the fill comes behind the first stage's staging -- the row's address hangs on the step counter
+        // (two dependent round trips on cold caches), and in front of the staging the first MFMA would wait for them
+        const int nbt = a.n_ct * (32 * NB * WN);
+#pragma unroll
+        for (int k = 0; k < TBL; ++k) {
+            const int i = tid + k * NTHR;
+            if (i < nbt) BTs[i] = t_bias[k] + t_tb[k];
+        }
+        for (int i = tid + TBL * NTHR; i < nbt; i += NTHR) {
+            const int c = i < a.Cout ? i : a.Cout - 1;
+            BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
+        }
+    }
     __syncthreads();
     stamp();
 #ifndef DDIF_EMU

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     constexpr int WIT = (NPC + 7) / 8, FIT = (NPF + 7) / 8;   // weight pieces per wave (a piece = 64 lanes x 16 B)
     constexpr float L2E = 1.4426950408889634f;
 
+    dd_touch_kernargs<sizeof(LaFuseArgs)>();  // every line of the argument block in ONE round trip (ddif_dev.h)
     DDIF_DYN_SMEM(smem);
     float* Hs = reinterpret_cast<float*>(smem);
     float* Aq = Hs + G::HS;

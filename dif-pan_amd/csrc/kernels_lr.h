@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     constexpr int NIT = (LH * LW + PSTEP - 1) / PSTEP;  // staging items per thread and phase
     static_assert(256 % C4 == 0, "staging geometry");
 
+    dd_touch_kernargs<sizeof(ConvArgs)>();  // every line of the argument block in ONE round trip (ddif_dev.h)
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);
     float* Red = As;  // reused after the last phase (barrier in between)

@@ -33,6 +33,7 @@ struct DwArgs {
 };
 
 __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
+    dd_touch_kernargs<sizeof(DwArgs)>();  // (ddif_dev.h: the argument block in one round trip)
     constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, CK = 32;
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);  // [IH*IW][CK]
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(DwArgs a) {
 // spends ~3600 vector instructions per wavefront on addressing (rocprofv3 SQ_INSTS_VALU) and is instruction-bound, not memory-bound.  Same tile
 // (8x16 pixels, 32-channel chunks = 8 quads), same arithmetic per element (bit-identical results).
 __global__ __launch_bounds__(256) void dw3x3_q4_kernel(DwArgs a) {
+    dd_touch_kernargs<sizeof(DwArgs)>();  // (ddif_dev.h: the argument block in one round trip)
     constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, CK = 32, NIT = (IH * IW * 8 + 255) / 256;
     DDIF_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);  // [IH*IW][CK]
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(256) void dw3x3_q4_kernel(DwArgs a) {
 // the WHOLE normalised image of its chunk (+ zero border) in LDS, float4 channel groups, one pass.  Emits dw3x3(xn) and
 // xn = GroupNorm(cat[in0, in1]); channel counts are multiples of 4.
 __global__ __launch_bounds__(256) void gn_dw3x3_small_kernel(DwArgs a) {
+    dd_touch_kernargs<sizeof(DwArgs)>();  // (ddif_dev.h: the argument block in one round trip)
     constexpr int CK = 32, HP = CK + 4;  // floats per staged pixel (16 B pad: conflict-free float4 rows)
     DDIF_DYN_SMEM(smem);
     float* Hs = reinterpret_cast<float*>(smem);  // [(H+2)*(W+2)][HP]
