@@ -169,15 +169,6 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     wg_work_range(nwork, &w0, &w1, a.xcd);
     if (w0 >= w1) return;
 
-    // tables (once per launch)
-    for (int i = tid; i < FEA; i += 512) {
-        GB[i] = a.gamma[i];
-        GB[FEA + i] = a.beta[i];
-        BQ[i] = a.bq[i];
-    }
-    for (int i = tid; i < 9 * FEA; i += 512) DW[i] = a.dw_w[i];
-    for (int i = tid; i < 32 * NBA; i += 512) BO[i] = i < a.dout ? a.bias[i] : 0.f;
-
     // raw staging: item = halo pixel * 4 + channel quad (geometry recomputed per use: divisions by constants, no registers held)
     const int c4 = tid & 3;
     float4 raw[NIT];
@@ -238,9 +229,25 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
 
     int gn_b = -1;
     float mean = 0.f, rstd = 1.f;
+    GnPartials gp0;  // the first sample's GroupNorm partials: requested with the first strip (one round trip on the cold caches of a launch), reduced behind the table fills
     {
         const int b = a.b0 + w0 / nstrips;
+        gn_load_partials(a.st0, a.np0, a.st1, a.np1, b, &gp0);
         load_raw(b, (w0 % nstrips) * TW, 0);
+    }
+    // tables (once per launch) -- AFTER the first strip's loads have been issued: the table fills wait for their own loads, and on the cold caches every launch starts with that is a
+    // round trip the first tile should share, not follow
+    for (int i = tid; i < FEA; i += 512) {
+        GB[i] = a.gamma[i];
+        GB[FEA + i] = a.beta[i];
+        BQ[i] = a.bq[i];
+    }
+    for (int i = tid; i < 9 * FEA; i += 512) DW[i] = a.dw_w[i];
+    for (int i = tid; i < 32 * NBA; i += 512) BO[i] = i < a.dout ? a.bias[i] : 0.f;
+    {
+        const int b = a.b0 + w0 / nstrips;
+        gn_reduce_partials(gp0, a.st0, a.np0, a.st1, a.np1, b, (double)FEA * a.H * a.W, &mean, &rstd);
+        gn_b = b;
     }
     __syncthreads();  // tables
 
