@@ -474,8 +474,31 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre) {  // 
         g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2 * hl) * (W + 2 * hl) * 32 + 4096) * sizeof(float);
     }
     if (g.rb < 1) g.rb = 0;  // W too wide (caller checks)
+    // the bf16x3 kernel (kernels_bwd.h conv3x3_wgrad_x3_kernel; DDIF_WGRAD_X3=0: the fp32 kernel everywhere): 8 | W, the largest band of <= 256 staging items
+    // (then <= 512) whose transposed bf16 tiles fit two workgroups per CU
+    static const bool x3_env = [] { const char* e = getenv("DDIF_WGRAD_X3"); return !e || atoi(e) != 0; }();
+    if (x3_env && W % 8 == 0) {
+        auto stride = [](int n) { return n + (((n / 8) % 2 == 0) ? 8 : 0); };  // an odd number of 16-byte slots
+        const int segs = W / 8, hl = centre ? 0 : 1, xw = centre ? W : W + 16;
+        for (int npf = 1; npf <= 2 && !g.x3; ++npf)
+            for (int rb = H < 16 ? H : 16; rb >= 1; --rb) {
+                const int items = (rb + rb + 2 * hl) * segs * 8, ys = stride(rb * W), xs = stride((rb + 2 * hl) * xw);
+                size_t smem = (size_t)2 * 96 * (ys + xs);
+                if (smem < 16384) smem = 16384;  // the epilogue's reduction scratch aliases the tiles
+                if (items > 256 * npf || smem > 76 * 1024) continue;
+                g.x3 = 1;
+                g.npf = npf;
+                g.rb = rb;
+                g.xw = xw;
+                g.ys = ys;
+                g.xs = xs;
+                g.smem = smem;
+                g.centre = centre ? 1 : 0;
+                break;
+            }
+    }
     const int bands = B * ((H + (g.rb ? g.rb : 1) - 1) / (g.rb ? g.rb : 1));
-    int want = (2 * 256) / (g.n_co * g.n_ci);
+    int want = (2 * 256) / (g.n_co * g.n_ci);  // (512 workgroups per launch: 384 the same, 256 slower -- gpurun_out/r05_t)
     if (want < 1) want = 1;
     if (want > bands) want = bands;
     if (want > 512) want = 512;
@@ -488,6 +511,10 @@ int wgrad_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     return 0;
 }
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw, float* bpart,
@@ -506,8 +533,15 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
         if ((1 << k) == W) a.wshift = k;
     a.bpartial = (db && bpart) ? bpart : nullptr;  // bias gradient fused: per-split column sums from the kernel, finished by the reduce kernel
     static const bool dump = getenv("DDIF_WGRAD_DUMP") != nullptr;  // development aid: geometry of every launch, in order (match against a kernel trace)
-    if (dump) fprintf(stderr, "[wgrad] B=%d H=%d W=%d Cin=%d Cout=%d centre=%d rb=%d nsplit=%d blocks=%d pf=%d smem=%zu\n", B, H, W, Cin, Cout, (int)centre, g.rb, g.nsplit, g.n_co * g.n_ci, g.pf, g.smem);
-    if (g.pf && g.centre && centre) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 1>), dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
+    if (dump) fprintf(stderr, "[wgrad] B=%d H=%d W=%d Cin=%d Cout=%d centre=%d rb=%d nsplit=%d blocks=%d pf=%d x3=%d smem=%zu\n", B, H, W, Cin, Cout, (int)centre, g.rb, g.nsplit, g.n_co * g.n_ci, g.pf, g.x3, g.smem);
+    if (g.x3) {
+        WgradX3Geom gm{g.rb, g.xw, g.ys, g.xs};
+        const dim3 grid(g.n_co * g.n_ci, g.nsplit);
+        if (centre && g.npf == 1) hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<1, 1>), grid, dim3(256), g.smem, s, a, gm);
+        else if (centre) hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<1, 2>), grid, dim3(256), g.smem, s, a, gm);
+        else if (g.npf == 1) hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<0, 1>), grid, dim3(256), g.smem, s, a, gm);
+        else hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<0, 2>), grid, dim3(256), g.smem, s, a, gm);
+    } else if (g.pf && g.centre && centre) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 1>), dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     // one workgroup per row of 32 input channels of the partial layout (capped), + one for the bias

@@ -221,6 +221,232 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// The weight gradient on the 16-bit matrix pipe (round 5).  conv3x3_wgrad_kernel above contracts TWO pixels per v_mfma_f32_32x32x2_f32 (64 cycles, and the
+// fp32 matrix op shares the vector datapath with the address / LDS instructions around it): 15-29 % of its own matrix bound at the 3x3 shapes, 3-9 % at the
+// 1x1 ones (profiles/r03_k_wgrad_by_shape.txt).  Here K = 16 pixels per v_mfma_f32_32x32x16_bf16 with BOTH operands split three ways (bf16x3, six exact
+// products, small terms first, fp32 accumulate -- the arithmetic of the forward / dgrad convs of the training step): 192 instead of 512 matrix cycles per
+// 16 pixels and tap, on a pipe of its own.
+//   * the contraction index is the PIXEL, so the operands need pixels contiguous per channel: the band is staged TRANSPOSED, [plane][channel][pixel] as bf16,
+//     by items of (8 consecutive pixels x 4 channels): eight float4 loads, split, twelve 16-byte LDS writes.  Channel stride = an odd number of 16-byte
+//     slots: the fragment reads (lane = channel) are conflict-free;
+//   * a 16-pixel group = two 8-pixel segments (lane half h = segment); the A fragment of lane (j, h) is dY^T[co = j][8 pixels], the B fragment of tap
+//     (ky, kx) is X[ci = j][the same 8 pixels shifted by (ky - 1, kx - 1)]: rows shift by whole rows of the staged tile, columns by ONE bf16 = 2 bytes --
+//     the aligned chunk plus one dword of each neighbour chunk, funnel-shifted (v_alignbit_b32, 4 per plane: VALU work beside the matrix pipe).  The X rows
+//     carry 8 zero pixels on either side (written once per launch), so the neighbours of the first / last segment exist;
+//   * everything else as above: the workgroup owns a (32 co x 32 ci) block and walks bands (sample, RB rows) of its K split, the next band's loads fly during
+//     the current band's MFMAs, four waves split the pixel groups and meet in LDS in fixed order, partial blocks [split][block][tap][32][32] reduced by
+//     wgrad_reduce_kernel in index order.  No atomics; bit-reproducible.  Needs 8 | W (the host falls back to the fp32 kernel otherwise).
+struct WgradX3Geom {
+    int rb, xw, ys, xs;  // rows per band; staged X row length (W + 16, or W for the halo-free 1x1 form); channel strides of the two tiles in bf16 elements
+};
+// ABL (tools/mbench_wgrad.cpp only): 1 = no global loads, 2 = no MFMAs, 4 = no staging (split + LDS writes), 8 = no partial stores, 16 = no fragment reads
+template <int CENTRE, int NPF, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(WgradArgs a, WgradX3Geom gm) {
+    dd_touch_kernargs<sizeof(WgradArgs) + sizeof(WgradX3Geom)>();
+    DDIF_DYN_SMEM(smem);
+    constexpr int HALO = CENTRE ? 0 : 1, LPAD = CENTRE ? 0 : 8;  // NPF: staging items per thread (the host picks the band so that it has <= 256 NPF items)
+    const int W = a.W, RB = gm.rb, XR = RB + 2 * HALO, XW = gm.xw, YS = gm.ys, XS = gm.xs, SEGS = W >> 3;
+    unsigned short* Yt = reinterpret_cast<unsigned short*>(smem);  // [3 planes][32 co][YS]      pixel p = r * W + x of the band
+    unsigned short* Xt = Yt + 3 * 32 * YS;                         // [3 planes][32 ci][XS]      pixel (r, x) at r * XW + LPAD + x, rows y0 - HALO ..
+    float* Rs = reinterpret_cast<float*>(smem);                    // epilogue: [4 waves][16 regs][64 lanes], aliases the tiles (barrier in between)
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DDIF_EMU
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int h = lane >> 5, j = lane & 31;
+    const int wg_x = blockIdx.x, wg_y = blockIdx.y;
+    const int cob = wg_x / a.n_ci, cib = wg_x % a.n_ci;
+    const int nbands = a.B * a.bands_y;
+    const int NYI = RB * SEGS * 8, NXI = XR * SEGS * 8, NIT = NYI + NXI;  // items: (row, segment, channel quad)
+    f32x16 acc[CENTRE ? 1 : 9];
+#pragma unroll
+    for (int t = 0; t < (CENTRE ? 1 : 9); ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bacc[NPF][4];  // bias gradient: this thread's dY items summed over their 8 pixels, per channel of the quad, over the bands
+#pragma unroll
+    for (int u = 0; u < NPF; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bacc[u][c] = 0.f;
+    const bool want_bias = a.bpartial && cib == 0;
+
+    if constexpr (!CENTRE) {  // the zero borders of the X rows: 8 pixels left and right of every (plane, channel, row)
+        for (int i = tid; i < 3 * 32 * XR * 2; i += 256) {
+            const int side = i & 1, r = (i >> 1) % XR, pc = (i >> 1) / XR;
+            *reinterpret_cast<uint4*>(&Xt[(size_t)pc * XS + r * XW + (side ? LPAD + W : 0)]) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    // per-thread item geometry (the same for every band): tensor, row relative to y0, element offset relative to pixel (b, y0, 0), validity of the channels
+    int it_off[NPF], it_row[NPF], it_dst[NPF];
+    unsigned it_ok = 0, it_isy = 0;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int i = u * 256 + tid;
+        const bool isy = i < NYI;
+        const int k = isy ? i : i - NYI;
+        // pixel group fastest, channel quad slowest: the eight lanes of an LDS write phase then hit consecutive 16-byte slots of ONE channel row (channel-quad-fastest
+        // puts them 4 channel strides apart: four-way conflicts); a wave's loads cover the same 128-byte lines either way
+        const int npg = (isy ? RB : XR) * SEGS, c4 = k / npg, pg = k - c4 * npg;
+        const int sg = pg % SEGS, r = pg / SEGS;
+        const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
+        const bool ok = (i < NIT) & (cc < Cc);
+        it_row[u] = isy ? r : r - HALO;
+        it_off[u] = ok ? (it_row[u] * W + sg * 8) * Cc + cc : 0;
+        it_dst[u] = isy ? (c4 * 4) * YS + r * W + sg * 8 : 3 * 32 * YS + (c4 * 4) * XS + r * XW + LPAD + sg * 8;  // element index from Yt, channel c4 * 4, plane 0
+        it_ok |= (ok ? 1u : 0u) << u;
+        it_isy |= (isy ? 1u : 0u) << u;
+    }
+    float4 pf[NPF][8];
+    auto fetch_band = [&](int b, int y0) {
+        const size_t by = ((size_t)b * a.H + y0) * W * a.Cout, bx = ((size_t)b * a.H + y0) * W * a.Cin;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            if (u * 256 >= NIT) break;  // (workgroup-uniform)
+            const int y = y0 + it_row[u];
+            const bool isy = (it_isy >> u) & 1u;
+            const bool ok = ((it_ok >> u) & 1u) & (y >= 0) & (y < a.H);
+            const float* src = ok ? (isy ? a.dy + by : a.x + bx) + it_off[u] : a.dy;  // (a.dy itself is always readable)
+            const int ps = ok ? (isy ? a.Cout : a.Cin) : 0;                           // pixel stride in floats
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (ABL & 1) {
+                    pf[u][e] = make_float4(0.25f, -0.5f, 0.125f, (float)e);
+                    continue;
+                }
+                const float4 ld = *reinterpret_cast<const float4*>(src + (size_t)e * ps);
+                pf[u][e] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto stage_band = [&]() {
+        if (ABL & 4) {
+            bacc[0][0] += pf[0][0].x + pf[0][7].w;
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            if (u * 256 + tid >= NIT) continue;
+            const bool isy = (it_isy >> u) & 1u;
+            const int cs = isy ? YS : XS, ps = 32 * cs;  // channel / plane strides
+            unsigned short* d = Yt + it_dst[u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dd_split3_pair((&pf[u][2 * q].x)[c], (&pf[u][2 * q + 1].x)[c], &hh[q], &mm[q], &ll[q]);
+                *reinterpret_cast<uint4*>(d + c * cs) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                *reinterpret_cast<uint4*>(d + c * cs + ps) = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+                *reinterpret_cast<uint4*>(d + c * cs + 2 * ps) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                if (isy) bacc[u][c] += (((&pf[u][0].x)[c] + (&pf[u][1].x)[c]) + ((&pf[u][2].x)[c] + (&pf[u][3].x)[c])) +
+                                    (((&pf[u][4].x)[c] + (&pf[u][5].x)[c]) + ((&pf[u][6].x)[c] + (&pf[u][7].x)[c]));
+            }
+        }
+    };
+    auto frag = [&](const unsigned short* p) -> float4 {
+        if (ABL & 16) return make_float4(1e-3f * (float)lane, 2e-3f, 3e-3f, 4e-3f);
+        return *reinterpret_cast<const float4*>(p);
+    };
+    auto x3 = [&](f32x16 c, const float4* A, const float4* Bv) -> f32x16 {  // planes: 0 hi, 1 mid, 2 lo
+        if (ABL & 2) {
+            c[0] += A[0].x * Bv[0].x + A[1].y * Bv[1].y + A[2].z * Bv[2].z + A[0].w * Bv[2].w;
+            return c;
+        }
+        c = DDIF_MFMA_32x32x16_BF16(A[2], Bv[0], c);
+        c = DDIF_MFMA_32x32x16_BF16(A[0], Bv[2], c);
+        c = DDIF_MFMA_32x32x16_BF16(A[1], Bv[1], c);
+        c = DDIF_MFMA_32x32x16_BF16(A[1], Bv[0], c);
+        c = DDIF_MFMA_32x32x16_BF16(A[0], Bv[1], c);
+        c = DDIF_MFMA_32x32x16_BF16(A[0], Bv[0], c);
+        return c;
+    };
+    auto funnel = [&](unsigned hi, unsigned lo) -> unsigned {  // ({hi, lo} >> 16)[31:0]
+#ifdef DDIF_EMU
+        return (lo >> 16) | (hi << 16);
+#else
+        return __builtin_amdgcn_alignbit(hi, lo, 16);
+#endif
+    };
+
+    if (wg_y < nbands) fetch_band(wg_y / a.bands_y, (wg_y % a.bands_y) * RB);
+    const int nhg = RB * SEGS, ngroups = (nhg + 1) >> 1;  // half-groups (8 pixels) / groups (16 pixels) of a band
+    for (int band = wg_y; band < nbands; band += gridDim.y) {
+        __syncthreads();  // previous band fully consumed (first band: the zero borders are written)
+        stage_band();
+        __syncthreads();
+        const int nb = band + gridDim.y;
+        if (nb < nbands) fetch_band(nb / a.bands_y, (nb % a.bands_y) * RB);  // in flight during this band's MFMAs
+        for (int g = wave; g < ngroups; g += 4) {
+            const int hg = 2 * g + h;
+            const bool pv = hg < nhg;  // odd number of segments in the band: the last group's second half does not exist
+            const int hgc = pv ? hg : nhg - 1;
+            const int r = hgc / SEGS, sg = hgc - r * SEGS;
+            float4 A[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                A[pl] = frag(Yt + (size_t)(pl * 32 + j) * YS + r * W + sg * 8);
+                if (!pv) A[pl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if constexpr (CENTRE) {
+                float4 Bv[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Bv[pl] = frag(Xt + (size_t)(pl * 32 + j) * XS + r * XW + sg * 8);
+                acc[0] = x3(acc[0], A, Bv);
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    float4 B0[3], B1[3], B2[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned short* row = Xt + (size_t)(pl * 32 + j) * XS + (r + ky) * XW + LPAD + sg * 8;  // pixel (r + ky - 1, 8 sg) of the sample
+                        const uint4 cur = (ABL & 16) ? make_uint4(lane, 2u, 3u, (unsigned)ky) : *reinterpret_cast<const uint4*>(row);
+                        const unsigned prev = (ABL & 16) ? 5u : *reinterpret_cast<const unsigned*>(row - 2), next = (ABL & 16) ? 7u : *reinterpret_cast<const unsigned*>(row + 8);
+                        B1[pl] = __builtin_bit_cast(float4, cur);
+                        B0[pl] = __builtin_bit_cast(float4, make_uint4(funnel(cur.x, prev), funnel(cur.y, cur.x), funnel(cur.z, cur.y), funnel(cur.w, cur.z)));   // x - 1
+                        B2[pl] = __builtin_bit_cast(float4, make_uint4(funnel(cur.y, cur.x), funnel(cur.z, cur.y), funnel(cur.w, cur.z), funnel(next, cur.w)));   // x + 1
+                    }
+                    acc[3 * ky + 0] = x3(acc[3 * ky + 0], A, B0);
+                    acc[3 * ky + 1] = x3(acc[3 * ky + 1], A, B1);
+                    acc[3 * ky + 2] = x3(acc[3 * ky + 2], A, B2);
+                }
+            }
+        }
+    }
+    __syncthreads();  // the tiles are dead: their LDS becomes the reduction scratch
+    if (want_bias) {  // the dY items of one channel quad are consecutive item indices: summed in index order
+        float* Bs = Rs;  // [NYI][4]
+#pragma unroll
+        for (int u = 0; u < NPF; ++u)
+            if (u * 256 + tid < NYI) *reinterpret_cast<float4*>(&Bs[(u * 256 + tid) * 4]) = make_float4(bacc[u][0], bacc[u][1], bacc[u][2], bacc[u][3]);
+        __syncthreads();
+        if (tid < 32) {
+            const int c4 = tid >> 2, c = tid & 3, npg = RB * SEGS;
+            float sb = 0.f;
+            for (int t = c4 * npg; t < (c4 + 1) * npg; ++t) sb += Bs[t * 4 + c];
+            a.bpartial[(size_t)wg_y * (gridDim.x / a.n_ci) * 32 + cob * 32 + tid] = sb;
+        }
+        __syncthreads();
+    }
+    float* outp = a.partial + ((size_t)wg_y * gridDim.x + wg_x) * 9 * 1024;
+#pragma unroll
+    for (int t = 0; t < (CENTRE ? 1 : 9); ++t) {
+        if (t > 0) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rs[(wave * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + k * 256;
+            const int r = e >> 6, l = e & 63;
+            const float s = (Rs[(0 * 16 + r) * 64 + l] + Rs[(1 * 16 + r) * 64 + l]) + (Rs[(2 * 16 + r) * 64 + l] + Rs[(3 * 16 + r) * 64 + l]);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+            if (!(ABL & 8) || s == 12345.678f) outp[(CENTRE ? 4 : t) * 1024 + row * 32 + col] = s;
+        }
+    }
+}
+
 // Fixed-order sum over the K splits, shared by the eight 32-thread SLICES of a 256-thread workgroup: thread (slice sl = tid >> 5, lane c = tid & 31)
 // adds the splits sl, sl + 8, ... of element c with eight loads in flight (a load-per-iteration loop pays one memory latency per split; one
 // thread per element pays nsplit / 8 of them -- 64 at 512 splits -- on a grid of a few dozen workgroups), the slices are combined through LDS

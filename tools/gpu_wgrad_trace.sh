@@ -10,7 +10,7 @@ grep "^\[wgrad\]" /tmp/tr_$tag.log > /tmp/geom_$tag.txt
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("/tmp/tr_$tag/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "conv3x3_wgrad_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "conv3x3_wgrad_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_x3_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 geo = [l.strip() for l in open("/tmp/geom_$tag.txt")]
 print("launches", len(rows), "geometry lines", len(geo))
