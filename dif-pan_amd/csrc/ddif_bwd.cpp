@@ -474,31 +474,32 @@ WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre) {  // 
         g.smem = ((size_t)g.rb * W * 32 + (size_t)(g.rb + 2 * hl) * (W + 2 * hl) * 32 + 4096) * sizeof(float);
     }
     if (g.rb < 1) g.rb = 0;  // W too wide (caller checks)
-    // the bf16x3 kernel (kernels_bwd.h conv3x3_wgrad_x3_kernel; DDIF_WGRAD_X3=0: the fp32 kernel everywhere): 8 | W, the largest band of <= 256 staging items
-    // (then <= 512) whose transposed bf16 tiles fit two workgroups per CU
+    // the bf16x3 kernel (kernels_bwd.h conv3x3_wgrad_x3_kernel; DDIF_WGRAD_X3=0: the fp32 kernel everywhere): 8 | W, W <= 128; the largest band of <= 256 staging
+    // items (RB rows of dY + RB new rows of X) whose transposed bf16 tiles fit two workgroups per CU (failing that, one)
     static const bool x3_env = [] { const char* e = getenv("DDIF_WGRAD_X3"); return !e || atoi(e) != 0; }();
-    if (x3_env && W % 8 == 0) {
+    if (x3_env && W % 8 == 0 && W <= 128) {
         auto stride = [](int n) { return n + (((n / 8) % 2 == 0) ? 8 : 0); };  // an odd number of 16-byte slots
         const int segs = W / 8, hl = centre ? 0 : 1, xw = centre ? W : W + 16;
-        for (int npf = 1; npf <= 2 && !g.x3; ++npf)
-            for (int rb = H < 16 ? H : 16; rb >= 1; --rb) {
-                const int items = (rb + rb + 2 * hl) * segs * 8, ys = stride(rb * W), xs = stride((rb + 2 * hl) * xw);
-                size_t smem = (size_t)2 * 96 * (ys + xs);
-                if (smem < 16384) smem = 16384;  // the epilogue's reduction scratch aliases the tiles
-                if (items > 256 * npf || smem > 76 * 1024) continue;
-                g.x3 = 1;
-                g.npf = npf;
-                g.rb = rb;
-                g.xw = xw;
-                g.ys = ys;
-                g.xs = xs;
-                g.smem = smem;
-                g.centre = centre ? 1 : 0;
-                break;
-            }
+        // the largest band of <= 256 staging items (RB x W / 8 <= 16) that fits the LDS: measured (tools/mbench_wgrad.cpp, gpurun_out/r05_t) full 256-item bands with ONE
+        // workgroup per CU beat smaller bands with two at every level (64 x 64: 25.9 vs 26.7 us, 32 x 32: 25.9 vs 30.1, 16 x 16: 13.2 vs 16.2)
+        for (int rb = H < 16 ? H : 16; rb >= 1 && !g.x3; --rb) {
+            if (rb * segs > 16) continue;
+            const int ys = stride(rb * W), xs = stride((rb + 2 * hl) * xw);
+            size_t smem = (size_t)2 * 96 * (ys + xs);
+            if (smem < 16384) smem = 16384;  // the epilogue's reduction scratch aliases the tiles
+            if (smem > 150 * 1024) continue;
+            g.x3 = 1;
+            g.rb = rb;
+            g.xw = xw;
+            g.ys = ys;
+            g.xs = xs;
+            g.smem = smem;
+            g.centre = centre ? 1 : 0;
+        }
     }
     const int bands = B * ((H + (g.rb ? g.rb : 1) - 1) / (g.rb ? g.rb : 1));
-    int want = (2 * 256) / (g.n_co * g.n_ci);  // (512 workgroups per launch: 384 the same, 256 slower -- gpurun_out/r05_t)
+    // workgroups per launch: two per CU -- one where the bf16x3 kernel's tiles leave room for one only (a second wave of workgroups costs 30 %: same measurement)
+    int want = ((g.x3 && g.smem > 76 * 1024) ? 256 : 512) / (g.n_co * g.n_ci);
     if (want < 1) want = 1;
     if (want > bands) want = bands;
     if (want > 512) want = 512;
@@ -511,10 +512,8 @@ int wgrad_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return 0;
 }
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw, float* bpart,
@@ -537,10 +536,8 @@ void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, 
     if (g.x3) {
         WgradX3Geom gm{g.rb, g.xw, g.ys, g.xs};
         const dim3 grid(g.n_co * g.n_ci, g.nsplit);
-        if (centre && g.npf == 1) hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<1, 1>), grid, dim3(256), g.smem, s, a, gm);
-        else if (centre) hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<1, 2>), grid, dim3(256), g.smem, s, a, gm);
-        else if (g.npf == 1) hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<0, 1>), grid, dim3(256), g.smem, s, a, gm);
-        else hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<0, 2>), grid, dim3(256), g.smem, s, a, gm);
+        if (centre) hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<1>, grid, dim3(256), g.smem, s, a, gm);
+        else hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<0>, grid, dim3(256), g.smem, s, a, gm);
     } else if (g.pf && g.centre && centre) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 1>), dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else if (g.pf) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(g.n_co * g.n_ci, g.nsplit), dim3(256), g.smem, s, a);

@@ -85,7 +85,7 @@ int linattn_prepare();
 void silu_fwd(hipStream_t s, const float* x, size_t n, float* y);
 void silu_bwd(hipStream_t s, const float* x, const float* da, size_t n, float* dx);
 struct WgradGeom { int n_co = 0, n_ci = 0, nsplit = 0, rb = 0, nbchunk = 0, pf = 0, centre = 0; size_t smem = 0, partial_floats = 0;
-                   int x3 = 0, xw = 0, ys = 0, xs = 0, npf = 1; };  // x3: the bf16x3 kernel (conv3x3_wgrad_x3_kernel) with its tile geometry
+                   int x3 = 0, xw = 0, ys = 0, xs = 0; };  // x3: the bf16x3 kernel (conv3x3_wgrad_x3_kernel) with its tile geometry
 WgradGeom wgrad_geom(int B, int Cin, int Cout, int H, int W, bool centre = false);
 int wgrad_prepare();
 void wgrad(hipStream_t s, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, const WgradGeom& g, bool centre, float* partial, float* dw,

@@ -227,28 +227,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
 // 1x1 ones (profiles/r03_k_wgrad_by_shape.txt).  Here K = 16 pixels per v_mfma_f32_32x32x16_bf16 with BOTH operands split three ways (bf16x3, six exact
 // products, small terms first, fp32 accumulate -- the arithmetic of the forward / dgrad convs of the training step): 192 instead of 512 matrix cycles per
 // 16 pixels and tap, on a pipe of its own.
-//   * the contraction index is the PIXEL, so the operands need pixels contiguous per channel: the band is staged TRANSPOSED, [plane][channel][pixel] as bf16,
+//   * the contraction index is the PIXEL, so the operands need pixels contiguous per channel: rows are staged TRANSPOSED, [plane][channel][pixel] as bf16,
 //     by items of (8 consecutive pixels x 4 channels): eight float4 loads, split, twelve 16-byte LDS writes.  Channel stride = an odd number of 16-byte
-//     slots: the fragment reads (lane = channel) are conflict-free;
+//     slots (fragment reads, lane = channel, conflict-free); items are numbered pixel-group-fastest (the eight lanes of a write phase hit consecutive slots);
 //   * a 16-pixel group = two 8-pixel segments (lane half h = segment); the A fragment of lane (j, h) is dY^T[co = j][8 pixels], the B fragment of tap
 //     (ky, kx) is X[ci = j][the same 8 pixels shifted by (ky - 1, kx - 1)]: rows shift by whole rows of the staged tile, columns by ONE bf16 = 2 bytes --
-//     the aligned chunk plus one dword of each neighbour chunk, funnel-shifted (v_alignbit_b32, 4 per plane: VALU work beside the matrix pipe).  The X rows
-//     carry 8 zero pixels on either side (written once per launch), so the neighbours of the first / last segment exist;
-//   * everything else as above: the workgroup owns a (32 co x 32 ci) block and walks bands (sample, RB rows) of its K split, the next band's loads fly during
-//     the current band's MFMAs, four waves split the pixel groups and meet in LDS in fixed order, partial blocks [split][block][tap][32][32] reduced by
-//     wgrad_reduce_kernel in index order.  No atomics; bit-reproducible.  Needs 8 | W (the host falls back to the fp32 kernel otherwise).
+//     the aligned chunk plus one dword of each neighbour chunk, funnel-shifted (VALU work beside the matrix pipe).  The X rows carry 8 zero pixels on either
+//     side (written once per launch), so the neighbours of the first / last segment exist;
+//   * a workgroup owns a (32 co x 32 ci) block and a CONTIGUOUS run of bands (sample, RB rows) of the K split; the X rows live in a ring of RB + 2 row slots
+//     (row y in slot (y + 1) mod (RB + 2)), so a band stages its RB rows of dY and only the RB NEW rows of X -- the two rows it shares with the previous band
+//     stay where they are (a band-per-item form staged RB + 2 rows of X per RB rows of dY: three for one at 64 x 64).  At the start of a run and of every
+//     sample the two leading rows (y0 - 1, y0) are staged by a step of their own;
+//   * the next band's loads fly during the current band's MFMAs, four waves split the pixel groups and meet in LDS in fixed order, partial blocks
+//     [split][block][tap][32][32] reduced by wgrad_reduce_kernel in index order.  No atomics; bit-reproducible.  Needs 8 | W and W <= 128 (the host falls back
+//     to the fp32 kernel otherwise).
 struct WgradX3Geom {
     int rb, xw, ys, xs;  // rows per band; staged X row length (W + 16, or W for the halo-free 1x1 form); channel strides of the two tiles in bf16 elements
 };
 // ABL (tools/mbench_wgrad.cpp only): 1 = no global loads, 2 = no MFMAs, 4 = no staging (split + LDS writes), 8 = no partial stores, 16 = no fragment reads
-template <int CENTRE, int NPF, int ABL = 0>
+template <int CENTRE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(WgradArgs a, WgradX3Geom gm) {
     dd_touch_kernargs<sizeof(WgradArgs) + sizeof(WgradX3Geom)>();
     DDIF_DYN_SMEM(smem);
-    constexpr int HALO = CENTRE ? 0 : 1, LPAD = CENTRE ? 0 : 8;  // NPF: staging items per thread (the host picks the band so that it has <= 256 NPF items)
+    constexpr int HALO = CENTRE ? 0 : 1, LPAD = CENTRE ? 0 : 8;
     const int W = a.W, RB = gm.rb, XR = RB + 2 * HALO, XW = gm.xw, YS = gm.ys, XS = gm.xs, SEGS = W >> 3;
     unsigned short* Yt = reinterpret_cast<unsigned short*>(smem);  // [3 planes][32 co][YS]      pixel p = r * W + x of the band
-    unsigned short* Xt = Yt + 3 * 32 * YS;                         // [3 planes][32 ci][XS]      pixel (r, x) at r * XW + LPAD + x, rows y0 - HALO ..
+    unsigned short* Xt = Yt + 3 * 32 * YS;                         // [3 planes][32 ci][XS]      row slot s, pixel x at s * XW + LPAD + x
     float* Rs = reinterpret_cast<float*>(smem);                    // epilogue: [4 waves][16 regs][64 lanes], aliases the tiles (barrier in between)
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef DDIF_EMU
@@ -260,90 +264,107 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(WgradArgs a, W
     const int wg_x = blockIdx.x, wg_y = blockIdx.y;
     const int cob = wg_x / a.n_ci, cib = wg_x % a.n_ci;
     const int nbands = a.B * a.bands_y;
-    const int NYI = RB * SEGS * 8, NXI = XR * SEGS * 8, NIT = NYI + NXI;  // items: (row, segment, channel quad)
+    const int band0 = (int)((long long)nbands * wg_y / gridDim.y), band1 = (int)((long long)nbands * (wg_y + 1) / gridDim.y);  // this split's run of bands
+    const int npg = RB * SEGS, NYI = npg * 8, NIT = 2 * NYI;  // items of a band: (row, segment, channel quad) of dY, then of the new X rows (host: NIT <= 256)
     f32x16 acc[CENTRE ? 1 : 9];
 #pragma unroll
     for (int t = 0; t < (CENTRE ? 1 : 9); ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bacc[NPF][4];  // bias gradient: this thread's dY items summed over their 8 pixels, per channel of the quad, over the bands
-#pragma unroll
-    for (int u = 0; u < NPF; ++u)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bacc[u][c] = 0.f;
+    float bacc[4] = {0.f, 0.f, 0.f, 0.f};  // bias gradient: this thread's dY item summed over its 8 pixels, per channel of the quad, over the bands
     const bool want_bias = a.bpartial && cib == 0;
 
-    if constexpr (!CENTRE) {  // the zero borders of the X rows: 8 pixels left and right of every (plane, channel, row)
+    if constexpr (!CENTRE) {  // the zero borders of the X row slots: 8 pixels left and right of every (plane, channel, slot)
         for (int i = tid; i < 3 * 32 * XR * 2; i += 256) {
             const int side = i & 1, r = (i >> 1) % XR, pc = (i >> 1) / XR;
             *reinterpret_cast<uint4*>(&Xt[(size_t)pc * XS + r * XW + (side ? LPAD + W : 0)]) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    // per-thread item geometry (the same for every band): tensor, row relative to y0, element offset relative to pixel (b, y0, 0), validity of the channels
-    int it_off[NPF], it_row[NPF], it_dst[NPF];
-    unsigned it_ok = 0, it_isy = 0;
-#pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-        const int i = u * 256 + tid;
-        const bool isy = i < NYI;
-        const int k = isy ? i : i - NYI;
-        // pixel group fastest, channel quad slowest: the eight lanes of an LDS write phase then hit consecutive 16-byte slots of ONE channel row (channel-quad-fastest
-        // puts them 4 channel strides apart: four-way conflicts); a wave's loads cover the same 128-byte lines either way
-        const int npg = (isy ? RB : XR) * SEGS, c4 = k / npg, pg = k - c4 * npg;
+    // this thread's item (the same for every band): tensor, row within the band, element offset relative to pixel (b, y0, 0), LDS element (row slot 0 for X)
+    const bool it_in = tid < NIT, it_isy = tid < NYI;
+    int it_r, it_off, it_dst;
+    bool it_cok;
+    {
+        const int k = it_isy ? tid : tid - NYI;
+        const int c4 = (k / npg) & 7, pg = k % npg;  // pixel group fastest, channel quad slowest
         const int sg = pg % SEGS, r = pg / SEGS;
-        const int cc = (isy ? cob : cib) * 32 + c4 * 4, Cc = isy ? a.Cout : a.Cin;
-        const bool ok = (i < NIT) & (cc < Cc);
-        it_row[u] = isy ? r : r - HALO;
-        it_off[u] = ok ? (it_row[u] * W + sg * 8) * Cc + cc : 0;
-        it_dst[u] = isy ? (c4 * 4) * YS + r * W + sg * 8 : 3 * 32 * YS + (c4 * 4) * XS + r * XW + LPAD + sg * 8;  // element index from Yt, channel c4 * 4, plane 0
-        it_ok |= (ok ? 1u : 0u) << u;
-        it_isy |= (isy ? 1u : 0u) << u;
+        const int cc = (it_isy ? cob : cib) * 32 + c4 * 4, Cc = it_isy ? a.Cout : a.Cin;
+        it_cok = it_in & (cc < Cc);
+        it_r = r;
+        it_off = it_cok ? sg * 8 * Cc + cc : 0;  // + row * W * Cc per band
+        it_dst = it_isy ? (c4 * 4) * YS + r * W + sg * 8 : 3 * 32 * YS + (c4 * 4) * XS + LPAD + sg * 8;
     }
-    float4 pf[NPF][8];
-    auto fetch_band = [&](int b, int y0) {
-        const size_t by = ((size_t)b * a.H + y0) * W * a.Cout, bx = ((size_t)b * a.H + y0) * W * a.Cin;
+    // the two leading rows of a run / of a sample (X rows y0 - 1 and y0): items (row of the pair, segment, channel quad)
+    const bool ld_in = !CENTRE && tid < 2 * SEGS * 8;
+    int ld_r = 0, ld_off = 0, ld_dst = 0;
+    bool ld_cok = false;
+    if constexpr (!CENTRE) {
+        const int c4 = (tid / (2 * SEGS)) & 7, pg = tid % (2 * SEGS);
+        const int sg = pg % SEGS, cc = cib * 32 + c4 * 4;
+        ld_r = pg / SEGS;
+        ld_cok = ld_in & (cc < a.Cin);
+        ld_off = ld_cok ? sg * 8 * a.Cin + cc : 0;
+        ld_dst = 3 * 32 * YS + (c4 * 4) * XS + LPAD + sg * 8;
+    }
+    auto load8 = [&](const float* src, int ps, bool ok, float4* v) {  // eight consecutive pixels of one channel quad
 #pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            if (u * 256 >= NIT) break;  // (workgroup-uniform)
-            const int y = y0 + it_row[u];
-            const bool isy = (it_isy >> u) & 1u;
-            const bool ok = ((it_ok >> u) & 1u) & (y >= 0) & (y < a.H);
-            const float* src = ok ? (isy ? a.dy + by : a.x + bx) + it_off[u] : a.dy;  // (a.dy itself is always readable)
-            const int ps = ok ? (isy ? a.Cout : a.Cin) : 0;                           // pixel stride in floats
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (ABL & 1) {
-                    pf[u][e] = make_float4(0.25f, -0.5f, 0.125f, (float)e);
-                    continue;
-                }
-                const float4 ld = *reinterpret_cast<const float4*>(src + (size_t)e * ps);
-                pf[u][e] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = 0; e < 8; ++e) {
+            if (ABL & 1) {
+                v[e] = make_float4(0.25f, -0.5f, 0.125f, (float)e);
+                continue;
             }
+            const float4 ld = *reinterpret_cast<const float4*>(src + (size_t)e * ps);
+            v[e] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto stage_band = [&]() {
+    auto split8 = [&](const float4* v, unsigned short* d, int cs, int ps) {  // -> three planes of [4 channels][8 pixels]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dd_split3_pair((&v[2 * q].x)[c], (&v[2 * q + 1].x)[c], &hh[q], &mm[q], &ll[q]);
+            *reinterpret_cast<uint4*>(d + c * cs) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            *reinterpret_cast<uint4*>(d + c * cs + ps) = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<uint4*>(d + c * cs + 2 * ps) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+        }
+    };
+    auto slot_of = [&](int s) { return s >= XR ? s - XR : s; };  // (s < 2 XR)
+    float4 pf[8];
+    auto fetch_band = [&](int b, int y0) {  // dY rows y0 .. y0 + RB - 1 and the NEW X rows (3x3: y0 + 1 .. y0 + RB; 1x1: the same rows as dY)
+        if (!it_in) return;
+        const int y = y0 + it_r + (it_isy ? 0 : HALO);
+        const bool ok = it_cok & (y < a.H);
+        const int Cc = it_isy ? a.Cout : a.Cin;
+        const float* src = ok ? (it_isy ? a.dy : a.x) + ((size_t)b * a.H + y) * W * Cc + it_off : a.dy;  // (a.dy itself is always readable)
+        load8(src, ok ? Cc : 0, ok, pf);
+    };
+    auto stage_band = [&](int y0) {
+        if (!it_in) return;
         if (ABL & 4) {
-            bacc[0][0] += pf[0][0].x + pf[0][7].w;
+            bacc[0] += pf[0].x + pf[7].w;
             return;
         }
+        const int cs = it_isy ? YS : XS;
+        const int slot = (it_isy || CENTRE) ? 0 : slot_of((y0 + 2) % XR + it_r);  // X row y0 + 1 + r lives in slot (y0 + 2 + r) mod XR
+        split8(pf, Yt + it_dst + ((CENTRE && !it_isy) ? it_r * XW : slot * XW), cs, 32 * cs);
+        if (it_isy) {
 #pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            if (u * 256 + tid >= NIT) continue;
-            const bool isy = (it_isy >> u) & 1u;
-            const int cs = isy ? YS : XS, ps = 32 * cs;  // channel / plane strides
-            unsigned short* d = Yt + it_dst[u];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                unsigned hh[4], mm[4], ll[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dd_split3_pair((&pf[u][2 * q].x)[c], (&pf[u][2 * q + 1].x)[c], &hh[q], &mm[q], &ll[q]);
-                *reinterpret_cast<uint4*>(d + c * cs) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-                *reinterpret_cast<uint4*>(d + c * cs + ps) = make_uint4(mm[0], mm[1], mm[2], mm[3]);
-                *reinterpret_cast<uint4*>(d + c * cs + 2 * ps) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-                if (isy) bacc[u][c] += (((&pf[u][0].x)[c] + (&pf[u][1].x)[c]) + ((&pf[u][2].x)[c] + (&pf[u][3].x)[c])) +
-                                    (((&pf[u][4].x)[c] + (&pf[u][5].x)[c]) + ((&pf[u][6].x)[c] + (&pf[u][7].x)[c]));
-            }
+            for (int c = 0; c < 4; ++c)
+                bacc[c] += (((&pf[0].x)[c] + (&pf[1].x)[c]) + ((&pf[2].x)[c] + (&pf[3].x)[c])) + (((&pf[4].x)[c] + (&pf[5].x)[c]) + ((&pf[6].x)[c] + (&pf[7].x)[c]));
         }
+    };
+    auto stage_lead = [&](int b, int y0) {  // X rows y0 - 1 and y0 (row y0 - 1 of the first band of a sample is the zero border: masked)
+        if (!ld_in) return;
+        const int y = y0 - 1 + ld_r;
+        const bool ok = ld_cok & (y >= 0) & (y < a.H);
+        const float* src = ok ? a.x + ((size_t)b * a.H + y) * W * a.Cin + ld_off : a.x;
+        float4 v[8];
+        load8(src, ok ? a.Cin : 0, ok, v);
+        if (ABL & 4) {
+            bacc[1] += v[0].x + v[7].w;
+            return;
+        }
+        split8(v, Yt + ld_dst + slot_of(y0 % XR + ld_r) * XW, XS, 32 * XS);
     };
     auto frag = [&](const unsigned short* p) -> float4 {
         if (ABL & 16) return make_float4(1e-3f * (float)lane, 2e-3f, 3e-3f, 4e-3f);
@@ -370,18 +391,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(WgradArgs a, W
 #endif
     };
 
-    if (wg_y < nbands) fetch_band(wg_y / a.bands_y, (wg_y % a.bands_y) * RB);
-    const int nhg = RB * SEGS, ngroups = (nhg + 1) >> 1;  // half-groups (8 pixels) / groups (16 pixels) of a band
-    for (int band = wg_y; band < nbands; band += gridDim.y) {
+    if (band0 < band1) fetch_band(band0 / a.bands_y, (band0 % a.bands_y) * RB);
+    const int ngroups = (npg + 1) >> 1;  // 16-pixel groups of a band (npg half-groups of 8 pixels)
+    for (int band = band0; band < band1; ++band) {
+        const int b = band / a.bands_y, by = band - b * a.bands_y, y0 = by * RB;
         __syncthreads();  // previous band fully consumed (first band: the zero borders are written)
-        stage_band();
+        if (!CENTRE && (band == band0 || by == 0)) stage_lead(b, y0);  // (workgroup-uniform)
+        stage_band(y0);
         __syncthreads();
-        const int nb = band + gridDim.y;
-        if (nb < nbands) fetch_band(nb / a.bands_y, (nb % a.bands_y) * RB);  // in flight during this band's MFMAs
+        if (band + 1 < band1) fetch_band((band + 1) / a.bands_y, ((band + 1) % a.bands_y) * RB);  // in flight during this band's MFMAs
+        const int sb = CENTRE ? 0 : y0 % XR;  // X row y0 - 1 lives in slot y0 mod XR
         for (int g = wave; g < ngroups; g += 4) {
             const int hg = 2 * g + h;
-            const bool pv = hg < nhg;  // odd number of segments in the band: the last group's second half does not exist
-            const int hgc = pv ? hg : nhg - 1;
+            const bool pv = hg < npg;  // odd number of segments in the band: the last group's second half does not exist
+            const int hgc = pv ? hg : npg - 1;
             const int r = hgc / SEGS, sg = hgc - r * SEGS;
             float4 A[3];
 #pragma unroll
@@ -398,9 +421,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(WgradArgs a, W
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     float4 B0[3], B1[3], B2[3];
+                    const int slot = slot_of(sb + r + ky);  // X row y0 + r + ky - 1
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned short* row = Xt + (size_t)(pl * 32 + j) * XS + (r + ky) * XW + LPAD + sg * 8;  // pixel (r + ky - 1, 8 sg) of the sample
+                        const unsigned short* row = Xt + (size_t)(pl * 32 + j) * XS + slot * XW + LPAD + sg * 8;
                         const uint4 cur = (ABL & 16) ? make_uint4(lane, 2u, 3u, (unsigned)ky) : *reinterpret_cast<const uint4*>(row);
                         const unsigned prev = (ABL & 16) ? 5u : *reinterpret_cast<const unsigned*>(row - 2), next = (ABL & 16) ? 7u : *reinterpret_cast<const unsigned*>(row + 8);
                         B1[pl] = __builtin_bit_cast(float4, cur);
@@ -417,15 +441,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(WgradArgs a, W
     __syncthreads();  // the tiles are dead: their LDS becomes the reduction scratch
     if (want_bias) {  // the dY items of one channel quad are consecutive item indices: summed in index order
         float* Bs = Rs;  // [NYI][4]
-#pragma unroll
-        for (int u = 0; u < NPF; ++u)
-            if (u * 256 + tid < NYI) *reinterpret_cast<float4*>(&Bs[(u * 256 + tid) * 4]) = make_float4(bacc[u][0], bacc[u][1], bacc[u][2], bacc[u][3]);
+        if (tid < NYI) *reinterpret_cast<float4*>(&Bs[tid * 4]) = make_float4(bacc[0], bacc[1], bacc[2], bacc[3]);
         __syncthreads();
         if (tid < 32) {
-            const int c4 = tid >> 2, c = tid & 3, npg = RB * SEGS;
-            float sb = 0.f;
-            for (int t = c4 * npg; t < (c4 + 1) * npg; ++t) sb += Bs[t * 4 + c];
-            a.bpartial[(size_t)wg_y * (gridDim.x / a.n_ci) * 32 + cob * 32 + tid] = sb;
+            const int c4 = tid >> 2, c = tid & 3;
+            float sb2 = 0.f;
+            for (int t = c4 * npg; t < (c4 + 1) * npg; ++t) sb2 += Bs[t * 4 + c];
+            a.bpartial[(size_t)wg_y * (gridDim.x / a.n_ci) * 32 + cob * 32 + tid] = sb2;
         }
         __syncthreads();
     }

@@ -52,16 +52,16 @@ static void run(int B, int H, int W, int Cin, int Cout, int rb_x3, int nsplit_x3
     WgradArgs a1 = a; a1.rb = rb_x3; a1.bands_y = (H + rb_x3 - 1) / rb_x3; a1.partial = p1;
     WgradX3Geom gm{rb_x3, CENTRE ? W : W + 16, stride8(rb_x3 * W), stride8((rb_x3 + 2 * hl) * (CENTRE ? W : W + 16))};
     size_t smem1 = (size_t)2 * 96 * (gm.ys + gm.xs); if (smem1 < 16384) smem1 = 16384;
-    const int items = (rb_x3 + rb_x3 + 2 * hl) * (W / 8) * 8;
+    const int items = 2 * rb_x3 * (W / 8) * 8;
     printf("B=%d %dx%d %d->%d %s: fp32 kernel rb=%d nsplit=%d %.1f us | x3 rb=%d nsplit=%d items=%d smem=%zu:", B, H, W, Cin, Cout, CENTRE ? "1x1" : "3x3", rb_old, nsplit_old, t0, rb_x3, nsplit_x3,
            items, smem1);
-    if (items > 256) { printf(" (needs NPF = 2: skipped)\n"); return; }
-#define RUNX(ABL) { auto k1 = conv3x3_wgrad_x3_kernel<CENTRE, 1, ABL>; CK_(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+    if (items > 256) { printf(" (more than 256 items: skipped)\n"); return; }
+#define RUNX(ABL) { auto k1 = conv3x3_wgrad_x3_kernel<CENTRE, ABL>; CK_(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
         printf("  abl%-2d %.1f", ABL, time_it([&] { hipLaunchKernelGGL(k1, dim3(nblk, nsplit_x3), dim3(256), smem1, 0, a1, gm); })); }
-    RUNX(0) RUNX(1) RUNX(2) RUNX(4) RUNX(8) RUNX(16) RUNX(18) RUNX(31)
+    RUNX(0) RUNX(1) RUNX(4) RUNX(18) RUNX(31)
     printf(" us\n");
     // compare: sum of the partial blocks over the splits
-    { auto k1 = conv3x3_wgrad_x3_kernel<CENTRE, 1, 0>; hipLaunchKernelGGL(k1, dim3(nblk, nsplit_x3), dim3(256), smem1, 0, a1, gm); hipLaunchKernelGGL(k0, dim3(nblk, nsplit_old), dim3(256), smem0, 0, a0); }
+    { auto k1 = conv3x3_wgrad_x3_kernel<CENTRE, 0>; hipLaunchKernelGGL(k1, dim3(nblk, nsplit_x3), dim3(256), smem1, 0, a1, gm); hipLaunchKernelGGL(k0, dim3(nblk, nsplit_old), dim3(256), smem0, 0, a0); }
     CK_(hipDeviceSynchronize());
     std::vector<float> h0(pfl0), h1(pfl1);
     CK_(hipMemcpy(h0.data(), p0, pfl0 * 4, hipMemcpyDeviceToHost)); CK_(hipMemcpy(h1.data(), p1, pfl1 * 4, hipMemcpyDeviceToHost));
@@ -81,15 +81,31 @@ static void run(int B, int H, int W, int Cin, int Cout, int rb_x3, int nsplit_x3
 int main() {
     CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
     run<0>(32, 64, 64, 32, 32, 1, 512, 1, 256);
-    run<0>(32, 64, 64, 32, 32, 1, 256, 1, 256);
+    run<0>(32, 64, 64, 32, 32, 2, 256, 1, 256);
+    run<0>(32, 64, 64, 32, 32, 2, 512, 1, 256);
+    run<0>(32, 64, 64, 64, 32, 1, 256, 1, 256);
+    run<0>(32, 64, 64, 64, 32, 2, 128, 1, 256);
+    run<0>(32, 64, 64, 64, 32, 2, 256, 1, 256);
     run<0>(32, 32, 32, 64, 64, 3, 128, 4, 128);
     run<0>(32, 32, 32, 64, 64, 2, 128, 4, 128);
+    run<0>(32, 32, 32, 64, 64, 4, 64, 4, 128);
+    run<0>(32, 32, 32, 64, 64, 4, 128, 4, 128);
     run<0>(32, 16, 16, 64, 64, 6, 96, 8, 64);
+    run<0>(32, 16, 16, 64, 64, 4, 128, 8, 64);
+    run<0>(32, 16, 16, 64, 64, 8, 64, 8, 64);
+    run<0>(32, 16, 16, 64, 64, 8, 128, 8, 64);
     run<0>(32, 8, 8, 128, 128, 8, 32, 8, 32);
-    run<0>(32, 8, 8, 128, 128, 8, 16, 8, 32);
+    run<0>(32, 8, 8, 128, 128, 4, 32, 8, 32);
     run<1>(32, 64, 64, 64, 32, 2, 256, 1, 256);
+    run<1>(32, 64, 64, 64, 32, 1, 256, 1, 256);
+    run<1>(32, 64, 64, 64, 32, 2, 384, 1, 256);
     run<1>(32, 64, 64, 128, 64, 2, 64, 1, 64);
+    run<1>(32, 64, 64, 128, 64, 1, 64, 1, 64);
+    run<1>(32, 64, 64, 128, 64, 2, 96, 1, 64);
     run<1>(32, 32, 32, 64, 64, 4, 128, 4, 128);
+    run<1>(32, 32, 32, 64, 64, 2, 128, 4, 128);
+    run<1>(32, 16, 16, 128, 64, 8, 64, 8, 64);
+    run<1>(32, 16, 16, 128, 64, 4, 64, 8, 64);
     run<1>(32, 8, 8, 128, 128, 8, 32, 8, 32);
     return 0;
 }
