@@ -533,6 +533,7 @@ int Net::commit(hipStream_t stream) {
     }
     merged_stale = false;
     last_ptrs.clear();
+    refresh_keys.clear();
     dconv.clear();  // re-derived on demand (build_dgrad_packs) from the recipes of THIS commit
     dgrad_filled = false;
     // plans of the previous generation may still have launches in flight on their own (side) streams that read the blobs freed below
@@ -597,14 +598,29 @@ int Net::commit(hipStream_t stream) {
 int Net::refresh_device(int n, const char* const* keys, const float* const* ptrs, hipStream_t stream) {
     if (!committed) return fail(DDIF_ERR_STATE, "ddif_net_refresh: ddif_net_commit has not been called");
     if (n < 1 || !keys || !ptrs) return fail(DDIF_ERR_INVALID, "ddif_net_refresh: bad arguments");
+#ifndef DDIF_EMU
+    for (hipEvent_t e : reader_events) (void)hipStreamWaitEvent(stream, e, 0);  // (a never-recorded or completed event does not block)
+#endif
+    // the training loop calls this every iteration with the same keys and (almost always) the same pointers: the key -> pointer map of 702 strings is only
+    // rebuilt when either moved (the call sits in front of every iteration's first launch, with the GPU idle behind it)
+    bool same = (int)refresh_keys.size() == n && d_recs != nullptr;
+    for (int i = 0; i < n && same; ++i) {
+        if (!keys[i] || !ptrs[i]) return fail(DDIF_ERR_INVALID, "ddif_net_refresh: NULL key / pointer at %d", i);
+        same = refresh_in_ptrs[i] == ptrs[i] && refresh_keys[i] == keys[i];
+    }
+    if (same) {
+        hipLaunchKernelGGL(refresh_blob_kernel, dim3((unsigned)refresh_blocks), dim3(256), 0, stream, (const RefreshRec*)d_recs, n_recs);
+        DDIF_HIPCHK(hipGetLastError());
+        merged_stale = true;
+        if (dgrad_blob) dgrad_filled = true;
+        return 0;
+    }
     std::map<std::string, const float*> by_key;
     for (int i = 0; i < n; ++i) {
         if (!keys[i] || !ptrs[i]) return fail(DDIF_ERR_INVALID, "ddif_net_refresh: NULL key / pointer at %d", i);
         by_key[keys[i]] = ptrs[i];
     }
-#ifndef DDIF_EMU
-    for (hipEvent_t e : reader_events) (void)hipStreamWaitEvent(stream, e, 0);  // (a never-recorded or completed event does not block)
-#endif
+    refresh_keys.clear();  // (set again below, once the table is known to match these arguments)
     std::vector<const float*> flat;
     flat.reserve(recipes.size() * 2);
     for (auto& r : recipes) {
@@ -653,6 +669,8 @@ int Net::refresh_device(int n, const char* const* keys, const float* const* ptrs
         refresh_blocks = blk;
         last_ptrs = flat;
     }
+    refresh_keys.assign(keys, keys + n);
+    refresh_in_ptrs.assign(ptrs, ptrs + n);
     hipLaunchKernelGGL(refresh_blob_kernel, dim3((unsigned)refresh_blocks), dim3(256), 0, stream, (const RefreshRec*)d_recs, n_recs);
     DDIF_HIPCHK(hipGetLastError());
     merged_stale = true;
@@ -738,6 +756,7 @@ int Net::build_dgrad_packs() {
     }
     recipes.insert(recipes.end(), extra.begin(), extra.end());
     last_ptrs.clear();  // the device table must be rebuilt
+    refresh_keys.clear();
     return 0;
 }
 

@@ -104,6 +104,8 @@ struct Net {
     bool merged_stale = false;        // the eval-only merged ffn[3] o ffn[2] weights were NOT refreshed (train-mode plans do not use them)
     void* d_recs = nullptr;           // device RefreshRec table of the last refresh
     std::vector<const float*> last_ptrs;
+    std::vector<std::string> refresh_keys;         // arguments of the last successful refresh (the map is rebuilt only when they change)
+    std::vector<const float*> refresh_in_ptrs;
     int n_recs = 0;
     long long refresh_blocks = 0;
     int refresh_device(int n, const char* const* keys, const float* const* ptrs, hipStream_t stream);

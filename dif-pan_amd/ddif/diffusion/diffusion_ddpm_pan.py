@@ -363,7 +363,7 @@ class GaussianDiffusion(nn.Module):
         if float(getattr(self, "p2_loss_weight_gamma", 0.0)) != 0.0:
             raise DdifError("training: p2 loss weighting is not implemented by the backward pass")
         model = self.model
-        named = [(n, p) for n, p in model.named_parameters()]
+        named = model.named_parameter_list() if hasattr(model, "named_parameter_list") else [(n, p) for n, p in model.named_parameters()]
         plan = self._native_plan(x_start, cond, named)
         gb = getattr(plan, "_grad_bufs", None)
         if gb is None:
@@ -421,7 +421,7 @@ class GaussianDiffusion(nn.Module):
         b = x_start.shape[0]
         t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
         noise = default(noise, lambda: torch.randn_like(x_start))
-        named = [(n, p) for n, p in model.named_parameters()]
+        named = model.named_parameter_list() if hasattr(model, "named_parameter_list") else [(n, p) for n, p in model.named_parameters()]
         a, s = self._schedule_rows(t)
         x_self_cond = None
         if self.self_condition and random.random() < 0.5:

@@ -8,6 +8,7 @@ calls on CPU tensors or without the built library raise `DdifError`.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -45,6 +46,25 @@ def _default_init(key: str, shape, shapes: Dict[str, tuple]) -> torch.Tensor:
         fan_in *= s
     bound = 1.0 / math.sqrt(fan_in)
     return (torch.rand(shape) * 2 - 1) * bound
+
+
+# A process-wide counter bumped whenever ANY torch module registers a parameter, a buffer or a submodule: what invalidates UNetSR3's cached
+# parameter list (`_param_cache`).  (torch >= 2.0 global registration hooks; they return None = "leave the value alone".)
+_REG_EPOCH = [0]
+_PARAM_CACHE = os.environ.get("DDIF_PARAM_CACHE", "1") != "0"  # DDIF_PARAM_CACHE=0: the pre-round-5 behaviour (A/B switch)
+
+
+def _bump_reg_epoch(*_args):
+    _REG_EPOCH[0] += 1
+    return None
+
+
+for _hook_name in ("register_module_parameter_registration_hook", "register_module_module_registration_hook", "register_module_buffer_registration_hook"):
+    _reg = getattr(torch.nn.modules.module, _hook_name, None)
+    if _reg is None:  # an older torch: no cache (every call re-walks the module tree)
+        _REG_EPOCH = None
+        break
+    _reg(_bump_reg_epoch)
 
 
 class UNetSR3(nn.Module):
@@ -96,8 +116,32 @@ class UNetSR3(nn.Module):
         self._weights_sig = None
 
     # ---- weights -> library -----------------------------------------------------------------------------------------
+    def _param_cache(self):
+        """[(state-dict key, parameter)] and the bare parameter list, walked ONCE: `named_parameters()` over the 702 parameters costs 1.6 ms of Python,
+        and the training loop needs the list several times per iteration (signature, refresh, bind) -- with the GPU idle meanwhile.  Valid until any
+        module registers a parameter / submodule / buffer (a process-wide epoch bumped by torch's registration hooks) or `_apply` (.to / .cuda / .float)
+        runs on this module."""
+        c = self.__dict__.get("_pcache")
+        epoch = object() if (_REG_EPOCH is None or not _PARAM_CACHE) else _REG_EPOCH[0]  # (no hooks / DDIF_PARAM_CACHE=0: every call re-walks)
+        if c is None or c["epoch"] != epoch:
+            named = [(n, p) for n, p in self.named_parameters()]
+            plist = [p for _, p in named]
+            c = self.__dict__["_pcache"] = {"epoch": epoch, "named": named, "plist": plist,
+                                            "devices": {p.device for p in plist}}
+        return c
+
+    def named_parameter_list(self):
+        """`list(self.named_parameters())`, cached (see `_param_cache`)."""
+        return self._param_cache()["named"]
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_pcache", None)
+        out = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_pcache", None)
+        return out
+
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self._param_cache()["plist"])
 
     def mark_weights_dirty(self):
         """The parameters were written behind torch's back (raw-pointer kernels such as the fused optimizer step): the packed copy the
@@ -123,9 +167,9 @@ class UNetSR3(nn.Module):
         sig = self._signature()
         net = self._net
         committed = getattr(net, "device_refreshed", None) is not None
-        if train and committed and all(p.device == device for p in self.parameters()):
+        if train and committed and self._param_cache()["devices"] == {device}:
             if sig != self._weights_sig:
-                net.refresh_from_device(self.named_parameters())
+                net.refresh_from_device(self.named_parameter_list(), tuple(s[0] for s in sig))
                 self._weights_sig = sig
             return net
         if sig != self._weights_sig or getattr(net, "device_refreshed", False):
