@@ -10,6 +10,7 @@
 
   DDIF_F16=0    the split-operand convs on bf16x3 (six products) instead of f16x2 (three);
   DDIF_LAFUSE=0 the decoder's linear-attention half as three launches instead of the fused block (csrc/kernels_lafuse.h);
+  DDIF_S2_F16=0 the Downsample convs on the exact-fp32 8 x 8 tiling instead of the f16x2 stride-2 tilings (round 5);
   DDIF_WRES=0 / DDIF_XCD=0  the 16-channel-stage tiling of the 32 -> 32 convs / the dispatcher's round-robin work partition instead of the resident-weights
                 tiling / the XCD-contiguous partition (round 5): bit-identical results either way.
 
@@ -30,8 +31,9 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
          "or test_forward_matches_oracle_other_sizes and 8x8")
 
 
-@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0"])
+@pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"},
+                                 {"DDIF_S2_F16": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
