@@ -27,8 +27,9 @@ struct ConvBwd {
     float *x_nhwc = nullptr, *dy_nhwc = nullptr, *wpack = nullptr, *wpack_x3 = nullptr, *partial = nullptr, *bpart = nullptr;
     Tensor dx;        // NHWC output of the dgrad conv
     std::vector<Op> prog;
-    int n_chunks = 0, nb_pad = 0, n_co = 0, n_ci = 0, nsplit = 0, rb = 4, nbchunk = 0;
-    size_t wg_smem = 0;
+    int n_chunks = 0, nb_pad = 0, nbchunk = 0;
+    tk::WgradGeom g3, g1;      // weight-gradient launch geometry of the 3x3 / the 1x1 (centre-tap) form: the training step's (tk::wgrad_geom)
+    float* wbpart = nullptr;   // per-split bias partials of the fused bias gradient
     bool centre_only = false;  // a 1x1 conv riding the 3x3 kernels: dW is (Cout, Cin) from the centre tap
 };
 int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device);
@@ -96,27 +97,16 @@ int convbwd_init(ConvBwd& c, int B, int Cin, int Cout, int H, int W, int device)
         s.name = "conv3x3.dgrad";
         TRY(c.plan.add_conv(c.prog, s, &c.dx));
     }
-    // wgrad: (co block, ci block) x K splits; rows per band = the largest of {4, 2, 1} whose tiles fit 150 KB of LDS
-    c.n_co = (Cout + 31) / 32;
-    c.n_ci = (Cin + 31) / 32;
-    for (c.rb = 4; c.rb >= 1; c.rb >>= 1) {
-        c.wg_smem = ((size_t)c.rb * W * 32 + (size_t)(c.rb + 2) * (W + 2) * 32 + 4096) * sizeof(float);
-        if (c.wg_smem <= 150 * 1024) break;
-    }
-    if (!rc && c.rb < 1) rc = ddif::fail(DDIF_ERR_INVALID, "ddif_convbwd_create: W=%d is too wide for the wgrad kernel's LDS tiles", W);
+    // wgrad: the launches of the training step (tk::wgrad_geom / tk::wgrad below): the bf16x3 kernel where the width allows it, the fp32 kernel otherwise
+    c.g3 = tk::wgrad_geom(B, Cin, Cout, H, W, false);
+    c.g1 = tk::wgrad_geom(B, Cin, Cout, H, W, true);
+    if (!rc && (c.g3.rb < 1 || c.g1.rb < 1)) rc = ddif::fail(DDIF_ERR_INVALID, "ddif_convbwd_create: W=%d is too wide for the wgrad kernel's LDS tiles", W);
     if (!rc) {
-        const int bands = B * ((H + c.rb - 1) / c.rb);
-        int want = (2 * 256) / (c.n_co * c.n_ci);  // ~2 workgroups per CU in total
-        if (want < 1) want = 1;
-        if (want > bands) want = bands;
-        if (want > 256) want = 256;
-        c.nsplit = want;
-        TRY(c.plan.dalloc(&c.partial, (size_t)c.nsplit * c.n_co * c.n_ci * 9 * 1024));
+        TRY(c.plan.dalloc(&c.partial, std::max(c.g3.partial_floats, c.g1.partial_floats) + 64));
+        TRY(c.plan.dalloc(&c.wbpart, (size_t)std::max(c.g3.nsplit, c.g1.nsplit) * c.g3.n_co * 32 + 64));
         c.nbchunk = (int)std::min<size_t>(512, std::max<size_t>(1, (size_t)B * H * W / 16));  // >= 16 pixels per chunk
         TRY(c.plan.dalloc(&c.bpart, (size_t)c.nbchunk * Cout));
-        if (!rc && c.wg_smem > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(ddif::conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.wg_smem) != hipSuccess)
-            rc = ddif::fail(DDIF_ERR_HIP, "ddif_convbwd_create: hipFuncSetAttribute failed");
+        TRY(tk::wgrad_prepare());
     }
     return rc;
 }
@@ -131,27 +121,9 @@ void convbwd_core(ConvBwd& c, hipStream_t s, const float* w, bool want_dx, float
         StepCtx ctx;
         for (auto& op : c.prog) op.run(s, ctx);
     }
-    if (dw) {
-        WgradArgs a{};
-        a.x = c.x_nhwc;
-        a.dy = c.dy_nhwc;
-        a.B = c.B; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout;
-        a.n_ci = c.n_ci;
-        a.rb = c.rb;
-        a.bands_y = (c.H + c.rb - 1) / c.rb;
-        a.partial = c.partial;
-        a.centre_only = c.centre_only ? 1 : 0;
-        a.wshift = -1;
-        a.bpartial = nullptr;
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<0>, dim3(c.n_co * c.n_ci, c.nsplit), dim3(256), c.wg_smem, s, a);
-        const int rrows = c.n_co * c.n_ci * 32 * (c.centre_only ? 1 : 9);
-        const unsigned rgrid = (unsigned)(rrows < 2048 ? rrows : 2048);
-        if (c.centre_only)
-            hipLaunchKernelGGL(wgrad_reduce_centre_kernel, dim3(rgrid), dim3(256), 256 * sizeof(float), s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci, c.Cout,
-                               c.Cin, dw, (const float*)nullptr, (float*)nullptr);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 256 * sizeof(float), s, (const float*)c.partial, c.nsplit, c.n_co * c.n_ci, c.n_ci, c.Cout, c.Cin,
-                               dw, (const float*)nullptr, (float*)nullptr);
+    if (dw) {  // (+ the bias gradient from the same launch: column sums of the dY bands already staged)
+        tk::wgrad(s, c.x_nhwc, c.dy_nhwc, c.B, c.H, c.W, c.Cin, c.Cout, c.centre_only ? c.g1 : c.g3, c.centre_only, c.partial, dw, c.wbpart, db);
+        return;
     }
     if (db) {
         hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(c.nbchunk), dim3(256), 256 * sizeof(float), s, (const float*)c.dy_nhwc, (size_t)c.B * HW, c.Cout, c.nbchunk, c.bpart);

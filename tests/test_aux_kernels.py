@@ -123,12 +123,15 @@ def test_fused_adamw_clip_ema_matches_torch(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("shape", [(2, 32, 32, 16, 16), (1, 64, 32, 8, 8), (2, 16, 48, 12, 20), (3, 8, 8, 5, 7)],
-                         ids=["32-32@16", "64-32@8", "16-48@12x20", "8-8@5x7"])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 16, 16), (1, 64, 32, 8, 8), (2, 16, 48, 12, 20), (3, 8, 8, 5, 7), (2, 12, 40, 6, 24), (1, 32, 64, 5, 16), (1, 8, 16, 3, 128)],
+                         ids=["32-32@16", "64-32@8", "16-48@12x20", "8-8@5x7", "12-40@6x24", "32-64@5x16", "8-16@3x128"])
 def test_conv3x3_backward_matches_autograd(backend, shape):
     """dgrad / wgrad / dbias of the 3x3 conv (first building block) against torch autograd on the CPU in
-    fp32 -- the reference's own backward IS autograd through nn.Conv2d (diffusion_engine.py:233).  Floating point: the
-    kernels use exact-fp32 MFMAs with a different summation order; tolerance 2e-5 relative to the gradient's scale."""
+    fp32 -- the reference's own backward IS autograd through nn.Conv2d (diffusion_engine.py:233).  Floating point: split-operand
+    (bf16x3) MFMAs with fp32 accumulation and a different summation order; tolerance 2e-5 relative to the gradient's scale.
+    Widths that are multiples of 8 (<= 128) take the bf16x3 weight-gradient kernel (kernels_bwd.h conv3x3_wgrad_x3_kernel): 24 = an odd number of
+    8-pixel segments, 5 rows = a ragged last band, 12 / 40 channels = partial 32-channel blocks, 128 = the widest row it stages; 20 and 7 take the
+    exact-fp32 kernel."""
     from ddif import runtime
 
     dev = _dev(backend)
