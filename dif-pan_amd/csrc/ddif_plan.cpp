@@ -78,6 +78,15 @@ ConvVariant variant_for_cfg(int cfg) {
             if (cfg == 37) { v.fn = conv_mfma_kernel<KS, S, U, 16, 16, 32, 8, 1, 1, 1, PRO, VEC, EPI, 0, 5>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, 32, 1, PRO, 8, 5>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = v.wr = true; }
         }
     }
+    if constexpr (KS == 3 && S == 1 && U == 0 && VEC == 2 && PRO == PRO_NONE && EPI == 0) {
+        // the stem (cat[self_cond, x] inside ONE 16-channel chunk: float4 staging with a per-thread source select) on the f16x2 tilings 27 / 28 (round 5; until then the
+        // exact-fp32 tilings: 38.8 us per launch at B = 64 for 2.4 GFLOP)
+        switch (cfg) {
+            case 27: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 3>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = true; break;
+            case 28: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 3>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.f16 = true; break;
+            default: break;
+        }
+    }
     if constexpr (KS == 3 && S == 2 && U == 0 && VEC == 1 && PRO == PRO_NONE && EPI == 0) {
         // the Downsample convs on the f16x2 path (round 5; until then the exact-fp32 8 x 8 tiling 2: 43.6 / 26.5 us per launch at the 32 x 32 / 16 x 16 outputs for
         // 1.2 GFLOP each): the 8 x 16 x 32 and 8 x 8 x 64 tilings 28 / 29 with a stride-2 halo tile (17 x 33 / 17 x 17 staged pixels)
@@ -207,8 +216,9 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
         if (wide || Cout <= 32) return b1 ? 48 : (f16 ? 28 : 8);
         return b1 ? 49 : (f16 ? 29 : 9);
     }
-    static const bool s2_f16 = [] { const char* e = getenv("DDIF_S2_F16"); return !e || atoi(e) != 0; }();  // DDIF_S2_F16=0: the Downsample convs stay on the exact-fp32 tiling
+    static const bool s2_f16 = [] { const char* e = getenv("DDIF_S2_F16"); return !e || atoi(e) != 0; }();  // DDIF_S2_F16=0: the Downsample convs and the stem stay on the exact-fp32 tilings
     if (ks == 3 && vec == 1 && stride == 2 && !ups_ && x3 && f16ok && !b1 && s2_f16 && pro == PRO_NONE && Wout >= 16) return Cout <= 32 ? 28 : 29;
+    if (ks == 3 && vec == 2 && stride == 1 && !ups_ && x3 && f16ok && !b1 && s2_f16 && pro == PRO_NONE && wide && Cout <= 32) return (Hout >= 32 && Wout >= 32) ? 27 : 28;  // the stem
     if (ks == 3 && vec == 1 && wide && !ups_) {
         const long items32 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
         if (Hout >= 32 && Wout >= 32 && items32 >= 2L * num_cus()) return (Cout % 64 == 0 && items32 >= 4L * num_cus()) ? 6 : 5;

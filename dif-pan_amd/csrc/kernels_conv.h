@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr int DUMMY = DWM ? CK : (X3 ? NPL * PS : CK);  // pad slot of pixel 0 of the buffer the staging items go to (Hs for the
                                                           // depthwise prologue, else the A buffer): items past the end write here
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per workgroup");
-    static_assert(!X3 || (CK % 16 == 0 && VEC == 1), "bf16x3 path: 16-channel slabs, float4 staging");
+    static_assert(!X3 || (CK % 16 == 0 && (VEC == 1 || (VEC == 2 && F16 && PRO == PRO_NONE))), "split-operand paths: 16-channel slabs, float4 staging (per-thread source select: the stem on f16x2)");
     static_assert(TH * TW == 32 * MB * WM, "pixel tile must match the wave layout");
     static_assert(CK % 8 == 0 && NTHR % C4 == 0, "chunk size");
     static_assert(NITEMS <= 32, "valid mask is 32 bits");

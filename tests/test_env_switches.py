@@ -10,7 +10,7 @@
 
   DDIF_F16=0    the split-operand convs on bf16x3 (six products) instead of f16x2 (three);
   DDIF_LAFUSE=0 the decoder's linear-attention half as three launches instead of the fused block (csrc/kernels_lafuse.h);
-  DDIF_S2_F16=0 the Downsample convs on the exact-fp32 8 x 8 tiling instead of the f16x2 stride-2 tilings (round 5);
+  DDIF_S2_F16=0 the Downsample convs and the stem on the exact-fp32 tilings instead of the f16x2 ones (round 5);
   DDIF_WRES=0 / DDIF_XCD=0  the 16-channel-stage tiling of the 32 -> 32 convs / the dispatcher's round-robin work partition instead of the resident-weights
                 tiling / the XCD-contiguous partition (round 5): bit-identical results either way.
 

@@ -7,4 +7,4 @@ for rep in 1 2 3; do for v in 0 1; do
   DDIF_S2_F16=$v python3 bench.py --steps 2 --warmup 1 --T 200 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; r=json.load(sys.stdin); print('DDIF_S2_F16=$v ms per denoising step %.4f' % r['roofline']['whole_step']['ms_per_denoising_step'])"
 done; done
 DDIF_OP_TIMING=$R/gpurun_out/r05_y_op_timing.csv python3 bench.py --steps 1 --warmup 1 --T 40 --no-cpu-baseline > /dev/null 2>&1
-grep "down" $R/gpurun_out/r05_y_op_timing.csv
+grep "down\|stem" $R/gpurun_out/r05_y_op_timing.csv
