@@ -97,6 +97,9 @@ def parse_args(argv=None):
     ap.add_argument("--lib", default=None, help="development aid: another build of libddif.so to benchmark (A/B of kernel variants)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: CPUs this process may run on (sched_getaffinity)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity probe of the default line (N = 1, config wv3)")
+    ap.add_argument("--no-bracket", action="store_true", help="skip the exact-fp32 bracket run of the default line (a child process with DDIF_F16=0 DDIF_X3=0)")
+    ap.add_argument("--no-shares", action="store_true", help="gf2_dpm50 at N = 1: skip the per-rank shares (32 / 16 / 8 tiles) behind projected_strong_scaling")
     return ap.parse_args(argv)
 
 
@@ -230,7 +233,10 @@ def main():
         solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(lms, 0.0, 1.0))
         assert solver._fused_target() is not None  # the whole solver loop runs inside libddif
 
-    def one_step(seed):
+    ag_pairs = []  # (start, end) HIP events around every all-gather of the timed region (read after the final synchronise: nothing waits on them inside it)
+
+    def one_step(seed, timed=False):
+        ag_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if (timed and dist.is_initialized()) else None
         plan.set_cond(cond, force=True)  # once-per-tile precompute is part of the job
         if solver is not None:
             if strong:  # x_T of the whole scene from one seeded stream, this rank's block of it: independent of the GPU count
@@ -242,7 +248,12 @@ def main():
             res = diffusion(cond, mode="ddpm_sample", seed=seed, tile0=tile0, device_rng=True)
         sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
         if dist.is_initialized():
+            if ag_ev is not None:
+                ag_ev[0].record()
             dist.all_gather_into_tensor(gathered, sr)  # the only exchange: every rank ends with all tiles
+            if ag_ev is not None:
+                ag_ev[1].record()
+                ag_pairs.append(ag_ev)
             sr = gathered
         if strong:
             return stitch_tiles(sr, ny, nx)  # (C, 512, 512): the fused scene
@@ -267,17 +278,34 @@ def main():
     t0 = time.perf_counter()
     out = None
     for k in range(args.steps):
-        out = one_step(2000 + k)
+        out = one_step(2000 + k, timed=True)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0  # this rank's own time (before the closing barrier): a straggler GPU shows in per_rank_ms_per_step below
     if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = plan.prof_collect()
     log("timed region: %.3f s for %d step(s); %d of %d planned denoising steps profiled" % (dt, args.steps, prof["steps_recorded"], n_prof_planned))
+    rccl = None
     if dist.is_initialized():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # what the one line the driver keeps must show of a multi-GPU run: how many ranks RCCL really had, every rank's own time, the stitch collective's cost
+        mine = torch.tensor([dt_rank / args.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = [float(v) for v in allr.tolist()]
+        ag_us = [1e3 * a.elapsed_time(b) for a, b in ag_pairs]
+        ag_bytes = gathered.numel() * gathered.element_size()
+        ag_mean = sum(ag_us) / len(ag_us) if ag_us else None
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                "per_rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank), "all": per_rank},
+                "allgather": {"bytes_gathered": ag_bytes, "us_mean": ag_mean, "us_max": max(ag_us) if ag_us else None, "calls": len(ag_us),
+                              "algorithmic_gbytes_per_s": (ag_bytes / (ag_mean * 1e-6) / 1e9) if ag_mean else None,
+                              "bus_gbytes_per_s": ((world - 1) / world * ag_bytes / (ag_mean * 1e-6) / 1e9) if ag_mean else None,
+                              "note": "all_gather_into_tensor of the fused tiles (the only exchange of the path), HIP events on the launch stream, rank 0; "
+                                      "bus = (N-1)/N x bytes / time (ring convention)"}}
     assert out is not None and bool(torch.isfinite(out).all())
     drift = None
     if bf16:
@@ -417,6 +445,16 @@ def main():
         },
         "build_id": build_id(),
     }
+    if rccl is not None:
+        result["rccl"] = rccl
+    if rank == 0 and world == 1 and strong and not args.no_shares and total == 64:
+        result["projected_strong_scaling"] = strong_scaling_shares(diffusion, net, cf, C, P, H, T, n_evals, order, dev, dt / args.steps * 1e3)
+    if rank == 0 and world == 1 and args.config == "wv3" and not args.no_parity:
+        result["parity"] = parity_probe(net, dev)
+    if rank == 0 and world == 1 and args.config == "wv3" and not args.no_bracket and "DDIF_X3" not in os.environ and "DDIF_F16" not in os.environ:
+        result["exact_fp32"] = exact_fp32_bracket(B, H)
+        if result["exact_fp32"].get("ms_per_denoising_step"):
+            result["ms_per_step_exact_fp32"] = result["exact_fp32"]["ms_per_denoising_step"] * T
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("gpu result: %s" % json.dumps({k: result[k] for k in ("value", "ms_per_step")}))
@@ -428,6 +466,107 @@ def main():
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def parity_probe(net, dev):
+    """The benchmarked build and math mode against the REAL reference's own output (VERDICT r5 #3b): the B = 1 golden of BASELINE configs[1]
+    (tests/golden/ddpm_wv3_64_T1000.npz -- the reference's p_sample_loop, T = 1000, 64 x 64 x 8, generated by tools/make_golden.py in the build
+    container) re-run through the HIP path with the reference's noise stream, outside the timed region.  Data only: no oracle code runs here."""
+    import math
+
+    import numpy as np
+    import torch
+
+    import golden_cases as gc
+    from ddif.diffusion.diffusion_ddpm_pan import GaussianDiffusion, make_beta_schedule
+    from ddif_testlib import reference_noise_stream
+
+    cid, ds, B1, H, W, T, seed = [c for c in gc.DDPM_CASES if c[0] == "ddpm_wv3_64_T1000"][0]
+    path = os.path.join(gc.GOLDEN_DIR, cid + ".npz")
+    if not os.path.exists(path):
+        return {"golden": cid, "error": "golden vector not found"}
+    ref = torch.from_numpy(np.load(path)["out"])
+    tiles = gc.tiles_for(ds, B1, H, W, seed=seed)
+    d = GaussianDiffusion(net, image_size=H, channels=8, pred_mode="x_start", loss_type="l1", device=dev, clamp_range=(0, 1))
+    d.set_new_noise_schedule(betas=make_beta_schedule("cosine", T, cosine_s=8e-3), device=dev)
+    xT, noise = reference_noise_stream(seed, (B1, 8, H, W), T)
+    t0 = time.perf_counter()
+    out = d(tiles["cond"].to(dev), mode="ddpm_sample", x_T=xT.to(dev), noise=noise.to(dev)).cpu()
+    dt = time.perf_counter() - t0
+    lms = tiles["cond"][:, :8]
+
+    def psnr(a, b):
+        mse = float(torch.mean((a.double() - b.double()) ** 2))
+        return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+    sr_hip, sr_ref = (out + lms).clip(0, 1), (ref + lms).clip(0, 1)  # diffusion_engine.py:446-447
+    mode = "exact fp32 MFMA" if os.environ.get("DDIF_X3") == "0" else ("bf16x3 split" if os.environ.get("DDIF_F16") == "0" else "f16x2 split (default)")
+    p = {"golden": cid, "against": "the reference's own p_sample_loop output (tools/make_golden.py), B = 1, T = %d, 64x64x8, the reference's noise stream" % T,
+         "max_abs": float((out - ref).abs().max()), "psnr_diff_db": abs(psnr(sr_hip, tiles["gt"]) - psnr(sr_ref, tiles["gt"])),
+         "tolerance": {"max_abs": 1e-4, "psnr_diff_db": 1e-3}, "mode": mode, "seconds": dt}
+    p["within_tolerance"] = bool(p["max_abs"] <= 1e-4 and p["psnr_diff_db"] <= 1e-3)
+    log("parity probe (%s): max|hip - reference| = %.3e, PSNR difference %.2e dB after %d steps" % (mode, p["max_abs"], p["psnr_diff_db"], T))
+    return p
+
+
+def exact_fp32_bracket(B, H, T=100):
+    """The same workload on the EXACT fp32 instruction (v_mfma_f32_32x32x2_f32 everywhere: DDIF_F16=0 DDIF_X3=0, read by the library at load time, hence a
+    child process) -- the bracket the f16x2 headline is quoted between ('the line must carry the bracket').  One job of T denoising
+    steps outside the timed region; ms per denoising step does not depend on T."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.update({"DDIF_F16": "0", "DDIF_X3": "0"})
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--T", str(T), "--batch", str(B), "--tile", str(H), "--no-cpu-baseline", "--no-bracket"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")][-1]
+        j = json.loads(line)
+        out = {"ms_per_denoising_step": j["ms_per_step"] / T, "T": T, "launches_per_denoising_step": j["config"]["launches_per_denoising_step"], "dtype": j["dtype"],
+               "env": "DDIF_F16=0 DDIF_X3=0", "parity": j.get("parity"), "seconds": time.perf_counter() - t0}
+        log("exact-fp32 bracket: %.3f ms per denoising step (%d launches)" % (out["ms_per_denoising_step"], out["launches_per_denoising_step"]))
+        return out
+    except Exception as e:  # the bracket must never take the headline down with it
+        log("exact-fp32 bracket failed: %r" % (e,))
+        return {"error": repr(e)[:300]}
+
+
+def strong_scaling_shares(diffusion, net, cf, C, P, H, T, n_evals, order, dev, ms64):
+    """gf2_dpm50 at N = 1: what ONE rank of an N-GPU run of the same scene computes (64 / N tiles), measured on this GPU, and the strong-scaling
+    speed-up those shares project (compute share only; the 4 MB all-gather + stitch at N > 1 is not in it).  VERDICT r5 #2."""
+    import torch
+
+    from ddif.solver.dpm_solver import DPM_Solver, ImageSpaceClamp, NoiseScheduleVP, model_wrapper
+    from ddif.synth import synth_tiles
+
+    shares = {"64": ms64}
+    tiles_all = synth_tiles(64, C, P, H, H, seed=100, order=order)
+    for n in (32, 16, 8):
+        cond = tiles_all["cond"][:n].contiguous().to(dev)
+        lms = cond[:, :C].contiguous()
+        plan = diffusion._plan(cond)
+        ns = NoiseScheduleVP("discrete", betas=diffusion.betas)
+        fn = model_wrapper(net, ns, model_type="x_start", guidance_type="classifier-free", guidance_scale=1.0, condition=cond)
+        solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(lms, 0.0, 1.0))
+
+        def job(seed):
+            plan.set_cond(cond, force=True)
+            xT = torch.randn((64, C, H, H), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))[:n].contiguous()
+            return (solver.sample(xT, steps=n_evals, order=2, skip_type="time_uniform", method="multistep") + lms).clip(0, 1)
+
+        job(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(3):
+            job(2 + k)
+        torch.cuda.synchronize()
+        shares[str(n)] = (time.perf_counter() - t0) / 3 * 1e3
+    proj = {str(64 // int(k)): ms64 / v for k, v in shares.items()}
+    log("per-rank shares (ms per scene job): %s -> projected speed-up by GPU count %s" % (shares, proj))
+    return {"ms_per_job_by_tiles_per_gpu": shares, "projected_speedup_by_gpus": proj,
+            "note": "each share = the job of ONE rank holding 64 / N tiles of the scene, timed on this one GPU (3 jobs after 1 warm-up); "
+                    "speed-up = share(64) / share(64 / N); the all-gather + stitch of N > 1 is not included"}
 
 
 def bench_training(args, cf, rank, world, dev):

@@ -18,6 +18,7 @@ struct AttnBlockArgs {
     int B;
     int b0;               // first sample
     int xcd;              // samples of one XCD contiguous (workgroup w runs on XCD w % 8; ddif_dev.h wg_work_range)
+    long long* dbg;       // microbenchmark instrumentation (ABL & 1, tools/mbench_attn.cpp) only
 };
 
 }  // namespace ddif

@@ -50,12 +50,21 @@ ConvVariant lr_for(int ks, int pro, int epi, int math) {
 
 // Fused bottleneck attention block (kernels_attn.h): launch helper (the kernel lives in this translation unit)
 size_t attn_block_smem() { return AttnBlockGeom::smem; }
+// DDIF_ATTN_NW=8: eight wavefronts per sample instead of four; same values either way (kernels_attn.h), tests/test_env_switches.py.  Measured in round 6
+// (profiles/r06/attn_block_stamps.txt): 22.3 vs 23.3 us per launch -- the block is bound by the matrix pipe of its ONE CU (qkv: 288 bf16 MFMAs per wave = 9.2 k of the
+// 12.8 k cycles of that stage; attention core on the exact fp32 MFMA: 8.2 k of 22.4 k), a second wave per SIMD has no idle pipe to fill.  Four stays the default.
+static int attn_nw() {
+    static const int v = [] { const char* e = getenv("DDIF_ATTN_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    return v;
+}
 int attn_block_prepare() {
-    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     return 0;
 }
 void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(attn_block_kernel, dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
+    if (attn_nw() == 4) hipLaunchKernelGGL(attn_block_kernel<4>, dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
+    else hipLaunchKernelGGL(attn_block_kernel<8>, dim3(grid), dim3(512), AttnBlockGeom::smem, s, a);
 }
 
 // mb = 2: 8x8 pixel tiles, mb = 4: 8x16.  The per-sample time bias needs no variant of its own here (the epilogue reads

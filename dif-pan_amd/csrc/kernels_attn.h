@@ -17,6 +17,10 @@
 // core) except that the softmax exponentials use v_exp_f32 (~1 ulp, as SiLU does everywhere) instead of expf.
 // Measured (B = 64): 26 us per launch against 49 us for the three launches it replaces.  A three-slab weight ring and
 // fetching all out-projection slabs before the attention core measured slower (33 us: 512 registers, 52 spilled).
+// Round 6: NW = 8 wavefronts per sample instead of 4 (two per SIMD: with one, every LDS / L2 latency of the chain stood in front of an idle
+// matrix pipe).  The (cout block, token block) pairs of the two 1x1 convs and the eight heads are dealt out over the waves -- wave w takes
+// token block w & 1 of cout blocks 3 (w >> 1) .. + 2 (qkv) / w >> 1 (out) and head w -- so every product, every accumulation order and every
+// stored value is the same as with four waves; only the order in which the per-wave statistics partials are added differs.
 #pragma once
 #include "kernels_conv.h"
 #include "attn_args.h"
@@ -31,7 +35,14 @@ struct AttnBlockGeom {
     static constexpr size_t smem = (size_t)(AFL + QFL + 16) * sizeof(float);
 };
 
-__global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
+// ABL (tools/mbench_attn.cpp only): 1 = s_memtime stamps of thread 0 at the stage boundaries into a.dbg
+template <int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
+    static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per sample");
+    constexpr int MBW = 8 / NW;       // token blocks per wave in the two 1x1 convs (NW = 8: one, chosen by the wave's parity)
+    constexpr int HPW = 8 / NW;       // heads per wave
+    constexpr int TPP = 2 * NW;       // tokens per staging pass (32 float4 channel groups per token)
+    constexpr int NIT = 64 / TPP;
     using G = AttnBlockGeom;
     constexpr int N = G::N, C = G::C, NSLAB = G::NSLAB, APIX = G::APIX, QROW = G::QROW, D = 16;
     dd_touch_kernargs<sizeof(AttnBlockArgs)>();  // every line of the argument block in ONE round trip (ddif_dev.h)
@@ -47,7 +58,16 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     const int h = lane >> 5, j = lane & 31;
-    const int c4 = tid & 31, p0 = tid >> 5;  // staging: 32 float4 channel groups x 8 tokens per pass
+    const int c4 = tid & 31, p0 = tid >> 5;  // staging: 32 float4 channel groups x TPP tokens per pass
+    [[maybe_unused]] int dbg_n = 0;
+    auto stamp = [&]() {
+#ifndef DDIF_EMU
+        if ((ABL & 1) && a.dbg && tid == 0 && dbg_n < 31) a.dbg[blockIdx.x * 32 + dbg_n++] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    };
+    stamp();  // 0: entry
+    const int mb0 = (NW == 8) ? (wave & 1) : 0;   // first token block of this wave in the 1x1 convs
+    const int cw = (NW == 8) ? (wave >> 1) : wave;  // its cout-block group
 
     const unsigned ga = gridDim.x;
     const int bw = (a.xcd && (ga & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (ga >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;  // XCD-contiguous sample order
@@ -55,23 +75,30 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
         // ---- (1) loads in one burst: GroupNorm partials, the sample, affine parameters, first weight slab
         GnPartials gp;
         gn_load_partials(a.st, a.np, nullptr, 0, b, &gp);
-        float4 sv[8];
+        float4 sv[NIT];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) sv[it] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + p0 + it * 8) * C + c4 * 4);
+        for (int it = 0; it < NIT; ++it) sv[it] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + p0 + it * TPP) * C + c4 * 4);
         const float4 gq = *reinterpret_cast<const float4*>(a.gamma + c4 * 4);
         const float4 bq = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
-        // qkv weights of this wave: cout blocks 3w .. 3w+2, slab s, plane q at ((nb * 8 + s) * 3 + q) KiB
-        const char* wq = reinterpret_cast<const char*>(a.wqkv) + (size_t)lane * 16;
+        // qkv weights of this wave: cout blocks 3 cw .. 3 cw + 2, slab s, plane q at ((nb * 8 + s) * 3 + q) KiB
+        // (wave-uniform base + 32-bit lane offset: the loads take the SGPR-base form; per-lane 64-bit addresses of all 72 fragments were precomputed and spilled)
+        const char* wq = reinterpret_cast<const char*>(a.wqkv) + (size_t)(3 * cw) * (NSLAB * 3 * 1024);
+        unsigned lo16 = (unsigned)lane * 16u;
+#ifndef DDIF_EMU
+        asm volatile("" : "+v"(lo16));  // opaque per sample: keeps hipcc from hoisting the 96 fragment offsets (loop-invariant VGPR adds) out of the sample loop into spilled registers
+#endif
         float4 wr[2][3][3];  // [ring slot][cout block][plane]
         auto load_qkv_w = [&](int slot, int s) {
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) wr[slot][nb][q] = *reinterpret_cast<const float4*>(wq + ((((size_t)(3 * wave + nb)) * NSLAB + s) * 3 + q) * 1024);
+                for (int q = 0; q < 3; ++q) wr[slot][nb][q] = *reinterpret_cast<const float4*>(wq + ((nb * NSLAB + s) * 3 + q) * 1024 + lo16);
         };
         load_qkv_w(0, 0);
+        stamp();  // 1: first burst issued
         float mean, rstd;
         gn_reduce_partials(gp, a.st, a.np, nullptr, 0, b, (double)C * N, &mean, &rstd);
+        stamp();  // 2: statistics reduced (the partials have arrived)
         {
             float ga[4], gb[4];
 #pragma unroll
@@ -81,8 +108,8 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
             }
             const int slab = c4 >> 2, cin_slab = (c4 & 3) * 4;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int tok = p0 + it * 8;
+            for (int it = 0; it < NIT; ++it) {
+                const int tok = p0 + it * TPP;
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaf((&sv[it].x)[i], ga[i], gb[i]);
@@ -95,13 +122,15 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
                 *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
             }
         }
+        stamp();  // 3: xn staged (the sample has arrived)
         __syncthreads();
+        stamp();  // 4: barrier
 
-        // ---- (2) qkv = xn . Wqkv^T : 2 token blocks x 3 cout blocks per wave, K = 8 slabs
+        // ---- (2) qkv = xn . Wqkv^T : MBW token blocks x 3 cout blocks per wave, K = 8 slabs
         {
-            f32x16 acc[2][3];
+            f32x16 acc[MBW][3];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
@@ -109,16 +138,16 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
 #pragma unroll
             for (int s = 0; s < NSLAB; ++s) {
                 if (s + 1 < NSLAB) load_qkv_w((s + 1) & 1, s + 1);
-                float4 xa[2][3];
+                float4 xa[MBW][3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[(mb * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
+                    for (int mb = 0; mb < MBW; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[((mb0 + mb) * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
                 DDIF_SCHED_FENCE();
 #pragma unroll
                 for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
+                    for (int mb = 0; mb < MBW; ++mb) {
                         f32x16 c = acc[mb][nb];
                         const float4* w = wr[s & 1][nb];
                         c = DDIF_MFMA_32x32x16_BF16(w[2], xa[mb][0], c);  // lo * hi
@@ -131,32 +160,34 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
                     }
                 DDIF_SCHED_FENCE();
             }
-            // lane (j, h) owns token mb*32 + j and, per quad g, couts nb*32 + 8g + 4h .. +3
+            // lane (j, h) owns token (mb0 + mb)*32 + j and, per quad g, couts nb*32 + 8g + 4h .. +3
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(&Qs[(mb * 32 + j) * QROW + (3 * wave + nb) * 32 + 8 * g + 4 * h]) =
+                        *reinterpret_cast<float4*>(&Qs[((mb0 + mb) * 32 + j) * QROW + (3 * cw + nb) * 32 + 8 * g + 4 * h]) =
                             make_float4(acc[mb][nb][4 * g + 0], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]);
         }
-        // out-projection weights of this wave (cout block `wave`): first slab, in flight during the attention core
-        const char* wo = reinterpret_cast<const char*>(a.wout) + (size_t)lane * 16;
+        // out-projection weights of this wave (cout block `cw`): first slab, in flight during the attention core
+        const char* wo = reinterpret_cast<const char*>(a.wout) + (size_t)cw * (NSLAB * 3 * 1024);
         float4 wo_r[2][3];
         auto load_out_w = [&](int slot, int s) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) wo_r[slot][q] = *reinterpret_cast<const float4*>(wo + ((((size_t)wave) * NSLAB + s) * 3 + q) * 1024);
+            for (int q = 0; q < 3; ++q) wo_r[slot][q] = *reinterpret_cast<const float4*>(wo + (s * 3 + q) * 1024 + lo16);
         };
         load_out_w(0, 0);
+        stamp();  // 5: qkv contraction done and written
         __syncthreads();  // qkv complete in LDS; xn (As) is dead
+        stamp();  // 6: barrier
 
-        // ---- (3) attention core: heads 2w, 2w+1; n = 64 keys = one key block
+        // ---- (3) attention core: heads HPW w .. + HPW - 1; n = 64 keys = one key block
         {
             const int jj = lane & 15, g4 = lane >> 4;
 #pragma unroll 1
-            for (int hh = 0; hh < 2; ++hh) {
-                const int hd = 2 * wave + hh;
+            for (int hh = 0; hh < HPW; ++hh) {
+                const int hd = HPW * wave + hh;
                 const float* base = Qs + hd * 3 * D;  // + token * QROW + {0, D, 2D} + d
                 float4 qf[4], kf[4];
 #pragma unroll
@@ -230,34 +261,36 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
                     }
             }
         }
+        stamp();  // 7: attention core done
         __syncthreads();  // o planes complete
+        stamp();  // 8: barrier
 
-        // ---- (4) out = o . Wout^T + bias + x : cout block `wave`, 2 token blocks, K = 8 slabs
+        // ---- (4) out = o . Wout^T + bias + x : cout block `cw`, MBW token blocks, K = 8 slabs
         {
-            f32x16 acc[2];
+            f32x16 acc[MBW];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-            // epilogue operands: bias and the residual rows of this lane's two tokens
-            float4 bo[4], er[2][4];
+            // epilogue operands: bias and the residual rows of this lane's tokens
+            float4 bo[4], er[MBW][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bo[g] = *reinterpret_cast<const float4*>(a.bout + wave * 32 + 8 * g + 4 * h);
+                bo[g] = *reinterpret_cast<const float4*>(a.bout + cw * 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) er[mb][g] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + mb * 32 + j) * C + wave * 32 + 8 * g + 4 * h);
+                for (int mb = 0; mb < MBW; ++mb) er[mb][g] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + (mb0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h);
             }
 #pragma unroll
             for (int s = 0; s < NSLAB; ++s) {
                 if (s + 1 < NSLAB) load_out_w((s + 1) & 1, s + 1);
-                float4 xa[2][3];
+                float4 xa[MBW][3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[(mb * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
+                    for (int mb = 0; mb < MBW; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[((mb0 + mb) * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
                 DDIF_SCHED_FENCE();
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
+                for (int mb = 0; mb < MBW; ++mb) {
                     f32x16 c = acc[mb];
                     const float4* w = wo_r[s & 1];
                     c = DDIF_MFMA_32x32x16_BF16(w[2], xa[mb][0], c);
@@ -270,15 +303,16 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
                 }
                 DDIF_SCHED_FENCE();
             }
+            stamp();  // 9: out contraction issued
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = (acc[mb][4 * g + i] + (&bo[g].x)[i]) + (&er[mb][g].x)[i];
-                    *reinterpret_cast<float4*>(a.out + ((size_t)b * N + mb * 32 + j) * C + wave * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(a.out + ((size_t)b * N + (mb0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
                     s1 += (v[0] + v[1]) + (v[2] + v[3]);
                     s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 }
@@ -290,10 +324,18 @@ __global__ __launch_bounds__(256) void attn_block_kernel(AttnBlockArgs a) {
                 }
             }
         }
+        stamp();  // 10: epilogue stores issued
         __syncthreads();  // (also: As / Qs are free for the next sample)
+        stamp();  // 11: barrier
         if (a.st_out && tid == 0) {
-            a.st_out[(size_t)b * 2 + 0] = ((double)Sst[0] + (double)Sst[2]) + ((double)Sst[4] + (double)Sst[6]);
-            a.st_out[(size_t)b * 2 + 1] = ((double)Sst[1] + (double)Sst[3]) + ((double)Sst[5] + (double)Sst[7]);
+            double t0 = ((double)Sst[0] + (double)Sst[2]) + ((double)Sst[4] + (double)Sst[6]);
+            double t1 = ((double)Sst[1] + (double)Sst[3]) + ((double)Sst[5] + (double)Sst[7]);
+            if (NW == 8) {
+                t0 += ((double)Sst[8] + (double)Sst[10]) + ((double)Sst[12] + (double)Sst[14]);
+                t1 += ((double)Sst[9] + (double)Sst[11]) + ((double)Sst[13] + (double)Sst[15]);
+            }
+            a.st_out[(size_t)b * 2 + 0] = t0;
+            a.st_out[(size_t)b * 2 + 1] = t1;
         }
     }
 }

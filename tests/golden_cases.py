@@ -81,6 +81,18 @@ DDPM_CASES = [
 ]
 DDPM_SNAPSHOTS = {"ddpm_wv3_16_T10": [1, 2, 10]}
 
+# round 6: config-exact goldens from the real reference.  Kept out of DDPM_CASES / DPM_CASES so that the CPU oracle suite does not
+# re-run minutes of 64 x 64 chains; the GPU suite compares the HIP path with them directly.
+#   two more BASELINE configs[1] tiles (different cond / noise realisations) for the B = 64, T = 1000 test
+DDPM_BIG_CASES = [
+    ("ddpm_wv3_64_T1000_b", "wv3", 1, 64, 64, 1000, 15),
+    ("ddpm_wv3_64_T1000_c", "wv3", 1, 64, 64, 1000, 16),
+]
+#   BASELINE configs[3] (CAVE, 128 x 128, T = 2000): the reference's full 2000-step chain, final `out` only
+DDPM_FULL_CASES = [
+    ("ddpm_cave_128_T2000", "cave", 1, 128, 128, 2000, 53),
+]
+
 DDIM_CASES = [  # (case id, dataset, B, H, W, T, section_counts, seed)
     ("ddim_wv3_32_T500_25", "wv3", 1, 32, 32, 500, "ddim25", 21),
     ("ddim_gf2_16_T1000_25", "gf2", 2, 16, 16, 1000, "ddim25", 22),
@@ -91,6 +103,11 @@ DPM_CASES = [  # (case id, dataset, H, W, T, steps, order, seed)   (B = 1: refer
     ("dpm_gf2_32_T1000_s50_o2", "gf2", 32, 32, 1000, 50, 2, 32),
     ("dpm_wv3_16_T500_s12_o3", "wv3", 16, 16, 500, 12, 3, 33),
     ("dpm_wv3_16_T500_s6_o3", "wv3", 16, 16, 500, 6, 3, 34),
+]
+
+# BASELINE configs[2] at its benchmarked tile size (GF2 64 x 64, DPM-Solver++ 2M, 50 evaluations), B = 1 (SURVEY D-8)
+DPM_BIG_CASES = [
+    ("dpm_gf2_64_T1000_s50_o2", "gf2", 64, 64, 1000, 50, 2, 36),
 ]
 
 DPM_SKIP_CASES = [  # (case id, dataset, H, W, T, steps, order, seed, skip_type)

@@ -14,6 +14,8 @@
   DDIF_WRES=0 / DDIF_XCD=0  the 16-channel-stage tiling of the 32 -> 32 convs / the dispatcher's round-robin work partition instead of the resident-weights
                 tiling / the XCD-contiguous partition (round 5): bit-identical results either way.
 
+  DDIF_ATTN_NW=8  the fused bottleneck attention block on eight wavefronts per sample instead of four (round 6: measured neutral, not the default): same values.
+
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
 kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04_t_*, r03_b_*) were deleted together with
 their code."""
@@ -32,8 +34,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
 
 
 @pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"},
-                                 {"DDIF_S2_F16": "0"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0"])
+                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)

@@ -5,6 +5,7 @@ numeric vectors (inputs' checksums, expected outputs) and the reference's state-
 written into the repository.
 
     python tools/make_golden.py [--only fwd,sched,ddpm,ddim,dpm,loss,psnr] [--skip-long]
+    python tools/make_golden.py --only ddpmbig,dpmbig,ddpmfull     (round 6: the config-exact cases; not part of the default set)
 """
 import argparse
 import json
@@ -261,8 +262,13 @@ def main():
                     out[f"ddim25_from_T{T}.{k}"] = v.clone()
         save("schedules", **out)
 
-    if "ddpm" in only:
-        for cid, ds, B, H, W, T, seed in gc.DDPM_CASES:
+    ddpm_cases = list(gc.DDPM_CASES) if "ddpm" in only else []
+    if "ddpmbig" in only:  # round 6: two more configs[1] tiles (about a minute each on 8 cores)
+        ddpm_cases += gc.DDPM_BIG_CASES
+    if "ddpmfull" in only:  # round 6: the full CAVE 128 x 128 T = 2000 chain (one-off: 15-25 minutes on 8 cores)
+        ddpm_cases += gc.DDPM_FULL_CASES
+    if ddpm_cases:
+        for cid, ds, B, H, W, T, seed in ddpm_cases:
             if args.skip_long and T * H * W > 100 * 32 * 32:
                 continue
             C = gc.DATASETS[ds][0]
@@ -297,8 +303,11 @@ def main():
             out = d(cond, mode="ddim_sample", section_counts=sect)
             save(cid, out=out, cond_chk=chk(cond), num_timesteps_after=d.num_timesteps)
 
-    if "dpm" in only:
-        for cid, ds, H, W, T, steps, order, seed in gc.DPM_CASES:
+    dpm_cases = list(gc.DPM_CASES) if "dpm" in only else []
+    if "dpmbig" in only:  # round 6: configs[2] at the benchmarked tile size
+        dpm_cases += gc.DPM_BIG_CASES
+    if dpm_cases:
+        for cid, ds, H, W, T, steps, order, seed in dpm_cases:
             C = gc.DATASETS[ds][0]
             cond = gc.tiles_for(ds, 1, H, W, seed=seed)["cond"]
             d = make_diffusion(D, net_for(ds), C, T, H)
