@@ -397,6 +397,19 @@ int Net::commit(hipStream_t stream) {
             add_vec(L.p + ".cond_inj.body.1.bias");
             add_conv(L.p + ".cond_inj.body.3", true);
             add_conv(L.p + ".cond_inj.x_conv", true);
+            // round 6, inference only (no refresh recipe, like the f16 packs): the x_conv weights in the per-lane A-operand order of the register GEMM that folds
+            // x_conv + FiLM into the PRODUCER's epilogue (kernels_conv.h EPI_XF): [32-cout block][lane = 32 h + j][s = 4 g + i] = W_x[32 nb + j][8 g + 4 h + i]
+            if (const HostTensor* wx = get(L.p + ".cond_inj.x_conv.weight")) {
+                if (wx->shape.size() == 4 && wx->shape[1] == 32 && wx->shape[0] % 32 == 0 && wx->shape[2] == 1) {
+                    const int co = (int)wx->shape[0];
+                    std::vector<float> r((size_t)co * 32);
+                    for (int nb = 0; nb < co / 32; ++nb)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int sx = 0; sx < 16; ++sx)
+                                r[((size_t)nb * 64 + ln) * 16 + sx] = wx->v[(size_t)(32 * nb + (ln & 31)) * 32 + 8 * (sx >> 2) + 4 * (ln >> 5) + (sx & 3)];
+                    vec_off[L.p + ".cond_inj.x_conv.xf"] = b.add(r.data(), r.size());
+                }
+            }
         }
     }
     for (auto& L : mid) {

@@ -186,6 +186,10 @@ static int xcd_mask() {
     static const int v = [] { const char* e = getenv("DDIF_XCD"); return e ? atoi(e) : 15; }();
     return v;
 }
+static int xf_enabled() {  // DDIF_XF=0: CondInjection.x_conv + FiLM as a launch of its own everywhere (the form of rounds 1-5); tests/test_env_switches.py
+    static const int v = [] { const char* e = getenv("DDIF_XF"); return e ? atoi(e) : 1; }();
+    return v;
+}
 static int lr_enabled() {  // DDIF_LR=0: the 8x8 / 16x16 levels on the general conv kernel (kernels_conv.h) as well; covered by tests/test_env_switches.py
     static const int lr = [] { const char* e = getenv("DDIF_LR"); return e ? atoi(e) : 1; }();
     return lr;
@@ -467,6 +471,17 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         }
     }
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    // round 6: the next block's x_conv + FiLM as a second output of this conv (kernels_conv.h EPI_XF) -- where the chosen f16x2 tiling has such an instantiation
+    // and one wave holds all 32 couts of its pixels; otherwise the request is left undone and the caller emits the 1x1 launch as before
+    bool xf = false;
+    if (s.xf && !train_mode && xf_enabled() && var.f16 && !var.lr && pc.ks == 3 && pc.cout == 32 && !s.ups && s.tb_off < 0 && !s.samp && s.xf->pc && s.xf->w && s.xf->film &&
+        s.xf->pc->cin == 32 && s.xf->pc->bias && (s.xf->pc->cout == 32 || s.xf->pc->cout == 64) && &prog == &step) {
+        const ConvVariant vx = get_xf_variant(s.stride, s.pro, cfg, vec, epi, s.xf->pc->cout / 32);
+        if (vx.fn && vx.smem == var.smem) {
+            var = vx;
+            xf = true;
+        }
+    }
     if ((s.pro == PRO_GN || s.pro == PRO_GN_SILU || s.pro == PRO_GN_DW) && (!s.in0.st || (s.in1.p && !s.in1.st) || !s.gamma || !s.beta))
         return fail(DDIF_ERR_STATE, "%s: GroupNorm prologue without producer statistics", s.name);
     if (&prog == &step) {  // liveness of everything this launch touches (dry pass)
@@ -481,6 +496,9 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         use(s.cso_sm);
     }
     if (int e = alloc_tensor(out, pc.cout, Hout, Wout, &prog == &step)) return e;
+    if (xf) {
+        if (int e = alloc_tensor(&s.xf->out, s.xf->pc->cout, Hout, Wout, true)) return e;
+    }
     ConvArgs a{};
     a.in0 = s.in0.p;
     a.in1 = s.in1.p;
@@ -524,6 +542,18 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         a.st_out = out->st;
     }
     a.n_ct = gy;
+    if (xf) {
+        if (gy != 1 || !s.stats) return fail(DDIF_ERR_STATE, "%s: x_conv fold needs one cout tile and output statistics", s.name);
+        s.xf->out.np = a.tiles_x * a.tiles_y;
+        if (int e = dalloc(&s.xf->out.st, (size_t)B * s.xf->out.np * 2)) return e;
+        a.xf_w = s.xf->w;
+        a.xf_b = s.xf->pc->bias;
+        a.xf_film = s.xf->film;
+        a.xf_out = s.xf->out.p;
+        a.xf_st = s.xf->out.st;
+        a.xf_cout = s.xf->pc->cout;
+        s.xf->done = true;
+    }
     a.xcd = (xcd_mask() & (var.lr ? 2 : 1)) ? 1 : 0;
     if (var.f16 && raw_in) {  // (the kernels only look at it in their raw-input f16x2 instantiations)
         a.range_flag = d_range;
@@ -533,7 +563,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const long items_per_sample = (long)a.tiles_x * a.tiles_y * gy;
     const long nwork = (long)B * items_per_sample;
     const int gy0 = (pc.cout + var.nt - 1) / var.nt;
-    const size_t smem = var.lr ? var.smem : var.smem + conv_smem_extra(s.pro, var.wr ? 1 : pc.n_chunks, var.wr ? 32 : pc.ck, gy0 * var.nt);
+    const size_t smem = var.lr ? var.smem : var.smem + conv_smem_extra(s.pro, var.wr ? 1 : pc.n_chunks, var.wr ? 32 : pc.ck, gy0 * var.nt, xf ? s.xf->pc->cout : 0);
     long cap = (long)num_cus() * wg_per_cu(smem, var.wg_cap);
     if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
     const dim3 grid((unsigned)(nwork < cap ? nwork : cap), 1u);
@@ -580,6 +610,11 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     }
     op.flop = 2.0 * B * Hout * Wout * (double)pc.cout * (c0 + c1) * pc.ks * pc.ks;
     op.bytes = 4.0 * B * ((double)Hin * Win * (c0 + c1) + (double)Hout * Wout * pc.cout);
+    if (xf) {  // + the folded 1x1 conv and its FiLM operands / output
+        op.label += " + x_conv+FiLM";
+        op.flop += 2.0 * B * Hout * Wout * 32.0 * s.xf->pc->cout;
+        op.bytes += 4.0 * B * (double)Hout * Wout * 3.0 * s.xf->pc->cout;
+    }
     op.cls = (Hout * Wout <= 256) ? 2 : (pc.ks == 3 ? 0 : 1);
     op.mfma_w = var.b1 ? 1 : (var.f16 ? 3 : (var.x3 ? 6 : 16));
     op.timed = op.cls == 0;
@@ -695,7 +730,7 @@ int Plan::build_impl() {
     }
 
     // helpers shared by the step program
-    auto resblock = [&](const std::string& rb, Tensor in, Tensor* out) -> int {
+    auto resblock = [&](const std::string& rb, Tensor in, Tensor* out, XfReq* xf = nullptr) -> int {
         const PackedConv *c1 = PC(rb + ".block1.block.3"), *c2 = PC(rb + ".block2.block.3");
         if (!c1 || !c2) return fail(DDIF_ERR_MISSING, "%s: conv weights missing", rb.c_str());
         Tensor h1;
@@ -772,6 +807,7 @@ int Plan::build_impl() {
         s2.beta = V(rb + ".block2.block.0.bias");
         s2.res = in.p;
         s2.stats = true;
+        s2.xf = xf;
         s2.name = "res.conv2";
         return add_conv(step, s2, out);
     };
@@ -862,7 +898,62 @@ int Plan::build_impl() {
     std::vector<Tensor> feats;
     std::vector<int> feat_mod;  // train: index in tmods of the module that produced each feature
     int lev = 0;
-    for (auto& L : net->downs) {
+    // cond-only FiLM branch of an encoder block: body(cond) -> scale | shift (sr3_dwt.py:379-391); built when first asked for -- by the block itself, or one
+    // layer earlier by the conv that folds the block's x_conv + FiLM into its epilogue (round 6)
+    std::map<const Layer*, std::pair<Tensor, Tensor>> film_cache;  // block -> (hid, film)
+    auto film_of = [&](const Layer& Lb, int at_lev, Tensor* hid_out, Tensor* film_out) -> int {
+        auto it = film_cache.find(&Lb);
+        if (it != film_cache.end()) {
+            *hid_out = it->second.first;
+            *film_out = it->second.second;
+            return 0;
+        }
+        const std::string ci = Lb.p + ".cond_inj";
+        Tensor hid, film;
+        ConvSpec s;
+        s.pc = PC(ci + ".body.0");
+        if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.body.0 missing", ci.c_str());
+        s.in0 = cenc[at_lev];
+        s.use_bias = false;
+        s.stats = true;
+        s.name = "film.body0";
+        DDIF_TRY(add_conv(pre, s, &hid));
+        ConvSpec s2;
+        s2.pc = PC(ci + ".body.3");
+        if (!s2.pc) return fail(DDIF_ERR_MISSING, "%s.body.3 missing", ci.c_str());
+        s2.in0 = hid;
+        s2.pro = PRO_GN_SILU;
+        s2.gamma = V(ci + ".body.1.weight");
+        s2.beta = V(ci + ".body.1.bias");
+        s2.name = "film.body3";
+        DDIF_TRY(add_conv(pre, s2, &film));
+        film_cache[&Lb] = std::make_pair(hid, film);
+        *hid_out = hid;
+        *film_out = film;
+        return 0;
+    };
+    // the fold request a producer conv at index li (stem / Downsample / the last conv of a block) hands to add_conv: the NEXT layer must be an encoder block
+    XfReq xf_req;           // of the layer being built (add_conv fills out / done)
+    bool xf_have = false;   // the previous layer's producer has already written this block's y = FiLM(x_conv(.))
+    Tensor xf_y;
+    auto xf_prepare = [&](size_t li, int next_lev) -> int {
+        xf_req = XfReq();
+        if (train_mode || li + 1 >= net->downs.size()) return 0;
+        const Layer& Ln = net->downs[li + 1];
+        if (Ln.kind == L_STEM || Ln.kind == L_DOWN) return 0;
+        const std::string ci = Ln.p + ".cond_inj";
+        const PackedConv* px = PC(ci + ".x_conv");
+        const float* wxf = V(ci + ".x_conv.xf");
+        if (!px || !wxf) return 0;
+        Tensor hid, film;
+        DDIF_TRY(film_of(Ln, next_lev, &hid, &film));
+        xf_req.pc = px;
+        xf_req.w = wxf;
+        xf_req.film = film.p;
+        return 0;
+    };
+    for (size_t li = 0; li < net->downs.size(); ++li) {
+        auto& L = net->downs[li];
         if (L.kind == L_STEM) {
             const PackedConv* pc = PC(L.p);
             if (!pc) return fail(DDIF_ERR_MISSING, "%s missing", L.p.c_str());
@@ -877,7 +968,11 @@ int Plan::build_impl() {
             }
             s.stats = true;
             s.name = "stem";
+            DDIF_TRY(xf_prepare(li, lev));
+            s.xf = &xf_req;
             DDIF_TRY(add_conv(step, s, &cur));
+            xf_have = xf_req.done;
+            xf_y = xf_req.out;
             if (train_mode) {
                 TrainMod m;
                 m.kind = TrainMod::STEM;
@@ -894,7 +989,11 @@ int Plan::build_impl() {
             s.stats = true;
             s.name = "down";
             const Tensor din = cur;
+            DDIF_TRY(xf_prepare(li, lev + 1));
+            s.xf = &xf_req;
             DDIF_TRY(add_conv(step, s, &cur));
+            xf_have = xf_req.done;
+            xf_y = xf_req.out;
             ++lev;
             if (train_mode) {
                 TrainMod m;
@@ -908,26 +1007,10 @@ int Plan::build_impl() {
             const std::string ci = L.p + ".cond_inj";
             // cond-only: body(cond) -> FiLM scale|shift   (sr3_dwt.py:379-391)
             Tensor hid, film;
-            {
-                ConvSpec s;
-                s.pc = PC(ci + ".body.0");
-                if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.body.0 missing", ci.c_str());
-                s.in0 = cenc[lev];
-                s.use_bias = false;
-                s.stats = true;
-                s.name = "film.body0";
-                DDIF_TRY(add_conv(pre, s, &hid));
-                ConvSpec s2;
-                s2.pc = PC(ci + ".body.3");
-                if (!s2.pc) return fail(DDIF_ERR_MISSING, "%s.body.3 missing", ci.c_str());
-                s2.in0 = hid;
-                s2.pro = PRO_GN_SILU;
-                s2.gamma = V(ci + ".body.1.weight");
-                s2.beta = V(ci + ".body.1.bias");
-                s2.name = "film.body3";
-                DDIF_TRY(add_conv(pre, s2, &film));
-            }
+            DDIF_TRY(film_of(L, lev, &hid, &film));
             Tensor y;
+            const bool y_folded = xf_have;  // the producer one layer up wrote y already (EPI_XF)
+            xf_have = false;
             ConvSpec s;
             s.pc = PC(ci + ".x_conv");
             if (!s.pc) return fail(DDIF_ERR_MISSING, "%s.x_conv missing", ci.c_str());
@@ -969,13 +1052,20 @@ int Plan::build_impl() {
                 m.t[4] = cenc_pad[lev];
                 m.lev = lev;
                 tmods.push_back(m);
+            } else if (y_folded) {
+                y = xf_y;
             } else {
             s.film = film.p;
             s.stats = true;
             s.name = "film.x_conv";
             DDIF_TRY(add_conv(step, s, &y));
             }
-            DDIF_TRY(resblock(L.p + ".res_block", y, &cur));
+            // the block's last conv folds the NEXT block's x_conv + FiLM when nothing (attention) sits between them
+            xf_req = XfReq();
+            if (!L.attn) DDIF_TRY(xf_prepare(li, lev));
+            DDIF_TRY(resblock(L.p + ".res_block", y, &cur, (!train_mode && !L.attn) ? &xf_req : nullptr));
+            xf_have = xf_req.done;
+            xf_y = xf_req.out;
             if (L.attn) {
                 Tensor t2;
                 DDIF_TRY(attention(L.p + ".attn", cur, &t2));

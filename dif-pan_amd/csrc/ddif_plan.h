@@ -57,6 +57,7 @@ struct ConvVariant {
 enum { MATH_BF16X3 = 0, MATH_F16X2 = 1, MATH_BF16X1 = 2 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, int math = MATH_BF16X3);
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3);  // ddif_lr.cpp
+ConvVariant get_xf_variant(int stride, int pro, int cfg, int vec, int epi, int nbx);      // EPI_XF instantiations (f16x2 3x3 convs with 32 couts; ddif_xf.cpp)
 // ddif_set_math_mode (include/ddif.h): 0 = fp32-class split products (default), 1 = the bf16 throughput variant, for plans built afterwards
 extern int g_math_mode;
 // ddif_set_f16_raw (include/ddif.h): 1 (default) = convs without a GroupNorm prologue may run f16x2 on their raw input, watched by the plan's range flag;
@@ -109,6 +110,15 @@ struct AttnBlockArgs;
 int attn_block_prepare();                                                        // ddif_lr.cpp (kernels_attn.h)
 void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s);
 
+// round 6: ask add_conv() to fold the NEXT block's CondInjection (x_conv + FiLM) into this conv's epilogue (kernels_conv.h EPI_XF); `done` and `out` come back
+struct XfReq {
+    const PackedConv* pc = nullptr;  // the x_conv (bias, shapes)
+    const float* w = nullptr;        // its register-GEMM pack (Net::vec "<block>.cond_inj.x_conv.xf")
+    const float* film = nullptr;     // scale | shift of that block, [B, H, W, 2 cout]
+    Tensor out;                      // y, with statistics partials
+    bool done = false;
+};
+
 struct ConvSpec {
     const PackedConv* pc = nullptr;
     Tensor in0, in1;           // in1.p == nullptr: single source
@@ -132,6 +142,7 @@ struct ConvSpec {
     bool stats = false;
     bool exact = false;                 // force the exact-fp32 MFMA instantiation of kernels_conv.h (gradient convs; pc->w only)
     bool samp = false;                  // the network's final conv: also look up the sampler-epilogue variant (EPI_SAMP)
+    XfReq* xf = nullptr;                // fold request (honoured only where an EPI_XF instantiation of the chosen tiling exists)
     const char* name = "conv";
 };
 

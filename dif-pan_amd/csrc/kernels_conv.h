@@ -85,6 +85,15 @@ struct ConvArgs {
     // bf16x3 (full fp32 range).  Null: not checked.  (A plain store of 1 by any number of threads: no atomics needed.)
     int* range_flag;
     int xcd;                 // wg_work_range: XCD-contiguous work partition (ddif_dev.h)
+    // EPI_XF (round 6): the NEXT block's CondInjection (x_conv 1x1 + FiLM, models/sr3_dwt.py:376-396) in this conv's epilogue -- a second output
+    //   y = (W_x out + b_x) * (1 + scale) + shift      with its own GroupNorm partials,
+    // computed from the accumulator registers (see the epilogue); `out` itself (the skip feature) is still written.
+    const float* xf_w;       // x_conv weights in per-lane A-operand order of the register GEMM: [32-cout block][lane][16] (ddif_net.cpp pack_xf)
+    const float* xf_b;       // x_conv bias [xf_cout]
+    const float* xf_film;    // [B, Hout, Wout, 2 * xf_cout]: scale | shift of the next block
+    float* xf_out;           // [B, Hout, Wout, xf_cout]
+    double* xf_st;           // partials of xf_out, [B][tiles_x * tiles_y][2]
+    int xf_cout;             // 32 * NBX
 };
 
 template <int F>
@@ -102,7 +111,11 @@ struct StageKind {
 // 16 = per-SAMPLE time-bias rows (tbias_stride != 0: forward() / p_losses with one t per sample; in the samplers every
 // sample shares the step's row and bias + time bias sit in LDS for the whole launch).
 // 64 = sampler update in the epilogue (ConvArgs::s_*; diffusion_ddpm_pan.py:418-442 p_sample / :594-621 ddim_sample on the final conv's output).
-enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_COLST = 32, EPI_SAMP = 64 };
+// 128 / 256 = EPI_XF1 / EPI_XF2 (round 6): the next block's x_conv (32 -> 32 / 64 channels) + FiLM as a second output of this conv.  Needs the whole cout range of a
+// pixel in ONE wave (NB = WN = 1, Cout = 32).  The accumulator layout of D^T = W^T X^T -- lane (j, h) holds couts 8g + 4h + i of pixel j -- IS a B operand of
+// v_mfma_f32_32x32x2_f32 for a contraction over those couts when step s = 4g + i contracts cout 8g + 4h + i (k = h): the K order of a GEMM is free, the x_conv
+// weights are packed in that order, and the 32 x 32 product costs 16 exact-fp32 MFMAs per 32 pixels with no data movement at all.
+enum { EPI_FILM = 1, EPI_SOUT = 2, EPI_RES = 4, EPI_SILU = 8, EPI_TBS = 16, EPI_COLST = 32, EPI_SAMP = 64, EPI_XF1 = 128, EPI_XF2 = 256 };
 // VEC (input staging): 0 = scalar loads, any channel counts;  1 = float4 loads, every CK-channel chunk lies in ONE source
 // (c1 == 0 or c0 % CK == 0): the source base is wave-uniform (SGPR) and a load costs one VALU add;  2 = float4 loads with
 // a per-thread source select (the stem's cat[x, x] with 8 + 8 channels).
@@ -163,7 +176,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     constexpr bool GNP = (PRO == PRO_GN || PRO == PRO_GN_SILU || PRO == PRO_GN_DW);
     constexpr bool FILM = (EPI & EPI_FILM) != 0, SOUT = (EPI & EPI_SOUT) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0, TBS = (EPI & EPI_TBS) != 0;
     constexpr bool SAMP = (EPI & EPI_SAMP) != 0;
+    constexpr int NBX = (EPI & EPI_XF1) ? 1 : ((EPI & EPI_XF2) ? 2 : 0);  // 32-cout blocks of the folded x_conv
+    constexpr bool XF = NBX > 0;
     static_assert(!SAMP || (!SOUT && !RES && !FILM), "sampler epilogue: the plain vector epilogue of the final conv");
+    static_assert(!XF || (MB == 1 && NB == 1 && WN == 1 && !SOUT && !SAMP && !FILM && !SILU && PRO != PRO_GN_DW), "x_conv + FiLM fold: one wave holds all 32 couts of its pixels");
     static_assert(!DWM || (KS == 1 && STRIDE == 1 && !UPS && VEC == 1), "depthwise staging is for plain 1x1 convs");
     static_assert(PRO != PRO_COLSM || VEC == 1, "column-softmax prologue needs uniform-source float4 staging");
     constexpr int LPAD = DWM ? 1 : PAD;
@@ -195,8 +211,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     double* red = reinterpret_cast<double*>(smem + (size_t)(2 * ABUF + NWB * WBUF) * sizeof(float));  // [2][2 * NW]
     float* Hs = reinterpret_cast<float*>(smem + (size_t)(2 * ABUF + NWB * WBUF) * sizeof(float) + 4 * NW * sizeof(double));  // [HBUF]
     float* DWs = Hs + HBUF;                       // [9][Ctot]
-    float* GBs = DWs + DWMAX;                     // GroupNorm gamma | beta, [2][n_chunks * CK] (host adds the bytes)
+    [[maybe_unused]] double* redx = reinterpret_cast<double*>(DWs + DWMAX);  // XF: [2][2 * NW] partials of the second output
+    float* GBs = DWs + DWMAX + (XF ? 8 * NW : 0); // GroupNorm gamma | beta, [2][n_chunks * CK] (host adds the bytes)
     float* BTs = GBs + (GNP ? 2 * a.n_chunks * CK : 0);  // bias (+ the step's time-bias row) of all n_ct * NT couts
+    [[maybe_unused]] float* BXs = BTs + a.n_ct * (32 * NB * WN);  // XF: x_conv bias [32 * NBX]
 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef DDIF_EMU
@@ -240,6 +258,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 
     int abase[MB], e_my[MB], e_mx[MB];
     unsigned e_off[MB], e_foff[MB];  // byte offset of this lane's pixel (+ 4h couts) from the tile's first output / FiLM element
+    [[maybe_unused]] unsigned e_xoff[MB], e_xfoff[MB];  // XF: the same for the second output / its scale | shift tensor
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = (wm * MB + mb) * 32 + j;
@@ -248,6 +267,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         e_mx[mb] = m % TW;
         e_off[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * a.Cout + 4 * h) * 4);
         e_foff[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * 2 * a.Cout + 4 * h) * 4);
+        if constexpr (XF) {
+            e_xoff[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * (32 * NBX) + 4 * h) * 4);
+            e_xfoff[mb] = (unsigned)(((e_my[mb] * a.Wout + e_mx[mb]) * 2 * (32 * NBX) + 4 * h) * 4);
+        }
+    }
+    // XF: this lane's A fragments of the register GEMM, resident for the whole launch: step s = 4g + i contracts cout 8g + 4h + i (k = h); lane (j, h) supplies W_x[32 nx + j][that cout]
+    [[maybe_unused]] float xw[XF ? NBX : 1][16];
+    if constexpr (XF) {
+#pragma unroll
+        for (int nx = 0; nx < NBX; ++nx)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(a.xf_w + ((size_t)(nx * 64 + lane) * 16 + 4 * q));
+                xw[nx][4 * q + 0] = t.x;
+                xw[nx][4 * q + 1] = t.y;
+                xw[nx][4 * q + 2] = t.z;
+                xw[nx][4 * q + 3] = t.w;
+            }
     }
 
     // ---- per-thread staging geometry: constant for the whole kernel (no divisions inside the stage loop) ----
@@ -580,6 +617,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             }
             a.st_out[pi + 0] = t0;
             a.st_out[pi + 1] = t1;
+            if constexpr (XF) {  // the second output's partial of the same item (n_ct = 1)
+                const double* rx = redx + pend_par * 2 * NW;
+                double u0 = (rx[0] + rx[2]) + (rx[4] + rx[6]), u1 = (rx[1] + rx[3]) + (rx[5] + rx[7]);
+                if (NW == 8) {
+                    u0 += (rx[8] + rx[10]) + (rx[12] + rx[14]);
+                    u1 += (rx[9] + rx[11]) + (rx[13] + rx[15]);
+                }
+                a.xf_st[pi + 0] = u0;
+                a.xf_st[pi + 1] = u1;
+            }
         }
         pend = false;
     };
@@ -612,6 +659,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         float4 e_res[(LAST && RES) ? MB : 1][(LAST && RES) ? NB : 1][4];
         float4 e_fs[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4], e_fh[(LAST && FILM) ? MB : 1][(LAST && FILM) ? NB : 1][4];
         [[maybe_unused]] float4 e_xi[(LAST && SAMP) ? MB : 1][(LAST && SAMP) ? NB : 1][4], e_xl[(LAST && SAMP) ? MB : 1][(LAST && SAMP) ? NB : 1][4];  // x_t, lms
+        [[maybe_unused]] float4 e_xs[(LAST && XF) ? NBX : 1][4], e_xh[(LAST && XF) ? NBX : 1][4];  // XF: scale / shift of the second output (MB = 1)
+        [[maybe_unused]] unsigned e_pxo = 0;  // XF: this item's byte offset of the lane's pixel in the second output
         bool full = true;
         unsigned e_po[MB], e_pf[MB];  // this item's byte offsets (clamped to the tile origin for pixels outside the image)
         bool e_pok[MB];
@@ -654,6 +703,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                             }
                         }
                     }
+                if constexpr (XF) {
+                    const char* xfb = reinterpret_cast<const char*>(a.xf_film + tile_pix * 2 * (32 * NBX));
+                    const unsigned pf = e_pok[0] ? e_xfoff[0] : (unsigned)(16 * h);
+                    e_pxo = e_pok[0] ? e_xoff[0] : (unsigned)(16 * h);
+#pragma unroll
+                    for (int nx = 0; nx < NBX; ++nx)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            e_xs[nx][g] = *reinterpret_cast<const float4*>(xfb + (pf + (unsigned)((nx * 32 + 8 * g) * 4)));
+                            e_xh[nx][g] = *reinterpret_cast<const float4*>(xfb + (size_t)(32 * NBX) * 4 + (pf + (unsigned)((nx * 32 + 8 * g) * 4)));
+                        }
+                }
             }
         }
         // (2) prefetch stage +2
@@ -778,10 +839,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             // (4) epilogue of work item Cp: lane (j, h) owns pixel j of each 32-pixel block and, per accumulator quad g,
             //     the 4 consecutive couts 8g + 4h .. +3 of each 32-cout block
             float s1 = 0.f, s2 = 0.f;
+            [[maybe_unused]] float sx1 = 0.f, sx2 = 0.f;  // XF: statistics of the second output
             if constexpr (!SOUT) {
                 char* obase = reinterpret_cast<char*>(a.out + tile_el);
                 auto epi = [&](auto guard) {
                     constexpr bool GUARD = decltype(guard)::LAST;  // StageKind<1> = bounds-checked stores
+                    [[maybe_unused]] float vx[16];  // XF: the 16 output values of this lane = the B operand of the register GEMM
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -799,6 +862,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                                     if constexpr (SILU) x = dd_silu(x);
                                     if constexpr (RES) x += (&e_res[mb][nb][g].x)[i];
                                     v[i] = x;
+                                    if constexpr (XF) vx[4 * g + i] = x;
                                 }
                                 if constexpr (SAMP) {
                                     if (e_pok[mb] && co < a.Cout) {
@@ -837,6 +901,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                                     s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                                 }
                             }
+                    if constexpr (XF) {
+                        // y = (W_x out + b_x) * (1 + scale) + shift on the values just stored (pixels outside the image carry finite garbage in their own column only)
+                        char* xobase = reinterpret_cast<char*>(a.xf_out + (size_t)((Cp.b * a.Hout + Cp.oy0) * a.Wout + Cp.ox0) * (32 * NBX));
+#pragma unroll
+                        for (int nx = 0; nx < NBX; ++nx) {
+                            f32x16 c2;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) c2[r] = 0.f;
+#pragma unroll
+                            for (int sx = 0; sx < 16; ++sx) c2 = DDIF_MFMA_32x32x2(xw[nx][sx], vx[sx], c2);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const float4 bx = *reinterpret_cast<const float4*>(&BXs[nx * 32 + 8 * g + 4 * h]);
+                                float y[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) y[i] = (c2[4 * g + i] + (&bx.x)[i]) * (1.f + (&e_xs[nx][g].x)[i]) + (&e_xh[nx][g].x)[i];
+                                if (!GUARD || e_pok[0]) {
+                                    *reinterpret_cast<float4*>(xobase + (e_pxo + (unsigned)((nx * 32 + 8 * g) * 4))) = make_float4(y[0], y[1], y[2], y[3]);
+                                    sx1 += (y[0] + y[1]) + (y[2] + y[3]);
+                                    sx2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+                                }
+                            }
+                        }
+                    }
                 };
                 if (full && (nbg0 + NB) * 32 <= a.Cout) epi(StageKind<0>{});
                 else epi(StageKind<1>{});
@@ -869,6 +957,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                 if (lane == 63) {
                     red[pend_par * 2 * NW + wave * 2 + 0] = d1;
                     red[pend_par * 2 * NW + wave * 2 + 1] = d2;
+                }
+                if constexpr (XF) {
+                    const double x1 = (double)wave_sum_fast(sx1), x2 = (double)wave_sum_fast(sx2);
+                    if (lane == 63) {
+                        redx[pend_par * 2 * NW + wave * 2 + 0] = x1;
+                        redx[pend_par * 2 * NW + wave * 2 + 1] = x2;
+                    }
                 }
                 pend = true;
                 pend_pos = Cp;
@@ -993,6 +1088,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             const int c = i < a.Cout ? i : a.Cout - 1;
             BTs[i] = a.bias[c] + (TBS ? 0.f : tbrow[c]);
         }
+        if constexpr (XF) {
+            if (tid < 32 * NBX) BXs[tid] = a.xf_b[tid];
+        }
     }
     __syncthreads();
     stamp();
@@ -1031,8 +1129,10 @@ constexpr size_t conv_smem_bytes() {  // NBT = n-blocks (of 32 couts) per workgr
     return (size_t)(2 * IH * (IW * lda + rp) + ((MATH == 2 || MATH == 5) ? 1 : 2) * NBT * wchunk + dw) * sizeof(float) + 4 * NW * sizeof(double);
 }
 // GroupNorm prologues keep gamma | beta of all input channels in LDS; every kernel keeps bias (+ time bias) of all couts
-inline size_t conv_smem_extra(int pro, int n_chunks, int ck, int cout_pad) {
-    return ((pro == PRO_GN || pro == PRO_GN_SILU || pro == PRO_GN_DW) ? (size_t)2 * n_chunks * ck : 0) * sizeof(float) + (size_t)cout_pad * sizeof(float);
+inline size_t conv_smem_extra(int pro, int n_chunks, int ck, int cout_pad, int xf_cout = 0) {
+    // (xf_cout: the folded x_conv's bias + the second output's statistics partials, [2][2 * 8 waves] doubles)
+    return ((pro == PRO_GN || pro == PRO_GN_SILU || pro == PRO_GN_DW) ? (size_t)2 * n_chunks * ck : 0) * sizeof(float) + (size_t)cout_pad * sizeof(float) +
+           (xf_cout ? (size_t)xf_cout * sizeof(float) + 32 * sizeof(double) : 0);
 }
 
 }  // namespace ddif
