@@ -2,6 +2,7 @@
 // builds in parallel with the conv kernel families.
 #include "ddif_plan.h"
 #include "kernels_lafuse.h"
+#include "kernels_lafuse8.h"
 
 namespace ddif {
 
@@ -42,6 +43,33 @@ int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_onl
     if (a.H == 32) return la_launch_t<32, 8>(a, nbq, nba, grid, s, prepare_only);
     if (a.H == 16) return la_launch_t<16, 16>(a, nbq, nba, grid, s, prepare_only);  // a 16 x 16 sample = one workgroup
     return fail(DDIF_ERR_INVALID, "linattn_fused: H = %d", a.H);
+}
+
+// the 8 x 8 level (kernels_lafuse8.h): half a sample per workgroup, 256 (128 + 128) or 192 (128 + 64) feature channels, 128 output channels
+bool lafuse8_supported(int H, int W, int c0, int c1, int dout) {
+    return H == 8 && W == 8 && c0 % 64 == 0 && c1 % 64 == 0 && (c0 + c1 == 256 || c0 + c1 == 192) && dout == 128;
+}
+int lafuse8_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only) {
+    const int nbq = (a.c0 + a.c1) / 32;
+    if (nbq == 8) {
+        auto fn = linattn8_fused_kernel<8>;
+        if (prepare_only) {
+            DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaFuse8Geom<8>::smem));
+            return 0;
+        }
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(512), LaFuse8Geom<8>::smem, s, a);
+        return 0;
+    }
+    if (nbq == 6) {
+        auto fn = linattn8_fused_kernel<6>;
+        if (prepare_only) {
+            DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaFuse8Geom<6>::smem));
+            return 0;
+        }
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(512), LaFuse8Geom<6>::smem, s, a);
+        return 0;
+    }
+    return fail(DDIF_ERR_INVALID, "linattn8_fused: %d feature channels", a.c0 + a.c1);
 }
 
 }  // namespace ddif

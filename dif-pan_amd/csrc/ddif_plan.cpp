@@ -11,155 +11,20 @@
 namespace ddif {
 
 // ------------------------------------------------------------------------------------------------ conv variants
-namespace {
-// cfg: 0 = 8x16 pixels x 32 couts, 1 = 8x16 x 64, 3 = 8x16 x 128 (1x1 convs only: a wide cout tile stages -- and for
-// PRO_GN_DW recomputes -- the input once instead of once per 32 couts), 2 = 8x8 x 64, 4 = 8x8 x 128 (1x1 only);
-// 5 = 16x16 x 32 and 6 = 16x16 x 64 with EIGHT wavefronts (plain 3x3 convs at the high-resolution levels: twice the
-// MFMAs per staged input / weight element, see kernels_conv.h)
-template <int KS, int S, int U, int CK, int PRO, int VEC, int EPI = 0>
-ConvVariant variant_for_cfg(int cfg) {
-    ConvVariant v;
-    switch (cfg) {
-        case 0: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO>(); v.th = 8; v.tw = 16; v.nt = 32; break;
-        case 2: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO>(); v.th = 8; v.tw = 8; v.nt = 64; break;
-        default: break;
-    }
-    if constexpr (KS == 1 && VEC == 1) {
-        switch (cfg) {
-            case 1: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, PRO>(); v.th = 8; v.tw = 16; v.nt = 64; break;
-            case 3: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 4, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 4, PRO>(); v.th = 8; v.tw = 16; v.nt = 128; break;
-            case 4: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO>(); v.th = 8; v.tw = 8; v.nt = 128; break;
-            default: break;
-        }
-        if constexpr (CK == 32) {  // bf16x3 instantiations of the same five tilings (cfg + 12)
-            switch (cfg) {
-                case 12: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
-                case 13: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 64; v.x3 = true; break;
-                case 15: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 4, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 4, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 128; v.x3 = true; break;
-                case 14: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = true; break;
-                case 16: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 128; v.x3 = true; break;
-                // bf16x1 (MATH = 4, the throughput variant): the same five tilings (cfg + 52); the 32-cout tile too (no split to pay for)
-                case 52: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.b1 = true; break;
-                case 53: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 2, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 2, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 64; v.x3 = v.b1 = true; break;
-                case 55: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 4, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 4, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 128; v.x3 = v.b1 = true; break;
-                case 54: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 4>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.b1 = true; break;
-                case 56: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 2, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 4, PRO, 4, 4>(); v.th = 8; v.tw = 8; v.nt = 128; v.x3 = v.b1 = true; break;
-                default: break;
-            }
-        }
-    }
-    if constexpr (KS == 3 && S == 1 && VEC == 1) {
-        switch (cfg) {
-            // bf16x3 (MATH = 1): 7 = 16x16 x 32 on eight waves, 8 = 8x16 x 32 on four, 9 = 8x8 x 64 on four
-            case 7: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 1>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = true; break;
-            case 8: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 1>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = true; break;
-            case 9: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 1>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 1>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = true; break;
-            // bf16x1 (MATH = 4, the throughput variant): the same three tilings (+ 40)
-            case 47: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 4>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.b1 = true; break;
-            case 48: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 4>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.b1 = true; break;
-            case 49: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 4>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 4>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.b1 = true; break;
-            default: break;
-        }
-    }
-    if constexpr (KS == 3 && S == 1 && VEC == 1 && (PRO == PRO_NONE || PRO == PRO_GN_SILU)) {
-        switch (cfg) {
-            // f16x2 (MATH = 3): the bf16x3 tilings 7 / 8 / 9 (+ 20).  (A 16x16 x 64-cout tiling on eight waves measured 0.5 % faster on the
-            // step at B = 64 -- 4.75 vs 4.775 ms -- but a cout tile that depends on the item count regroups the GroupNorm partials, and
-            // tiles of a batch are then no longer bit-equal to single-tile runs: not kept.)
-            case 27: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 3>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = true; break;
-            case 28: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 3>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.f16 = true; break;
-            case 29: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 3>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.f16 = true; break;
-            default: break;
-        }
-        if constexpr (U == 0) {
-            // 37 = tiling 27 with RESIDENT weights (MATH = 5, round 5): 32 input channels as ONE stage per work item, the cout tile's weights copied into
-            // LDS once per workgroup.  Same pack, same accumulation order, same partials as 27 -- bit-identical results, 3-6 % faster in isolation
-            // (profiles/r05_a_mbench_resident.txt).  Chosen by add_conv for 32 -> <= 32 channel convs.
-            if (cfg == 37) { v.fn = conv_mfma_kernel<KS, S, U, 16, 16, 32, 8, 1, 1, 1, PRO, VEC, EPI, 0, 5>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, 32, 1, PRO, 8, 5>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = v.wr = true; }
-        }
-    }
-    if constexpr (KS == 3 && S == 1 && U == 0 && VEC == 2 && PRO == PRO_NONE && EPI == 0) {
-        // the stem (cat[self_cond, x] inside ONE 16-channel chunk: float4 staging with a per-thread source select) on the f16x2 tilings 27 / 28 (round 5; until then the
-        // exact-fp32 tilings: 38.8 us per launch at B = 64 for 2.4 GFLOP)
-        switch (cfg) {
-            case 27: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8, 3>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = true; break;
-            case 28: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 3>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.f16 = true; break;
-            default: break;
-        }
-    }
-    if constexpr (KS == 3 && S == 2 && U == 0 && VEC == 1 && PRO == PRO_NONE && EPI == 0) {
-        // the Downsample convs on the f16x2 path (round 5; until then the exact-fp32 8 x 8 tiling 2: 43.6 / 26.5 us per launch at the 32 x 32 / 16 x 16 outputs for
-        // 1.2 GFLOP each): the 8 x 16 x 32 and 8 x 8 x 64 tilings 28 / 29 with a stride-2 halo tile (17 x 33 / 17 x 17 staged pixels)
-        switch (cfg) {
-            case 28: v.fn = conv_mfma_kernel<KS, S, U, 8, 16, CK, 4, 1, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 16, CK, 1, PRO, 4, 3>(); v.th = 8; v.tw = 16; v.nt = 32; v.x3 = v.f16 = true; break;
-            case 29: v.fn = conv_mfma_kernel<KS, S, U, 8, 8, CK, 2, 2, 1, 1, PRO, VEC, EPI, 0, 3>; v.smem = conv_smem_bytes<KS, S, U, 8, 8, CK, 2, PRO, 4, 3>(); v.th = 8; v.tw = 8; v.nt = 64; v.x3 = v.f16 = true; break;
-            default: break;
-        }
-    }
-    if constexpr (KS == 3 && S == 1 && U == 0 && VEC == 1) {
-        switch (cfg) {
-            case 5: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 1, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 1, PRO, 8>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; break;
-            case 6: v.fn = conv_mfma_kernel<KS, S, U, 16, 16, CK, 8, 1, 1, 2, PRO, VEC, EPI>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, CK, 2, PRO, 8>(); v.th = 16; v.tw = 16; v.nt = 64; v.nthr = 512; break;
-            default: break;
-        }
-    }
-    return v;
-}
-template <int KS, int S, int U, int CK, int PRO, int VEC>
-ConvVariant variant_small_tiles(int cfg) {  // stride-2: the 8x16 halo would not fit comfortably in LDS
-    return (cfg >= 2) ? variant_for_cfg<KS, S, U, CK, PRO, VEC>(cfg) : ConvVariant();
-}
-}  // namespace
-
+// The instantiations live in three translation units of their own (conv_variants.h: ddif_conv_k1.cpp = 1x1 convs, ddif_conv_k3.cpp = 3x3 convs with the plain
+// epilogue, ddif_conv_k3e.cpp = 3x3 convs with an epilogue variant; ddif_xf.cpp = EPI_XF; ddif_lr.cpp = the low-resolution kernel): they build in parallel, and
+// the plan builder below no longer recompiles 150 kernels when its logic changes.
 // vec (kernels_conv.h VEC): 0 = scalar staging (stem with C = 31, cond convs with 9 / 11 / 34 / 40 input channels; only the
 // prologue-free 3x3 / 1x1 kernels), 1 = float4 staging with one source per channel chunk, 2 = float4 staging with a
 // per-thread source select (stem: cat[x, x] of 8 + 8 or 4 + 4 channels inside one 16-channel chunk).
 // epi: EPI_* bits (kernels_conv.h) -- FiLM (CondInjection.x_conv), scalar output path (Cout % 4 != 0), residual add.
 // Only the combinations the network uses are instantiated.
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, int math) {
-    ConvVariant v;
     if (cfg == 20 || cfg == 21)
-        return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi, (math == MATH_F16X2 && pro == PRO_COLSM) ? MATH_BF16X3 : math) : v;
-    const bool plain = stride == 1 && !ups;
-    if (epi == EPI_FILM) {
-        if (ks == 1 && ck == 32 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_FILM>(cfg); v.name = "conv1x1_film"; }
-    } else if (epi == EPI_SOUT) {
-        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_SOUT>(cfg); v.name = "conv3x3_gn_silu_sout"; }
-    } else if (epi == EPI_RES) {
-        if (vec != 1 || !plain) return v;
-        if (ks == 3 && ck == 16 && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_RES>(cfg); v.name = "conv3x3_gn_silu_res"; }
-        else if (ks == 3 && ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv3x3_res"; }
-        else if (ks == 1 && ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1, EPI_RES>(cfg); v.name = "conv1x1_res"; }
-        else if (ks == 1 && ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1, EPI_RES>(cfg); v.name = "conv1x1_colsoftmax_res"; }
-    } else if (epi == EPI_TBS) {
-        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_TBS>(cfg); v.name = "conv3x3_gn_silu_tbs"; }
-    } else if (epi == EPI_SAMP) {
-        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_GN_SILU && cfg >= 7 && cfg != 20 && cfg != 21) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1, EPI_SAMP>(cfg); v.name = "conv3x3_gn_silu_sampler"; }
-    } else if (epi == EPI_SILU) {
-        if (ks == 3 && ck == 16 && vec == 1 && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1, EPI_SILU>(cfg); v.name = "conv3x3_silu"; }
-    } else if (epi != 0) {
-        return v;
-    } else if (vec == 2) {
-        if (ks == 3 && ck == 16 && plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 2>(cfg); v.name = "conv3x3_cat"; }
-    } else if (ks == 3 && ck == 16) {  // 3x3 convs always use 16-channel chunks
-        if (!vec) {
-            if (plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv3x3_scalar"; }
-        } else if (plain && pro == PRO_GN_SILU) { v = variant_for_cfg<3, 1, 0, 16, PRO_GN_SILU, 1>(cfg); v.name = "conv3x3_gn_silu"; }
-        else if (plain && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3"; }
-        else if (stride == 2 && !ups && pro == PRO_NONE) { v = variant_small_tiles<3, 2, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3_s2"; }
-        else if (stride == 1 && ups && pro == PRO_NONE) { v = variant_for_cfg<3, 1, 1, 16, PRO_NONE, 1>(cfg); v.name = "conv3x3_up2"; }
-    } else if (ks == 1 && plain) {
-        if (!vec) {
-            if (ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 0>(cfg); v.name = "conv1x1_scalar"; }
-            else if (ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE, 0>(cfg); v.name = "conv1x1_ck16_scalar"; }
-        } else if (ck == 32 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 32, PRO_NONE, 1>(cfg); v.name = "conv1x1"; }
-        else if (ck == 16 && pro == PRO_NONE) { v = variant_for_cfg<1, 1, 0, 16, PRO_NONE, 1>(cfg); v.name = "conv1x1_ck16"; }
-        else if (ck == 32 && pro == PRO_GN) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN, 1>(cfg); v.name = "conv1x1_gn"; }
-        else if (ck == 32 && pro == PRO_GN_SILU) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_SILU, 1>(cfg); v.name = "conv1x1_gn_silu"; }
-        else if (ck == 32 && pro == PRO_COLSM) { v = variant_for_cfg<1, 1, 0, 32, PRO_COLSM, 1>(cfg); v.name = "conv1x1_colsoftmax"; }
-        else if (ck == 32 && pro == PRO_GN_DW) { v = variant_for_cfg<1, 1, 0, 32, PRO_GN_DW, 1>(cfg); v.name = "conv1x1_gn_dw3x3"; }
-    }
-    return v;
+        return (stride == 1 && !ups && vec == 1) ? get_lr_variant(ks, cfg == 20 ? 2 : 4, pro, epi, (math == MATH_F16X2 && pro == PRO_COLSM) ? MATH_BF16X3 : math) : ConvVariant();
+    if (ks == 1) return get_conv_variant_k1(stride, ups, ck, pro, cfg, vec, epi);
+    if (ks == 3) return epi ? get_conv_variant_k3e(stride, ups, ck, pro, cfg, vec, epi) : get_conv_variant_k3(stride, ups, ck, pro, cfg, vec);
+    return ConvVariant();
 }
 
 static int num_cus();
@@ -184,6 +49,10 @@ static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention 
 // (profiles/r05_k_xcd_ab.txt).  Results do not depend on it -- the partition only decides WHICH workgroup computes an item (tests/test_env_switches.py).
 static int xcd_mask() {
     static const int v = [] { const char* e = getenv("DDIF_XCD"); return e ? atoi(e) : 15; }();
+    return v;
+}
+static int la8_enabled() {  // DDIF_LA8=0: the decoder's linear-attention half at the 8 x 8 level as three launches (rounds 3-5) instead of the fused kernel of round 6 (kernels_lafuse8.h)
+    static const int v = [] { const char* e = getenv("DDIF_LA8"); return e ? atoi(e) : 1; }();
     return v;
 }
 static int xf_enabled() {  // DDIF_XF=0: CondInjection.x_conv + FiLM as a launch of its own everywhere (the form of rounds 1-5); tests/test_env_switches.py
@@ -1382,8 +1251,10 @@ int Plan::build_impl() {
         {
             const PackedConv* pm = PC(ci + ".attn_mix");
             const float* wr = V(ci + ".attn_res.weight");
-            bool ok = lafuse_enabled() && f16_enabled() && x3_enabled() && lr_enabled() && pm && wr && pq1->w_f16 && pq1->bias && pm->bias && Hl * Wl >= 256 &&
-                      pq1->cout == fea && pq1->ck == 32 && pm->ck == 32 && pm->cin == 2 * fea && cur.C % 16 == 0 && skip.C % 16 == 0 && lafuse_supported(Hl, fea, pm->cout);
+            // (round 6) the 8 x 8 level has a kernel of its own: half a sample per workgroup, the waves split the output channels (kernels_lafuse8.h)
+            const bool la8 = la8_enabled() && lafuse8_supported(Hl, Wl, cur.C, skip.C, pm ? pm->cout : 0);
+            bool ok = lafuse_enabled() && f16_enabled() && x3_enabled() && lr_enabled() && pm && wr && pq1->w_f16 && pq1->bias && pm->bias && (Hl * Wl >= 256 || la8) &&
+                      pq1->cout == fea && pq1->ck == 32 && pm->ck == 32 && pm->cin == 2 * fea && cur.C % 16 == 0 && skip.C % 16 == 0 && (la8 || lafuse_supported(Hl, fea, pm->cout));
             if (ok) {  // f16x2 range of depthwise(GroupNorm(.)): (sqrt(N) max|gamma| + max|beta|) * 9 max|w_dw| inside the scaled half range
                 auto ig = net->vec_absmax.find(pn_g), ib = net->vec_absmax.find(pn_b), iw = net->vec_absmax.find(q0w);
                 ok = ig != net->vec_absmax.end() && ib != net->vec_absmax.end() && iw != net->vec_absmax.end() &&
@@ -1435,8 +1306,8 @@ int Plan::build_impl() {
                 a.bias = pm->bias;
                 a.out = amix.p;
                 a.dout = pm->cout;
-                if (!dry) DDIF_TRY(lafuse_launch(a, 1, nullptr, true));
-                const int nstrips = (Wl + lafuse_strip(Hl) - 1) / lafuse_strip(Hl);
+                if (!dry) DDIF_TRY(la8 ? lafuse8_launch(a, 1, nullptr, true) : lafuse_launch(a, 1, nullptr, true));
+                const int nstrips = la8 ? 2 : (Wl + lafuse_strip(Hl) - 1) / lafuse_strip(Hl);
                 long cap = num_cus();
                 if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
                 Op op;
@@ -1451,9 +1322,11 @@ int Plan::build_impl() {
                 op.cls = (Hl * Wl <= 256) ? 2 : 1;
                 // q.1 on f16x2 (x3), attn_out / attn_res on bf16x3 (x6): weight of the sum
                 op.mfma_w = (3.0 * fea * fea + 6.0 * 2.0 * fea * pm->cout) / ((double)fea * fea + 9.0 * fea + 2.0 * fea * pm->cout);
-                op.run = [a, nstrips, cap](hipStream_t st, const StepCtx&) {
+                if (la8) op.name = "linattn8_fused";
+                op.run = [a, nstrips, cap, la8](hipStream_t st, const StepCtx&) {
                     const long nw = (long)a.B * nstrips;
-                    (void)lafuse_launch(a, (int)(nw < cap ? nw : cap), st, false);
+                    if (la8) (void)lafuse8_launch(a, (int)(nw < cap ? nw : cap), st, false);
+                    else (void)lafuse_launch(a, (int)(nw < cap ? nw : cap), st, false);
                 };
                 step.push_back(std::move(op));
                 fused_attn = true;

@@ -57,6 +57,9 @@ struct ConvVariant {
 enum { MATH_BF16X3 = 0, MATH_F16X2 = 1, MATH_BF16X1 = 2 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, int math = MATH_BF16X3);
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3);  // ddif_lr.cpp
+ConvVariant get_conv_variant_k1(int stride, int ups, int ck, int pro, int cfg, int vec, int epi);   // ddif_conv_k1.cpp
+ConvVariant get_conv_variant_k3(int stride, int ups, int ck, int pro, int cfg, int vec);            // ddif_conv_k3.cpp
+ConvVariant get_conv_variant_k3e(int stride, int ups, int ck, int pro, int cfg, int vec, int epi);  // ddif_conv_k3e.cpp
 ConvVariant get_xf_variant(int stride, int pro, int cfg, int vec, int epi, int nbx);      // EPI_XF instantiations (f16x2 3x3 convs with 32 couts; ddif_xf.cpp)
 // ddif_set_math_mode (include/ddif.h): 0 = fp32-class split products (default), 1 = the bf16 throughput variant, for plans built afterwards
 extern int g_math_mode;
@@ -68,6 +71,8 @@ struct LaFuseArgs;
 bool lafuse_supported(int H, int fea, int dout);
 int lafuse_strip(int H);
 int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only);
+bool lafuse8_supported(int H, int W, int c0, int c1, int dout);  // the 8 x 8 level (kernels_lafuse8.h)
+int lafuse8_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only);
 // launchers of kernels that live in other translation units (every non-template kernel header is compiled into exactly one object)
 namespace tk {
 // kernels_train.h  (ddif_train.cpp)

@@ -18,6 +18,8 @@
 
   DDIF_XF=0     CondInjection.x_conv + FiLM as a 1x1 launch of its own everywhere instead of riding in the producer conv's epilogue (round 6, EPI_XF).
 
+  DDIF_LA8=0    the decoder's linear-attention half at the 8 x 8 level as three launches instead of the fused kernel of round 6 (csrc/kernels_lafuse8.h).
+
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
 kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04_t_*, r03_b_*) were deleted together with
 their code."""
@@ -36,8 +38,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
 
 
 @pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"},
-                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}, {"DDIF_XF": "0"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8", "XF=0"])
+                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}, {"DDIF_XF": "0"}, {"DDIF_LA8": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8", "XF=0", "LA8=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
