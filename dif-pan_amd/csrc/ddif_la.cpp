@@ -27,6 +27,9 @@ int la_launch_t(const LaFuseArgs& a, int nbq, int nba, int grid, hipStream_t s, 
         case 22: return la_launch1<TH, TW, 2, 2>(a, grid, s, prep);
         case 32: return la_launch1<TH, TW, 3, 2>(a, grid, s, prep);
         case 42: return la_launch1<TH, TW, 4, 2>(a, grid, s, prep);
+        case 62:  // 128 + 64 channels -> 64: the first decoder block of the 16 x 16 level (round 6; 42 spilled registers, still one launch instead of three)
+            if constexpr (TH == 16) return la_launch1<TH, TW, 6, 2>(a, grid, s, prep);
+            [[fallthrough]];
         default: return fail(DDIF_ERR_INVALID, "linattn_fused: no instantiation for %d q blocks / %d output blocks", nbq, nba);
     }
 }
@@ -34,6 +37,8 @@ int la_launch_t(const LaFuseArgs& a, int nbq, int nba, int grid, hipStream_t s, 
 
 // shapes the fused kernel carries: whole columns of 64 or 32 rows, 64 / 96 / 128 feature channels, 32 / 64 output channels
 bool lafuse_supported(int H, int fea, int dout) {
+    static const bool la6 = [] { const char* e = getenv("DDIF_LA6"); return !e || atoi(e) != 0; }();  // DDIF_LA6=0: the 192-channel block of the 16 x 16 level as three launches (rounds 4-5)
+    if (H == 16 && fea == 192 && dout == 64 && la6) return true;
     return (H == 64 || H == 32 || H == 16) && fea % 32 == 0 && fea >= 64 && fea <= 128 && dout % 32 == 0 && dout >= 32 && dout <= 64;
 }
 int lafuse_strip(int H) { return 256 / H; }

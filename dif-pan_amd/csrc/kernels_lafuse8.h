@@ -295,6 +295,12 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
         for (int i = 0; i < NR0; ++i)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) wm0[i][pl] = mix_piece(kh * NSH + i, pl);
+        // ... and the second round with it: the per-sample folded weights come from HBM / Infinity Cache at B = 64 (25 MB per launch), requested behind the barrier
+        // below they stood in front of the contraction (9.6 k ticks at B = 64 against 4.8 k at B = 8, tools/mbench_la8.cpp); the chunk loop's fragments are dead here
+#pragma unroll
+        for (int i = 0; i < NR1; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wm1[i][pl] = mix_piece(kh * NSH + NR0 + i, pl);
 
         // ---- q complete: softmax over the 8 rows of every column.  Lane (j, h) of wave w holds channels 32 w + 8 g + 4 h + i of pixel j = 8 xl + y: the lanes
         //      8 xl .. 8 xl + 7 are ONE column
@@ -329,10 +335,6 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
         __syncthreads();  // p complete
         stamp();
         // ---- acc_a += M_b[output block nr][K half kh] p
-#pragma unroll
-        for (int i = 0; i < NR1; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wm1[i][pl] = mix_piece(kh * NSH + NR0 + i, pl);
         auto mix_step = [&](int sl, const float4* f) {
             float4 xp[3];
 #pragma unroll
