@@ -152,7 +152,7 @@ def _dpm_solver(ds, cond, T, corrector=True):
     return DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=corr)
 
 
-@pytest.mark.parametrize("case", gc.DPM_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("case", gc.DPM_CASES + gc.DPM_BIG_CASES, ids=lambda c: c[0])  # (+ round 6: BASELINE configs[2] at its benchmarked 64 x 64 tile size)
 def test_dpm_solver_matches_reference_golden(case):
     cid, ds, H, W, T, steps, order, seed = case
     g = _load(cid)
@@ -220,49 +220,28 @@ def test_ddpm_cave_128_T2000_first_steps_match_oracle():
     assert _maxerr(out, ref) <= 1e-4
 
 
-def test_ddpm_cave_128_T2000_full_chain_sits_on_the_oracle_at_both_ends():
-    """BASELINE configs[3] END TO END at its size: one CAVE 128 x 128 patch through all T = 2000 steps of p_sample_loop (diffusion_ddpm_pan.py:445-507).
-    The CPU oracle cannot walk 2000 steps at this size, so the chain is pinned where it can: (1) its first 20 steps against the oracle from x_T;
-    (2) its last 20 steps against the oracle started from the library's own state after 1980 steps, same noise; (3) the single 2000-step call is
-    bit-equal to the 1980 + 20 composition, finite, and a valid image after the reference's (x + lms).clip(0, 1).  Noise: one explicit tensor for all
-    2000 steps, drawn on the device (4 GB); the oracle gets the 40 slices it needs."""
-    ds, B, H, T, n, seed = "cave", 1, 128, 2000, 20, 43
+@pytest.mark.parametrize("case", gc.DDPM_FULL_CASES, ids=lambda c: c[0])
+def test_ddpm_cave_128_T2000_full_chain_matches_the_reference_golden(case):
+    """BASELINE configs[3] END TO END at its size against the REAL reference (round 6): one CAVE 128 x 128 patch through all T = 2000 steps of
+    p_sample_loop (diffusion_ddpm_pan.py:445-507) with the reference's own noise stream; expected value = the final `out` of the reference's 2000-step chain
+    (tests/golden/ddpm_cave_128_T2000.npz, tools/make_golden.py --only ddpmfull: 19 minutes of CPU in the build container).  Until round 6 this chain was only
+    pinned at its two ends against the oracle."""
+    cid, ds, B, H, W, T, seed = case
+    g = _load(cid)
     C = gc.DATASETS[ds][0]
-    cond = gc.tiles_for(ds, B, H, H, seed=seed)["cond"]
-    gdev = torch.Generator(device=DEV).manual_seed(seed)
-    xT = torch.randn((B, C, H, H), device=DEV, generator=gdev)
-    noise = torch.randn((T, B, C, H, H), device=DEV, generator=gdev)
+    tiles = gc.tiles_for(ds, B, H, W, seed=seed)
+    cond = tiles["cond"]
+    xT, noise = reference_noise_stream(seed, (B, C, H, W), T)  # 4 GB on the host, then on the device
     d = make_diffusion(net_for(ds), C, T, H, DEV)
-    plan = d._plan(cond.to(DEV))
-    c1, c2 = d.posterior_mean_coef1.cpu(), d.posterior_mean_coef2.cpu()
-    cz = (0.5 * d.posterior_log_variance_clipped.cpu()).exp()
-    order = list(reversed(range(T)))
-
-    def run(steps, x0, nz):
-        return plan.sample_ddpm([float(i) for i in steps], [float(c1[i]) for i in steps], [float(c2[i]) for i in steps],
-                                [0.0 if i == 0 else float(cz[i]) for i in steps], x0, nz.contiguous(), 0, 0, (0.0, 1.0), DEV)
-
-    tabs = O.schedule_tables(O.cosine_betas(T))
-    sd, cfg = gc.weights_for(ds), gc.cfg_for(ds)
-    # (1) the first n steps from x_T
-    first = run(order[:n], xT, noise[:n])
-    it = iter([xT.cpu()] + [noise[k].cpu() for k in range(n)])
-    with torch.no_grad():
-        ref = O.ddpm_sample(sd, cfg, cond, tabs, noise_fn=lambda s: next(it), timesteps=order[:n])
-    assert _maxerr(first, ref) <= 1e-4
-    # (2) the last n steps from the library's own state after T - n steps
-    mid = run(order[:T - n], xT, noise[:T - n])
-    assert bool(torch.isfinite(mid).all())
-    last = run(order[T - n:], mid, noise[T - n:])
-    it = iter([mid.cpu()] + [noise[k].cpu() for k in range(T - n, T)])
-    with torch.no_grad():
-        ref = O.ddpm_sample(sd, cfg, cond, tabs, noise_fn=lambda s: next(it), timesteps=order[T - n:])
-    assert _maxerr(last, ref) <= 1e-4
-    # (3) the whole chain in one call
-    full = run(order, xT, noise)
-    assert torch.equal(full, last)
-    sr = (full + cond[:, :C].to(DEV)).clip(0, 1)
-    assert bool(torch.isfinite(full).all()) and float(sr.std()) > 1e-3
+    out = d(cond.to(DEV), mode="ddpm_sample", x_T=xT.to(DEV), noise=noise.to(DEV)).cpu()
+    del noise
+    ref = torch.from_numpy(g["out"])
+    assert bool(torch.isfinite(out).all())
+    assert _maxerr(out, ref) <= 1e-4  # north-star per-pixel atol
+    lms = cond[:, :C]
+    sr_hip, sr_ref = (out + lms).clip(0, 1), (ref + lms).clip(0, 1)  # diffusion_engine.py:446-447
+    assert abs(O.psnr(sr_hip, tiles["gt"]) - O.psnr(sr_ref, tiles["gt"])) <= 1e-3  # north-star PSNR tolerance (dB)
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("case", gc.FORWARD_BIG_CASES, ids=lambda c: c[0])

@@ -110,7 +110,7 @@ def test_ddim_matches_reference(case):
     assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 2e-5
 
 
-@pytest.mark.parametrize("case", gc.DPM_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("case", gc.DPM_CASES + gc.DPM_BIG_CASES, ids=lambda c: c[0])  # (+ round 6: GF2 at the benchmarked 64 x 64 tile size, ~10 s)
 def test_dpm_solver_matches_reference(case):
     cid, ds, H, W, T, steps, order, seed = case
     g = _load(cid)
