@@ -136,7 +136,8 @@ def self_launch(args):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # (WORLD_SIZE alone -- exported by a scheduler, no rendezvous -- is not a launcher: ADVICE r5)
+    if args.gpus > 1 and not under_launcher:
         self_launch(args)
 
     import torch
@@ -149,9 +150,9 @@ def main():
     from ddif.sharding import shard_range, stitch_tiles
     from ddif.synth import synth_state_dict, synth_tiles
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
     if args.gpus != world:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -161,7 +162,7 @@ def main():
     # under a launcher (WORLD_SIZE in the environment) the process group is RCCL even at world size 1, and every collective of the multi-GPU path
     # runs (an all-gather / all-reduce over one rank): `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` is the RCCL smoke of the
     # 1-GPU lease (tests/test_rccl_world1.py).  `python bench.py` (the driver's N = 1 line) has no process group and no collectives.
-    if "WORLD_SIZE" in os.environ:
+    if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -668,7 +669,8 @@ def bench_training(args, cf, rank, world, dev):
                 "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                              "algorithmic_gflop_per_iteration": step_flop / 1e9,
                              "peak_note": "whole training iteration: algorithmic flops (3 x un-hoisted forward + self-conditioning forwards) / wall time vs the dense fp32 "
-                                          "matrix peak; the weight-gradient kernels run the exact fp32 MFMA, forward / dgrad convs the bf16x3 path",
+                                          "matrix peak; forward / dgrad convs and the 3x3 weight gradients (conv3x3_wgrad_x3_kernel, DDIF_WGRAD_X3=1) run bf16x3 split products, "
+                                          "the exact fp32 MFMA weight-gradient kernel remains the fallback for widths that are not a multiple of 8 or exceed 128",
                              "path": "native reverse launch program (csrc/ddif_train.cpp, ddif_plan_train_step): NHWC end to end, device-side weight refresh"},
                 "build_id": build_id()}
         if dist.is_initialized():

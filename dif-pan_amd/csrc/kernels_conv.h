@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     flush_stats();
     stamp();
     if constexpr (RANGE) {
-        if (a.range_flag && !(r_max < 65520.f)) *a.range_flag = 1;  // a scaled half of this launch overflowed (or was NaN): the output is not to be trusted
+        if (a.range_flag && !(r_max < 65520.f)) *a.range_flag = 1;  // a scaled half of this launch overflowed (inf included; a staged NaN does NOT raise it -- fmaxf drops NaN operands -- and propagates to the output as it would in the reference)
     }
 }
 

@@ -123,10 +123,18 @@ class UNetSR3(nn.Module):
         runs on this module."""
         c = self.__dict__.get("_pcache")
         epoch = object() if (_REG_EPOCH is None or not _PARAM_CACHE) else _REG_EPOCH[0]  # (no hooks / DDIF_PARAM_CACHE=0: every call re-walks)
+        if c is not None and c["epoch"] == epoch:
+            # cheap validation on every use (ADVICE r5): writers the hooks do not see -- `net.submodule.to(...)`, direct `_parameters[...]` assignment,
+            # `torch.utils.swap_tensors` -- replace Parameter OBJECTS; the first / last entries of every child module's dict catch a replaced or converted block
+            pl = c["plist"]
+            own = self._parameters
+            if len(own) != c["n_own"] or (pl and (pl[0] is not next(iter(own.values()), pl[0]) or pl[-1].device != c["dev_last"] or pl[0].device != c["dev_first"])):
+                c = None
         if c is None or c["epoch"] != epoch:
             named = [(n, p) for n, p in self.named_parameters()]
             plist = [p for _, p in named]
-            c = self.__dict__["_pcache"] = {"epoch": epoch, "named": named, "plist": plist,
+            c = self.__dict__["_pcache"] = {"epoch": epoch, "named": named, "plist": plist, "n_own": len(self._parameters),
+                                            "dev_first": plist[0].device if plist else None, "dev_last": plist[-1].device if plist else None,
                                             "devices": {p.device for p in plist}}
         return c
 

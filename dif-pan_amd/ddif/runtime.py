@@ -383,7 +383,12 @@ class PlanHandle:
         self.train = train
         self.h = None
         self.f16_raw = get_f16_raw()  # this plan's convs on raw inputs: f16x2 under the range watch, or (after the watch fired once) bf16x3
+        self.math_mode = get_math_mode()  # the conv arithmetic this plan is built -- and keyed in NetHandle.plans -- under; a rebuild (range fallback) restores it
         self.range_fallbacks = 0
+        # the range watch costs ONE stream synchronisation + 4-byte read per inference call (forward / sample_*): DDIF_RANGE_CHECK=0 or plan.range_check = False
+        # turns it off for callers that must not block (their activations are then their own responsibility); it is skipped by itself inside a stream capture
+        self.range_check = os.environ.get("DDIF_RANGE_CHECK", "1") != "0"
+        self._prof_args = None
         self._create()
         self._cond_ref = None
         self._cond_ver = None
@@ -394,12 +399,16 @@ class PlanHandle:
         if self.train:
             self.lib.check(self.lib.dll.ddif_plan_create_train(C.byref(h), self.net.h, self.B, self.H, self.W), "ddif_plan_create_train")
         else:
-            prev = get_f16_raw()
+            prev, prev_mode = get_f16_raw(), get_math_mode()
             try:
                 set_f16_raw(self.f16_raw)
+                if prev_mode != self.math_mode:
+                    set_math_mode(self.math_mode)
                 self.lib.check(self.lib.dll.ddif_plan_create(C.byref(h), self.net.h, self.B, self.H, self.W), "ddif_plan_create")
             finally:
                 set_f16_raw(prev)
+                if prev_mode != self.math_mode:
+                    set_math_mode(prev_mode)
         self.h = h
 
     def _range_overflow(self, device) -> bool:
@@ -414,10 +423,15 @@ class PlanHandle:
         activations beyond 4094 in front of a conv without GroupNorm -- rebuild the plan with those convs on bf16x3 (full fp32 range), restore its
         cond caches and repeat the call: any checkpoint runs (reference utils/misc.py:89-122), never a NaN image."""
         out = enqueue()
-        if self.train or not self._range_overflow(device):
+        if self.train or not self.range_check:
+            return out
+        dev = torch.device(device)
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return out  # a synchronisation would invalidate the caller's capture: the flag stays set (sticky) and the first call outside a capture reads it
+        if not self._range_overflow(device):
             return out
         if not self.f16_raw:
-            raise DdifError("activations outside the fp16 range although this plan keeps raw-input convs on bf16x3 (status -5, DDIF_ERR_RANGE): non-finite input?")
+            raise DdifError("activations outside the fp16 range although this plan keeps raw-input convs on bf16x3 (status -5, DDIF_ERR_RANGE): an infinite input?")
         import warnings
 
         warnings.warn("ddif: an activation in front of a conv without GroupNorm left the f16x2 range (|x| >= 4094); this plan is rebuilt with those "
@@ -432,6 +446,8 @@ class PlanHandle:
         if cond is not None:
             self.lib.check(self.lib.dll.ddif_plan_set_cond(self.h, _ptr(cond), _stream(self.lib, cond.device)), "ddif_plan_set_cond")
             self._cond_ref = None  # (the next set_cond of the caller re-validates its own tensor)
+        if self._prof_args is not None:  # the destroyed plan took its profiling state with it: re-arm (events recorded so far are lost, the caller's collect sees the rest)
+            self.lib.check(self.lib.dll.ddif_prof_begin(self.h, *self._prof_args), "ddif_prof_begin")
         out = enqueue()
         if self._range_overflow(device):
             raise DdifError("activations outside the fp16 range after the bf16x3 fallback (status -5, DDIF_ERR_RANGE)")
@@ -657,6 +673,7 @@ class PlanHandle:
 
     # -- measurement --------------------------------------------------------------------------------------------
     def prof_begin(self, every_n_steps: int, max_events: int):
+        self._prof_args = (int(every_n_steps), int(max_events))
         self.lib.check(self.lib.dll.ddif_prof_begin(self.h, every_n_steps, max_events), "ddif_prof_begin")
 
     def prof_collect(self) -> dict:

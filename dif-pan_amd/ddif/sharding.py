@@ -38,6 +38,16 @@ def stitch_tiles(tiles: torch.Tensor, ny: int, nx: int) -> torch.Tensor:
     return tiles.reshape(ny, nx, C, h, w).permute(2, 0, 3, 1, 4).reshape(C, ny * h, nx * w).contiguous()
 
 
+def _collectives_on(t: torch.Tensor) -> bool:
+    """Run the stitch collective?  Yes with more than one rank; at world size 1 only when the group is RCCL ("nccl") and the tensor lives on a GPU -- a one-rank
+    gloo group (a CPU-side launcher, a unit test) must not be handed CUDA tensors."""
+    if not dist.is_initialized():
+        return False
+    if dist.get_world_size() > 1:
+        return True
+    return dist.get_backend() == "nccl" and t.is_cuda
+
+
 def sample_sharded(diffusion, cond_all: torch.Tensor, mode: str = "ddpm_sample", seed: int = 0, x_T: torch.Tensor = None,
                    tile_base: int = 0, **kw) -> torch.Tensor:
     """Sample every tile of `cond_all` (n_tiles, 2C+4P, h, w; the same tensor on every rank) with the tiles split over
@@ -54,9 +64,9 @@ def sample_sharded(diffusion, cond_all: torch.Tensor, mode: str = "ddpm_sample",
         kw = dict(kw, x_T=x_T[lo:hi].contiguous())
     res = diffusion(cond, mode=mode, seed=seed, tile0=tile_base + lo, device_rng=x_T is None, **kw)
     sr = (res + cond[:, :C]).clip(0, 1)  # diffusion_engine.py:446-447
-    if not dist.is_initialized():
+    if not _collectives_on(sr):
         return sr
-    # (with a process group the collective runs even at world size 1 -- a copy -- so that a 1-GPU run under a launcher exercises RCCL: tests/test_rccl_world1.py)
+    # (with an RCCL process group the collective runs even at world size 1 -- a copy -- so that a 1-GPU run under a launcher exercises RCCL: tests/test_rccl_world1.py)
     out = torch.empty((cond_all.shape[0],) + tuple(sr.shape[1:]), dtype=sr.dtype, device=sr.device)
     dist.all_gather_into_tensor(out, sr.contiguous())
     return out
@@ -96,7 +106,7 @@ def sample_scene_dpmpp(net, diffusion, cond_all: torch.Tensor, x_T_all: torch.Te
     solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++", correcting_x0_fn=ImageSpaceClamp(lms, 0.0, 1.0))
     res = solver.sample(x_T_all[lo:hi].contiguous(), steps=steps, order=order, skip_type="time_uniform", method="multistep")
     sr = (res + lms).clip(0, 1)  # diffusion_engine.py:446-447
-    if dist.is_initialized():
+    if _collectives_on(sr):
         out = torch.empty((n,) + tuple(sr.shape[1:]), dtype=sr.dtype, device=sr.device)
         dist.all_gather_into_tensor(out, sr.contiguous())
         sr = out
