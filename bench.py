@@ -33,7 +33,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between the ranks of a node needs it on this driver
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (also set by the ddif package; here for the self-launched ranks: profiles/r05_a_kernarg_ab.txt)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (also set by the ddif package; here for the self-launched ranks: profiles/r05/a_kernarg_ab.txt)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "dif-pan_amd"), ROOT, os.path.join(ROOT, "tests")):
@@ -737,7 +737,7 @@ def committed_traffic():
     benchmarked (same sha1 over csrc/); otherwise `traffic` is null and the stale file is named."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*hbm_traffic.json")))
     if not files:
         return None, {"traffic_from_committed_profile": False}
     bid = build_id()
@@ -746,10 +746,10 @@ def committed_traffic():
             with open(path) as f:
                 j = json.load(f)
             if j.get("build_id") == bid:
-                return float(j["class_hbm_bytes_per_launch"]), {"traffic_from_committed_profile": True, "traffic_source": "profiles/" + os.path.basename(path)}
+                return float(j["class_hbm_bytes_per_launch"]), {"traffic_from_committed_profile": True, "traffic_source": os.path.relpath(path, ROOT)}
         except (OSError, ValueError, KeyError):
             continue
-    return None, {"traffic_from_committed_profile": False, "traffic_stale_profile": "profiles/" + os.path.basename(files[-1])}
+    return None, {"traffic_from_committed_profile": False, "traffic_stale_profile": os.path.relpath(files[-1], ROOT)}
 
 
 def usable_cpus():

@@ -70,7 +70,7 @@ ConvVariant variant_for_cfg(int cfg) {
         if constexpr (U == 0) {
             // 37 = tiling 27 with RESIDENT weights (MATH = 5, round 5): 32 input channels as ONE stage per work item, the cout tile's weights copied into
             // LDS once per workgroup.  Same pack, same accumulation order, same partials as 27 -- bit-identical results, 3-6 % faster in isolation
-            // (profiles/r05_a_mbench_resident.txt).  Chosen by add_conv for 32 -> <= 32 channel convs.
+            // (profiles/r05/a_mbench_resident.txt).  Chosen by add_conv for 32 -> <= 32 channel convs.
             if (cfg == 37) { v.fn = conv_mfma_kernel<KS, S, U, 16, 16, 32, 8, 1, 1, 1, PRO, VEC, EPI, 0, 5>; v.smem = conv_smem_bytes<KS, S, U, 16, 16, 32, 1, PRO, 8, 5>(); v.th = 16; v.tw = 16; v.nt = 32; v.nthr = 512; v.x3 = v.f16 = v.wr = true; }
         }
     }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/ddif.h"
+#include "../../include/ddif_testops.h"
 #include "ddif_dev.h"
 
 namespace ddif {

@@ -46,7 +46,7 @@ static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention 
 // 4 = the fused linear-attention block, 8 = the per-sample kernels (bottleneck attention block, gn_dw3x3 of the low levels).  The dispatcher puts workgroup b on
 // XCD b % 8; with the map every kernel of the step gives XCD k the same eighth of the samples (tiles 8 k .. 8 k + 7 at B = 64), so halos, the cout tiles of a pixel
 // tile and a consumer's input (written by the same XCD one launch earlier) meet in that XCD's private L2: 3.90 -> 3.76 ms per denoising step, same box
-// (profiles/r05_k_xcd_ab.txt).  Results do not depend on it -- the partition only decides WHICH workgroup computes an item (tests/test_env_switches.py).
+// (profiles/r05/k_xcd_ab.txt).  Results do not depend on it -- the partition only decides WHICH workgroup computes an item (tests/test_env_switches.py).
 static int xcd_mask() {
     static const int v = [] { const char* e = getenv("DDIF_XCD"); return e ? atoi(e) : 15; }();
     return v;
@@ -72,7 +72,7 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
     if (allow_lr && x3 && lr_enabled() && vec == 1 && stride == 1 && !ups_ && Hout * Wout <= 256 && Cout % 4 == 0 && cin % 16 == 0 && c0 % 16 == 0 &&
         ck == (ks == 3 ? 16 : 32))
         // (smaller tiles -- 4 x 8 pixels at the 8 x 8 level, 8 x 8 at 16 x 16: twice the workgroups, each with half the matrix work -- measured
-        //  SLOWER, 1.375 -> 1.42 / 1.49 / 1.54 ms for the class, profiles/r04_f_lr_tiles_ab.txt: the items are latency chains that also stream the
+        //  SLOWER, 1.375 -> 1.42 / 1.49 / 1.54 ms for the class, profiles/r04/f_lr_tiles_ab.txt: the items are latency chains that also stream the
         //  weights once per item; more of them only adds weight traffic)
         return (Hout <= 8 && Wout <= 8) ? 20 : 21;
     if (ks == 1 && vec == 1) {

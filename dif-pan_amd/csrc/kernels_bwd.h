@@ -55,7 +55,7 @@ struct WgradArgs {
 // the MFMA loop -- a band's loads are then hidden instead of serialised in front of its MFMAs.  PF = 0: any band size, loads in batches
 // of eight before the LDS writes.
 // CENTRE = 1 (1x1 convs, only with PF): the X band is the SAME pixel set as the dY band -- no halo rows / columns are fetched or staged (the
-// 3x3 form loaded three rows of X to use one: the 1x1 weight gradients ran at 3-9 % of their matrix time, profiles/r03_k_wgrad_by_shape.txt)
+// 3x3 form loaded three rows of X to use one: the 1x1 weight gradients ran at 3-9 % of their matrix time, profiles/r03/k_wgrad_by_shape.txt)
 constexpr int WG_PF = 9, WG_PF_CENTRE = 13;  // prefetch registers (float4 per thread): 3x3 keeps 144 accumulators and must stay at 2 waves / SIMD
 template <int PF, int CENTRE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int wg_x = blockIdx.x, wg_y = blockIdx.y;  // (an XCD-aware renumbering -- the block pairs of one K split on one XCD, so that their re-reads of the
-    // bands hit that L2 -- measured nothing: 41.8 / 20.1 us per launch against 42.0 / 19.7, profiles/r03_z9; removed)
+    // bands hit that L2 -- measured nothing: 41.8 / 20.1 us per launch against 42.0 / 19.7, profiles/r03/z9; removed)
     const int cob = wg_x / a.n_ci, cib = wg_x % a.n_ci;
     const int nbands = a.B * a.bands_y;
     const int NY = RB * W * 8, NX = (RB + 2 * HALO) * IW * 8, NTOT = NY + NX;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
 // The weight gradient on the 16-bit matrix pipe (round 5).  conv3x3_wgrad_kernel above contracts TWO pixels per v_mfma_f32_32x32x2_f32 (64 cycles, and the
 // fp32 matrix op shares the vector datapath with the address / LDS instructions around it): 15-29 % of its own matrix bound at the 3x3 shapes, 3-9 % at the
-// 1x1 ones (profiles/r03_k_wgrad_by_shape.txt).  Here K = 16 pixels per v_mfma_f32_32x32x16_bf16 with BOTH operands split three ways (bf16x3, six exact
+// 1x1 ones (profiles/r03/k_wgrad_by_shape.txt).  Here K = 16 pixels per v_mfma_f32_32x32x16_bf16 with BOTH operands split three ways (bf16x3, six exact
 // products, small terms first, fp32 accumulate -- the arithmetic of the forward / dgrad convs of the training step): 192 instead of 512 matrix cycles per
 // 16 pixels and tap, on a pipe of its own.
 //   * the contraction index is the PIXEL, so the operands need pixels contiguous per channel: rows are staged TRANSPOSED, [plane][channel][pixel] as bf16,

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     constexpr int NPC = G::NPC, NPF = G::NPF;
     constexpr int WIT = (NPC + 7) / 8, FIT = (NPF + 7) / 8;   // weight pieces per wave (a piece = 64 lanes x 16 B)
     constexpr float L2E = 1.4426950408889634f;
+    constexpr bool PAIRDW = (NBQ == 2 && NBA == 1);  // depthwise stage on vertically adjacent pixel pairs (round 6): the 32 + 32 -> 32 blocks of the 64 x 64 level
 
     dd_touch_kernargs<sizeof(LaFuseArgs)>();  // every line of the argument block in ONE round trip (ddif_dev.h)
     DDIF_DYN_SMEM(smem);
@@ -308,6 +309,64 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
             __syncthreads();
             stamp();  // 2: barrier
             // (c) depthwise 3x3 of the chunk -> dwq (two half planes, pre-scaled), and the centre pixels = xn (three bf16 planes);
+            //     pixels are numbered column-major: p = x * TH + y.  Round 6: a thread owns TWO VERTICALLY ADJACENT pixels (p0 = 2 (tid / 4), p0 + 1: same column,
+            //     TH is even) and walks the four halo rows they share once -- 12 tile reads + 9 weight reads per thread and chunk instead of 18 + 18: the stage
+            //     issues 36 ds_read_b128 per thread otherwise (295 KB per chunk at 128 B / clk ~ the 2.0-2.4 k ticks the stamps show; measured 73.8 -> 69.6 us
+            //     per launch at 64 x 64, the stage 1.8-2.4 k -> 1.5-2.0 k ticks: the rest is its FMAs and splits).  Only where it does not spill (PAIRDW).  One halo row
+            //     and two weight rows live at a time (all reads hoisted, as hipcc prefers, push the accumulators into scratch); same products, same order per pixel.
+            if constexpr (PAIRDW) {
+              if (!(ABL & 8)) {
+                const int p0 = (tid >> 2) * 2, x = p0 / TH, y = p0 % TH;
+                float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+                float4 wprev[3], wcur[3];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // halo row y + r: tap row r of pixel a (r < 3), tap row r - 1 of pixel b (r > 0)
+                    float4 hv[3];
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        hv[tx] = *reinterpret_cast<const float4*>(&Hs[((y + r) * HW + x + tx) * LDH + 4 * c4]);
+                        if (r > 0) wprev[tx] = wcur[tx];
+                        if (r < 3) wcur[tx] = *reinterpret_cast<const float4*>(&DW[(3 * r + tx) * FEA + 16 * k + 4 * c4]);
+                    }
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        if (r < 3) {
+                            sa[0] = fmaf(hv[tx].x, wcur[tx].x, sa[0]);
+                            sa[1] = fmaf(hv[tx].y, wcur[tx].y, sa[1]);
+                            sa[2] = fmaf(hv[tx].z, wcur[tx].z, sa[2]);
+                            sa[3] = fmaf(hv[tx].w, wcur[tx].w, sa[3]);
+                        }
+                        if (r > 0) {
+                            sb[0] = fmaf(hv[tx].x, wprev[tx].x, sb[0]);
+                            sb[1] = fmaf(hv[tx].y, wprev[tx].y, sb[1]);
+                            sb[2] = fmaf(hv[tx].z, wprev[tx].z, sb[2]);
+                            sb[3] = fmaf(hv[tx].w, wprev[tx].w, sb[3]);
+                        }
+                    }
+                    if (r == 1 || r == 2) {  // the centre tap of pixel a / b IS xn = GroupNorm(cat[h, skip]): three bf16 planes, written at once (nothing kept)
+                        const int p = p0 + (r - 1);
+                        unsigned h01, m01, l01, h23, m23, l23;
+                        dd_split3_pair(hv[1].x, hv[1].y, &h01, &m01, &l01);
+                        dd_split3_pair(hv[1].z, hv[1].w, &h23, &m23, &l23);
+                        *reinterpret_cast<uint2*>(&Ax[p * LDX + 2 * c4]) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(&Ax[p * LDX + 8 + 2 * c4]) = make_uint2(m01, m23);
+                        *reinterpret_cast<uint2*>(&Ax[p * LDX + 16 + 2 * c4]) = make_uint2(l01, l23);
+                    }
+                    DDIF_SCHED_FENCE();
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int p = p0 + it;
+                    const float* sv = it ? sb : sa;
+                    unsigned h01, l01, h23, l23;
+                    dd_split2_pair(sv[0] * DDIF_F16_ASCALE, sv[1] * DDIF_F16_ASCALE, &h01, &l01);
+                    dd_split2_pair(sv[2] * DDIF_F16_ASCALE, sv[3] * DDIF_F16_ASCALE, &h23, &l23);
+                    *reinterpret_cast<uint2*>(&Aq[p * LDQ + 2 * c4]) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(&Aq[p * LDQ + 8 + 2 * c4]) = make_uint2(l01, l23);
+                }
+            }
+            } else {
+            // (the form of rounds 4-5: two items per thread, 18 + 18 reads each -- kept where the pair form spills: measured 45.5 vs 48.6 us at 32 x 32, NBQ = 4)
             //     pixels are numbered column-major: p = x * TH + y.  One tap ROW at a time (3 + 3 LDS reads in flight): all 18 reads of an
             //     item hoisted, as hipcc prefers, cost 72 registers and pushed the accumulators into scratch.
 #pragma unroll
@@ -345,6 +404,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
                 *reinterpret_cast<uint2*>(&Ax[p * LDX + 2 * c4]) = make_uint2(h01, h23);
                 *reinterpret_cast<uint2*>(&Ax[p * LDX + 8 + 2 * c4]) = make_uint2(m01, m23);
                 *reinterpret_cast<uint2*>(&Ax[p * LDX + 16 + 2 * c4]) = make_uint2(l01, l23);
+            }
             }
             store_weights();
             stamp();  // 3: depthwise + split stage done

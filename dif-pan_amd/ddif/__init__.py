@@ -10,7 +10,7 @@ All tensor work runs in hand-written gfx950 kernels behind the C ABI of include/
 import os as _os
 
 # Kernel arguments in device memory instead of host-coherent memory: the first scalar loads of every launch (its argument block) stop being a PCIe
-# round trip -- 1.5 % of a denoising step of 146 dependent launches (profiles/r05_a_kernarg_ab.txt).  Read by the HIP runtime when it initialises,
+# round trip -- 1.5 % of a denoising step of 146 dependent launches (profiles/r05/a_kernarg_ab.txt).  Read by the HIP runtime when it initialises,
 # i.e. effective when this package is imported before the first GPU call of the process; a user's own setting wins.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 

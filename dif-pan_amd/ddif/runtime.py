@@ -125,41 +125,6 @@ class _Lib:
         d.ddif_optim_destroy.argtypes = [vp]
         d.ddif_optim_destroy.restype = None
         d.ddif_optim_step.argtypes = [vp, f32, f32, f32, f32, f32, C.c_int64, f32, i32, f32, C.POINTER(C.c_float), vp]
-        d.ddif_convbwd_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
-        d.ddif_convbwd_destroy.argtypes = [vp]
-        d.ddif_convbwd_destroy.restype = None
-        d.ddif_convbwd_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
-        d.ddif_blockbwd_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
-        d.ddif_blockbwd_create_ex.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32, i32, i32]
-        d.ddif_blockbwd_destroy.argtypes = [vp]
-        d.ddif_blockbwd_destroy.restype = None
-        d.ddif_blockbwd_run.argtypes = [vp] + [vp] * 13
-        d.ddif_dwconv3x3_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
-        d.ddif_convfwd_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32, i32, i32]
-        d.ddif_convfwd_destroy.argtypes = [vp]
-        d.ddif_convfwd_destroy.restype = None
-        d.ddif_convfwd_run.argtypes = [vp, vp, vp, vp, vp, vp]
-        d.ddif_dwconv3x3_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
-        d.ddif_groupnorm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
-        d.ddif_swish_fwd.argtypes = [vp, C.c_int64, vp, vp]
-        d.ddif_film_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
-        d.ddif_add_scaled.argtypes = [vp, vp, vp, i32, C.c_int64, vp, vp]
-        d.ddif_linear_fwd.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
-        d.ddif_selfattn_core_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
-        d.ddif_linattn_core_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
-        d.ddif_q_sample.argtypes = [vp, vp, vp, vp, i32, C.c_int64, vp, vp]
-        d.ddif_l1_loss_fwd.argtypes = [vp, vp, C.c_int64, vp, vp]
-        d.ddif_film_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
-        d.ddif_selfattn_core_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
-        d.ddif_linattn_core_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
-        d.ddif_linattn_nhwc_workspace.argtypes = [i32, i32, i32, i32, i32]
-        d.ddif_linattn_nhwc_workspace.restype = C.c_int64
-        d.ddif_linattn_nhwc_fwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
-        d.ddif_linattn_nhwc_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
-        d.ddif_linear_bwd.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
-        d.ddif_groupnorm_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
-        d.ddif_swish_bwd.argtypes = [vp, vp, C.c_int64, vp, vp]
-        d.ddif_l1_loss_bwd.argtypes = [vp, vp, C.c_int64, C.c_float, vp, vp]
         self.emulated = bool(d.ddif_is_emulated())
 
     def check(self, rc: int, what: str):
@@ -828,199 +793,3 @@ def _bump_versions(tensors):
     except TypeError:
         for t in tensors:
             inc(t)
-
-
-class Conv3x3Backward:
-    """Backward of nn.Conv2d(Cin, Cout, 3, padding=1) (autograd under loss.backward(), reference diffusion_engine.py:233):
-    returns (dx, dw, db) for x (B,Cin,H,W), w (Cout,Cin,3,3), dy (B,Cout,H,W) -- hand-written dgrad / wgrad kernels."""
-
-    def __init__(self, B, Cin, Cout, H, W, device):
-        self.lib = get_lib()
-        dev = torch.device(device)
-        idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
-        h = C.c_void_p()
-        self.lib.check(self.lib.dll.ddif_convbwd_create(C.byref(h), B, Cin, Cout, H, W, idx), "ddif_convbwd_create")
-        self.h, self.shape, self.device = h, (B, Cin, Cout, H, W), dev
-
-    def __call__(self, x, w, dy, need_dx=True, need_dw=True, need_db=True):
-        B, Cin, Cout, H, W = self.shape
-        for nm, t, shp in (("x", x, (B, Cin, H, W)), ("w", w, (Cout, Cin, 3, 3)), ("dy", dy, (B, Cout, H, W))):
-            _check_tensor(self.lib, t, nm)
-            _check_shape(t, nm, shp)
-        x, w, dy = x.contiguous(), w.contiguous(), dy.contiguous()
-        dx = torch.empty_like(x) if need_dx else None
-        dw = torch.empty_like(w) if need_dw else None
-        db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if need_db else None
-        self.lib.check(self.lib.dll.ddif_convbwd_run(self.h, _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
-                                                     _stream(self.lib, x.device)), "ddif_convbwd_run")
-        return dx, dw, db
-
-    def __del__(self):
-        try:
-            if getattr(self, "h", None):
-                self.lib.dll.ddif_convbwd_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
-
-
-class BlockBackward:
-    """Backward of one `Block` of the denoiser (reference models/sr3_dwt.py:288-300: GroupNorm(1 group) -> Swish -> Dropout ->
-    conv3x3) as autograd runs it under loss.backward() (diffusion_engine.py:233).  `mask` is the dropout site's mask (0 or
-    1/(1-p), what `PlanHandle.train_sites` / `set_train_masks` carry), None in eval mode.  Returns a dict with dx, dgamma,
-    dbeta, dw, db and dy_plane_sums (B, Cout) -- the gradient of the time bias FeatureWiseAffine adds behind block1."""
-
-    PRO = {"none": 0, "gn": 1, "gn_silu": 2, "silu": 3}
-    RESAMPLE = {"plain": 0, "down2": 1, "up2": 2}
-
-    def __init__(self, B, Cin, Cout, H, W, device, ks=3, pro="gn_silu", resample="plain"):
-        self.lib = get_lib()
-        dev = torch.device(device)
-        idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
-        h = C.c_void_p()
-        self.lib.check(self.lib.dll.ddif_blockbwd_create_ex(C.byref(h), B, Cin, Cout, H, W, ks, self.PRO[pro], self.RESAMPLE[resample], idx),
-                       "ddif_blockbwd_create_ex")
-        self.h, self.shape, self.device, self.ks, self.pro = h, (B, Cin, Cout, H, W), dev, ks, pro
-        self.out_hw = {"plain": (H, W), "down2": ((H - 1) // 2 + 1, (W - 1) // 2 + 1), "up2": (2 * H, 2 * W)}[resample]
-
-    def __call__(self, x, gamma, beta, w, dy, mask=None, need_dx=True):
-        B, Cin, Cout, H, W = self.shape
-        named = [("x", x, (B, Cin, H, W)), ("w", w, (Cout, Cin, self.ks, self.ks)), ("dy", dy, (B, Cout) + self.out_hw)]
-        if self.pro in ("gn", "gn_silu"):
-            named += [("gamma", gamma, (Cin,)), ("beta", beta, (Cin,))]
-        else:
-            gamma = beta = None
-        if mask is not None:
-            named.append(("mask", mask, (B, Cin, H, W)))
-        for nm, t, shp in named:
-            _check_tensor(self.lib, t, nm)
-            _check_shape(t, nm, shp)
-        x, w, dy = x.contiguous(), w.contiguous(), dy.contiguous()
-        gamma = gamma.contiguous() if gamma is not None else None
-        beta = beta.contiguous() if beta is not None else None
-        mask = mask.contiguous() if mask is not None else None
-        f = dict(dtype=torch.float32, device=x.device)
-        gn = self.pro in ("gn", "gn_silu")
-        out = {"dx": torch.empty_like(x) if need_dx else None, "dgamma": torch.empty((Cin,), **f) if gn else None,
-               "dbeta": torch.empty((Cin,), **f) if gn else None,
-               "dw": torch.empty_like(w), "db": torch.empty((Cout,), **f), "dy_plane_sums": torch.empty((B, Cout), **f)}
-        self.lib.check(self.lib.dll.ddif_blockbwd_run(self.h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mask), _ptr(w), _ptr(dy), _ptr(out["dx"]),
-                                                      _ptr(out["dgamma"]), _ptr(out["dbeta"]), _ptr(out["dw"]), _ptr(out["db"]),
-                                                      _ptr(out["dy_plane_sums"]), _stream(self.lib, x.device)), "ddif_blockbwd_run")
-        return out
-
-    def __del__(self):
-        try:
-            if getattr(self, "h", None):
-                self.lib.dll.ddif_blockbwd_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
-
-
-# ---- stateless backward ops (include/ddif.h "stateless backward ops"): each returns the gradients autograd would produce --------
-def _ops_prepare(named):
-    lib = get_lib()
-    out = []
-    for nm, t, shp in named:
-        _check_tensor(lib, t, nm)
-        _check_shape(t, nm, shp)
-        _check_current_device(t, nm)
-        out.append(t.contiguous())
-    return lib, out
-
-
-def dwconv3x3_backward(x, w, dy):
-    """Depthwise conv3x3 (groups = C, pad 1, no bias; reference models/sr3_dwt.py:507-520): (dx, dw)."""
-    B, Cc, H, W = x.shape
-    lib, (x, w, dy) = _ops_prepare([("x", x, (B, Cc, H, W)), ("w", w, (Cc, 1, 3, 3)), ("dy", dy, (B, Cc, H, W))])
-    dx, dw = torch.empty_like(x), torch.empty_like(w)
-    lib.check(lib.dll.ddif_dwconv3x3_bwd(_ptr(x), _ptr(w), _ptr(dy), B, Cc, H, W, _ptr(dx), _ptr(dw), _stream(lib, x.device)), "ddif_dwconv3x3_bwd")
-    return dx, dw
-
-
-def film_backward(xc, scale_shift, dout):
-    """CondInjection's xc * (1 + scale) + shift (reference :395-396): (dxc, dscale_shift)."""
-    B, Cc, H, W = xc.shape
-    lib, (xc, ss, dout) = _ops_prepare([("xc", xc, (B, Cc, H, W)), ("scale_shift", scale_shift, (B, 2 * Cc, H, W)), ("dout", dout, (B, Cc, H, W))])
-    dxc, dss = torch.empty_like(xc), torch.empty_like(ss)
-    lib.check(lib.dll.ddif_film_bwd(_ptr(xc), _ptr(ss), _ptr(dout), B, Cc, H, W, _ptr(dxc), _ptr(dss), _stream(lib, xc.device)), "ddif_film_bwd")
-    return dxc, dss
-
-
-def selfattn_core_backward(qkv, dout, heads=8):
-    """SelfAttention core (reference :345-358): gradient of qkv (B, 3C, H, W) given that of the weighted sum (B, C, H, W)."""
-    B, C3, H, W = qkv.shape
-    lib, (qkv, dout) = _ops_prepare([("qkv", qkv, (B, C3, H, W)), ("dout", dout, (B, C3 // 3, H, W))])
-    dqkv = torch.empty_like(qkv)
-    lib.check(lib.dll.ddif_selfattn_core_bwd(_ptr(qkv), _ptr(dout), B, C3 // 3, H, W, heads, _ptr(dqkv), _stream(lib, qkv.device)), "ddif_selfattn_core_bwd")
-    return dqkv
-
-
-def linattn_core_backward(q_pre, kv_pre, dout, heads=8):
-    """FastAttnCondInjection core (reference :545-566): (dq_pre, dkv_pre) given the gradient of the attention output."""
-    B, qd, H, W = q_pre.shape
-    lib, (q_pre, kv_pre, dout) = _ops_prepare([("q_pre", q_pre, (B, qd, H, W)), ("kv_pre", kv_pre, (B, 2 * qd, H, W)), ("dout", dout, (B, qd, H, W))])
-    dq, dkv = torch.empty_like(q_pre), torch.empty_like(kv_pre)
-    lib.check(lib.dll.ddif_linattn_core_bwd(_ptr(q_pre), _ptr(kv_pre), _ptr(dout), B, qd, H, W, heads, _ptr(dq), _ptr(dkv), _stream(lib, q_pre.device)),
-              "ddif_linattn_core_bwd")
-    return dq, dkv
-
-
-def linear_backward(x, w, dy):
-    """nn.Linear (reference :59-64, 241-258): (dx, dw, db)."""
-    B, nin = x.shape
-    nout = w.shape[0]
-    lib, (x, w, dy) = _ops_prepare([("x", x, (B, nin)), ("w", w, (nout, nin)), ("dy", dy, (B, nout))])
-    dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty((nout,), dtype=torch.float32, device=x.device)
-    lib.check(lib.dll.ddif_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), B, nin, nout, _ptr(dx), _ptr(dw), _ptr(db), _stream(lib, x.device)), "ddif_linear_bwd")
-    return dx, dw, db
-
-
-def swish_backward(x, dy):
-    lib, (x, dy) = _ops_prepare([("x", x, tuple(x.shape)), ("dy", dy, tuple(x.shape))])
-    dx = torch.empty_like(x)
-    lib.check(lib.dll.ddif_swish_bwd(_ptr(x), _ptr(dy), x.numel(), _ptr(dx), _stream(lib, x.device)), "ddif_swish_bwd")
-    return dx
-
-
-def l1_loss_backward(pred, target, upstream=1.0):
-    """F.l1_loss(pred, target) (mean) backward (reference diffusion/diffusion_ddpm_pan.py:742-749)."""
-    lib, (pred, target) = _ops_prepare([("pred", pred, tuple(pred.shape)), ("target", target, tuple(pred.shape))])
-    dp = torch.empty_like(pred)
-    lib.check(lib.dll.ddif_l1_loss_bwd(_ptr(pred), _ptr(target), pred.numel(), C.c_float(upstream), _ptr(dp), _stream(lib, pred.device)), "ddif_l1_loss_bwd")
-    return dp
-
-
-def groupnorm_backward(x, gamma, dy):
-    """GroupNorm(1 group, eps 1e-5) alone (reference models/sr3_dwt.py:540-573 prenorm_x): (dx, dgamma, dbeta)."""
-    B, Cc, H, W = x.shape
-    lib, (x, gamma, dy) = _ops_prepare([("x", x, (B, Cc, H, W)), ("gamma", gamma, (Cc,)), ("dy", dy, (B, Cc, H, W))])
-    dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
-    ws = torch.empty((B * (2 * Cc + 4),), dtype=torch.float64, device=x.device)
-    lib.check(lib.dll.ddif_groupnorm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), B, Cc, H, W, _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream(lib, x.device)),
-              "ddif_groupnorm_bwd")
-    return dx, dg, db
-
-
-def linattn_nhwc(q_pre, kv_pre, heads=8):
-    """The linear attention core as the native training step runs it: q_pre (B,H,W,qd), kv_pre (B,H,W,2qd), NHWC.  Returns (out (B,H,W,qd),
-    workspace) -- the workspace carries the contexts `linattn_nhwc_backward` needs."""
-    B, H, W, qd = q_pre.shape
-    lib, (q_pre, kv_pre) = _ops_prepare([("q_pre", q_pre, (B, H, W, qd)), ("kv_pre", kv_pre, (B, H, W, 2 * qd))])
-    n = lib.dll.ddif_linattn_nhwc_workspace(B, qd, H, W, heads)
-    if n < 0:
-        lib.check(int(n), "ddif_linattn_nhwc_workspace")  # negative = refused: the message is in ddif_last_error
-    ws = torch.empty((n,), dtype=torch.float32, device=q_pre.device)
-    out = torch.empty_like(q_pre)
-    lib.check(lib.dll.ddif_linattn_nhwc_fwd(_ptr(q_pre), _ptr(kv_pre), B, qd, H, W, heads, _ptr(out), _ptr(ws), _stream(lib, q_pre.device)), "ddif_linattn_nhwc_fwd")
-    return out, ws
-
-
-def linattn_nhwc_backward(q_pre, kv_pre, dout, workspace, heads=8):
-    B, H, W, qd = q_pre.shape
-    lib, (q_pre, kv_pre, dout) = _ops_prepare([("q_pre", q_pre, (B, H, W, qd)), ("kv_pre", kv_pre, (B, H, W, 2 * qd)), ("dout", dout, (B, H, W, qd))])
-    dq, dkv = torch.empty_like(q_pre), torch.empty_like(kv_pre)
-    lib.check(lib.dll.ddif_linattn_nhwc_bwd(_ptr(q_pre), _ptr(kv_pre), _ptr(dout), B, qd, H, W, heads, _ptr(dq), _ptr(dkv), _ptr(workspace),
-                                            _stream(lib, q_pre.device)), "ddif_linattn_nhwc_bwd")
-    return dq, dkv

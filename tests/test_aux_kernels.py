@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import golden_cases as gc
+import ddif_testops
 from ddif_testlib import use_emulator, use_gpu_library
 from oracle import ddif_oracle as O
 
@@ -143,7 +144,7 @@ def test_conv3x3_backward_matches_autograd(backend, shape):
     dy = torch.randn(B, Cout, H, W, generator=g)
     y = torch.nn.functional.conv2d(x, w, b, padding=1)
     y.backward(dy)
-    op = runtime.Conv3x3Backward(B, Cin, Cout, H, W, dev)
+    op = ddif_testops.Conv3x3Backward(B, Cin, Cout, H, W, dev)
     dx, dw, db = op(x.detach().to(dev), w.detach().to(dev), dy.to(dev))
     for got, want, nm in ((dx, x.grad, "dx"), (dw, w.grad, "dw"), (db, b.grad, "db")):
         err = float((got.cpu() - want).abs().max())
@@ -182,7 +183,7 @@ def test_block_backward_matches_autograd(backend, shape, drop):
         mask = (torch.rand(B, Cin, H, W, generator=g) >= drop).float() / (1.0 - drop)
     dy = torch.randn(B, Cout, H, W, generator=g)
     _block_forward(x, gamma, beta, mask, w, b).backward(dy)
-    op = runtime.BlockBackward(B, Cin, Cout, H, W, dev)
+    op = ddif_testops.BlockBackward(B, Cin, Cout, H, W, dev)
     args = [t.detach().to(dev) for t in (x, gamma, beta, w, dy)]
     got = op(*args, mask=None if mask is None else mask.to(dev))
     want = {"dx": x.grad, "dgamma": gamma.grad, "dbeta": beta.grad, "dw": w.grad, "db": b.grad, "dy_plane_sums": dy.sum(dim=(2, 3))}
@@ -215,7 +216,7 @@ def test_resnet_block_backward_composed_from_block_backwards(backend):
     out = _block_forward(h1, p[1]["gamma"], p[1]["beta"], mask2, p[1]["w"], p[1]["b"]) + x
     dout = torch.randn(B, Cc, H, W, generator=g)
     out.backward(dout)
-    op = runtime.BlockBackward(B, Cc, Cc, H, W, dev)
+    op = ddif_testops.BlockBackward(B, Cc, Cc, H, W, dev)
     d = lambda t: t.detach().to(dev)
     g2 = op(d(h1), d(p[1]["gamma"]), d(p[1]["beta"]), d(p[1]["w"]), d(dout), mask=mask2.to(dev))
     g1 = op(d(x), d(p[0]["gamma"]), d(p[0]["beta"]), d(p[0]["w"]), g2["dx"])
@@ -260,7 +261,7 @@ def test_conv_op_backward_variants_match_autograd(backend, ks, pro, resample, sh
     y = torch.nn.functional.conv2d(a, w, b, padding=ks // 2, stride=2 if resample == "down2" else 1)
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy)
-    op = runtime.BlockBackward(B, Cin, Cout, H, W, dev, ks=ks, pro=pro, resample=resample)
+    op = ddif_testops.BlockBackward(B, Cin, Cout, H, W, dev, ks=ks, pro=pro, resample=resample)
     d = lambda t: t.detach().to(dev)
     got = op(d(x), d(gamma), d(beta), d(w), d(dy))
     want = {"dx": x.grad, "dw": w.grad, "db": b.grad, "dy_plane_sums": dy.sum(dim=(2, 3))}

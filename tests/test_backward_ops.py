@@ -30,7 +30,7 @@ def _close(got, want, name, rel=3e-5):
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 24, 9, 13), (2, 128, 8, 8)], ids=["64@16", "24@9x13", "128@8"])
 def test_depthwise3x3_backward(backend, shape):
     """FastAttnCondInjection.q[0] / kv[0] (models/sr3_dwt.py:507-520): conv3x3, groups = C, no bias."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B, Cc, H, W = shape
@@ -47,7 +47,7 @@ def test_depthwise3x3_backward(backend, shape):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_film_backward(backend):
     """CondInjection: xc * (1 + scale) + shift with scale, shift = y.chunk(2, dim=1) (models/sr3_dwt.py:393-396)."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B, Cc, H, W = 2, 32, 16, 12
@@ -67,7 +67,7 @@ def test_film_backward(backend):
 def test_self_attention_core_backward(backend, shape):
     """SelfAttention between its two 1x1 convs (models/sr3_dwt.py:345-358; oracle.self_attention): per-head [q|k|v] interleave,
     scale 1/sqrt(C)."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B, Cc, H, W = shape
@@ -88,7 +88,7 @@ def test_self_attention_core_backward(backend, shape):
 def test_linear_attention_core_backward(backend, shape):
     """FastAttnCondInjection between q / kv and attn_out (models/sr3_dwt.py:545-566; oracle.fast_attn_cond_injection):
     softmax over H of q, over W of k, q * 1/sqrt(d), ctx = k v^T, out = ctx^T q."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B, qd, H, W = shape
@@ -115,7 +115,7 @@ def test_linear_attention_core_nhwc_forward_and_backward(backend, shape):
     """The same core in the form the native training step runs (csrc/kernels_linattn.h: row / column workgroups, contexts summed from
     per-workgroup partials) at the shapes of the batch-32 step's decoder blocks and at ragged ones (line groups with a short tail):
     output and both gradients against torch autograd in fp64."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B, qd, H, W = shape
@@ -146,7 +146,7 @@ def test_linear_attention_core_nhwc_forward_and_backward(backend, shape):
 def test_time_mlp_backward_chain(backend):
     """noise_level_mlp = Linear(32,128) -> Swish -> Linear(128,32) and one FeatureWiseAffine Linear(32, C) (models/sr3_dwt.py:59-64,
     241-258; oracle.time_embedding), chained from the library's linear / swish backward ops."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B = 4
@@ -172,7 +172,7 @@ def test_time_mlp_backward_chain(backend):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_l1_loss_backward(backend):
     """loss = F.l1_loss(model_out, target) (diffusion/diffusion_ddpm_pan.py:742-749)."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     g = torch.Generator().manual_seed(8)
@@ -189,7 +189,7 @@ def test_l1_loss_backward(backend):
 def test_groupnorm_alone_backward(backend, shape):
     """FastAttnCondInjection.prenorm_x (models/sr3_dwt.py:540): its output feeds q[0] and attn_res, so the GroupNorm backward runs on
     the sum of both consumers' gradients."""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B, Cc, H, W = shape
@@ -210,7 +210,7 @@ def test_cond_conv_weight_gradient_through_zero_padded_channels(backend):
     """CondInjection.body[0] = conv3x3(cond_L: 9 channels -> 4c, no bias) (models/sr3_dwt.py:380): the conv backward needs 4 | Cin,
     so the 9 cond channels (and the weights) are zero-padded to 12; the padded channels' weight gradient is zero, the rest is dW.
     (dx is not needed: cond is data.)"""
-    from ddif import runtime
+    import ddif_testops as runtime
 
     dev = _dev(backend)
     B, Cin, Cout, H, W = 2, 9, 128, 16, 16
@@ -234,9 +234,9 @@ def test_cond_conv_weight_gradient_through_zero_padded_channels(backend):
                                   dict(cin=32, cout=8, ks=3, H=16, W=16), dict(cin=11, cout=22, ks=1, H=8, W=8)],
                          ids=["3x3", "stem-like", "1x1", "down", "down-odd", "up", "cond-9ch", "final-8", "kv1-11ch"])
 def test_training_graph_conv_forward(backend, case):
-    """Every conv shape of the network through ddif.functional.conv2d against F.conv2d (channel counts that are not multiples of 4
+    """Every conv shape of the network through ddif_testops.conv2d against F.conv2d (channel counts that are not multiples of 4
     are zero-padded inside)."""
-    from ddif import functional as DF
+    import ddif_testops as DF
 
     dev = _dev(backend)
     g = torch.Generator().manual_seed(case["cin"] + case["cout"])
@@ -254,7 +254,7 @@ def test_training_graph_conv_forward(backend, case):
 def test_training_graph_elementwise_and_attention_forward(backend):
     """group_norm (+SiLU, +mask), depthwise conv, FiLM, residual / DropPath add, Linear, Swish and the two attention cores against
     the oracle's formulas (oracle/ddif_oracle.py: resnet_block, cond_injection, fast_attn_cond_injection, self_attention, time_embedding)."""
-    from ddif import functional as DF
+    import ddif_testops as DF
 
     dev = _dev(backend)
     g = torch.Generator().manual_seed(11)

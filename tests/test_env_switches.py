@@ -21,7 +21,7 @@
   DDIF_LA8=0    the decoder's linear-attention half at the 8 x 8 level as three launches instead of the fused kernel of round 6 (csrc/kernels_lafuse8.h).
 
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
-kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04_t_*, r03_b_*) were deleted together with
+kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04/t_*, r03_b_*) were deleted together with
 their code."""
 import os
 import subprocess

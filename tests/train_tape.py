@@ -3,7 +3,7 @@ and `loss.backward()`, diffusion_engine.py:230-233).
 
 The inference plan (csrc/ddif_plan.cpp) fuses GroupNorm / SiLU / FiLM / softmax into conv prologues and epilogues and keeps no
 intermediate; a training step needs them.  This module therefore walks the reference's module graph op by op through
-`ddif.functional` (every op is a C-ABI call into libddif: include/ddif.h "forward ops of the TRAINING graph" and the backward ops),
+`tests/ddif_testops.py` (every op is a C-ABI call into libddif: include/ddif.h "forward ops of the TRAINING graph" and the backward ops),
 keeps what the backward pass needs, and then walks it in reverse -- a hand-written autograd tape for exactly this network.  Python
 only orders the calls and owns the tensors (as the reference's Python does for torch ops); the arithmetic is in the library.
 Correctness first: convs run on the exact-fp32 MFMA kernels with NCHW <-> NHWC conversion around each call; 1x1 convs ride the 3x3
@@ -20,8 +20,9 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as TF  # ONLY interpolate() on the constant cond image
 
-from ddif import functional as F  # TEST SCAFFOLDING since round 4: the product trains through ddif_plan_train_step (csrc/ddif_train.cpp)
-from ddif import runtime as R
+import ddif_testops as F  # TEST SCAFFOLDING (tests/ddif_testops.py): the product trains through ddif_plan_train_step (csrc/ddif_train.cpp)
+import ddif_testops as R  # (the backward ops lived in ddif/runtime.py until round 6)
+from ddif import runtime as RT
 from ddif.layout import layer_plan
 
 

@@ -1,4 +1,4 @@
-// MEASURED AND NOT ADOPTED (round 5; profiles/r05_r_lr_chain.txt): consecutive low-resolution conv launches as ONE kernel behind XCD-local barriers.
+// MEASURED AND NOT ADOPTED (round 5; profiles/r05/r_lr_chain.txt): consecutive low-resolution conv launches as ONE kernel behind XCD-local barriers.
 // Development code for tools/mbench_chain.cpp -- nothing in the product includes this file.
 // The layer body is the product's conv_lr_kernel with its __global__ head replaced (tools/chain/make_body.sh generates tools/chain/_gen/kernels_lr_body.h from
 // dif-pan_amd/csrc/kernels_lr.h: the product's kernel text stays the single source).
@@ -46,7 +46,7 @@ __device__ __forceinline__ void xcd_barrier(unsigned* ctr, int* fault) {
 // boundary) and a boundary costs 2.8 us even between empty kernels; with the XCD-contiguous work partition (ddif_dev.h wg_work_range, xcd = 1) and 8 | B the
 // workgroups of ONE XCD produce everything the same workgroups consume in the next layer -- samples never cross XCDs -- so consecutive layers need a barrier
 // among the 32 workgroups of an XCD only, and their hand-off never leaves that XCD's L2:  xcd_barrier (below), 1.0 us (tools/probes/xcdsync.cpp,
-// profiles/r05_r_xcdsync_probe.txt), the consumer's input is L2-hot and its weight ring / argument lines can be in flight under the wait.
+// profiles/r05/r_xcdsync_probe.txt), the consumer's input is L2-hot and its weight ring / argument lines can be in flight under the wait.
 //   * grid = 256 workgroups of 256 threads, all co-resident (one per CU); every spin is bounded and raises the plan's fault flag instead of hanging;
 //   * the vector L1 is NOT invalidated (buffer_inv sc1, the only form that does it, costs 7.5 us: measured): the host only chains layers whose inputs are fresh in
 //     the kernel -- nothing a layer writes may have been read or written by an earlier layer of the same chain (a plan would have to check that) -- so no L1 can

@@ -1,4 +1,4 @@
-// MEASURED AND NOT ADOPTED (profiles/r05_c_resblock_resident_gate.txt; kept under tools/ with its micro-benchmark, not part of the product).
+// MEASURED AND NOT ADOPTED (profiles/r05/c_resblock_resident_gate.txt; kept under tools/ with its micro-benchmark, not part of the product).
 // Resident ResnetBlock of the 8 x 8 level (round 5): GroupNorm -> SiLU -> conv3x3 + time bias -> GroupNorm -> SiLU -> conv3x3 + residual
 // in ONE launch, one workgroup per sample, the whole sample on chip between the two convolutions.
 //
