@@ -428,9 +428,10 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
                         accq[nb] = c;
                         continue;
                     }
-                    c = DDIF_MFMA_32x32x16_F16(f1, xq[0], c);  // lo * hi
-                    c = DDIF_MFMA_32x32x16_F16(f0, xq[1], c);  // hi * lo
-                    c = DDIF_MFMA_32x32x16_F16(f0, xq[0], c);  // hi * hi
+                    // D = X W: rows = the wave's pixels, columns = the block's q channels (see the softmax section) -- the products and their order are those of W X
+                    c = DDIF_MFMA_32x32x16_F16(xq[0], f1, c);  // hi * lo
+                    c = DDIF_MFMA_32x32x16_F16(xq[1], f0, c);  // lo * hi
+                    c = DDIF_MFMA_32x32x16_F16(xq[0], f0, c);  // hi * hi
                     accq[nb] = c;
                 }
 #pragma unroll
@@ -457,85 +458,83 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
             // (no barrier here: the next chunk's GroupNorm stage writes Hs, which nobody reads any more; Aq / Ax / Wc are rewritten behind its barrier)
         }
 
-        // ---- q complete: column softmax over H, one 32-channel block of q at a time.  Lane (j, h) of wave w holds, per block nb and quad g, the
-        //      channels 32 nb + 8 g + 4 h + i of pixel p = 32 w + j, i.e. of column p / TH, row p % TH: the 32 lanes j of a half are 32 rows of
-        //      ONE column.  Then a += M_b p through the wave's own LDS region (bf16x3 planes in A-operand order); the M_b fragments of the block
-        //      come through LDS as well (fetched once per workgroup, double-buffered by block parity).
-        float* Apw = Ap + (32 * wave) * APS;
+        // ---- q complete: column softmax over H, one 32-channel block of q at a time.  Round 6: the q contraction is issued as D = X W (rows = pixels, columns = q
+        //      channels -- the operands of stage (d) swapped), so lane (j, h) of wave w holds, per block nb, channel 32 nb + j of the SIXTEEN pixels
+        //      32 w + 8 g + 4 h + i: rows of one image column (TH >= 32) or of two (TH = 16: g < 2 / g >= 2).  Max and sum over a column are then in-register
+        //      trees + ONE cross-half exchange (lanes l, l ^ 32) instead of sixteen 5-step cross-lane all-reduces each (the section was 43 % of a work item, all
+        //      VALU / DPP issue: tools/mbench_la.cpp stamps), the bias and the reciprocal are one value per lane instead of sixteen, and the two wave halves of a
+        //      64-row column meet ONCE per block: each normalises with its own maximum and the pair exchanges (max, sum) -- the online-softmax identity
+        //      p = e^(q - m_w) e^(m_w - M) / (S_w e^(m_w - M) + S_p e^(m_p - M)) -- behind the barrier that publishes the block's M_b fragments.
+        //      p goes back to the pixel-per-lane operand layout through a per-wave fp32 tile in LDS ([32 pixels][32 channels + 4]), is split into bf16 planes on the
+        //      way out and feeds a += M_b p straight from registers.
+        constexpr int NCW = (TH == 16) ? 2 : 1;  // image columns per wavefront
+        constexpr int RPC = 16 / NCW;            // accumulator registers per column
+        constexpr int TLD = 36;                  // floats per pixel row of the transpose tile (9 sixteen-byte slots: conflict-free float4 reads)
+        float* Tw = Ap + wave * (32 * TLD);
 #pragma unroll
         for (int nb = 0; nb < ((ABL & 16) ? 0 : NBQ); ++nb) {
             DDIF_SCHED_FENCE();
-            float e[16], fac[16];
-            float* Cs = Cst + (nb & 1) * (2 * 8 * 2 * 16);  // [max | sum][wave][half][value]
+            float e[16], mx[NCW], sm[NCW];
+            float* Cs = Cst + (nb & 1) * (2 * 8 * 2 * 16);  // [wave][j][max | sum]
+            const float bj = BQ[32 * nb + j];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bq4 = *reinterpret_cast<const float4*>(&BQ[32 * nb + 8 * g + 4 * h]);
+            for (int r = 0; r < 16; ++r) e[r] = fmaf(accq[nb][r], DDIF_F16_OSCALE, bj);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    e[4 * g + i] = fmaf(accq[nb][4 * g + i], DDIF_F16_OSCALE, (&bq4.x)[i]);
-                    fac[4 * g + i] = half_allmax<(TH >= 32)>(e[4 * g + i]);
+            for (int cg = 0; cg < NCW; ++cg) {
+                float m = e[cg * RPC];
+#pragma unroll
+                for (int r = 1; r < RPC; ++r) m = fmaxf(m, e[cg * RPC + r]);
+                m = fmaxf(m, __shfl_xor(m, 32));  // the other half's 8 (TH = 16) / 16 rows of the same column and channel
+                float sacc = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPC; ++r) {
+                    const float ex = dd_exp2_fast((e[cg * RPC + r] - m) * L2E);
+                    e[cg * RPC + r] = ex;
+                    sacc += ex;
                 }
+                sacc += __shfl_xor(sacc, 32);
+                mx[cg] = m;
+                sm[cg] = sacc;
             }
-            if constexpr (TH == 64) {  // a column spans the wave pair (2x, 2x + 1): the pair's maxima meet in LDS
-                if (j == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; r += 4) *reinterpret_cast<float4*>(&Cs[(wave * 2 + h) * 16 + r]) = make_float4(fac[r], fac[r + 1], fac[r + 2], fac[r + 3]);
-                }
+            if constexpr (TH == 64) {  // a column spans the wave pair (2x, 2x + 1): (max, sum) of this half
+                if (h == 0) *reinterpret_cast<float2*>(&Cs[(wave * 32 + j) * 2]) = make_float2(mx[0], sm[0]);
             }
-            // first block: every wave is past the last chunk's fragment reads (Ap aliases Hs, Aq, Ax); every block: M_b fragments + maxima visible
+            // first block: every wave is past the last chunk's fragment reads (Ap aliases Hs, Aq, Ax); every block: M_b fragments + the pair's statistics visible
             store_mix(nb & 1);
             if (nb + 1 < NBQ) load_mix(wmix_b, nb + 1);
             __syncthreads();
+            float fac[NCW];
             if constexpr (TH == 64) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    const float4 o = *reinterpret_cast<const float4*>(&Cs[((wave ^ 1) * 2 + h) * 16 + r]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fac[r + i] = fmaxf(fac[r + i], (&o.x)[i]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                e[r] = dd_exp2_fast((e[r] - fac[r]) * L2E);
-                fac[r] = half_allsum<(TH >= 32)>(e[r]);
-            }
-            if constexpr (TH == 64) {
-                float* Ss = Cs + 8 * 2 * 16;
-                if (j == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; r += 4) *reinterpret_cast<float4*>(&Ss[(wave * 2 + h) * 16 + r]) = make_float4(fac[r], fac[r + 1], fac[r + 2], fac[r + 3]);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    const float4 o = *reinterpret_cast<const float4*>(&Ss[((wave ^ 1) * 2 + h) * 16 + r]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)  // (both waves of the pair form the same bits: even wave's sum + odd wave's sum)
-                        fac[r + i] = dd_rcp_fast((wave & 1) ? (&o.x)[i] + fac[r + i] : fac[r + i] + (&o.x)[i]);
-                }
+                const float2 o = *reinterpret_cast<const float2*>(&Cs[((wave ^ 1) * 32 + j) * 2]);
+                const float M = fmaxf(mx[0], o.x);
+                const float cme = dd_exp2_fast((mx[0] - M) * L2E), cpt = dd_exp2_fast((o.x - M) * L2E);
+                // (both waves of the pair form the same bits: even wave's term + odd wave's term)
+                const float S = (wave & 1) ? (o.y * cpt + sm[0] * cme) : (sm[0] * cme + o.y * cpt);
+                fac[0] = cme * dd_rcp_fast(S);
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) fac[r] = dd_rcp_fast(fac[r]);
+                for (int cg = 0; cg < NCW; ++cg) fac[cg] = dd_rcp_fast(sm[cg]);
             }
-            if (nb > 0) DDIF_WAVE_LDS_SYNC();  // the previous block's fragment reads are done
+            if (nb > 0) DDIF_WAVE_LDS_SYNC();  // the previous block's tile reads are done
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // channels 32 nb + 8 g + 4 h + i  ->  slab g / 2 of the block, k half g % 2, elements 4 h + i
-                unsigned h01, m01, l01, h23, m23, l23;
-                dd_split3_pair(e[4 * g + 0] * fac[4 * g + 0], e[4 * g + 1] * fac[4 * g + 1], &h01, &m01, &l01);
-                dd_split3_pair(e[4 * g + 2] * fac[4 * g + 2], e[4 * g + 3] * fac[4 * g + 3], &h23, &m23, &l23);
-                float* d = &Apw[j * APS + (g >> 1) * 28 + (g & 1) * 4 + 2 * h];
-                *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
-                *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
-                *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
-            }
+            for (int r = 0; r < 16; ++r)  // pixel 8 g + 4 h + i of the wave, channel j
+                Tw[((r >> 2) * 8 + 4 * h + (r & 3)) * TLD + j] = e[r] * fac[r / RPC];
             DDIF_WAVE_LDS_SYNC();
             const float* Fb = Fm + (nb & 1) * NPF * 256 + lane * 4;
 #pragma unroll
             for (int k16 = 0; k16 < 2; ++k16) {
+                // lane (j, h) as B operand: pixel j, channels 16 k16 + 8 h .. + 7 of the block
+                const float4 t0 = *reinterpret_cast<const float4*>(&Tw[j * TLD + 16 * k16 + 8 * h]);
+                const float4 t1 = *reinterpret_cast<const float4*>(&Tw[j * TLD + 16 * k16 + 8 * h + 4]);
+                unsigned hh[4], mm[4], ll[4];
+                dd_split3_pair(t0.x, t0.y, &hh[0], &mm[0], &ll[0]);
+                dd_split3_pair(t0.z, t0.w, &hh[1], &mm[1], &ll[1]);
+                dd_split3_pair(t1.x, t1.y, &hh[2], &mm[2], &ll[2]);
+                dd_split3_pair(t1.z, t1.w, &hh[3], &mm[3], &ll[3]);
                 float4 xp[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xp[pl] = *reinterpret_cast<const float4*>(&Apw[j * APS + k16 * 28 + pl * 8 + 4 * h]);
+                xp[0] = make_float4(__builtin_bit_cast(float, hh[0]), __builtin_bit_cast(float, hh[1]), __builtin_bit_cast(float, hh[2]), __builtin_bit_cast(float, hh[3]));
+                xp[1] = make_float4(__builtin_bit_cast(float, mm[0]), __builtin_bit_cast(float, mm[1]), __builtin_bit_cast(float, mm[2]), __builtin_bit_cast(float, mm[3]));
+                xp[2] = make_float4(__builtin_bit_cast(float, ll[0]), __builtin_bit_cast(float, ll[1]), __builtin_bit_cast(float, ll[2]), __builtin_bit_cast(float, ll[3]));
 #pragma unroll
                 for (int na = 0; na < NBA; ++na) {
                     float4 f[3];
