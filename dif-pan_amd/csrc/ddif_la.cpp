@@ -15,7 +15,7 @@ int la_launch1(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only) 
         DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));
         return 0;
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), G::smem, s, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(2 * TH * TW), G::smem, s, a);
     return 0;
 }
 template <int TH, int TW>
@@ -41,12 +41,19 @@ bool lafuse_supported(int H, int fea, int dout) {
     if (H == 16 && fea == 192 && dout == 64 && la6) return true;
     return (H == 64 || H == 32 || H == 16) && fea % 32 == 0 && fea >= 64 && fea <= 128 && dout % 32 == 0 && dout >= 32 && dout <= 64;
 }
-int lafuse_strip(int H) { return 256 / H; }
-int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only) {
+// image columns per workgroup: 256 pixels on eight wavefronts (nw = 8) or 128 on four (nw = 4, round 6: chosen by the plan when the eight-wave grid would leave CUs idle)
+int lafuse_strip(int H, int nw) { return 32 * nw / H; }
+int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only, int nw) {
     const int nbq = (a.c0 + a.c1) / 32, nba = a.dout / 32;
-    if (a.H == 64) return la_launch_t<64, 4>(a, nbq, nba, grid, s, prepare_only);
-    if (a.H == 32) return la_launch_t<32, 8>(a, nbq, nba, grid, s, prepare_only);
-    if (a.H == 16) return la_launch_t<16, 16>(a, nbq, nba, grid, s, prepare_only);  // a 16 x 16 sample = one workgroup
+    if (nw == 4) {
+        if (a.H == 64) return la_launch_t<64, 2>(a, nbq, nba, grid, s, prepare_only);
+        if (a.H == 32) return la_launch_t<32, 4>(a, nbq, nba, grid, s, prepare_only);
+        if (a.H == 16) return la_launch_t<16, 8>(a, nbq, nba, grid, s, prepare_only);
+    } else {
+        if (a.H == 64) return la_launch_t<64, 4>(a, nbq, nba, grid, s, prepare_only);
+        if (a.H == 32) return la_launch_t<32, 8>(a, nbq, nba, grid, s, prepare_only);
+        if (a.H == 16) return la_launch_t<16, 16>(a, nbq, nba, grid, s, prepare_only);  // a 16 x 16 sample = one workgroup
+    }
     return fail(DDIF_ERR_INVALID, "linattn_fused: H = %d", a.H);
 }
 

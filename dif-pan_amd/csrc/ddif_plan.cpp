@@ -1306,8 +1306,16 @@ int Plan::build_impl() {
                 a.bias = pm->bias;
                 a.out = amix.p;
                 a.dout = pm->cout;
-                if (!dry) DDIF_TRY(la8 ? lafuse8_launch(a, 1, nullptr, true) : lafuse_launch(a, 1, nullptr, true));
-                const int nstrips = la8 ? 2 : (Wl + lafuse_strip(Hl) - 1) / lafuse_strip(Hl);
+                // four-wave workgroups of 128 pixels instead of eight-wave ones of 256 when the latter would not fill the CUs (round 6; same results either way:
+                // kernels_lafuse.h).  DDIF_LA_NW = 8 / 4 forces one form (tests/test_env_switches.py).
+                int la_nw = 8;
+                if (!la8) {
+                    static const int nw_env = [] { const char* e = getenv("DDIF_LA_NW"); return e ? atoi(e) : 0; }();
+                    const long wg8 = (long)B * ((Wl + lafuse_strip(Hl, 8) - 1) / lafuse_strip(Hl, 8));
+                    la_nw = nw_env == 4 || nw_env == 8 ? nw_env : (wg8 < num_cus() ? 4 : 8);
+                }
+                if (!dry) DDIF_TRY(la8 ? lafuse8_launch(a, 1, nullptr, true) : lafuse_launch(a, 1, nullptr, true, la_nw));
+                const int nstrips = la8 ? 2 : (Wl + lafuse_strip(Hl, la_nw) - 1) / lafuse_strip(Hl, la_nw);
                 long cap = num_cus();
                 if (g_debug_grid_cap > 0 && g_debug_grid_cap < cap) cap = g_debug_grid_cap;
                 Op op;
@@ -1323,10 +1331,10 @@ int Plan::build_impl() {
                 // q.1 on f16x2 (x3), attn_out / attn_res on bf16x3 (x6): weight of the sum
                 op.mfma_w = (3.0 * fea * fea + 6.0 * 2.0 * fea * pm->cout) / ((double)fea * fea + 9.0 * fea + 2.0 * fea * pm->cout);
                 if (la8) op.name = "linattn8_fused";
-                op.run = [a, nstrips, cap, la8](hipStream_t st, const StepCtx&) {
+                op.run = [a, nstrips, cap, la8, la_nw](hipStream_t st, const StepCtx&) {
                     const long nw = (long)a.B * nstrips;
                     if (la8) (void)lafuse8_launch(a, (int)(nw < cap ? nw : cap), st, false);
-                    else (void)lafuse_launch(a, (int)(nw < cap ? nw : cap), st, false);
+                    else (void)lafuse_launch(a, (int)(nw < cap ? nw : cap), st, false, la_nw);
                 };
                 step.push_back(std::move(op));
                 fused_attn = true;

@@ -69,8 +69,8 @@ extern int g_f16_raw;
 // fused linear-attention block (kernels_lafuse.h, ddif_la.cpp)
 struct LaFuseArgs;
 bool lafuse_supported(int H, int fea, int dout);
-int lafuse_strip(int H);
-int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only);
+int lafuse_strip(int H, int nw = 8);
+int lafuse_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only, int nw = 8);
 bool lafuse8_supported(int H, int W, int c0, int c1, int dout);  // the 8 x 8 level (kernels_lafuse8.h)
 int lafuse8_launch(const LaFuseArgs& a, int grid, hipStream_t s, bool prepare_only);
 // launchers of kernels that live in other translation units (every non-template kernel header is compiled into exactly one object)

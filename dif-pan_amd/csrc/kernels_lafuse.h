@@ -52,20 +52,21 @@ struct LaFuseArgs {
 
 template <int TH, int TW, int NBQ, int NBA>
 struct LaFuseGeom {
+    static constexpr int NPX = TH * TW, NWV = NPX / 32;  // pixels / wavefronts of a workgroup (256 / 8, or 128 / 4: round 6)
     static constexpr int HH = TH + 2, HW = TW + 2;      // halo tile
     static constexpr int LDH = 24;                      // floats per halo pixel (16 channels + pad: conflict-free depthwise reads)
     static constexpr int LDQ = 20;                      // dwq: 2 half planes x 32 B + 16 B pad
     static constexpr int LDX = 28;                      // xn: 3 bf16 planes x 32 B + 16 B pad
     static constexpr int APS = 60;                      // p: 2 slabs x (3 planes x 32 B) + pad, floats per pixel (conflict-free fragment reads)
-    static constexpr int HS = HH * HW * LDH, AQ = 256 * LDQ, AX = 256 * LDX;
+    static constexpr int HS = HH * HW * LDH, AQ = NPX * LDQ, AX = NPX * LDX;
     static constexpr int NPC = 2 * NBQ + 3 * NBA;       // 1 KiB weight pieces of one chunk: q.1 (hi | lo per block), attn_res (3 planes per block)
     static constexpr int WC = NPC * 256;                // floats
     static constexpr int NPF = 6 * NBA;                 // pieces of one 32-channel block of M_b: [block][k16][plane]
     static constexpr int FM = 2 * NPF * 256;            // double-buffered by block parity
-    static constexpr int AP = 256 * APS;                // aliases Hs | Aq | Ax once the chunk loop is over (written behind the first block's barrier)
+    static constexpr int AP = NPX * APS;                // aliases Hs | Aq | Ax once the chunk loop is over (written behind the first block's barrier)
     static constexpr int FEA = 32 * NBQ;
     static constexpr int TAB = 2 * FEA + 9 * FEA + FEA + 32 * NBA;  // gamma | beta | depthwise | q bias | output bias
-    static constexpr int CST = 2 * 2 * 8 * 2 * 16;      // column statistics exchange, double-buffered by block parity: [parity][max | sum][wave][half][value]
+    static constexpr int CST = 2 * NWV * 32 * 2;        // (max, sum) exchange of the wave pairs of 64-row columns, double-buffered by block parity: [parity][wave][j][max | sum]
     // Fm is NOT aliased: block 0's fragments are written while other waves may still read the last chunk's Ax / Wc
     static constexpr int MAIN = ((HS + AQ + AX + WC) > AP ? (HS + AQ + AX + WC) : AP) + FM;
     static constexpr size_t smem = (size_t)(MAIN + TAB + CST) * sizeof(float);
@@ -125,15 +126,21 @@ __device__ __forceinline__ float half_allsum(float v) {
 
 // ABL (tools/mbench_la.cpp only): 1 = no input loads, 2 = no weight loads, 4 = no MFMAs, 8 = no depthwise / split stage, 16 = no softmax + attn_out part,
 // 32 = no output stores, 64 = s_memtime stamps of thread 0 into a.dbg
+// Round 6: TH * TW = 256 pixels on eight wavefronts, or 128 pixels on FOUR.  A wave's work does not depend on the workgroup's size (32 pixels x all output channels,
+// weights shared through LDS), and the kernel is bound by vector issue with two waves per SIMD: when the eight-wave grid would leave CUs idle (16 x 16 level at
+// B = 64: 64 workgroups; every level at 8-16 tiles per GPU) the host launches twice as many four-wave workgroups and every wave has a SIMD to itself.  Same
+// per-pixel arithmetic in the same order: results do not depend on the choice (tests/test_env_switches.py DDIF_LA_NW).
 template <int TH, int TW, int NBQ, int NBA, int ABL = 0>
-__global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
+__global__ __launch_bounds__(TH * TW * 2) void linattn_fused_kernel(LaFuseArgs a) {
     using G = LaFuseGeom<TH, TW, NBQ, NBA>;
-    static_assert(TH * TW == 256 && (TH == 16 || TH == 32 || TH == 64), "a workgroup owns 256 pixels = whole columns of the sample");
+    constexpr int NW = G::NWV, NTHR = 64 * NW;
+    static_assert((TH * TW == 256 || TH * TW == 128) && (TH == 16 || TH == 32 || TH == 64), "a workgroup owns 256 or 128 pixels = whole columns of the sample");
+    static_assert(TH != 64 || NW % 2 == 0, "64-row columns span a wave pair");
     constexpr int HH = G::HH, HW = G::HW, LDH = G::LDH, LDQ = G::LDQ, LDX = G::LDX, APS = G::APS, FEA = G::FEA;
     constexpr int NCH = 2 * NBQ;                              // 16-channel chunks
-    constexpr int NIT = (HH * HW * 4 + 511) / 512;            // raw float4 items per thread and chunk
+    constexpr int NIT = (HH * HW * 4 + NTHR - 1) / NTHR;      // raw float4 items per thread and chunk
     constexpr int NPC = G::NPC, NPF = G::NPF;
-    constexpr int WIT = (NPC + 7) / 8, FIT = (NPF + 7) / 8;   // weight pieces per wave (a piece = 64 lanes x 16 B)
+    constexpr int WIT = (NPC + NW - 1) / NW, FIT = (NPF + NW - 1) / NW;   // weight pieces per wave (a piece = 64 lanes x 16 B)
     constexpr float L2E = 1.4426950408889634f;
     constexpr bool PAIRDW = (NBQ == 2 && NBA == 1);  // depthwise stage on vertically adjacent pixel pairs (round 6): the 32 + 32 -> 32 blocks of the 64 x 64 level
 
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
         rok = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int pix = (tid + it * 512) >> 2;
+            const int pix = (tid + it * NTHR) >> 2;
             const bool in = pix < HH * HW;
             const int pc = in ? pix : HH * HW - 1;
             const int y = pc / HW - 1, x = x0 + pc % HW - 1;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     auto load_weights = [&](const float* wmix_b, int k) {
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
-            const int pc = wave + 8 * i;
+            const int pc = wave + NW * i;
             const int p = pc < NPC ? pc : NPC - 1;  // (waves past the end re-read the last piece; not written)
             const float* src;
             if (p < 2 * NBQ) src = a.wq + ((size_t)(((p >> 1) * a.nchq + (k >> 1)) * 2 + (k & 1)) * 2 + (p & 1)) * 256;
@@ -209,14 +216,14 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     auto store_weights = [&]() {
 #pragma unroll
         for (int i = 0; i < WIT; ++i)
-            if (wave + 8 * i < NPC) *reinterpret_cast<float4*>(&Wc[(wave + 8 * i) * 256 + lane * 4]) = wst[i];
+            if (wave + NW * i < NPC) *reinterpret_cast<float4*>(&Wc[(wave + NW * i) * 256 + lane * 4]) = wst[i];
     };
     // the 6 NBA pieces of block nb of M_b: piece (na * 2 + k16) * 3 + pl
     float4 fst[FIT];
     auto load_mix = [&](const float* wmix_b, int nb) {
 #pragma unroll
         for (int i = 0; i < FIT; ++i) {
-            const int pc = wave + 8 * i;
+            const int pc = wave + NW * i;
             const int p = pc < NPF ? pc : NPF - 1;
             const float* src = wmix_b + ((size_t)(((p / 6) * a.nch_mix + nb) * 2 + (p % 6) / 3) * 3 + p % 3) * 256;
             fst[i] = (ABL & 2) ? make_float4(1e-3f, 2e-3f, 3e-3f, (float)nb) : *reinterpret_cast<const float4*>(src + lane * 4);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     auto store_mix = [&](int par) {
 #pragma unroll
         for (int i = 0; i < FIT; ++i)
-            if (wave + 8 * i < NPF) *reinterpret_cast<float4*>(&Fm[(par * NPF + wave + 8 * i) * 256 + lane * 4]) = fst[i];
+            if (wave + NW * i < NPF) *reinterpret_cast<float4*>(&Fm[(par * NPF + wave + NW * i) * 256 + lane * 4]) = fst[i];
     };
 
     int gn_b = -1;
@@ -238,13 +245,13 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
     }
     // tables (once per launch) -- AFTER the first strip's loads have been issued: the table fills wait for their own loads, and on the cold caches every launch starts with that is a
     // round trip the first tile should share, not follow
-    for (int i = tid; i < FEA; i += 512) {
+    for (int i = tid; i < FEA; i += NTHR) {
         GB[i] = a.gamma[i];
         GB[FEA + i] = a.beta[i];
         BQ[i] = a.bq[i];
     }
-    for (int i = tid; i < 9 * FEA; i += 512) DW[i] = a.dw_w[i];
-    for (int i = tid; i < 32 * NBA; i += 512) BO[i] = i < a.dout ? a.bias[i] : 0.f;
+    for (int i = tid; i < 9 * FEA; i += NTHR) DW[i] = a.dw_w[i];
+    for (int i = tid; i < 32 * NBA; i += NTHR) BO[i] = i < a.dout ? a.bias[i] : 0.f;
     {
         const int b = a.b0 + w0 / nstrips;
         gn_reduce_partials(gp0, a.st0, a.np0, a.st1, a.np1, b, (double)FEA * a.H * a.W, &mean, &rstd);
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const bool ok = (rok >> it) & 1u;
-                    const int pix = (tid + it * 512) >> 2;
+                    const int pix = (tid + it * NTHR) >> 2;
                     float4 v;
                     v.x = ok ? fmaf(raw[it].x, ga[0], gb[0]) : 0.f;
                     v.y = ok ? fmaf(raw[it].y, ga[1], gb[1]) : 0.f;
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
             //     item hoisted, as hipcc prefers, cost 72 registers and pushed the accumulators into scratch.
 #pragma unroll
             for (int it = 0; it < ((ABL & 8) ? 0 : 2); ++it) {
-                const int item = tid + it * 512, p = item >> 2;
+                const int item = tid + it * NTHR, p = item >> 2;
                 const int x = p / TH, y = p % TH;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
                 float4 cen = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(512) void linattn_fused_kernel(LaFuseArgs a) {
         for (int nb = 0; nb < ((ABL & 16) ? 0 : NBQ); ++nb) {
             DDIF_SCHED_FENCE();
             float e[16], mx[NCW], sm[NCW];
-            float* Cs = Cst + (nb & 1) * (2 * 8 * 2 * 16);  // [wave][j][max | sum]
+            float* Cs = Cst + (nb & 1) * (NW * 32 * 2);  // [wave][j][max | sum]
             const float bj = BQ[32 * nb + j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) e[r] = fmaf(accq[nb][r], DDIF_F16_OSCALE, bj);
