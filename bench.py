@@ -450,9 +450,13 @@ def main():
         result["rccl"] = rccl
     if rank == 0 and world == 1 and strong and not args.no_shares and total == 64:
         result["projected_strong_scaling"] = strong_scaling_shares(diffusion, net, cf, C, P, H, T, n_evals, order, dev, dt / args.steps * 1e3)
-    if rank == 0 and world == 1 and args.config == "wv3" and not args.no_parity:
+    # the probe and the bracket belong to the full default line only: not to shortened profiling runs (--T), and never under a profiler -- the bracket starts a
+    # child process, and a process spawned from under rocprofv3's preloaded tool is exactly the exec the GPU boxes forbid (a --pmc pass hung on it in round 6)
+    profiled = any(k in os.environ for k in ("ROCPROFILER_REGISTER_LIBRARY", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    full_line = rank == 0 and world == 1 and args.config == "wv3" and T == cf["T"] and not profiled
+    if full_line and not args.no_parity:
         result["parity"] = parity_probe(net, dev)
-    if rank == 0 and world == 1 and args.config == "wv3" and not args.no_bracket and "DDIF_X3" not in os.environ and "DDIF_F16" not in os.environ:
+    if full_line and not args.no_bracket and "DDIF_X3" not in os.environ and "DDIF_F16" not in os.environ:
         result["exact_fp32"] = exact_fp32_bracket(B, H)
         if result["exact_fp32"].get("ms_per_denoising_step"):
             result["ms_per_step_exact_fp32"] = result["exact_fp32"]["ms_per_denoising_step"] * T

@@ -57,14 +57,22 @@ static int attn_nw() {
     static const int v = [] { const char* e = getenv("DDIF_ATTN_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
     return v;
 }
+// DDIF_ATTN_SPLIT=1: one workgroup per sample (rounds 3-5) instead of two (round 6, kernels_attn.h SPLIT = 2: the token halves of a sample on two CUs); same values
+int attn_block_split() {
+    static const int v = [] { const char* e = getenv("DDIF_ATTN_SPLIT"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    return attn_nw() == 8 ? 1 : v;
+}
 int attn_block_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     return 0;
 }
+// grid: workgroups to launch (<= a.B * attn_block_split(); each walks samples / halves with that stride)
 void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
-    if (attn_nw() == 4) hipLaunchKernelGGL(attn_block_kernel<4>, dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
-    else hipLaunchKernelGGL(attn_block_kernel<8>, dim3(grid), dim3(512), AttnBlockGeom::smem, s, a);
+    if (attn_nw() == 8) hipLaunchKernelGGL(attn_block_kernel<8>, dim3(grid), dim3(512), AttnBlockGeom::smem, s, a);
+    else if (attn_block_split() == 2) hipLaunchKernelGGL((attn_block_kernel<4, 0, 2>), dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
+    else hipLaunchKernelGGL(attn_block_kernel<4>, dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
 }
 
 // mb = 2: 8x8 pixel tiles, mb = 4: 8x16.  The per-sample time bias needs no variant of its own here (the epilogue reads

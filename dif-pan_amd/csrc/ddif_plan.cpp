@@ -688,8 +688,9 @@ int Plan::build_impl() {
             // sample (kernels_attn.h); other sizes take the three-launch path below
             use(in.p);
             DDIF_TRY(alloc_tensor(out, in.C, in.H, in.W, true));
-            out->np = 1;
-            DDIF_TRY(dalloc(&out->st, (size_t)B * 2));
+            const int asplit = attn_block_split();  // workgroups (= statistics partials) per sample
+            out->np = asplit;
+            DDIF_TRY(dalloc(&out->st, (size_t)B * 2 * asplit));
             DDIF_TRY(attn_block_prepare());
             AttnBlockArgs a{};
             a.x = in.p;
@@ -713,7 +714,7 @@ int Plan::build_impl() {
             op.flop = 2.0 * B * 64 * 128.0 * (384 + 128) + 4.0 * B * 8 * 64.0 * 64 * 16;
             op.bytes = 8.0 * B * 64 * 128;
             const int ncu = num_cus();
-            op.run = [a, ncu](hipStream_t s, const StepCtx&) { attn_block_launch(a, a.B < ncu ? a.B : ncu, s); };
+            op.run = [a, ncu, asplit](hipStream_t s, const StepCtx&) { attn_block_launch(a, a.B * asplit < ncu ? a.B * asplit : ncu, s); };
             step.push_back(std::move(op));
             return 0;
         }

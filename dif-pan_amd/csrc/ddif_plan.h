@@ -114,6 +114,7 @@ void dw3x3_plain(hipStream_t s, const float* in, int C, int B, int H, int W, con
 struct AttnBlockArgs;
 int attn_block_prepare();                                                        // ddif_lr.cpp (kernels_attn.h)
 void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s);
+int attn_block_split();  // workgroups per sample (2 since round 6; DDIF_ATTN_SPLIT=1: one)
 
 // round 6: ask add_conv() to fold the NEXT block's CondInjection (x_conv + FiLM) into this conv's epilogue (kernels_conv.h EPI_XF); `done` and `out` come back
 struct XfReq {

@@ -36,9 +36,17 @@ struct AttnBlockGeom {
 };
 
 // ABL (tools/mbench_attn.cpp only): 1 = s_memtime stamps of thread 0 at the stage boundaries into a.dbg
-template <int NW, int ABL = 0>
+// SPLIT = 2 (round 6): a sample on TWO workgroups = two CUs.  The block is bound by the matrix pipe of its CU (profiles/r06/attn_block_stamps.txt) and B = 64
+// samples occupy 64 of 256 CUs: workgroup (b, half) stages the whole sample and computes q, k, v of all 64 tokens (k and v of every token are needed by every query;
+// q of the other half is the redundant sixth), then runs the attention core and the out-projection + residual for ITS 32 query tokens only -- 464 instead of 640
+// matrix instructions per wave, no exchange between the two workgroups, one statistics partial each.  Every value is computed by the same instruction sequence as
+// with one workgroup per sample.
+template <int NW, int ABL = 0, int SPLIT = 1>
 __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per sample");
+    static_assert(SPLIT == 1 || (SPLIT == 2 && NW == 4), "token-half split: four wavefronts");
+    constexpr int QT = 4 / SPLIT;     // 16-query tiles of a workgroup
+    constexpr int MBO = (8 / NW) / SPLIT > 0 ? (8 / NW) / SPLIT : 1;  // token blocks per wave in the out-projection
     constexpr int MBW = 8 / NW;       // token blocks per wave in the two 1x1 convs (NW = 8: one, chosen by the wave's parity)
     constexpr int HPW = 8 / NW;       // heads per wave
     constexpr int TPP = 2 * NW;       // tokens per staging pass (32 float4 channel groups per token)
@@ -71,7 +79,9 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
 
     const unsigned ga = gridDim.x;
     const int bw = (a.xcd && (ga & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (ga >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;  // XCD-contiguous sample order
-    for (int b = a.b0 + bw; b < a.b0 + a.B; b += gridDim.x) {
+    for (int wk = bw; wk < a.B * SPLIT; wk += gridDim.x) {
+        const int b = a.b0 + wk / SPLIT;
+        const int half = wk % SPLIT;  // SPLIT = 2: this workgroup's 32 query tokens
         // ---- (1) loads in one burst: GroupNorm partials, the sample, affine parameters, first weight slab
         GnPartials gp;
         gn_load_partials(a.st, a.np, nullptr, 0, b, &gp);
@@ -189,17 +199,16 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
             for (int hh = 0; hh < HPW; ++hh) {
                 const int hd = HPW * wave + hh;
                 const float* base = Qs + hd * 3 * D;  // + token * QROW + {0, D, 2D} + d
-                float4 qf[4], kf[4];
+                float4 qf[QT], kf[4];
 #pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    qf[t4] = *reinterpret_cast<const float4*>(base + (t4 * 16 + jj) * QROW + 4 * g4);
-                    kf[t4] = *reinterpret_cast<const float4*>(base + (t4 * 16 + jj) * QROW + D + 4 * g4);
-                }
-                f32x4 st[4][4];  // [kt][qt]: S^T tiles; value r <-> key 16 kt + 4 g4 + r, query 16 qt + jj
+                for (int t4 = 0; t4 < 4; ++t4) kf[t4] = *reinterpret_cast<const float4*>(base + (t4 * 16 + jj) * QROW + D + 4 * g4);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) qf[qt] = *reinterpret_cast<const float4*>(base + ((half * QT + qt) * 16 + jj) * QROW + 4 * g4);
+                f32x4 st[4][QT];  // [kt][qt]: S^T tiles; value r <-> key 16 kt + 4 g4 + r, query 16 (half QT + qt) + jj
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int qt = 0; qt < 4; ++qt) {
+                    for (int qt = 0; qt < QT; ++qt) {
                         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) c = DDIF_MFMA_16x16x4((&kf[kt].x)[kk], (&qf[qt].x)[kk], c);
@@ -209,9 +218,9 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
                     }
                 // softmax over keys = over the rows of S^T: 16 values per lane (4 key tiles x 4 regs) + xor-shuffles 16, 32.  The
                 // tiles are overwritten with p = exp(s - max) (one v_exp_f32 per logit, reused by the P V pass)
-                float inv[4];
+                float inv[QT];
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     float bm = -INFINITY;
 #pragma unroll
                     for (int kt = 0; kt < 4; ++kt)
@@ -232,9 +241,9 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
                     ps += __shfl_xor(ps, 32);
                     inv[qt] = 1.f / ps;
                 }
-                f32x4 oacc[4];
+                f32x4 oacc[QT];
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) oacc[qt][r] = 0.f;
 #pragma unroll
@@ -243,18 +252,18 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vf[r] = base[(kt * 16 + 4 * g4 + r) * QROW + 2 * D + jj];
 #pragma unroll
-                    for (int qt = 0; qt < 4; ++qt)
+                    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) oacc[qt] = DDIF_MFMA_16x16x4(st[kt][qt][r] * inv[qt], vf[r], oacc[qt]);
                 }
-                // O tile: col = jj = channel hd*16 + jj, row = 4 g4 + r = query 16 qt + 4 g4 + r  -> slab hd of the o planes
+                // O tile: col = jj = channel hd*16 + jj, row = 4 g4 + r = query 16 (half QT + qt) + 4 g4 + r  -> slab hd of the o planes
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         unsigned q0, q1, q2;
                         dd_split3(oacc[qt][r], &q0, &q1, &q2);
-                        unsigned short* d16 = reinterpret_cast<unsigned short*>(&As[(qt * 16 + 4 * g4 + r) * APIX + hd * 24]) + jj;
+                        unsigned short* d16 = reinterpret_cast<unsigned short*>(&As[((half * QT + qt) * 16 + 4 * g4 + r) * APIX + hd * 24]) + jj;
                         d16[0] = (unsigned short)q0;
                         d16[16] = (unsigned short)q1;  // next plane: + 8 floats = 16 halves
                         d16[32] = (unsigned short)q2;
@@ -265,32 +274,33 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
         __syncthreads();  // o planes complete
         stamp();  // 8: barrier
 
-        // ---- (4) out = o . Wout^T + bias + x : cout block `cw`, MBW token blocks, K = 8 slabs
+        // ---- (4) out = o . Wout^T + bias + x : cout block `cw`, MBO token blocks (SPLIT = 2: this workgroup's half), K = 8 slabs
         {
-            f32x16 acc[MBW];
+            const int mo0 = (SPLIT == 2) ? half : mb0;
+            f32x16 acc[MBO];
 #pragma unroll
-            for (int mb = 0; mb < MBW; ++mb)
+            for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             // epilogue operands: bias and the residual rows of this lane's tokens
-            float4 bo[4], er[MBW][4];
+            float4 bo[4], er[MBO][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bo[g] = *reinterpret_cast<const float4*>(a.bout + cw * 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) er[mb][g] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + (mb0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h);
+                for (int mb = 0; mb < MBO; ++mb) er[mb][g] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + (mo0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h);
             }
 #pragma unroll
             for (int s = 0; s < NSLAB; ++s) {
                 if (s + 1 < NSLAB) load_out_w((s + 1) & 1, s + 1);
-                float4 xa[MBW][3];
+                float4 xa[MBO][3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int mb = 0; mb < MBW; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[((mb0 + mb) * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
+                    for (int mb = 0; mb < MBO; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[((mo0 + mb) * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
                 DDIF_SCHED_FENCE();
 #pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) {
+                for (int mb = 0; mb < MBO; ++mb) {
                     f32x16 c = acc[mb];
                     const float4* w = wo_r[s & 1];
                     c = DDIF_MFMA_32x32x16_BF16(w[2], xa[mb][0], c);
@@ -306,13 +316,13 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
             stamp();  // 9: out contraction issued
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < MBW; ++mb)
+            for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = (acc[mb][4 * g + i] + (&bo[g].x)[i]) + (&er[mb][g].x)[i];
-                    *reinterpret_cast<float4*>(a.out + ((size_t)b * N + (mb0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(a.out + ((size_t)b * N + (mo0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
                     s1 += (v[0] + v[1]) + (v[2] + v[3]);
                     s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 }
@@ -334,8 +344,8 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
                 t0 += ((double)Sst[8] + (double)Sst[10]) + ((double)Sst[12] + (double)Sst[14]);
                 t1 += ((double)Sst[9] + (double)Sst[11]) + ((double)Sst[13] + (double)Sst[15]);
             }
-            a.st_out[(size_t)b * 2 + 0] = t0;
-            a.st_out[(size_t)b * 2 + 1] = t1;
+            a.st_out[((size_t)b * SPLIT + half) * 2 + 0] = t0;  // (one partial per workgroup: np = SPLIT)
+            a.st_out[((size_t)b * SPLIT + half) * 2 + 1] = t1;
         }
     }
 }

@@ -15,16 +15,16 @@ if [ "$1" != "skip-tests" ]; then
 fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python3 $R/bench.py --steps 1 --warmup 1 --T 20 --no-cpu-baseline > $R/gpurun_out/${tag}_bench_T20.json 2> /tmp/prof_$tag.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python3 $R/bench.py --steps 1 --warmup 1 --T 20 --no-cpu-baseline --no-parity --no-bracket > $R/gpurun_out/${tag}_bench_T20.json 2> /tmp/prof_$tag.log
 cp $(find /tmp/prof_$tag -name "*kernel_stats.csv") $R/gpurun_out/${tag}_kernel_stats_T20_B64.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python3 $R/bench.py --steps 1 --warmup 0 --T 4 --no-cpu-baseline > /dev/null 2> /tmp/pmc_$c.log
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python3 $R/bench.py --steps 1 --warmup 0 --T 4 --no-cpu-baseline --no-parity --no-bracket > /dev/null 2> /tmp/pmc_$c.log
   python3 $R/tools/pmc_summary.py $(find /tmp/pmc_$c -name "*counter_collection.csv") 60 > $R/gpurun_out/${tag}_pmc_$c.csv
 done
 python3 $R/tools/pmc_traffic.py $R/gpurun_out/${tag}_pmc_FETCH_SIZE.csv $R/gpurun_out/${tag}_pmc_WRITE_SIZE.csv $R/gpurun_out/${tag}_hbm_traffic.json
 rm -rf /tmp/pmc_mfma
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --output-format csv -d /tmp/pmc_mfma -o p -- python3 $R/bench.py --steps 1 --warmup 0 --T 4 --no-cpu-baseline > /dev/null 2> /tmp/pmc_mfma.log
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --output-format csv -d /tmp/pmc_mfma -o p -- python3 $R/bench.py --steps 1 --warmup 0 --T 4 --no-cpu-baseline --no-parity --no-bracket > /dev/null 2> /tmp/pmc_mfma.log
 f=$(find /tmp/pmc_mfma -name "*counter_collection.csv")
 if [ -n "$f" ]; then
   python3 $R/tools/pmc_summary.py $f 60 > $R/gpurun_out/${tag}_pmc_mfma.csv
@@ -33,7 +33,7 @@ else
   tail -5 /tmp/pmc_mfma.log
 fi
 cd $R
-DDIF_OP_TIMING=$R/gpurun_out/${tag}_op_timing_T40_B64.csv python3 bench.py --steps 1 --warmup 1 --T 40 --no-cpu-baseline > /dev/null 2>&1
+DDIF_OP_TIMING=$R/gpurun_out/${tag}_op_timing_T40_B64.csv python3 bench.py --steps 1 --warmup 1 --T 40 --no-cpu-baseline --no-parity --no-bracket > /dev/null 2>&1
 cp gpurun_out/${tag}_hbm_traffic.json profiles/$rnd/${ser}_hbm_traffic.json 2>/dev/null   # so that the bench line below can tie its traffic to this build
 python3 bench.py > gpurun_out/${tag}_bench_T1000_B64.json 2> gpurun_out/${tag}_bench_T1000_B64.log
 cat gpurun_out/${tag}_bench_T1000_B64.json
@@ -48,7 +48,7 @@ python3 tools/parity_report.py --full > gpurun_out/${tag}_parity_report_f16x2.tx
 DDIF_F16=0 DDIF_X3=0 python3 tools/parity_report.py --full > gpurun_out/${tag}_parity_report_exact_fp32.txt 2>&1
 cd /tmp
 rm -rf /tmp/prof_train_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train_$tag -o p -- python3 $R/bench.py --config wv3_train_b32 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> /tmp/prof_train_$tag.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train_$tag -o p -- python3 $R/bench.py --config wv3_train_b32 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> /tmp/prof_train_$tag.log
 cp $(find /tmp/prof_train_$tag -name "*kernel_stats.csv") $R/gpurun_out/${tag}_train_kernel_stats.csv
 cd $R
 python3 - <<PY
