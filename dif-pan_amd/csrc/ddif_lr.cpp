@@ -57,21 +57,24 @@ static int attn_nw() {
     static const int v = [] { const char* e = getenv("DDIF_ATTN_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
     return v;
 }
-// DDIF_ATTN_SPLIT=1: one workgroup per sample (rounds 3-5) instead of two (round 6, kernels_attn.h SPLIT = 2: the token halves of a sample on two CUs); same values
+// DDIF_ATTN_SPLIT = 1 / 2: one / two workgroups per sample instead of four (round 6, kernels_attn.h SPLIT: the query tokens of a sample on up to four CUs, k and v
+// recomputed by each, no exchange); same values.  Measured at B = 64: 22.5 / 16.6 / 15.8 us per launch, 3.418 / 3.366 / 3.344 ms per step (profiles/r06/attn_split_ab.txt)
 int attn_block_split() {
-    static const int v = [] { const char* e = getenv("DDIF_ATTN_SPLIT"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    static const int v = [] { const char* e = getenv("DDIF_ATTN_SPLIT"); const int x = e ? atoi(e) : 4; return (x == 1 || x == 2) ? x : 4; }();
     return attn_nw() == 8 ? 1 : v;
 }
 int attn_block_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     return 0;
 }
 // grid: workgroups to launch (<= a.B * attn_block_split(); each walks samples / halves with that stride)
 void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
     if (attn_nw() == 8) hipLaunchKernelGGL(attn_block_kernel<8>, dim3(grid), dim3(512), AttnBlockGeom::smem, s, a);
     else if (attn_block_split() == 2) hipLaunchKernelGGL((attn_block_kernel<4, 0, 2>), dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
+    else if (attn_block_split() == 4) hipLaunchKernelGGL((attn_block_kernel<4, 0, 4>), dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
     else hipLaunchKernelGGL(attn_block_kernel<4>, dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
 }
 

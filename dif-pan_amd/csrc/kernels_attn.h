@@ -36,7 +36,7 @@ struct AttnBlockGeom {
 };
 
 // ABL (tools/mbench_attn.cpp only): 1 = s_memtime stamps of thread 0 at the stage boundaries into a.dbg
-// SPLIT = 2 (round 6): a sample on TWO workgroups = two CUs.  The block is bound by the matrix pipe of its CU (profiles/r06/attn_block_stamps.txt) and B = 64
+// SPLIT = 2 / 4 (round 6): a sample on TWO / FOUR workgroups = CUs (4: sixteen query tokens each; the out-projection then runs on a half-used 32-token block).  The block is bound by the matrix pipe of its CU (profiles/r06/attn_block_stamps.txt) and B = 64
 // samples occupy 64 of 256 CUs: workgroup (b, half) stages the whole sample and computes q, k, v of all 64 tokens (k and v of every token are needed by every query;
 // q of the other half is the redundant sixth), then runs the attention core and the out-projection + residual for ITS 32 query tokens only -- 464 instead of 640
 // matrix instructions per wave, no exchange between the two workgroups, one statistics partial each.  Every value is computed by the same instruction sequence as
@@ -44,7 +44,7 @@ struct AttnBlockGeom {
 template <int NW, int ABL = 0, int SPLIT = 1>
 __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per sample");
-    static_assert(SPLIT == 1 || (SPLIT == 2 && NW == 4), "token-half split: four wavefronts");
+    static_assert(SPLIT == 1 || ((SPLIT == 2 || SPLIT == 4) && NW == 4), "token split: four wavefronts");
     constexpr int QT = 4 / SPLIT;     // 16-query tiles of a workgroup
     constexpr int MBO = (8 / NW) / SPLIT > 0 ? (8 / NW) / SPLIT : 1;  // token blocks per wave in the out-projection
     constexpr int MBW = 8 / NW;       // token blocks per wave in the two 1x1 convs (NW = 8: one, chosen by the wave's parity)
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
     const int bw = (a.xcd && (ga & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (ga >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;  // XCD-contiguous sample order
     for (int wk = bw; wk < a.B * SPLIT; wk += gridDim.x) {
         const int b = a.b0 + wk / SPLIT;
-        const int half = wk % SPLIT;  // SPLIT = 2: this workgroup's 32 query tokens
+        const int half = wk % SPLIT;  // this workgroup's 64 / SPLIT query tokens: 16 QT half .. + 16 QT - 1
         // ---- (1) loads in one burst: GroupNorm partials, the sample, affine parameters, first weight slab
         GnPartials gp;
         gn_load_partials(a.st, a.np, nullptr, 0, b, &gp);
@@ -276,7 +276,9 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
 
         // ---- (4) out = o . Wout^T + bias + x : cout block `cw`, MBO token blocks (SPLIT = 2: this workgroup's half), K = 8 slabs
         {
-            const int mo0 = (SPLIT == 2) ? half : mb0;
+            const int mo0 = (SPLIT == 2) ? half : (SPLIT == 4 ? (half >> 1) : mb0);
+            // SPLIT = 4: the out-projection runs on the 32-token block that holds this workgroup's 16 tokens (the other rows: stale finite planes, results dropped)
+            const bool mine = (SPLIT != 4) || ((j >> 4) == (half & 1));
             f32x16 acc[MBO];
 #pragma unroll
             for (int mb = 0; mb < MBO; ++mb)
@@ -322,9 +324,11 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = (acc[mb][4 * g + i] + (&bo[g].x)[i]) + (&er[mb][g].x)[i];
-                    *reinterpret_cast<float4*>(a.out + ((size_t)b * N + (mo0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
-                    s1 += (v[0] + v[1]) + (v[2] + v[3]);
-                    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    if (mine) {
+                        *reinterpret_cast<float4*>(a.out + ((size_t)b * N + (mo0 + mb) * 32 + j) * C + cw * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+                        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
                 }
             if (a.st_out) {
                 const float t1 = wave_sum_fast(s1), t2 = wave_sum_fast(s2);  // total in lane 63
