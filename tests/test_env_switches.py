@@ -23,7 +23,7 @@
   DDIF_LA_NW=4 / 8  the fused linear-attention block on four-wave workgroups of 128 pixels / eight-wave ones of 256 everywhere (round 6; by default the plan
                 picks four where eight would leave CUs idle): same results either way.
 
-  DDIF_ATTN_SPLIT=1  the fused bottleneck attention block on ONE workgroup per sample (rounds 3-5) instead of two (round 6: the token halves on two CUs).
+  DDIF_ATTN_SPLIT=1 / 2  the fused bottleneck attention block on ONE / TWO workgroups per sample instead of four (round 6: the query tokens of a sample on up to four CUs).
 
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
 kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04/t_*, r03_b_*) were deleted together with
@@ -43,8 +43,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
 
 
 @pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"},
-                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}, {"DDIF_XF": "0"}, {"DDIF_LA8": "0"}, {"DDIF_LA_NW": "4"}, {"DDIF_LA_NW": "8"}, {"DDIF_ATTN_SPLIT": "1"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8", "XF=0", "LA8=0", "LA_NW=4", "LA_NW=8", "ATTN_SPLIT=1"])
+                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}, {"DDIF_XF": "0"}, {"DDIF_LA8": "0"}, {"DDIF_LA_NW": "4"}, {"DDIF_LA_NW": "8"}, {"DDIF_ATTN_SPLIT": "1"}, {"DDIF_ATTN_SPLIT": "2"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8", "XF=0", "LA8=0", "LA_NW=4", "LA_NW=8", "ATTN_SPLIT=1", "ATTN_SPLIT=2"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)

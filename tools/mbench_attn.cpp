@@ -17,7 +17,7 @@ void run(int B) {
     float *x, *out, *wq, *wo, *vec; double *st, *sto; long long* dbg;
     const size_t nwq = (size_t)12 * 8 * 3 * 256, nwo = (size_t)4 * 8 * 3 * 256;
     CK_(hipMalloc(&x, n * 4)); CK_(hipMalloc(&out, n * 4)); CK_(hipMalloc(&wq, nwq * 4)); CK_(hipMalloc(&wo, nwo * 4)); CK_(hipMalloc(&vec, 4096 * 4));
-    CK_(hipMalloc(&st, (size_t)B * 64 * 16)); CK_(hipMalloc(&sto, (size_t)B * 32)); CK_(hipMalloc(&dbg, 256 * 32 * 8)); CK_(hipMemset(dbg, 0, 256 * 32 * 8));
+    CK_(hipMalloc(&st, (size_t)B * 64 * 16)); CK_(hipMalloc(&sto, (size_t)B * 64)); CK_(hipMalloc(&dbg, 256 * 32 * 8)); CK_(hipMemset(dbg, 0, 256 * 32 * 8));
     std::vector<float> h(n); for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-3f;
     CK_(hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(vec, h.data(), 4096 * 4, hipMemcpyHostToDevice));
     CK_(hipMemset(wq, 0x11, nwq * 4)); CK_(hipMemset(wo, 0x11, nwo * 4));
@@ -52,6 +52,6 @@ void run(int B) {
 }
 
 int main() {
-    for (int B : {64, 8}) { run<4>(B); run<4, 2>(B); run<8>(B); }
+    for (int B : {64, 8}) { run<4>(B); run<4, 2>(B); run<4, 4>(B); run<8>(B); }
     return 0;
 }
