@@ -85,13 +85,24 @@ static int pick_cfg(int ks, int ck, int pro, int vec, int stride, int ups_, int 
     }
     if (ks == 3 && vec == 1 && stride == 1 && x3) {
         const bool f16 = f16ok && (pro == PRO_NONE || pro == PRO_GN_SILU);
-        if (wide && Hout >= 32 && Wout >= 32) return b1 ? 47 : (f16 ? 27 : 7);
+        // 16 x 16-pixel tiles on eight waves where they fill the CUs; below that (8-16 tiles per GPU: what one rank of a strong-scaling run holds) the four-wave
+        // 8 x 16 tiling gives twice the workgroups and every wave a SIMD to itself.  Results do not depend on the choice bit for bit: same products per pixel, and
+        // the 16 x 16 tilings write their statistics partials per 8 x 16 half tile (ConvArgs::st_halves).  DDIF_TILE16=1 / 0 forces one form.
+        static const int tile16_env = [] { const char* e = getenv("DDIF_TILE16"); return e ? atoi(e) : -1; }();
+        const long items16 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
+        const bool big = tile16_env >= 0 ? tile16_env != 0 : items16 >= num_cus();
+        if (wide && Hout >= 32 && Wout >= 32 && big) return b1 ? 47 : (f16 ? 27 : 7);
         if (wide || Cout <= 32) return b1 ? 48 : (f16 ? 28 : 8);
         return b1 ? 49 : (f16 ? 29 : 9);
     }
     static const bool s2_f16 = [] { const char* e = getenv("DDIF_S2_F16"); return !e || atoi(e) != 0; }();  // DDIF_S2_F16=0: the Downsample convs and the stem stay on the exact-fp32 tilings
     if (ks == 3 && vec == 1 && stride == 2 && !ups_ && x3 && f16ok && !b1 && s2_f16 && pro == PRO_NONE && Wout >= 16) return Cout <= 32 ? 28 : 29;
-    if (ks == 3 && vec == 2 && stride == 1 && !ups_ && x3 && f16ok && !b1 && s2_f16 && pro == PRO_NONE && wide && Cout <= 32) return (Hout >= 32 && Wout >= 32) ? 27 : 28;  // the stem
+    if (ks == 3 && vec == 2 && stride == 1 && !ups_ && x3 && f16ok && !b1 && s2_f16 && pro == PRO_NONE && wide && Cout <= 32) {  // the stem
+        static const int tile16_env = [] { const char* e = getenv("DDIF_TILE16"); return e ? atoi(e) : -1; }();
+        const long items16 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16);
+        const bool big = tile16_env >= 0 ? tile16_env != 0 : items16 >= num_cus();
+        return (Hout >= 32 && Wout >= 32 && big) ? 27 : 28;
+    }
     if (ks == 3 && vec == 1 && wide && !ups_) {
         const long items32 = (long)B * ((Hout + 15) / 16) * ((Wout + 15) / 16) * ((Cout + 31) / 32);
         if (Hout >= 32 && Wout >= 32 && items32 >= 2L * num_cus()) return (Cout % 64 == 0 && items32 >= 4L * num_cus()) ? 6 : 5;
@@ -405,15 +416,21 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     a.tiles_x = (Wout + var.tw - 1) / var.tw;
     a.tiles_y = (Hout + var.th - 1) / var.th;
     const int gy = (pc.cout + var.nt - 1) / var.nt;
+    // the eight-wave 16 x 16 tilings write their statistics partials per 8 x 16 half tile, exactly as the four-wave 8 x 16 tiling of the same conv would (kernels_conv.h
+    // ConvArgs::st_halves): the tiling may then depend on the number of work items without changing a single bit of what the consumer reads
+    const bool st_halves = !var.lr && var.th == 16 && var.tw == 16 && var.nthr == 512;
+    a.st_halves = st_halves ? 1 : 0;
+    a.tiles_y8 = (Hout + 7) / 8;
+    const int np_out = st_halves ? a.tiles_x * a.tiles_y8 : a.tiles_x * a.tiles_y;
     if (s.stats) {
-        out->np = a.tiles_x * a.tiles_y * gy;
+        out->np = np_out * gy;
         if (int e = dalloc(&out->st, (size_t)B * out->np * 2)) return e;
         a.st_out = out->st;
     }
     a.n_ct = gy;
     if (xf) {
         if (gy != 1 || !s.stats) return fail(DDIF_ERR_STATE, "%s: x_conv fold needs one cout tile and output statistics", s.name);
-        s.xf->out.np = a.tiles_x * a.tiles_y;
+        s.xf->out.np = np_out;
         if (int e = dalloc(&s.xf->out.st, (size_t)B * s.xf->out.np * 2)) return e;
         a.xf_w = s.xf->w;
         a.xf_b = s.xf->pc->bias;

@@ -94,6 +94,12 @@ struct ConvArgs {
     float* xf_out;           // [B, Hout, Wout, xf_cout]
     double* xf_st;           // partials of xf_out, [B][tiles_x * tiles_y][2]
     int xf_cout;             // 32 * NBX
+    // Round 6: the eight-wave 16 x 16-pixel tilings write their GroupNorm partials per 8 x 16 HALF tile (waves 0-3 / 4-7), at the indices and with the summation
+    // order of the four-wave 8 x 16 tiling of the same conv.  The conv outputs of the two tilings are bit-identical (same products, same K order per pixel), so with
+    // this the CONSUMER sees the same partial array either way, and the host may pick the tiling by how many workgroups a launch has (8-16 tiles per GPU: the
+    // 16 x 16 grid leaves CUs idle) without giving up that a tile of a batch is bit-equal to the tile run alone (tests/test_gpu_batch64.py).
+    int st_halves;           // 1: two partials per item (TH = 16, NW = 8 instantiations only)
+    int tiles_y8;            // ceil(Hout / 8): tile rows of the 8 x 16 tiling
 };
 
 template <int F>
@@ -609,6 +615,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
             const Pos p = pend_pos;
             const int t = (p.oy0 / TH) * a.tiles_x + p.ox0 / TW;
             const double* r = red + pend_par * 2 * NW;
+            if (NW == 8 && TH == 16 && a.st_halves) {
+                // one partial per 8 x 16 half tile: waves 0-3 = rows 0-7, waves 4-7 = rows 8-15, each summed as the four-wave tiling sums its tile
+                const int ty = p.oy0 / TH, tx = p.ox0 / TW;
+                const size_t np8 = (size_t)a.tiles_x * a.tiles_y8 * a.n_ct;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int ty8 = 2 * ty + hf;
+                    if (ty8 < a.tiles_y8) {  // (a bottom half below the image has no tile in the 8 x 16 tiling)
+                        const size_t pi = ((size_t)p.b * np8 + ((size_t)ty8 * a.tiles_x + tx) * a.n_ct + p.ct) * 2;
+                        const double* q = r + 8 * hf;
+                        a.st_out[pi + 0] = (q[0] + q[2]) + (q[4] + q[6]);
+                        a.st_out[pi + 1] = (q[1] + q[3]) + (q[5] + q[7]);
+                        if constexpr (XF) {
+                            const double* qx = redx + pend_par * 2 * NW + 8 * hf;
+                            a.xf_st[pi + 0] = (qx[0] + qx[2]) + (qx[4] + qx[6]);
+                            a.xf_st[pi + 1] = (qx[1] + qx[3]) + (qx[5] + qx[7]);
+                        }
+                    }
+                }
+            } else {
             const size_t pi = ((size_t)p.b * (tiles * a.n_ct) + (size_t)t * a.n_ct + p.ct) * 2;
             double t0 = (r[0] + r[2]) + (r[4] + r[6]), t1 = (r[1] + r[3]) + (r[5] + r[7]);
             if (NW == 8) {
@@ -626,6 +652,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                 }
                 a.xf_st[pi + 0] = u0;
                 a.xf_st[pi + 1] = u1;
+            }
             }
         }
         pend = false;

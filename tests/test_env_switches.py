@@ -25,6 +25,9 @@
 
   DDIF_ATTN_SPLIT=1 / 2  the fused bottleneck attention block on ONE / TWO workgroups per sample instead of four (round 6: the query tokens of a sample on up to four CUs).
 
+  DDIF_TILE16=1 / 0  the 3x3 convs of the 64 x 64 / 32 x 32 levels on 16 x 16-pixel tiles (eight waves) / 8 x 16 tiles (four waves) everywhere; by default the plan picks
+                the small tiles where the big ones would not fill the CUs (round 6).  Bit-identical results: the big tiles write half-tile statistics partials.
+
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
 kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04/t_*, r03_b_*) were deleted together with
 their code."""
@@ -43,8 +46,8 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
 
 
 @pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"},
-                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}, {"DDIF_XF": "0"}, {"DDIF_LA8": "0"}, {"DDIF_LA_NW": "4"}, {"DDIF_LA_NW": "8"}, {"DDIF_ATTN_SPLIT": "1"}, {"DDIF_ATTN_SPLIT": "2"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8", "XF=0", "LA8=0", "LA_NW=4", "LA_NW=8", "ATTN_SPLIT=1", "ATTN_SPLIT=2"])
+                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}, {"DDIF_XF": "0"}, {"DDIF_LA8": "0"}, {"DDIF_LA_NW": "4"}, {"DDIF_LA_NW": "8"}, {"DDIF_ATTN_SPLIT": "1"}, {"DDIF_ATTN_SPLIT": "2"}, {"DDIF_TILE16": "1"}, {"DDIF_TILE16": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8", "XF=0", "LA8=0", "LA_NW=4", "LA_NW=8", "ATTN_SPLIT=1", "ATTN_SPLIT=2", "TILE16=1", "TILE16=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
