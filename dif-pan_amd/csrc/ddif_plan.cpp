@@ -255,16 +255,20 @@ int Plan::build() {
     std::vector<int> placed;
     arena_bytes = 0;
     unaliased_bytes = 0;
+    // DDIF_ARENA_PAD=<bytes> (development aid): every tensor reserves that much more, which shifts the relative placement of the tensors of a launch -- the probe behind
+    // the "one ffn.0 instance of four takes 68-72 us instead of 47" question of rounds 5-6 (profiles/r06/arena_pad_probe.txt)
+    static const size_t arena_pad = [] { const char* e = getenv("DDIF_ARENA_PAD"); return e ? (size_t)atoll(e) & ~(size_t)255 : (size_t)0; }();
     for (int id : order) {
         Live& l = lives[id];
         unaliased_bytes += l.bytes;
+        const size_t need = l.bytes + arena_pad;
         std::vector<std::pair<size_t, size_t>> busy;  // address ranges of tensors alive at the same time
         for (int o : placed)
-            if (!(lives[o].last < l.first || l.last < lives[o].first)) busy.emplace_back(lives[o].off, lives[o].off + lives[o].bytes);
+            if (!(lives[o].last < l.first || l.last < lives[o].first)) busy.emplace_back(lives[o].off, lives[o].off + lives[o].bytes + arena_pad);
         std::sort(busy.begin(), busy.end());
         size_t off = 0;
         for (auto& r : busy) {
-            if (off + l.bytes <= r.first) break;
+            if (off + need <= r.first) break;
             if (r.second > off) off = r.second;
         }
         l.off = off;
@@ -485,8 +489,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     const int tb_off = s.tb_off;
     static const bool dump = getenv("DDIF_DUMP_PLAN") != nullptr;
     if (dump)
-        fprintf(stderr, "[ddif plan] %-34s %-24s ks=%d s=%d u=%d  %3d+%3d -> %3d  @%3dx%-3d pro=%d epi=%d cfg=%d items=%ld grid=%u smem=%zu\n", s.name, var.name, pc.ks, s.stride,
-                s.ups, c0, c1, pc.cout, Hout, Wout, s.pro, epi, cfg, nwork, grid.x, smem);
+        fprintf(stderr, "[ddif plan] %-34s %-24s ks=%d s=%d u=%d  %3d+%3d -> %3d  @%3dx%-3d pro=%d epi=%d cfg=%d items=%ld grid=%u smem=%zu  in@%p out@%p\n", s.name, var.name, pc.ks, s.stride,
+                s.ups, c0, c1, pc.cout, Hout, Wout, s.pro, epi, cfg, nwork, grid.x, smem, (const void*)s.in0.p, (const void*)out->p);
     Op op;
     op.name = var.name;
     {

@@ -109,17 +109,23 @@ torch.save({"y": y.cpu(), "out": out.cpu()}, sys.argv[1])
     import torch
 
     res = {}
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "small"):
         e = dict(os.environ)
-        e["DDIF_WRES"] = flag
+        e["DDIF_WRES"] = "0" if flag == "0" else "1"
         e["DDIF_XCD"] = "0" if flag == "0" else "15"  # ... and the XCD-contiguous work partition (ddif_dev.h wg_work_range): which workgroup computes an item, never what
+        # two tiles would not fill the CUs: since round 6 the plan would pick the four-wave 8 x 16 tiling by itself ("small" lets it); DDIF_TILE16=1 keeps the
+        # 16 x 16 tilings this test is about.  All three must agree bit for bit: the big tilings write half-tile statistics partials (ConvArgs::st_halves)
+        e["DDIF_TILE16"] = "0" if flag == "small" else "1"
         e["DDIF_DUMP_PLAN"] = "1"
         f = str(tmp_path / ("wres%s.pt" % flag))
         r = subprocess.run([sys.executable, "-c", code % (os.path.join(ROOT, "dif-pan_amd"), ROOT, os.path.join(ROOT, "tests")), f], env=e, cwd=ROOT, capture_output=True,
                            text=True, timeout=1500)
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-        res[flag] = (torch.load(f), r.stderr.count("cfg=37"))
+        res[flag] = (torch.load(f), r.stderr.count("cfg=37"), r.stderr.count("cfg=28"))
     assert res["0"][1] == 0 and res["1"][1] >= 15, (res["0"][1], res["1"][1])  # 14 ResnetBlock convs + the final conv at the 64 x 64 level
+    assert res["small"][1] == 0 and res["small"][2] >= 30, res["small"][1:]  # every 3x3 conv of the 64 x 64 / 32 x 32 levels on the 8 x 16 tiling
     assert torch.equal(res["0"][0]["y"], res["1"][0]["y"])
     assert torch.equal(res["0"][0]["out"], res["1"][0]["out"])
+    assert torch.equal(res["small"][0]["y"], res["1"][0]["y"])
+    assert torch.equal(res["small"][0]["out"], res["1"][0]["out"])
     assert bool(torch.isfinite(res["1"][0]["out"]).all())
