@@ -18,6 +18,7 @@
 
   DDIF_XF=0     CondInjection.x_conv + FiLM as a 1x1 launch of its own everywhere instead of riding in the producer conv's epilogue (round 6, EPI_XF).
 
+  DDIF_LA6=0    the 192-channel decoder block of the 16 x 16 level as three launches instead of linattn_fused (round 6).
   DDIF_LA8=0    the decoder's linear-attention half at the 8 x 8 level as three launches instead of the fused kernel of round 6 (csrc/kernels_lafuse8.h).
 
   DDIF_LA_NW=4 / 8  the fused linear-attention block on four-wave workgroups of 128 pixels / eight-wave ones of 256 everywhere (round 6; by default the plan
@@ -46,13 +47,31 @@ SLICE = ("test_forward_matches_reference_golden or test_ddpm_matches_reference_g
 
 
 @pytest.mark.parametrize("env", [{"DDIF_X3": "0"}, {"DDIF_GRAPH": "0"}, {"DDIF_X3": "0", "DDIF_GRAPH": "0"}, {"DDIF_LR": "0"}, {"DDIF_F16": "0"}, {"DDIF_LAFUSE": "0"},
-                                 {"DDIF_S2_F16": "0"}, {"DDIF_ATTN_NW": "8"}, {"DDIF_XF": "0"}, {"DDIF_LA8": "0"}, {"DDIF_LA_NW": "4"}, {"DDIF_LA_NW": "8"}, {"DDIF_ATTN_SPLIT": "1"}, {"DDIF_ATTN_SPLIT": "2"}, {"DDIF_TILE16": "1"}, {"DDIF_TILE16": "0"}],
-                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "ATTN_NW=8", "XF=0", "LA8=0", "LA_NW=4", "LA_NW=8", "ATTN_SPLIT=1", "ATTN_SPLIT=2", "TILE16=1", "TILE16=0"])
+                                 {"DDIF_S2_F16": "0"}, {"DDIF_XF": "0"}, {"DDIF_LA8": "0"}],
+                         ids=["X3=0", "GRAPH=0", "X3=0+GRAPH=0", "LR=0", "F16=0", "LAFUSE=0", "S2_F16=0", "XF=0", "LA8=0"])
 def test_parity_slice_under_switch(env):
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
                         "-k", SLICE, "-p", "no:cacheprovider"], env=e, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
+
+
+# the round-6 switches that only change WHICH workgroup / tiling computes a value (results identical): the forward goldens, incl. the 64 x 64 tile that reaches
+# every kernel they touch, are enough -- and keep the suite under ten minutes
+SLICE_FWD = "test_forward_matches_reference_golden"
+
+
+@pytest.mark.parametrize("env", [{"DDIF_ATTN_NW": "8"}, {"DDIF_LA_NW": "4"}, {"DDIF_LA_NW": "8"}, {"DDIF_ATTN_SPLIT": "1"}, {"DDIF_ATTN_SPLIT": "2"},
+                                 {"DDIF_TILE16": "1"}, {"DDIF_TILE16": "0"}, {"DDIF_LA6": "0"}],
+                         ids=["ATTN_NW=8", "LA_NW=4", "LA_NW=8", "ATTN_SPLIT=1", "ATTN_SPLIT=2", "TILE16=1", "TILE16=0", "LA6=0"])
+def test_forward_goldens_under_placement_switch(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-k", SLICE_FWD, "-p", "no:cacheprovider"], env=e, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
