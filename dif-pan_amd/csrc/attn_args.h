@@ -10,6 +10,8 @@ struct AttnBlockArgs {
     const float* gamma;   // norm.weight / norm.bias
     const float* beta;
     const float* wqkv;    // packed bf16x3 1x1 weights, 12 cout blocks x 8 slabs x 3 planes x 1 KiB
+    const float* wqkv_f16; // the same as f16x2 planes (12 x 8 slabs x 2 planes x 1 KiB; ddif_net.cpp pack_conv_f16) or null: the qkv conv on three products per fp32
+                          // product instead of six -- its input is GroupNorm output, bounded on the host like every f16x2 conv (round 6)
     const float* wout;    // packed bf16x3 1x1 weights, 4 cout blocks x 8 slabs x 3 planes x 1 KiB
     const float* bout;    // [128]
     float scale;          // 1 / sqrt(C)  (NOT 1 / sqrt(d): sr3_dwt.py:352)

@@ -68,12 +68,15 @@ int attn_block_prepare() {
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
+    DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel<4, 0, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBlockGeom::smem));
     return 0;
 }
-// grid: workgroups to launch (<= a.B * attn_block_split(); each walks samples / halves with that stride)
+// grid: workgroups to launch (<= a.B * attn_block_split(); each walks samples / parts with that stride).  a.wqkv_f16 != null (set by the plan when the f16x2
+// conditions hold): the qkv conv on f16x2 -- instantiated for the default form (four waves, four workgroups per sample) only
 void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
     if (attn_nw() == 8) hipLaunchKernelGGL(attn_block_kernel<8>, dim3(grid), dim3(512), AttnBlockGeom::smem, s, a);
     else if (attn_block_split() == 2) hipLaunchKernelGGL((attn_block_kernel<4, 0, 2>), dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
+    else if (attn_block_split() == 4 && a.wqkv_f16) hipLaunchKernelGGL((attn_block_kernel<4, 0, 4, true>), dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
     else if (attn_block_split() == 4) hipLaunchKernelGGL((attn_block_kernel<4, 0, 4>), dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
     else hipLaunchKernelGGL(attn_block_kernel<4>, dim3(grid), dim3(256), AttnBlockGeom::smem, s, a);
 }

@@ -720,6 +720,14 @@ int Plan::build_impl() {
             a.gamma = V(ap + ".norm.weight");
             a.beta = V(ap + ".norm.bias");
             a.wqkv = cq->w_x3;
+            {   // qkv on f16x2 (three products) where the f16x2 conditions of a GroupNorm-prologue conv hold: half packs exist (|w| < 64), and the bound
+                // sqrt(N) max|gamma| + max|beta| of GroupNorm's output stays inside the scaled half range; DDIF_ATTN_F16=0 keeps bf16x3 (tests/test_env_switches.py)
+                static const bool af16 = [] { const char* e = getenv("DDIF_ATTN_F16"); return !e || atoi(e) != 0; }();
+                auto ig = net->vec_absmax.find(a.gamma), ib = net->vec_absmax.find(a.beta);
+                const bool okr = ig != net->vec_absmax.end() && ib != net->vec_absmax.end() &&
+                                 std::sqrt((double)in.C * in.H * in.W) * ig->second + ib->second < DDIF_F16_AMAX;
+                a.wqkv_f16 = (af16 && f16_enabled() && cq->w_f16 && okr) ? cq->w_f16 : nullptr;
+            }
             a.wout = co->w_x3;
             a.bout = co->bias ? co->bias : zeros;
             a.scale = 1.0f / std::sqrt((float)in.C);  // 1/sqrt(C), not 1/sqrt(d)   (sr3_dwt.py:352)

@@ -41,8 +41,9 @@ struct AttnBlockGeom {
 // q of the other half is the redundant sixth), then runs the attention core and the out-projection + residual for ITS 32 query tokens only -- 464 instead of 640
 // matrix instructions per wave, no exchange between the two workgroups, one statistics partial each.  Every value is computed by the same instruction sequence as
 // with one workgroup per sample.
-template <int NW, int ABL = 0, int SPLIT = 1>
+template <int NW, int ABL = 0, int SPLIT = 1, bool F16Q = false>
 __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
+    constexpr int QPL = F16Q ? 2 : 3;  // operand planes of the qkv contraction (f16x2: hi, lo; bf16x3: hi, mid, lo)
     static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts per sample");
     static_assert(SPLIT == 1 || ((SPLIT == 2 || SPLIT == 4) && NW == 4), "token split: four wavefronts");
     constexpr int QT = 4 / SPLIT;     // 16-query tiles of a workgroup
@@ -92,17 +93,17 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
         const float4 bq = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
         // qkv weights of this wave: cout blocks 3 cw .. 3 cw + 2, slab s, plane q at ((nb * 8 + s) * 3 + q) KiB
         // (wave-uniform base + 32-bit lane offset: the loads take the SGPR-base form; per-lane 64-bit addresses of all 72 fragments were precomputed and spilled)
-        const char* wq = reinterpret_cast<const char*>(a.wqkv) + (size_t)(3 * cw) * (NSLAB * 3 * 1024);
+        const char* wq = reinterpret_cast<const char*>(F16Q ? a.wqkv_f16 : a.wqkv) + (size_t)(3 * cw) * (NSLAB * QPL * 1024);
         unsigned lo16 = (unsigned)lane * 16u;
 #ifndef DDIF_EMU
         asm volatile("" : "+v"(lo16));  // opaque per sample: keeps hipcc from hoisting the 96 fragment offsets (loop-invariant VGPR adds) out of the sample loop into spilled registers
 #endif
-        float4 wr[2][3][3];  // [ring slot][cout block][plane]
+        float4 wr[2][3][QPL];  // [ring slot][cout block][plane]
         auto load_qkv_w = [&](int slot, int s) {
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) wr[slot][nb][q] = *reinterpret_cast<const float4*>(wq + ((nb * NSLAB + s) * 3 + q) * 1024 + lo16);
+                for (int q = 0; q < QPL; ++q) wr[slot][nb][q] = *reinterpret_cast<const float4*>(wq + ((nb * NSLAB + s) * QPL + q) * 1024 + lo16);
         };
         load_qkv_w(0, 0);
         stamp();  // 1: first burst issued
@@ -115,6 +116,10 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
             for (int i = 0; i < 4; ++i) {
                 ga[i] = (&gq.x)[i] * rstd;
                 gb[i] = (&bq.x)[i] - mean * ga[i];
+                if constexpr (F16Q) {  // the activation scale of the f16x2 split rides in the affine map
+                    ga[i] *= DDIF_F16_ASCALE;
+                    gb[i] *= DDIF_F16_ASCALE;
+                }
             }
             const int slab = c4 >> 2, cin_slab = (c4 & 3) * 4;
 #pragma unroll
@@ -123,13 +128,21 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaf((&sv[it].x)[i], ga[i], gb[i]);
+                float* d = &As[tok * APIX + slab * 24 + cin_slab / 2];  // (f16x2 uses two of the slab's three plane slots)
+                if constexpr (F16Q) {
+                    unsigned h01, l01, h23, l23;
+                    dd_split2_pair(v[0], v[1], &h01, &l01);
+                    dd_split2_pair(v[2], v[3], &h23, &l23);
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(d + 8) = make_uint2(l01, l23);
+                } else {
                 unsigned h01, m01, l01, h23, m23, l23;
                 dd_split3_pair(v[0], v[1], &h01, &m01, &l01);
                 dd_split3_pair(v[2], v[3], &h23, &m23, &l23);
-                float* d = &As[tok * APIX + slab * 24 + cin_slab / 2];
                 *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
                 *reinterpret_cast<uint2*>(d + 8) = make_uint2(m01, m23);
                 *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
+                }
             }
         }
         stamp();  // 3: xn staged (the sample has arrived)
@@ -148,9 +161,9 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
 #pragma unroll
             for (int s = 0; s < NSLAB; ++s) {
                 if (s + 1 < NSLAB) load_qkv_w((s + 1) & 1, s + 1);
-                float4 xa[MBW][3];
+                float4 xa[MBW][QPL];
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < QPL; ++q)
 #pragma unroll
                     for (int mb = 0; mb < MBW; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[((mb0 + mb) * 32 + j) * APIX + s * 24 + q * 8 + 4 * h]);
                 DDIF_SCHED_FENCE();
@@ -160,17 +173,24 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
                     for (int mb = 0; mb < MBW; ++mb) {
                         f32x16 c = acc[mb][nb];
                         const float4* w = wr[s & 1][nb];
-                        c = DDIF_MFMA_32x32x16_BF16(w[2], xa[mb][0], c);  // lo * hi
-                        c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][2], c);  // hi * lo
-                        c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][1], c);  // mid * mid
-                        c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][0], c);  // mid * hi
-                        c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][1], c);  // hi * mid
-                        c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][0], c);  // hi * hi
+                        if constexpr (F16Q) {
+                            c = DDIF_MFMA_32x32x16_F16(w[1], xa[mb][0], c);  // lo * hi
+                            c = DDIF_MFMA_32x32x16_F16(w[0], xa[mb][1], c);  // hi * lo
+                            c = DDIF_MFMA_32x32x16_F16(w[0], xa[mb][0], c);  // hi * hi
+                        } else {
+                            c = DDIF_MFMA_32x32x16_BF16(w[QPL - 1], xa[mb][0], c);  // lo * hi
+                            c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][QPL - 1], c);  // hi * lo
+                            c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][1], c);  // mid * mid
+                            c = DDIF_MFMA_32x32x16_BF16(w[1], xa[mb][0], c);  // mid * hi
+                            c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][1], c);  // hi * mid
+                            c = DDIF_MFMA_32x32x16_BF16(w[0], xa[mb][0], c);  // hi * hi
+                        }
                         acc[mb][nb] = c;
                     }
                 DDIF_SCHED_FENCE();
             }
-            // lane (j, h) owns token (mb0 + mb)*32 + j and, per quad g, couts nb*32 + 8g + 4h .. +3
+            // lane (j, h) owns token (mb0 + mb)*32 + j and, per quad g, couts nb*32 + 8g + 4h .. +3 (f16x2: the accumulator carries the two operand scales)
+            constexpr float QS = F16Q ? DDIF_F16_OSCALE : 1.0f;
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
@@ -178,7 +198,7 @@ __global__ __launch_bounds__(64 * NW) void attn_block_kernel(AttnBlockArgs a) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         *reinterpret_cast<float4*>(&Qs[((mb0 + mb) * 32 + j) * QROW + (3 * cw + nb) * 32 + 8 * g + 4 * h]) =
-                            make_float4(acc[mb][nb][4 * g + 0], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]);
+                            make_float4(acc[mb][nb][4 * g + 0] * QS, acc[mb][nb][4 * g + 1] * QS, acc[mb][nb][4 * g + 2] * QS, acc[mb][nb][4 * g + 3] * QS);
         }
         // out-projection weights of this wave (cout block `cw`): first slab, in flight during the attention core
         const char* wo = reinterpret_cast<const char*>(a.wout) + (size_t)cw * (NSLAB * 3 * 1024);

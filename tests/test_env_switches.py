@@ -29,6 +29,8 @@
   DDIF_TILE16=1 / 0  the 3x3 convs of the 64 x 64 / 32 x 32 levels on 16 x 16-pixel tiles (eight waves) / 8 x 16 tiles (four waves) everywhere; by default the plan picks
                 the small tiles where the big ones would not fill the CUs (round 6).  Bit-identical results: the big tiles write half-tile statistics partials.
 
+  DDIF_ATTN_F16=0  the qkv conv of the bottleneck attention block on bf16x3 (six products) instead of f16x2 (three; round 6).
+
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
 kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04/t_*, r03_b_*) were deleted together with
 their code."""
@@ -66,8 +68,8 @@ SLICE_FWD = "test_forward_matches_reference_golden"
 
 # (independent switches share a child process: a child costs ~10 s of interpreter + library start-up whatever it runs)
 @pytest.mark.parametrize("env", [{"DDIF_LA_NW": "4", "DDIF_ATTN_SPLIT": "1", "DDIF_TILE16": "1"}, {"DDIF_LA_NW": "8", "DDIF_ATTN_SPLIT": "2", "DDIF_TILE16": "0"},
-                                 {"DDIF_ATTN_NW": "8", "DDIF_LA6": "0"}],
-                         ids=["LA_NW=4+ATTN_SPLIT=1+TILE16=1", "LA_NW=8+ATTN_SPLIT=2+TILE16=0", "ATTN_NW=8+LA6=0"])
+                                 {"DDIF_ATTN_NW": "8", "DDIF_LA6": "0"}, {"DDIF_ATTN_F16": "0"}],
+                         ids=["LA_NW=4+ATTN_SPLIT=1+TILE16=1", "LA_NW=8+ATTN_SPLIT=2+TILE16=0", "ATTN_NW=8+LA6=0", "ATTN_F16=0"])
 def test_forward_goldens_under_placement_switch(env):
     e = dict(os.environ)
     e.update(env)

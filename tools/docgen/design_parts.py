@@ -1,7 +1,7 @@
 STATUS = r'''Headline (BASELINE configs[1], B = 64 tiles of 64×64×8, T = 1000, one MI355X): **@@MS@@ ms per denoising step = @@MPS@@ MP/s** in the final set
 `profiles/r06/z_*` (build `@@BUILD@@`; the pool's boxes differ by ± 2–4 %: the same tree measured 3.27 on another box, `profiles/r06/n_*`), **132 launches** per
 step (146 in round 5), @@XCPU@@ × the 16-thread CPU port (@@XCPU1@@ × its B = 1 rate), `roofline.step_frac` @@SF@@ (0.183 in round 5). Driver-measured round 5: 3.541 ms.
-Every change below is a same-box interleaved A/B under `profiles/r06/`; together they measure −9 % (single A/Bs: −1.9, −2.0, −1.7, −1.2, −0.5, −0.4 %).
+Every change below is a same-box interleaved A/B under `profiles/r06/`; together they measure −9 % (single A/Bs: −1.9, −2.0, −1.7, −1.2, −0.5, −0.5, −0.4 %).
 
 | VERDICT r5 item | status | evidence |
 |---|---|---|
@@ -57,7 +57,7 @@ R6 = r'''Kept (each a same-box interleaved A/B; files under `profiles/r06/`):
 | change | mechanism | effect |
 |---|---|---|
 | transposed-q softmax in `linattn_fused` (`lafuse_softmax_lib_ab.txt`) | `D = XW` puts a column's rows into registers: max / sum are in-lane trees + one `ds_bpermute`; a wave pair exchanges (max, sum) once (online softmax) | 73.8 → 56.9 µs @64², step −1.9 % |
-| `attn_block` on 4 workgroups per sample (`attn_split_ab.txt`) | the block is bound by the matrix pipe of its CU (`attn_block_stamps.txt`); k, v recomputed by each, no exchange | 22.5 → 15.8 µs, step −2.0 % |
+| `attn_block` on 4 workgroups per sample, qkv on f16x2 (`attn_split_ab.txt`, `attn_f16_ab.txt`) | the block is bound by the matrix pipe of its CU (`attn_block_stamps.txt`); k, v recomputed by each, no exchange; half the products for the GroupNorm-bounded qkv conv | 22.5 → 15.8 µs, step −2.0 % and −0.5 % |
 | `linattn8_fused` (`la8_ab.txt`) | half a sample per workgroup, waves split the output channels, weights straight from L2 | 3 launches → 1 per block, step −1.7 % |
 | four-wave `linattn_fused` workgroups (`la_nw_ab.txt`) | a wave's work does not depend on the workgroup size; with idle CUs, give every wave its own SIMD | step −1.2 %, bit-identical |
 | 192-channel 16² block on `linattn_fused` (`la6_ab.txt`) | a sixth q block in registers (42 spilled) still beats three launches | step −0.5 % |
