@@ -64,7 +64,7 @@ R6 = r'''Kept (each a same-box interleaved A/B; files under `profiles/r06/`):
 | EPI_XF (`xf_fold_ab.txt`) | register GEMM on the accumulator layout, K order permuted to match | −4 launches, step −0.4 % |
 | 8×16 tiles at small batch + half-tile partials (`tile16_ab.txt`) | the partial array is independent of the tiling, so batch bit-equality survives | 8-tile share −4.2 % |
 
-Measured and not kept: `attn_block` on eight waves (23.3 vs 22.3 µs: the matrix pipe has no idle slots to fill); the pair-form depthwise stage for the
+Measured and not kept: `attn_block` on eight waves (23.3 vs 22.3 µs: the matrix pipe has no idle slots to fill); four-wave `linattn_fused` workgroups where the eight-wave grid already fills the CUs (+4.3 % on the step, `la_nw4_everywhere_ab.txt`); the pair-form depthwise stage for the
 multi-block `linattn_fused` variants (fewer LDS reads, 20–40 spilled registers: 45.5 → 48.6 µs at 32²; kept only where it does not spill: 73.8 → 69.6 µs);
 an arena-placement explanation of the one slow `ffn.0` (not reproducible: above). Learned about the part: a kernel whose waves reduce ACROSS lanes per value is
 vector-issue-bound long before memory matters — moving the reduction axis into registers by transposing the MFMA was worth more than any of round 5's
