@@ -74,5 +74,5 @@ spilled registers (an opaque `asm volatile("" : "+v"(x))` per iteration stops it
 `rocprofv3 --pmc` hangs the call (`bench.py` skips its bracket run when profiled).
 
 Still open, in order: the low-resolution class (1.15 ms at 0.10 of its floor: 65 dependent chains of ≈ 15 µs; `DESIGN_HISTORY.md` §7 has five rounds of
-what does not help), the eight `film.x_conv` launches under wide cout tiles, `linattn8_fused`'s table prologue (3.4 µs of 20), training (§0 #6), and any
+what does not help; stamped at the end of this round, `lr_stamps.txt`: with WARM caches an item still takes 8.8 µs in the kernel, 31 % of it before its loads are even issued -- 1 000 instructions of hoisted address geometry -- and 24 % staging at one wave per SIMD with 36 % of the halo tile being zero padding: row-wise staging geometry, the partial loads first and no work on padding are worth an estimated 1–1.5 µs per launch × 65), the eight `film.x_conv` launches under wide cout tiles, `linattn8_fused`'s table prologue (3.4 µs of 20), training (§0 #6), and any
 N > 1 measurement.'''
