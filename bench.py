@@ -463,7 +463,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("gpu result: %s" % json.dumps({k: result[k] for k in ("value", "ms_per_step")}))
-        cb = cpu_baseline(sd, cfg, tiles["cond"][:8].contiguous(), T, args.cpu_seconds, args.cpu_threads)
+        if solver is not None:  # configs[2]: the oracle's DPM-Solver++ multistep sampler on the host cores
+            cb = cpu_baseline_dpmpp(sd, cfg, tiles["cond"][:8].contiguous(), diffusion.betas.cpu(), n_evals, args.cpu_seconds, args.cpu_threads)
+        else:
+            cb = cpu_baseline(sd, cfg, tiles["cond"][:8].contiguous(), T, args.cpu_seconds, args.cpu_threads)
         result["cpu_baseline"] = cb
         result["vs_cpu_baseline"] = value / cb["value"]
         result["vs_cpu_baseline_b1"] = value / cb["by_batch"]["1"]["value"]
@@ -777,6 +780,43 @@ def usable_cpus():
         except (OSError, ValueError, IndexError):
             continue
     return n
+
+
+def cpu_baseline_dpmpp(sd, cfg, cond8, betas, nfe, budget_s, threads=0):
+    """The oracle's DPM-Solver++ 2M sampler (oracle/ddif_oracle.dpmpp_multistep_sample, pinned to the reference's goldens) on the host cores: whole jobs of a
+    REDUCED number of evaluations at B = 1 and B = 8, scaled to `nfe` (the cost of the solver is its model evaluations)."""
+    import torch
+
+    from oracle import ddif_oracle as O
+
+    if threads <= 0:
+        threads = usable_cpus()
+    torch.set_num_threads(threads)
+    C, H = cfg["out_channel"], cond8.shape[2]
+    by = {}
+    for bsz, share in ((1, 0.4), (8, 0.6)):
+        cond = cond8[:bsz].contiguous()
+        xT = torch.randn(bsz, C, H, H, generator=torch.Generator().manual_seed(1))
+
+        def run(n):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.dpmpp_multistep_sample(sd, cfg, cond, betas, xT, steps=n, order=2)
+            return time.perf_counter() - t0
+
+        run(2)  # warm-up (oneDNN primitive creation)
+        t_probe = run(3) / 3
+        n = int(max(3, min(nfe, share * budget_s / max(t_probe, 1e-4))))
+        dt = run(n)
+        per_eval = dt / n
+        mp = cond.shape[0] * H * H / 1e6
+        by[str(bsz)] = {"value": mp / (per_eval * nfe), "seconds_per_evaluation": per_eval, "evaluations_timed": n, "seconds_timed": dt}
+        log("cpu baseline (DPM-Solver++) B=%d: %.3f s per evaluation over %d -> %.3e MP/s" % (bsz, per_eval, n, by[str(bsz)]["value"]))
+    best = max(by, key=lambda k: by[k]["value"])
+    return {"value": by[best]["value"], "unit": "MP/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/ddif_oracle.dpmpp_multistep_sample (2M) on tiles %dx%dx%d: %d evaluations at B=1 (%.1f s) and %d at B=8 (%.1f s), each scaled to %d NFE; value = B=%s (the better)"
+                      % (H, H, C, by["1"]["evaluations_timed"], by["1"]["seconds_timed"], by["8"]["evaluations_timed"], by["8"]["seconds_timed"], nfe, best),
+            "best_batch": int(best), "by_batch": by, "host_cpus": os.cpu_count()}
 
 
 def cpu_baseline(sd, cfg, cond8, T, budget_s, threads=0):

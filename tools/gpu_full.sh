@@ -38,9 +38,9 @@ cp gpurun_out/${tag}_hbm_traffic.json profiles/$rnd/${ser}_hbm_traffic.json 2>/d
 python3 bench.py > gpurun_out/${tag}_bench_T1000_B64.json 2> gpurun_out/${tag}_bench_T1000_B64.log
 cat gpurun_out/${tag}_bench_T1000_B64.json
 python3 bench.py --config wv3_bf16 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_wv3_bf16.json 2> gpurun_out/${tag}_bench_wv3_bf16.log
-python3 bench.py --config gf2_dpm50 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_gf2_dpm50.json 2> gpurun_out/${tag}_bench_gf2_dpm50.log
+python3 bench.py --config gf2_dpm50 --steps 3 --warmup 1 --cpu-seconds 12 > gpurun_out/${tag}_bench_gf2_dpm50.json 2> gpurun_out/${tag}_bench_gf2_dpm50.log
 # (what one rank of an N-GPU strong-scaling run of the same scene holds -- 32 / 16 / 8 tiles -- is measured by that line itself since round 6: projected_strong_scaling)
-python3 bench.py --config cave128_t2000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${tag}_bench_cave128_t2000.json 2> gpurun_out/${tag}_bench_cave128_t2000.log
+python3 bench.py --config cave128_t2000 --steps 1 --warmup 0 --cpu-seconds 12 > gpurun_out/${tag}_bench_cave128_t2000.json 2> gpurun_out/${tag}_bench_cave128_t2000.log
 python3 bench.py --config wv3_train_b32 --steps 10 --warmup 3 --cpu-seconds 15 > gpurun_out/${tag}_bench_wv3_train_b32.json 2> gpurun_out/${tag}_bench_wv3_train_b32.log
 # BASELINE configs[4] as stated is a GLOBAL batch of 32 over 8 GPUs: the per-rank share is 4 tiles
 python3 bench.py --config wv3_train_b32 --batch 4 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_wv3_train_b4_share.json 2> /dev/null
