@@ -37,8 +37,8 @@ MEASURE = r'''**Headline line** (`profiles/r06/z_bench_T1000_B64.json`; driver c
 | configuration (`bench.py --config`) | result | note |
 |---|---|---|
 | `wv3_bf16` (configs[1] "bf16": conv operands rounded once, one product; never a parity configuration) | @@BF@@ MP/s, @@BFMS@@ ms per step | drift vs the fp32-class path after T = 1000: max @@BFD@@ |
-| `gf2_dpm50` (configs[2]: one 512² scene = 64 tiles, DPM-Solver++ 2M, 50 NFE) | @@GF@@ MP/s, @@GFMS@@ ms per scene | per-rank shares: §6 |
-| `cave128_t2000` (configs[3]: 8 patches of 128×128×31, T = 2000) | @@CV@@ MP/s, @@CVMS@@ s per job | full chain vs the reference golden: 1.3e-6 (§4) |
+| `gf2_dpm50` (configs[2]: one 512² scene = 64 tiles, DPM-Solver++ 2M, 50 NFE) | @@GF@@ MP/s, @@GFMS@@ ms per scene | @@GFX@@ × the oracle's DPM-Solver++ on 16 host threads (`cpu_baseline` in the line); per-rank shares: §6 |
+| `cave128_t2000` (configs[3]: 8 patches of 128×128×31, T = 2000) | @@CV@@ MP/s, @@CVMS@@ s per job | @@CVX@@ × the CPU port; full chain vs the reference golden: 1.3e-6 (§4) |
 | `wv3_train_b32` (configs[4]: one training iteration, batch 32 per GPU) | @@TRV@@ tiles/s, **@@TR@@ ms** per iteration | per-rank share of the stated global batch (4 tiles): @@T4@@ ms |
 
 PCIe-inclusive rate: the boundary takes device tensors; uploading a job's cond + x_T (64 tiles × 28 channels × 64² × 4 B = 29 MB) costs < 1 ms of a 3.3 s job.'''

@@ -39,7 +39,7 @@ sub = {
  'EX': '%.2f' % r['exact_fp32']['ms_per_denoising_step'], 'ACH': '%.1f' % rf['achieved'], 'FR': '%.3f' % rf['frac'], 'ALU': '%.1f' % rf['avg_launch_us'],
  'TRF': '%.1f' % ((rf['traffic'] or 0) / 1e6), 'TRX': '%.2f' % ((rf['traffic'] or 0) / rf['algorithmic_bytes_per_launch']), 'BUSY': '%.3f' % busy, 'CLASSES': classes,
  'CPU': '%.2e' % r['cpu_baseline']['value'], 'BF': '%.4f' % bf['value'], 'BFMS': '%.3f' % (bf['ms_per_step'] / 1000), 'BFD': '%.1e' % bf['drift']['max_abs'],
- 'GF': '%.3f' % gf['value'], 'GFMS': '%.1f' % gf['ms_per_step'], 'CV': '%.4f' % cv['value'], 'CVMS': '%.2f' % (cv['ms_per_step'] / 1000), 'TRV': '%.0f' % tr['value'], 'TR': '%.2f' % tr['ms_per_step'],
+ 'GF': '%.3f' % gf['value'], 'GFX': '%.0f' % gf.get('vs_cpu_baseline', 0), 'CVX': '%.0f' % cv.get('vs_cpu_baseline', 0), 'GFMS': '%.1f' % gf['ms_per_step'], 'CV': '%.4f' % cv['value'], 'CVMS': '%.2f' % (cv['ms_per_step'] / 1000), 'TRV': '%.0f' % tr['value'], 'TR': '%.2f' % tr['ms_per_step'],
  'T4': '%.1f' % t4['ms_per_step'], 'S64': '%.1f' % sh['64'], 'S32': '%.1f' % sh['32'], 'S16': '%.1f' % sh['16'], 'S8': '%.1f' % sh['8'], 'P2': '%.2f' % pj['2'], 'P4': '%.2f' % pj['4'], 'P8': '%.2f' % pj['8'],
  'NGPU': ngpu, 'TGPU': tgpu, 'NCPU': '134', 'PR': ser + '_', 'PARITY': par,
 }
