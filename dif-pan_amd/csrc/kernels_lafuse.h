@@ -245,13 +245,40 @@ __global__ __launch_bounds__(TH * TW * 2) void linattn_fused_kernel(LaFuseArgs a
     }
     // tables (once per launch) -- AFTER the first strip's loads have been issued: the table fills wait for their own loads, and on the cold caches every launch starts with that is a
     // round trip the first tile should share, not follow
-    for (int i = tid; i < FEA; i += NTHR) {
-        GB[i] = a.gamma[i];
-        GB[FEA + i] = a.beta[i];
-        BQ[i] = a.bq[i];
+    // (round 6: every table load is issued before any is stored -- the load -> store loops of the first form were one dependent round trip per iteration)
+    {
+        constexpr int NDW = (9 * FEA + NTHR - 1) / NTHR, NG = (FEA + NTHR - 1) / NTHR;
+        static_assert(32 * NBA <= NTHR, "output bias table: one pass");
+        float tg[NG], tb[NG], tq[NG], tdw[NDW];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = tid + k * NTHR, ic = i < FEA ? i : FEA - 1;
+            tg[k] = a.gamma[ic];
+            tb[k] = a.beta[ic];
+            tq[k] = a.bq[ic];
+        }
+        const float to = a.bias[tid < a.dout ? tid : a.dout - 1];
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) {
+            const int i = tid + k * NTHR;
+            tdw[k] = a.dw_w[i < 9 * FEA ? i : 9 * FEA - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = tid + k * NTHR;
+            if (i < FEA) {
+                GB[i] = tg[k];
+                GB[FEA + i] = tb[k];
+                BQ[i] = tq[k];
+            }
+        }
+        if (tid < 32 * NBA) BO[tid] = tid < a.dout ? to : 0.f;
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) {
+            const int i = tid + k * NTHR;
+            if (i < 9 * FEA) DW[i] = tdw[k];
+        }
     }
-    for (int i = tid; i < 9 * FEA; i += NTHR) DW[i] = a.dw_w[i];
-    for (int i = tid; i < 32 * NBA; i += NTHR) BO[i] = i < a.dout ? a.bias[i] : 0.f;
     {
         const int b = a.b0 + w0 / nstrips;
         gn_reduce_partials(gp0, a.st0, a.np0, a.st1, a.np1, b, (double)FEA * a.H * a.W, &mean, &rstd);
