@@ -1,7 +1,7 @@
 STATUS = r'''Headline (BASELINE configs[1], B = 64 tiles of 64×64×8, T = 1000, one MI355X): **@@MS@@ ms per denoising step = @@MPS@@ MP/s** in the final set
 `profiles/r06/z_*` (build `@@BUILD@@`, a slow box; 3.27 on the fastest seen, `profiles/r06/n_*`), **132 launches** per
 step (146 in round 5), @@XCPU@@ × the 16-thread CPU port (@@XCPU1@@ × its B = 1 rate), `roofline.step_frac` @@SF@@ (0.183 in round 5). Driver-measured round 5: 3.541 ms.
-**The whole round on one box** (round 5's final library against this one, interleaved three times, `profiles/r06/whole_round_lib_ab.txt`): **3.643 → 3.334 ms = −8.5 %**; this tree measured 3.27–3.59 ms across five boxes of the pool, round 5's 3.54–3.82: only same-box pairs are comparable, and every change below is one (single A/Bs: −1.9, −2.0, −1.7, −1.2, −0.5, −0.5, −0.4 %).
+**The whole round on one box** (round 5's final library against this one, interleaved three times, `profiles/r06/whole_round_lib_ab.txt`): **3.643 → 3.334 ms = −8.5 %**; this tree measured 3.27–3.59 ms across five boxes of the pool, round 5's 3.54–3.82: only same-box pairs are comparable, and every change below is one (single A/Bs: −1.9, −2.0, −1.7, −1.2, −0.7, −0.5, −0.5, −0.4 %).
 
 | VERDICT r5 item | status | evidence |
 |---|---|---|
@@ -61,6 +61,7 @@ R6 = r'''Kept (each a same-box interleaved A/B; files under `profiles/r06/`):
 | `linattn8_fused` (`la8_ab.txt`) | half a sample per workgroup, waves split the output channels, weights straight from L2 | 3 launches → 1 per block, step −1.7 % |
 | four-wave `linattn_fused` workgroups (`la_nw_ab.txt`) | a wave's work does not depend on the workgroup size; with idle CUs, give every wave its own SIMD | step −1.2 %, bit-identical |
 | 192-channel 16² block on `linattn_fused` (`la6_ab.txt`) | a sixth q block in registers (42 spilled) still beats three launches | step −0.5 % |
+| batched table loads in the `linattn*` prologues (`la_tables_lib_ab.txt`) | the load → store loops were one dependent round trip per iteration on cold caches | step −0.7 % |
 | EPI_XF (`xf_fold_ab.txt`) | register GEMM on the accumulator layout, K order permuted to match | −4 launches, step −0.4 % |
 | 8×16 tiles at small batch + half-tile partials (`tile16_ab.txt`) | the partial array is independent of the tiling, so batch bit-equality survives | 8-tile share −4.2 % |
 
