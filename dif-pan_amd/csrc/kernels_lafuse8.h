@@ -66,7 +66,7 @@ __device__ __forceinline__ float oct_allsum(float v) {
 }
 
 // LaFuseArgs as for linattn_fused_kernel with H = W = 8, c0 % 64 == 0, c1 % 64 == 0, c0 + c1 = 32 NBQ, dout = 128.
-// ABL (tools/mbench_la8.cpp only): 64 = s_memtime stamps of thread 0 into a.dbg
+// ABL (tools/mbench_la8.cpp only): 64 = s_memtime stamps of thread 0 into a.dbg, 128 = six more per 64-channel chunk
 template <int NBQ, int ABL = 0>
 __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
     using G = LaFuse8Geom<NBQ>;
@@ -188,6 +188,8 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
             acca[r] = 0.f;
         }
         const float* wmix_b = a.wmix + (size_t)b * a.wmix_bstride;
+        const float* wq_w = a.wq + (size_t)(qw ? wave : 0) * a.nchq * (2 * 2 * 256);  // (waves without a q block re-read block 0; never consumed)
+        const float* wr_w = wmix_b + ((size_t)nr * a.nch_mix + NBQ + kh) * (2 * 3 * 256);
         // this wave's weight pieces (1 KiB each, lane-linear): wave-uniform base + 32-bit lane offset
         unsigned lo4 = (unsigned)lane * 4u;
 #ifndef DDIF_EMU
@@ -197,19 +199,20 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
 #pragma unroll 1
         for (int k = 0; k < NCHK; ++k) {
             // (a) this chunk's B fragments: requested now, consumed in stage (d)
+            // (one wave-uniform base per chunk and constant piece offsets: the per-piece index expressions of the first form cost ~1 k ticks of address
+            //  arithmetic per chunk before the fourteen loads were out, tools/mbench_la8.cpp)
             float4 wqr[4][2], wrr[2][3];
+            const float* wqk = wq_w + (size_t)k * (2 * 2 * 2 * 256);   // this wave's q block: two 32-channel chunks x two k16 x two planes per 64-channel chunk
+            const float* wrk = wr_w + (size_t)k * (2 * 2 * 3 * 256);   // this wave's output block / K half: chunk NBQ + 2 k + kh
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    const int wv = qw ? wave : 0;  // (waves without a q block re-read block 0; never consumed)
-                    wqr[sl][pl] = *reinterpret_cast<const float4*>(a.wq + ((size_t)((((wv * a.nchq + 2 * k + (sl >> 1)) * 2 + (sl & 1)) * 2 + pl)) * 256) + lo4);
-                }
+                for (int pl = 0; pl < 2; ++pl) wqr[sl][pl] = *reinterpret_cast<const float4*>(wqk + ((sl >> 1) * 4 + (sl & 1) * 2 + pl) * 256 + lo4);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    wrr[t][pl] = *reinterpret_cast<const float4*>(wmix_b + ((size_t)((((nr * a.nch_mix + NBQ + 2 * k + kh) * 2 + t) * 3 + pl)) * 256) + lo4);
+                for (int pl = 0; pl < 3; ++pl) wrr[t][pl] = *reinterpret_cast<const float4*>(wrk + (t * 3 + pl) * 256 + lo4);
+            if (ABL & 128) stamp();  // c0: chunk's fragment loads issued
             // (b) GroupNorm of the raw halo tile -> Hs (zero padding comes after the normalisation: the depthwise conv pads xn)
             {
                 const float4 gq = *reinterpret_cast<const float4*>(&GB[64 * k + 4 * c4]);
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
                     if (pix < NHP) *reinterpret_cast<float4*>(&Hs[pix * LDH + 4 * c4]) = v;
                 }
             }
+            if (ABL & 128) stamp();  // c1: GroupNorm stage done (includes the wait for the raw tile)
             // the next chunk's (or the next item's first) raw tile flies during the stages below
             if (k + 1 < NCHK) {
                 load_raw(b, x0, k + 1);
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
                 load_raw(a.b0 + (wn >> 1), (wn & 1) * 4, 0);
             }
             __syncthreads();
+            if (ABL & 128) stamp();  // c2: barrier
             // (c) depthwise 3x3 of the chunk: one (pixel, channel quad) per thread; pixels are numbered column-major, p = 8 xl + y
             {
                 const int p = tid >> 4, xl = p >> 3, y = p & 7;
@@ -274,7 +279,9 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
                 *reinterpret_cast<uint2*>(&Ax[p * LDX + sl * 24 + 8 + e2]) = make_uint2(m01, m23);
                 *reinterpret_cast<uint2*>(&Ax[p * LDX + sl * 24 + 16 + e2]) = make_uint2(l01, l23);
             }
+            if (ABL & 128) stamp();  // c3: depthwise + split stage done
             __syncthreads();
+            if (ABL & 128) stamp();  // c4: barrier
             // (d) contraction of the chunk: 32 pixels x this wave's 32 q channels (4 slabs) and x its output block (2 of the 4 slabs)
             if (qw) {
 #pragma unroll
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(512) void linattn8_fused_kernel(LaFuseArgs a) {
                 acca = DDIF_MFMA_32x32x16_BF16(wrr[t][0], xr[1], acca);
                 acca = DDIF_MFMA_32x32x16_BF16(wrr[t][0], xr[0], acca);
             }
+            if (ABL & 128) stamp();  // c5: contraction issued (includes the wait for the fragments)
             // (no barrier here: the next chunk's GroupNorm stage writes Hs, which nobody reads any more; Aq / Ax are rewritten behind its barrier)
         }
         stamp();
