@@ -56,6 +56,17 @@ void run(int B) {
         for (int i = 1; i < 6; ++i) printf(" %lld", d[wg * 64 + i] - d[wg * 64 + i - 1]);
         printf("   total %lld\n", d[wg * 64 + 5] - d[wg * 64]);
     }
+    {   // per-chunk anatomy: weights issued | GroupNorm stage | barrier | depthwise + split | barrier | contraction issued
+        auto fc = linattn8_fused_kernel<NBQ, 64 | 128>;
+        CK_(hipFuncSetAttribute((const void*)fc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));
+        CK_(hipMemset(dbg, 0, 256 * 64 * 8));
+        hipLaunchKernelGGL(fc, dim3(grid), dim3(512), G::smem, 0, a);
+        CK_(hipDeviceSynchronize());
+        CK_(hipMemcpy(d.data(), dbg, d.size() * 8, hipMemcpyDeviceToHost));
+        printf("  chunk anatomy of wg 0 (deltas; per chunk: fragments issued | GN stage | barrier | depthwise | barrier | contraction issued):\n   ");
+        for (int i = 2; i < 2 + 6 * (NBQ / 2) + 1 && d[i]; ++i) printf(" %lld", d[i] - d[i - 1]);
+        printf("\n");
+    }
     hipFree(in0); hipFree(in1); hipFree(out); hipFree(wq); hipFree(wmix); hipFree(vec); hipFree(st); hipFree(dbg);
 }
 
