@@ -7,10 +7,10 @@
 namespace ddif {
 
 namespace {
-template <int KS, int MB, int PRO, int EPI, bool F16 = false, bool B1 = false>
+template <int KS, int MB, int PRO, int EPI, bool F16 = false, bool B1 = false, bool ROWS = false>
 ConvVariant lr_variant1(const char* name) {
     ConvVariant v;
-    v.fn = conv_lr_kernel<KS, MB, PRO, EPI, 0, F16, B1>;
+    v.fn = conv_lr_kernel<KS, MB, PRO, EPI, 0, F16, B1, ROWS>;
     using G = LrGeom<KS, MB, PRO, (EPI & EPI_COLST) != 0, F16, B1>;
     v.smem = G::smem;
     v.th = G::TH;
@@ -23,6 +23,16 @@ ConvVariant lr_variant1(const char* name) {
     v.lr = true;
     v.name = name;
     return v;
+}
+// the whole-width staging of the f16x2 3x3 convs (kernels_lr.h ROWS): same tile, same LDS footprint, same results
+template <int MB>
+ConvVariant lr_rows_for(int pro, int epi) {
+    if (pro == PRO_GN_SILU && epi == 0) return lr_variant1<3, MB, PRO_GN_SILU, 0, true, false, true>("lr3x3_gn_silu_rows");
+    if (pro == PRO_GN_SILU && epi == EPI_RES) return lr_variant1<3, MB, PRO_GN_SILU, EPI_RES, true, false, true>("lr3x3_gn_silu_res_rows");
+    if (pro == PRO_NONE && epi == EPI_SILU) return lr_variant1<3, MB, PRO_NONE, EPI_SILU, true, false, true>("lr3x3_silu_rows");
+    if (pro == PRO_NONE && epi == 0) return lr_variant1<3, MB, PRO_NONE, 0, true, false, true>("lr3x3_rows");
+    if (pro == PRO_NONE && epi == EPI_RES) return lr_variant1<3, MB, PRO_NONE, EPI_RES, true, false, true>("lr3x3_res_rows");
+    return ConvVariant();
 }
 template <int MB>
 ConvVariant lr_for(int ks, int pro, int epi, int math) {
@@ -83,8 +93,9 @@ void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
 
 // mb = 2: 8x8 pixel tiles, mb = 4: 8x16.  The per-sample time bias needs no variant of its own here (the epilogue reads
 // bias and time-bias rows straight from memory), so EPI_TBS is accepted and ignored.
-ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math) {
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math, bool rows) {
     epi &= ~EPI_TBS;
+    if (rows) return (ks == 3 && math == MATH_F16X2) ? (mb == 2 ? lr_rows_for<2>(pro, epi) : lr_rows_for<4>(pro, epi)) : ConvVariant();
     return mb == 2 ? lr_for<2>(ks, pro, epi, math) : lr_for<4>(ks, pro, epi, math);
 }
 

@@ -38,6 +38,10 @@ static int f16_enabled() {  // DDIF_F16=0: the split-operand convs stay on bf16x
 }
 int g_math_mode = [] { const char* e = getenv("DDIF_MATH"); return (e && std::strcmp(e, "bf16") == 0) ? 1 : 0; }();
 int g_f16_raw = [] { const char* e = getenv("DDIF_F16_RAW"); return e ? (atoi(e) != 0) : 1; }();
+static int lr_rows_enabled() {  // DDIF_LR_ROWS=0: the low-resolution 3x3 convs keep the general (pixel-item) staging where the row staging applies
+    static const int v = [] { const char* e = getenv("DDIF_LR_ROWS"); return e ? atoi(e) : 1; }();
+    return v;
+}
 static int lafuse_enabled() {  // DDIF_LAFUSE=0: the decoder's linear-attention half as three launches (q conv, column statistics, attn_out conv)
     static const int v = [] { const char* e = getenv("DDIF_LAFUSE"); return e ? atoi(e) : 1; }();
     return v;
@@ -355,6 +359,16 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
         }
     }
     if (!var.fn) return fail(DDIF_ERR_INVALID, "%s: no kernel variant (ks=%d stride=%d ups=%d ck=%d pro=%d cfg=%d vec=%d epi=%d)", s.name, pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi);
+    // round 6: a low-resolution 3x3 conv whose tile spans the whole image width (the 8x8 / 16x16 levels of a 64x64 tile) stages by rows (kernels_lr.h ROWS): same
+    // results, ~1.3 us less instruction issue per launch.  DDIF_LR_ROWS=0: the general staging everywhere (tests/test_env_switches.py)
+    bool lr_rows = false;
+    if (var.lr && var.f16 && pc.ks == 3 && Win == var.tw && Wout == Win && Hout == Hin && lr_rows_enabled()) {
+        const ConvVariant vr = get_lr_variant(3, cfg == 20 ? 2 : 4, s.pro, epi, MATH_F16X2, true);
+        if (vr.fn && vr.smem == var.smem) {
+            var = vr;
+            lr_rows = true;
+        }
+    }
     // round 6: the next block's x_conv + FiLM as a second output of this conv (kernels_conv.h EPI_XF) -- where the chosen f16x2 tiling has such an instantiation
     // and one wave holds all 32 couts of its pixels; otherwise the request is left undone and the caller emits the 1x1 launch as before
     bool xf = false;
@@ -468,7 +482,7 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     if (s.tb_off >= 0) {
         const ConvVariant vt = get_conv_variant(pc.ks, s.stride, s.ups, pc.ck, s.pro, cfg, vec, epi | EPI_TBS, math);
         if (!vt.fn || vt.smem != var.smem) return fail(DDIF_ERR_INVALID, "%s: no per-sample time-bias kernel variant", s.name);
-        fn_tbs = vt.fn;
+        fn_tbs = lr_rows ? var.fn : vt.fn;  // (the low-resolution kernel reads its time-bias rows from memory either way: ddif_lr.cpp)
         if (var.smem + 8192 > 64 * 1024)
             DDIF_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_tbs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(var.smem + 8192)));
     }

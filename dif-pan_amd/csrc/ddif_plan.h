@@ -56,7 +56,7 @@ struct ConvVariant {
 // operand format of a split-operand conv: what get_conv_variant / get_lr_variant instantiate and which weight pack the launch reads
 enum { MATH_BF16X3 = 0, MATH_F16X2 = 1, MATH_BF16X1 = 2 };
 ConvVariant get_conv_variant(int ks, int stride, int ups, int ck, int pro, int cfg, int vec, int epi, int math = MATH_BF16X3);
-ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3);  // ddif_lr.cpp
+ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math = MATH_BF16X3, bool rows = false);  // ddif_lr.cpp (rows: the whole-width staging, kernels_lr.h ROWS)
 ConvVariant get_conv_variant_k1(int stride, int ups, int ck, int pro, int cfg, int vec, int epi);   // ddif_conv_k1.cpp
 ConvVariant get_conv_variant_k3(int stride, int ups, int ck, int pro, int cfg, int vec);            // ddif_conv_k3.cpp
 ConvVariant get_conv_variant_k3e(int stride, int ups, int ck, int pro, int cfg, int vec, int epi);  // ddif_conv_k3e.cpp

@@ -65,7 +65,12 @@ struct LrGeom {
 // F16: the f16x2 split (ddif_dev.h; kernels_conv.h MATH = 3) instead of bf16x3 -- operands pre-scaled by 2^4 / 2^10 and split into two
 // half planes, three products per slab and tap, 2/3 of the weight stream and of the staged tile; the accumulator is scaled back in the epilogue
 // B1: the throughput variant (kernels_conv.h MATH = 4): one bf16 plane per operand, one product
-template <int KS, int MB, int PRO, int EPI, int ABL = 0, bool F16 = false, bool B1 = false>
+// ROWS (round 6, 3x3 only): the tile spans the whole image width (Win == TW, one tile column) -- what the 8x8 / 16x16 levels of a 64x64 tile are.  The staging item is
+// then a halo ROW and the thread's image column is fixed (PSTEP == TW): no per-item pixel decomposition, clamps or 64-bit index products (the general path spends
+// ~25 instructions on each of its 12-13 items before the first load goes out: profiles/r06/lr_stamps.txt), rows outside the image are skipped by a wave-uniform
+// branch instead of being loaded, normalised and masked (36 % of the 10 x 10 halo tile of an 8 x 8 sample is padding), and the two halo columns are zeroed once per
+// work item.  Same LDS image, same contraction: bit-identical results.
+template <int KS, int MB, int PRO, int EPI, int ABL = 0, bool F16 = false, bool B1 = false, bool ROWS = false>
 __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     constexpr bool COLST = (EPI & EPI_COLST) != 0;
     static_assert(!COLST || KS == 1, "column statistics epilogue: 1x1 convs");
@@ -81,8 +86,9 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     constexpr bool FILM = (EPI & EPI_FILM) != 0, RES = (EPI & EPI_RES) != 0, SILU = (EPI & EPI_SILU) != 0;
     constexpr int C4 = PC / 4;                          // float4 channel groups per staged pixel
     constexpr int PSTEP = 256 / C4;                     // pixels covered by one pass of the 256 threads
-    constexpr int NIT = (LH * LW + PSTEP - 1) / PSTEP;  // staging items per thread and phase
+    constexpr int NIT = ROWS ? LH : (LH * LW + PSTEP - 1) / PSTEP;  // staging items per thread and phase
     static_assert(256 % C4 == 0, "staging geometry");
+    static_assert(!ROWS || (KS == 3 && PSTEP == TW && PRO != PRO_COLSM), "row staging: 3x3 convs, one pass of the threads = one image row");
 
     dd_touch_kernargs<sizeof(ConvArgs)>();  // every line of the argument block in ONE round trip (ddif_dev.h)
     DDIF_DYN_SMEM(smem);
@@ -186,6 +192,19 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             const float* src = s0 ? a.in0 + (cok ? c : 0) : a.in1 + (c - a.c0);
             const int cs = s0 ? a.c0 : a.c1;
             okm = 0;
+            if constexpr (ROWS) {
+                const float* rp = src + (((size_t)b * a.Hin + oy0) * a.Win + p0) * cs;  // this thread's column of image row oy0
+                const ptrdiff_t rs = (ptrdiff_t)a.Win * cs;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int iy = oy0 - LP + it;
+                    if ((iy >= 0) & (iy < a.Hin)) {  // workgroup-uniform
+                        okm |= 1u << it;
+                        if (ABL & 4) sv[it] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);
+                        else sv[it] = *reinterpret_cast<const float4*>(rp + (ptrdiff_t)(it - LP) * rs);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int pix = p0 + it * PSTEP;
@@ -202,6 +221,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                     mxv[it] = *reinterpret_cast<const float4*>(a.cs_mx + so);
                     smv[it] = *reinterpret_cast<const float4*>(a.cs_sm + so);
                 }
+            }
             }
             if constexpr (GNP) {
                 gq4 = *reinterpret_cast<const float4*>(a.gamma + (cok ? c : 0));
@@ -227,8 +247,16 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int pix = p0 + it * PSTEP;
-                const bool ok = (okm >> it) & 1u;
+                const int pix = ROWS ? it * LW + p0 + LP : p0 + it * PSTEP;
+                if constexpr (ROWS) {
+                    if (!((okm >> it) & 1u)) {  // a row of zero padding (workgroup-uniform): nothing was loaded, nothing is normalised
+                        float* d = &As[it * AROW + (p0 + LP) * APIX + slab_l * SLF + cin_slab / 2];
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2*>(d + 8 * q) = make_uint2(0u, 0u);
+                        continue;
+                    }
+                }
+                const bool ok = ROWS ? cok : (okm >> it) & 1u;
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -245,8 +273,8 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
                     v[i] = ok ? x : 0.f;  // zero padding comes AFTER the activation (and channels past the end are zero)
                 }
                 if constexpr (RANGE) r_max = fmaxf(fmaxf(r_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                if (pix < LH * LW) {
-                    float* d = &As[(pix / LW) * AROW + (pix % LW) * APIX + slab_l * SLF + cin_slab / 2];
+                if (ROWS || pix < LH * LW) {
+                    float* d = ROWS ? &As[it * AROW + (p0 + LP) * APIX + slab_l * SLF + cin_slab / 2] : &As[(pix / LW) * AROW + (pix % LW) * APIX + slab_l * SLF + cin_slab / 2];
                     if constexpr (B1) {
                         *reinterpret_cast<uint2*>(d) = make_uint2(dd_bf16_pair(v[0], v[1]), dd_bf16_pair(v[2], v[3]));
                     } else if constexpr (F16) {
@@ -267,6 +295,13 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             }
         };
         stage_load(0);
+        if constexpr (ROWS) {  // the two halo columns: zero padding for every row and phase of the item (the K-partial exchange of the previous item overwrote them)
+            constexpr int Q = (APIX - 4) / 4;  // float4 per staged pixel
+            for (int i = tid; i < LH * 2 * Q; i += 256) {
+                const int r = i / (2 * Q), e = i - r * (2 * Q);
+                *reinterpret_cast<float4*>(&As[r * AROW + (e >= Q ? (LW - 1) * APIX + (e - Q) * 4 : e * 4)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         // the time-bias row LAST: its address waits for the step counter (a dependent scalar load); issued earlier, every load behind it in program order
         // would wait for that round trip too
         const float4 tq = *reinterpret_cast<const float4*>(tbrow + (size_t)b * a.tbias_stride + coc);

@@ -31,6 +31,9 @@
 
   DDIF_ATTN_F16=0  the qkv conv of the bottleneck attention block on bf16x3 (six products) instead of f16x2 (three; round 6).
 
+  DDIF_LR_ROWS=0  the low-resolution 3x3 convs on the general pixel-item staging where the plan would take the row staging (kernels_lr.h ROWS, round 6): the
+                same LDS image and contraction, so bit-identical results (checked below together with the tilings).
+
 All other A/B switches (round 1: wave-specialised conv, VALU attention, unfused depthwise, tile-shape overrides; round 5: the fused feed-forward
 kernel DDIF_FFNFUSE and the forked low-resolution region DDIF_SPLIT, both measured slower -- profiles/r04/t_*, r03_b_*) were deleted together with
 their code."""
@@ -68,8 +71,8 @@ SLICE_FWD = "test_forward_matches_reference_golden"
 
 # (independent switches share a child process: a child costs ~10 s of interpreter + library start-up whatever it runs)
 @pytest.mark.parametrize("env", [{"DDIF_LA_NW": "4", "DDIF_ATTN_SPLIT": "1", "DDIF_TILE16": "1"}, {"DDIF_LA_NW": "8", "DDIF_ATTN_SPLIT": "2", "DDIF_TILE16": "0"},
-                                 {"DDIF_ATTN_NW": "8", "DDIF_LA6": "0"}, {"DDIF_ATTN_F16": "0"}],
-                         ids=["LA_NW=4+ATTN_SPLIT=1+TILE16=1", "LA_NW=8+ATTN_SPLIT=2+TILE16=0", "ATTN_NW=8+LA6=0", "ATTN_F16=0"])
+                                 {"DDIF_ATTN_NW": "8", "DDIF_LA6": "0"}, {"DDIF_ATTN_F16": "0", "DDIF_LR_ROWS": "0"}],
+                         ids=["LA_NW=4+ATTN_SPLIT=1+TILE16=1", "LA_NW=8+ATTN_SPLIT=2+TILE16=0", "ATTN_NW=8+LA6=0", "ATTN_F16=0+LR_ROWS=0"])
 def test_forward_goldens_under_placement_switch(env):
     e = dict(os.environ)
     e.update(env)
@@ -131,21 +134,26 @@ torch.save({"y": y.cpu(), "out": out.cpu()}, sys.argv[1])
     import torch
 
     res = {}
-    for flag in ("0", "1", "small"):
+    for flag in ("0", "1", "small", "norows"):
         e = dict(os.environ)
         e["DDIF_WRES"] = "0" if flag == "0" else "1"
         e["DDIF_XCD"] = "0" if flag == "0" else "15"  # ... and the XCD-contiguous work partition (ddif_dev.h wg_work_range): which workgroup computes an item, never what
         # two tiles would not fill the CUs: since round 6 the plan would pick the four-wave 8 x 16 tiling by itself ("small" lets it); DDIF_TILE16=1 keeps the
         # 16 x 16 tilings this test is about.  All three must agree bit for bit: the big tilings write half-tile statistics partials (ConvArgs::st_halves)
         e["DDIF_TILE16"] = "0" if flag == "small" else "1"
+        if flag == "norows":  # ... and the general staging of the low-resolution 3x3 convs instead of the row staging (kernels_lr.h ROWS): the same LDS image
+            e["DDIF_LR_ROWS"] = "0"
         e["DDIF_DUMP_PLAN"] = "1"
         f = str(tmp_path / ("wres%s.pt" % flag))
         r = subprocess.run([sys.executable, "-c", code % (os.path.join(ROOT, "dif-pan_amd"), ROOT, os.path.join(ROOT, "tests")), f], env=e, cwd=ROOT, capture_output=True,
                            text=True, timeout=1500)
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-        res[flag] = (torch.load(f), r.stderr.count("cfg=37"), r.stderr.count("cfg=28"))
+        res[flag] = (torch.load(f), r.stderr.count("cfg=37"), r.stderr.count("cfg=28"), r.stderr.count("_rows "))
     assert res["0"][1] == 0 and res["1"][1] >= 15, (res["0"][1], res["1"][1])  # 14 ResnetBlock convs + the final conv at the 64 x 64 level
     assert res["small"][1] == 0 and res["small"][2] >= 30, res["small"][1:]  # every 3x3 conv of the 64 x 64 / 32 x 32 levels on the 8 x 16 tiling
+    assert res["1"][3] >= 40 and res["norows"][3] == 0, (res["1"][3], res["norows"][3])  # the 3x3 convs of the 16 x 16 / 8 x 8 levels stage by rows
+    assert torch.equal(res["norows"][0]["y"], res["1"][0]["y"])
+    assert torch.equal(res["norows"][0]["out"], res["1"][0]["out"])
     assert torch.equal(res["0"][0]["y"], res["1"][0]["y"])
     assert torch.equal(res["0"][0]["out"], res["1"][0]["out"])
     assert torch.equal(res["small"][0]["y"], res["1"][0]["y"])
