@@ -24,14 +24,14 @@ ConvVariant lr_variant1(const char* name) {
     v.name = name;
     return v;
 }
-// the whole-width staging of the f16x2 3x3 convs (kernels_lr.h ROWS): same tile, same LDS footprint, same results
-template <int MB>
+// the whole-width staging of the 3x3 convs (kernels_lr.h ROWS; f16x2 and bf16x3): same tile, same LDS footprint, same results
+template <int MB, bool F16>
 ConvVariant lr_rows_for(int pro, int epi) {
-    if (pro == PRO_GN_SILU && epi == 0) return lr_variant1<3, MB, PRO_GN_SILU, 0, true, false, true>("lr3x3_gn_silu_rows");
-    if (pro == PRO_GN_SILU && epi == EPI_RES) return lr_variant1<3, MB, PRO_GN_SILU, EPI_RES, true, false, true>("lr3x3_gn_silu_res_rows");
-    if (pro == PRO_NONE && epi == EPI_SILU) return lr_variant1<3, MB, PRO_NONE, EPI_SILU, true, false, true>("lr3x3_silu_rows");
-    if (pro == PRO_NONE && epi == 0) return lr_variant1<3, MB, PRO_NONE, 0, true, false, true>("lr3x3_rows");
-    if (pro == PRO_NONE && epi == EPI_RES) return lr_variant1<3, MB, PRO_NONE, EPI_RES, true, false, true>("lr3x3_res_rows");
+    if (pro == PRO_GN_SILU && epi == 0) return lr_variant1<3, MB, PRO_GN_SILU, 0, F16, false, true>("lr3x3_gn_silu_rows");
+    if (pro == PRO_GN_SILU && epi == EPI_RES) return lr_variant1<3, MB, PRO_GN_SILU, EPI_RES, F16, false, true>("lr3x3_gn_silu_res_rows");
+    if (pro == PRO_NONE && epi == EPI_SILU) return lr_variant1<3, MB, PRO_NONE, EPI_SILU, F16, false, true>("lr3x3_silu_rows");
+    if (pro == PRO_NONE && epi == 0) return lr_variant1<3, MB, PRO_NONE, 0, F16, false, true>("lr3x3_rows");
+    if (pro == PRO_NONE && epi == EPI_RES) return lr_variant1<3, MB, PRO_NONE, EPI_RES, F16, false, true>("lr3x3_res_rows");
     return ConvVariant();
 }
 template <int MB>
@@ -95,7 +95,11 @@ void attn_block_launch(const AttnBlockArgs& a, int grid, hipStream_t s) {
 // bias and time-bias rows straight from memory), so EPI_TBS is accepted and ignored.
 ConvVariant get_lr_variant(int ks, int mb, int pro, int epi, int math, bool rows) {
     epi &= ~EPI_TBS;
-    if (rows) return (ks == 3 && math == MATH_F16X2) ? (mb == 2 ? lr_rows_for<2>(pro, epi) : lr_rows_for<4>(pro, epi)) : ConvVariant();
+    if (rows) {
+        if (ks != 3 || math == MATH_BF16X1) return ConvVariant();
+        if (math == MATH_F16X2) return mb == 2 ? lr_rows_for<2, true>(pro, epi) : lr_rows_for<4, true>(pro, epi);
+        return mb == 2 ? lr_rows_for<2, false>(pro, epi) : lr_rows_for<4, false>(pro, epi);
+    }
     return mb == 2 ? lr_for<2>(ks, pro, epi, math) : lr_for<4>(ks, pro, epi, math);
 }
 

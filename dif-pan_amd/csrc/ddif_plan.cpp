@@ -362,8 +362,8 @@ int Plan::add_conv(std::vector<Op>& prog, const ConvSpec& s, Tensor* out) {
     // round 6: a low-resolution 3x3 conv whose tile spans the whole image width (the 8x8 / 16x16 levels of a 64x64 tile) stages by rows (kernels_lr.h ROWS): same
     // results, ~1.3 us less instruction issue per launch.  DDIF_LR_ROWS=0: the general staging everywhere (tests/test_env_switches.py)
     bool lr_rows = false;
-    if (var.lr && var.f16 && pc.ks == 3 && Win == var.tw && Wout == Win && Hout == Hin && lr_rows_enabled()) {
-        const ConvVariant vr = get_lr_variant(3, cfg == 20 ? 2 : 4, s.pro, epi, MATH_F16X2, true);
+    if (var.lr && !var.b1 && pc.ks == 3 && Win == var.tw && Wout == Win && Hout == Hin && lr_rows_enabled()) {
+        const ConvVariant vr = get_lr_variant(3, cfg == 20 ? 2 : 4, s.pro, epi, var.f16 ? MATH_F16X2 : MATH_BF16X3, true);
         if (vr.fn && vr.smem == var.smem) {
             var = vr;
             lr_rows = true;
