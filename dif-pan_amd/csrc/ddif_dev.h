@@ -178,6 +178,16 @@ __device__ __forceinline__ float dd_silu_scaled(float x, float inv_s) {
 #endif
 }
 
+// The sampler's device step counter (round 6): the load goes out where the value is read, but hipcc scheduled the dependent multiply -- and with it an s_waitcnt vmcnt(0) --
+// right behind the load, at the top of the kernel: one more serial L2 round trip in front of everything.  dd_late() hands the value through an opaque move at the place of its
+// first real use, so the wait lands there, behind the other loads of the burst.
+__device__ __forceinline__ int dd_late(int v) {
+#if !defined(DDIF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 // Kernel-argument lines touched at kernel entry (round 5).  The argument block of the big kernels is 300-400 bytes = 5-7 scalar-cache lines, the L2s (and the scalar
 // caches) start COLD at every kernel boundary on this part, and hipcc loads the fields of a by-value struct lazily, where they are first used: every first touch of another
 // line deep inside the prologue was one more Infinity-Cache round trip in the dependent chain in front of the first MFMA.  One s_load per 64-byte line, waited for inside the

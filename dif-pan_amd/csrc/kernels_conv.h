@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     const int Ctot = a.c0 + a.c1;
     const int GBN = a.n_chunks * CK;
     const int c4 = tid % C4;
-    const float* tbrow = a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0);
+    const int stepv = a.step_ptr ? *a.step_ptr : 0;  // the load goes out here; first used at the table fill below (dd_late)
+    const float* tbrow = a.tbias;                    // (+ the step's row offset from there on)
     // sampler epilogue: this step's coefficients (scalar loads, once per workgroup)
     [[maybe_unused]] SamplerRun s_run{};
     [[maybe_unused]] int s_k = 0;
@@ -1060,6 +1061,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     }
     if (GNP) gn_load_partials(a.st0, a.np0, a.st1, a.np1, R0.pos.b, &gp);
     // the step's time-bias row LAST: its address waits for the step counter (a dependent scalar load); issued earlier, every load behind it in program order waits too
+    tbrow = a.tbias + (size_t)dd_late(stepv) * a.tb_rowstride;
 #pragma unroll
     for (int k = 0; k < TBL; ++k) {
         const int i = tid + k * NTHR, c = i < a.Cout ? i : a.Cout - 1;

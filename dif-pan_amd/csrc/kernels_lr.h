@@ -108,11 +108,18 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
     int w0, w1;
     wg_work_range(nwork, &w0, &w1, a.xcd);
     const int Ctot = a.c0 + a.c1;
+    // (scalar copies: with the fields themselves hipcc turned the per-thread select `s0 ? a.c0 : a.c1` below into a select of kernel-argument ADDRESSES and a vector load
+    // from the argument segment -- one more serial round trip in front of the first staging load)
+#ifdef DDIF_EMU
+    const int ac0 = a.c0, ac1 = a.c1;
+#else
+    const int ac0 = __builtin_amdgcn_readfirstlane(a.c0), ac1 = __builtin_amdgcn_readfirstlane(a.c1);
+#endif
     const int NS = (Ctot + 15) / 16;                 // 16-channel slabs (channels past the end of the last one stage zeros)
     const int NSW = a.n_chunks * (KS == 3 ? 1 : 2);  // slabs in the packed weights (>= NS)
     const int NP = (NS + SP - 1) / SP;               // phases
     const int c4 = tid % C4, p0 = tid / C4;
-    const float* tbrow = a.tbias + (a.step_ptr ? (size_t)(*a.step_ptr) * a.tb_rowstride : 0);
+    const int stepv = a.step_ptr ? *a.step_ptr : 0;  // used late (dd_late at the time-bias load below)
 
     // A-fragment base of this lane for accumulator block mb: pixel m = mb*32 + j of the tile (+ tap offset later)
     int abase[MB];
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             const bool cok = c < Ctot;           // channels past the end stage zeros
             const bool s0 = !cok || c < a.c0;    // (padding channels read source 0, channel 0: always valid)
             const float* src = s0 ? a.in0 + (cok ? c : 0) : a.in1 + (c - a.c0);
-            const int cs = s0 ? a.c0 : a.c1;
+            const int cs = s0 ? ac0 : ac1;
             okm = 0;
             if constexpr (ROWS) {
                 const float* rp = src + (((size_t)b * a.Hin + oy0) * a.Win + p0) * cs;  // this thread's column of image row oy0
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
         }
         // the time-bias row LAST: its address waits for the step counter (a dependent scalar load); issued earlier, every load behind it in program order
         // would wait for that round trip too
-        const float4 tq = *reinterpret_cast<const float4*>(tbrow + (size_t)b * a.tbias_stride + coc);
+        const float4 tq = *reinterpret_cast<const float4*>(a.tbias + (size_t)dd_late(stepv) * a.tb_rowstride + (size_t)b * a.tbias_stride + coc);
 
         // ================= (2) first uses =================
         if (new_b) {  // every wavefront reduces the producer's partials itself (no barrier)
