@@ -41,6 +41,7 @@ sub = {
  'CPU': '%.2e' % r['cpu_baseline']['value'], 'BF': '%.4f' % bf['value'], 'BFMS': '%.3f' % (bf['ms_per_step'] / 1000), 'BFD': '%.1e' % bf['drift']['max_abs'],
  'GF': '%.3f' % gf['value'], 'GFX': '%.0f' % gf.get('vs_cpu_baseline', 0), 'CVX': '%.0f' % cv.get('vs_cpu_baseline', 0), 'GFMS': '%.1f' % gf['ms_per_step'], 'CV': '%.4f' % cv['value'], 'CVMS': '%.2f' % (cv['ms_per_step'] / 1000), 'TRV': '%.0f' % tr['value'], 'TR': '%.2f' % tr['ms_per_step'],
  'T4': '%.1f' % t4['ms_per_step'], 'S64': '%.1f' % sh['64'], 'S32': '%.1f' % sh['32'], 'S16': '%.1f' % sh['16'], 'S8': '%.1f' % sh['8'], 'P2': '%.2f' % pj['2'], 'P4': '%.2f' % pj['4'], 'P8': '%.2f' % pj['8'],
+ 'LRMS': '%.2f' % [c for c in ws['classes'] if c['class'].startswith('low-resolution')][0]['ms_per_step'], 'LRFR': '%.2f' % [c for c in ws['classes'] if c['class'].startswith('low-resolution')][0]['frac_of_floor'],
  'NGPU': ngpu, 'TGPU': tgpu, 'NCPU': '134', 'PR': ser + '_', 'PARITY': par,
 }
 s = open('DESIGN.md').read()
