@@ -10,6 +10,17 @@ bf = json.load(open(G + 'bench_wv3_bf16.json')); gf = json.load(open(G + 'bench_
 tr = json.load(open(G + 'bench_wv3_train_b32.json')); t4 = json.load(open(G + 'bench_wv3_train_b4_share.json'))
 busy = json.load(open(G + 'mfma_busy.json'))['whole_run_mfma_busy']
 sh = gf['projected_strong_scaling']['ms_per_job_by_tiles_per_gpu']; pj = gf['projected_strong_scaling']['projected_speedup_by_gpus']
+def whole_round():
+    # profiles/r06/whole_round_lib_ab.txt: lines 'other rep N ms/step X' (round 5's library) and 'tree rep N ms/step Y', the LAST block of the file
+    a, b = [], []
+    for ln in open('profiles/r06/whole_round_lib_ab.txt'):
+        mm = re.match(r'(other|tree) rep \d+ ms/step ([\d.]+)', ln)
+        if mm: (a if mm.group(1) == 'other' else b).append(float(mm.group(2)))
+    n = 3
+    a, b = a[-n:], b[-n:]
+    ma, mb = sum(a) / len(a), sum(b) / len(b)
+    return '%.3f → %.3f ms = −%.1f %%' % (ma, mb, 100 * (1 - mb / ma))
+WHOLE = whole_round()
 tests = open(G + 'tests.log').read()
 m = re.search(r'(\d+) passed.* in ([\d.]+)s', tests)
 ngpu, tgpu = (m.group(1), str(int(float(m.group(2))))) if m else ('?', '?')
@@ -42,6 +53,7 @@ sub = {
  'GF': '%.3f' % gf['value'], 'GFX': '%.0f' % gf.get('vs_cpu_baseline', 0), 'CVX': '%.0f' % cv.get('vs_cpu_baseline', 0), 'GFMS': '%.1f' % gf['ms_per_step'], 'CV': '%.4f' % cv['value'], 'CVMS': '%.2f' % (cv['ms_per_step'] / 1000), 'TRV': '%.0f' % tr['value'], 'TR': '%.2f' % tr['ms_per_step'],
  'T4': '%.1f' % t4['ms_per_step'], 'S64': '%.1f' % sh['64'], 'S32': '%.1f' % sh['32'], 'S16': '%.1f' % sh['16'], 'S8': '%.1f' % sh['8'], 'P2': '%.2f' % pj['2'], 'P4': '%.2f' % pj['4'], 'P8': '%.2f' % pj['8'],
  'LRMS': '%.2f' % [c for c in ws['classes'] if c['class'].startswith('low-resolution')][0]['ms_per_step'], 'LRFR': '%.2f' % [c for c in ws['classes'] if c['class'].startswith('low-resolution')][0]['frac_of_floor'],
+ 'WHOLE': WHOLE,
  'NGPU': ngpu, 'TGPU': tgpu, 'NCPU': '134', 'PR': ser + '_', 'PARITY': par,
 }
 s = open('DESIGN.md').read()
