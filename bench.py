@@ -172,6 +172,10 @@ def main():
         _rt.use_library(os.path.abspath(args.lib))
     lib = ddif.get_lib()
     assert not lib.emulated
+    if os.environ.get("DDIF_BENCH_GRID_CAP"):  # development aid (tools/gpu_r6v.sh): cap the persistent grid of every conv launch (the test hook ddif_debug_set_grid_cap)
+        from ddif import runtime as _rt
+
+        _rt.set_debug_grid_cap(int(os.environ["DDIF_BENCH_GRID_CAP"]))
     cf = CONFIGS[args.config]
     bf16 = cf.get("math") == "bf16"
     if bf16:
