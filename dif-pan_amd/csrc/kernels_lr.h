@@ -38,6 +38,14 @@ namespace ddif {
 #ifndef LR_ROWPAD
 #define LR_ROWPAD 1
 #endif
+// (kernels_lr.h K loop) keeps the prefetched LDS reads of the next step in front of the current step's MFMAs: a compiler-level memory fence, no instruction
+#if defined(DDIF_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+#define LR_PREFETCH_FENCE() ((void)0)
+#elif defined(LR_NO_FENCE)
+#define LR_PREFETCH_FENCE() ((void)0)
+#else
+#define LR_PREFETCH_FENCE() asm volatile("" ::: "memory")
+#endif
 template <int KS, int MB, int PRO, bool TALL = false, bool F16 = false, bool B1 = false>
 struct LrGeom {
     static constexpr int NPL = F16 ? 2 : (B1 ? 1 : 3);         // operand planes: f16x2 (hi, lo), bf16x3 (hi, mid, lo) or bf16x1 (the throughput variant)
@@ -330,49 +338,56 @@ __global__ __launch_bounds__(256) void conv_lr_kernel(ConvArgs a) {
             if (ph + 1 < NP) stage_load(ph + 1);  // in flight during this phase's MFMAs
             __syncthreads();
             // ---- this wave's K steps of the phase: slabs ph*SP + wave, + 4, ... (ring slot = tap for 3x3, slab-in-phase for 1x1)
+            // (round 6) The A fragments of step n + 1 are read from LDS BEFORE the MFMAs of step n are issued (two register sets), and the products of a step go out
+            // product-major over the accumulator blocks: two consecutive MFMAs never share an accumulator, so the waits hipcc puts between them cost an issue slot
+            // and not the ~43-cycle same-accumulator cliff (guide: MI355X_MICROARCH constants table).  Per accumulator the order of the products is unchanged: same bits.
             const int s_end = (ph + 1) * SP < NS ? (ph + 1) * SP : NS;
+            float4 xa[2][MB][NPL];
+            auto a_load = [&](int buf, int sl, int tap) {
+                const int aoff = (tap / KS) * AROW + (tap % KS) * APIX + sl * SLF;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) xa[buf][mb][q] = *reinterpret_cast<const float4*>(&As[abase[mb] + aoff + q * 8]);
+            };
 #pragma unroll
             for (int k = 0; k < SPW; ++k) {
                 const int sl = wave + 4 * k;  // slab within the phase
                 if (ph * SP + sl < s_end) {   // wave-uniform; only the last phase can be ragged
+                    a_load(0, sl, 0);         // (one exposed LDS latency per slab; the taps behind it are prefetched)
 #pragma unroll
                     for (int tap = 0; tap < TAPS; ++tap) {
                         constexpr int UU = U;
                         const int u = (k * TAPS + tap) % UU;
-                        const int aoff = (tap / KS) * AROW + (tap % KS) * APIX + sl * SLF;
-                        float4 xa[MB][NPL];
+                        const int cur = tap & 1;
+                        if (tap + 1 < TAPS) a_load(cur ^ 1, sl, tap + 1);
+                        LR_PREFETCH_FENCE();
+                        if (ABL & 2) {
 #pragma unroll
-                        for (int q = 0; q < NPL; ++q)
+                            for (int mb = 0; mb < MB; ++mb) acc[mb][0] += wr[u][0].x * xa[cur][mb][0].x + wr[u][NPL / 2].y * xa[cur][mb][NPL / 2].y + wr[u][NPL - 1].z * xa[cur][mb][NPL - 1].z;
+                        } else if constexpr (B1) {
 #pragma unroll
-                            for (int mb = 0; mb < MB; ++mb) xa[mb][q] = *reinterpret_cast<const float4*>(&As[abase[mb] + aoff + q * 8]);
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[cur][mb][0], acc[mb]);
+                        } else if constexpr (F16) {
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            f32x16 cacc = acc[mb];
-                            if (ABL & 2) {
-                                cacc[0] += wr[u][0].x * xa[mb][0].x + wr[u][NPL / 2].y * xa[mb][NPL / 2].y + wr[u][NPL - 1].z * xa[mb][NPL - 1].z;
-                                acc[mb] = cacc;
-                                continue;
-                            }
-                            if constexpr (B1) {
-                                acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][0], cacc);
-                                continue;
-                            }
-                            if constexpr (F16) {
-                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][NPL - 1], xa[mb][0], cacc);  // lo * hi
-                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[mb][NPL - 1], cacc);  // hi * lo
-                                cacc = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[mb][0], cacc);  // hi * hi
-                                acc[mb] = cacc;
-                                continue;
-                            }
-                            if constexpr (NPL == 3) {
-                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][2], xa[mb][0], cacc);  // lo * hi
-                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][2], cacc);  // hi * lo
-                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][1], cacc);  // mid * mid
-                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[mb][0], cacc);  // mid * hi
-                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][1], cacc);  // hi * mid
-                                cacc = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[mb][0], cacc);  // hi * hi
-                            }
-                            acc[mb] = cacc;
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_F16(wr[u][NPL - 1], xa[cur][mb][0], acc[mb]);  // lo * hi
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[cur][mb][NPL - 1], acc[mb]);  // hi * lo
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_F16(wr[u][0], xa[cur][mb][0], acc[mb]);        // hi * hi
+                        } else if constexpr (NPL == 3) {
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][2], xa[cur][mb][0], acc[mb]);  // lo * hi
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[cur][mb][2], acc[mb]);  // hi * lo
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[cur][mb][1], acc[mb]);  // mid * mid
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][1], xa[cur][mb][0], acc[mb]);  // mid * hi
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[cur][mb][1], acc[mb]);  // hi * mid
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) acc[mb] = DDIF_MFMA_32x32x16_BF16(wr[u][0], xa[cur][mb][0], acc[mb]);  // hi * hi
                         }
                         if (pf_slab < NS) ring_load(u);  // the step U ahead of this one (wave-uniform branch)
                         // NOTE: do not wrap the MFMA group in __builtin_amdgcn_sched_barrier here.  With fences before / after it
