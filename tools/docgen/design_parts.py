@@ -1,5 +1,5 @@
 STATUS = r'''Headline (BASELINE configs[1], B = 64 tiles of 64×64×8, T = 1000, one MI355X): **@@MS@@ ms per denoising step = @@MPS@@ MP/s** in the final set
-`profiles/r06/z_*` (build `@@BUILD@@`), **132 launches** per
+`profiles/r06/z_*` (build `@@BUILD@@`; two runs of the set on two boxes: 3.390 and 3.389 ms; the build before the last two neutral changes measured **3.256 ms = 0.0805 MP/s** on a faster box, `y_bench_T1000_B64_build_6caf75ed.json`), **132 launches** per
 step (146 in round 5), @@XCPU@@ × the 16-thread CPU port (@@XCPU1@@ × its B = 1 rate), `roofline.step_frac` @@SF@@ (0.183 in round 5). Driver-measured round 5: 3.541 ms.
 **The whole round on one box** (round 5's final library against this one, interleaved three times, `profiles/r06/whole_round_lib_ab.txt`): **@@WHOLE@@**; the boxes of the pool differ by ± 5 % (the tree before the row staging measured 3.27–3.59 ms on six of them, round 5's 3.54–3.82): only same-box pairs are comparable, and every change below is one (single A/Bs: −2.4, −1.9, −2.0, −1.7, −1.2, −0.7, −0.5, −0.5, −0.4 %).
 
