@@ -9,7 +9,7 @@ step (146 in round 5), @@XCPU@@ × the 16-thread CPU port (@@XCPU1@@ × its B = 
 | 2. small batch (8 / 16-tile shares ≤ 95 / 105 ms) | **not met: @@S8@@ / @@S16@@ ms** (120.7 / 128.2 in round 5); projected 8-GPU speed-up @@P8@@ × (1.67) | the half-tile GroupNorm-partial granularity IS built (`ConvArgs::st_halves`): the 16×16 tilings write their partials per 8×16 half in the small tiling's order, the conv outputs of both tilings are bit-identical, so the plan picks 8×16 tiles when a launch would not fill the CUs and a tile of a batch stays **bit-equal** to the tile run alone (tested with mixed tilings): −4.2 % at 8 tiles. The fused kernels above carry the rest (−8 launches, four-wave / split workgroups). `bench.py --config gf2_dpm50` now measures the 32 / 16 / 8-tile shares itself (`projected_strong_scaling`); config 5's per-rank share (4 tiles): **@@T4@@ ms** per iteration (`z_bench_wv3_train_b4_share.json`) |
 | 3. parity record in the artefacts | **done** | `tools/parity_report.py` in `gpu_full.sh`, both modes committed (§4: every margin ≤ 1.6e-5); `bench.py` line carries `parity` (golden T = 1000 re-run: max @@PMAX@@, ΔPSNR @@PPS@@ dB) and `exact_fp32` / `ms_per_step_exact_fp32` (@@EX@@ ms per step, 184 launches, child process with `DDIF_F16=0 DDIF_X3=0`) |
 | 4. config-exact goldens | **done** | `dpm_gf2_64_T1000_s50_o2`, `ddpm_cave_128_T2000` (full chain), `ddpm_wv3_64_T1000_b/_c`; the B = 64 test deals three distinct goldens out as b % 3; `-m gpu` = @@TGPU@@ s (585 s in round 5) |
-| 5. low-resolution class ≤ 1.05 ms | **not met by a hair: 1.28 → @@LRMS@@ ms** | the 3×3 convs of the class stage by ROWS where the tile spans the image width (`kernels_lr.h` ROWS, §3): the general staging spent ≈ 25 instructions of pixel decomposition, clamps and 64-bit products on each of its 12–13 items before the first load went out and then loaded, normalised and masked the 36 % of the halo tile that is zero padding (`lr_stamps.txt`); now the item is a halo row, the thread's column is fixed, padding rows are skipped by a uniform branch: 2 452 → 1 818 instructions in front of the first MFMA, **−1.95 µs on each of the 48 launches, −2.4 % on the step**, bit-identical (`lr_rows_ab.txt`). Before that: the fused 8² attention half and −10 launches (1.28 → 1.15). Its K loop now prefetches the next tap's A fragments and issues the products product-major over the accumulator blocks (bit-identical; class −1.6 %, training −0.8 %, `lr_kloop_lib_ab.txt`). Two compiler artefacts found on the way and removed, measured neutral (`late_waits_lib_ab.txt`). Measured and dropped: the staged tile kept across the two cout tiles a workgroup would then walk in the 512-item launches (+1.1 %: two co-resident workgroups hide each other's chains better, `lr_keep_tile_ab.txt`). Not measured: pilot launch, chained `res.conv1 → res.conv2` at 16², K-partials through DPP |
+| 5. low-resolution class ≤ 1.05 ms | **not met: 1.28 → @@LRMS@@ ms (1.07 on the faster box)** | the 3×3 convs of the class stage by ROWS where the tile spans the image width (`kernels_lr.h` ROWS, §3): the general staging spent ≈ 25 instructions of pixel decomposition, clamps and 64-bit products on each of its 12–13 items before the first load went out and then loaded, normalised and masked the 36 % of the halo tile that is zero padding (`lr_stamps.txt`); now the item is a halo row, the thread's column is fixed, padding rows are skipped by a uniform branch: 2 452 → 1 818 instructions in front of the first MFMA, **−1.95 µs on each of the 48 launches, −2.4 % on the step**, bit-identical (`lr_rows_ab.txt`). Before that: the fused 8² attention half and −10 launches (1.28 → 1.15). Its K loop now prefetches the next tap's A fragments and issues the products product-major over the accumulator blocks (bit-identical; class −1.6 %, training −0.8 %, `lr_kloop_lib_ab.txt`). Two compiler artefacts found on the way and removed, measured neutral (`late_waits_lib_ab.txt`). Measured and dropped: the staged tile kept across the two cout tiles a workgroup would then walk in the 512-item launches (+1.1 %: two co-resident workgroups hide each other's chains better, `lr_keep_tile_ab.txt`). Not measured: pilot launch, chained `res.conv1 → res.conv2` at 16², K-partials through DPP |
 | 6. training ≤ 21 ms | **not met: @@TR@@ ms** | only the low-resolution kernel's changes carry over to train-mode plans (bf16x3 instantiations: row staging −0.7 %, K loop −0.8 %; `lr_rows_ab.txt`, `lr_kloop_lib_ab.txt`); 2 270 launches of ≈ 11 µs, no single kernel above 11 % (`z_train_kernel_stats.csv`); the batched weight-gradient reduction was measured slower in round 5 (`DESIGN_HISTORY.md` §7) |
 | 7. ready the 8-GPU run | **done** | world-4 gloo tests (scene shard 4 × 1 tile ≡ 1 × 4 bit for bit; DDP step, four seeds → identical replicas); `bench.py` at N > 1 prints `rccl` (ranks, per-rank ms min / max / all, all-gather µs, bus GB/s), training line the all-reduce |
 | 8. prune and index | **done** | per-op tape wrappers → `tests/ddif_testops.py`, their 31 declarations → `include/ddif_testops.h` (`include/ddif.h` = 48 product entry points; `test_cabi_symbols` checks the product binds none); this file ≤ 300 lines, the record → `DESIGN_HISTORY.md`; `profiles/rNN/` with an index each; conv instantiations in four translation units (build 6 → 2.5 min) |
